@@ -1,0 +1,224 @@
+/*
+ * irs_hip.h -- C ABI of libirs_hip.so: the MI355X (gfx950) implementation of
+ * InfluentialRS's sequential next-item scoring and persuasion-path search.
+ *
+ * The reference (JackShDr/InfluentialRS) has NO native/FFI interface for this
+ * path: its boundary is the Python class API of model/influentialRS.py
+ * (SURVEY.md section 8b, row B1).  This ABI is therefore NEW and sits below
+ * that class API; each entry point names the reference call site whose
+ * arithmetic it replaces.  The Python front-end (influentialrs_amd/model/*)
+ * keeps the reference's class/method signatures and calls these through
+ * ctypes; INTEGRATION.md shows the binding a maintainer of the reference
+ * would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative IRS_E_* code otherwise;
+ *    no C++ exception crosses the ABI; irs_last_error() gives the message.
+ *  - every pointer marked "dev" is a device (HBM) pointer owned by the caller
+ *    (e.g. torch.Tensor.data_ptr()); the library never frees it.
+ *  - nothing is allocated after irs_create(): scratch lives in a caller-owned
+ *    workspace sized by irs_workspace_bytes() and bound by irs_bind_workspace().
+ *  - all work is enqueued on the caller's stream (a hipStream_t passed as
+ *    void*); no call synchronises the device unless documented.
+ *  - one context <-> one device, one stream at a time (not re-entrant).
+ *  - item ids crossing the ABI in "ids0" arguments are 0-based GLOBAL catalog
+ *    positions (reference item id = ids0 + 1, influentialRS.py:376,422;
+ *    0 is the pad id in sequences, which carry 1-based ids like the reference).
+ *  - total order used by every selection: score descending, then id
+ *    ascending (torch's own tie order is unspecified).
+ */
+#ifndef IRS_HIP_H
+#define IRS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IRS_ABI_VERSION 1
+
+/* error codes */
+#define IRS_OK 0
+#define IRS_E_INVALID (-1)     /* bad argument / shape */
+#define IRS_E_STATE (-2)       /* weights or workspace not bound */
+#define IRS_E_HIP (-3)         /* HIP runtime error (message has the hipError) */
+#define IRS_E_UNSUPPORTED (-4) /* shape outside the kernels' envelope */
+
+/* attention mask flavours */
+#define IRS_MASK_IRN 0    /* InfluentialNet as called: allowed = r_u[b], last column = 1.0
+                             (_generate_square_subsequent_mask, influentialRS.py:120-155,
+                             called at :183-184) + key padding (:171) */
+#define IRS_MASK_CAUSAL 1 /* SampleNet: 0 / -inf causal (uRS.py:47-50) + key padding (:53) */
+
+/* scoring precision of the catalog sweep */
+#define IRS_SWEEP_BF16 0 /* bf16 MFMA filter with a proven error bound, then exact fp32
+                            re-scoring of the survivors: results identical to IRS_SWEEP_F32 */
+#define IRS_SWEEP_F32 1  /* fp32 MFMA sweep (exact k-ordered fma chain) */
+
+/* per-row status bits written by the selection kernels */
+#define IRS_ROW_OK 0
+#define IRS_ROW_FALLBACK 1     /* candidate buffers overflowed; row was re-done by the exhaustive exact kernel */
+#define IRS_ROW_NO_CANDIDATE 2 /* every one of the k candidates is in the window
+                                  (the reference raises IndexError at influentialRS.py:429) */
+#define IRS_ROW_FEWER_THAN_K 4 /* catalog shard has fewer than k items; tail filled with (-inf, -1) */
+
+typedef struct irs_ctx irs_ctx;
+
+typedef struct irs_dims {
+    int64_t n_item;   /* catalog size N (global) */
+    int64_t n_user;   /* rows of user_embedder (0 for SampleNet) */
+    int32_t d;        /* emb_dim (even, <= 256) */
+    int32_t max_len;  /* L (<= 256) */
+    int32_t n_heads;  /* H, divides d; d / H <= 64 */
+    int32_t ffn_dim;  /* F */
+    int32_t n_layers;
+    int32_t u_dim;    /* u_emb_dim (0 for SampleNet) */
+    int32_t mask_mode;/* IRS_MASK_* */
+    int32_t max_rows; /* upper bound on rows (sequences / scored rows) per call */
+    int32_t max_k;    /* upper bound on k of irs_score_topk (reference: 100) */
+    int32_t reserved;
+} irs_dims;
+
+/* item-dimension shard held by this context: rows
+ * [item_lo, item_hi) of project.weight / project.bias. */
+typedef struct irs_shard {
+    int32_t rank;
+    int32_t world;
+    int64_t item_lo;
+    int64_t item_hi;
+} irs_shard;
+
+int irs_abi_version(void);
+const char *irs_last_error(const irs_ctx *ctx); /* ctx may be NULL: last create() error */
+
+int irs_create(irs_ctx **out, const irs_dims *dims, const irs_shard *shard);
+void irs_destroy(irs_ctx *ctx);
+
+/* ---- weights -----------------------------------------------------------
+ * Bind one float32 device tensor by its reference state_dict key
+ * (item_embedder.weight | word_embedder.weight,
+ * user_embedder.weight, pos_embedder.pe, user_mask_layer.{weight,bias},
+ * project.{weight,bias}, decoder.layers.<l>.{self_attn,multihead_attn}.
+ * {in_proj_weight,in_proj_bias,out_proj.weight,out_proj.bias},
+ * decoder.layers.<l>.linear{1,2}.{weight,bias}, decoder.layers.<l>.norm{1,2,3}.
+ * {weight,bias}); a leading "module." (nn.DataParallel, pipeline.py:43-44) is
+ * accepted.  project.weight / project.bias are the LOCAL shard rows
+ * ([item_hi-item_lo, d] / [item_hi-item_lo]).  numel is checked. */
+int irs_bind_weight(irs_ctx *ctx, const char *name, const float *dev_ptr, int64_t numel);
+
+/* Bytes of the derived-weight arena (bf16 MFMA-fragment-packed copy of the
+ * project shard, padded bias, per-layer cross-attention constants). */
+size_t irs_derived_bytes(const irs_ctx *ctx);
+/* Build the derived weights into the caller's arena (async on stream).
+ * Must be called after all weights are bound and again after any weight
+ * changes in place. */
+int irs_finalize_weights(irs_ctx *ctx, void *dev_arena, size_t bytes, void *stream);
+
+size_t irs_workspace_bytes(const irs_ctx *ctx);
+int irs_bind_workspace(irs_ctx *ctx, void *dev_ws, size_t bytes);
+
+/* ---- decoder (replaces InfluentialNet.decoding, influentialRS.py:157-200;
+ *      SampleNet.decoding, uRS.py:52-64) --------------------------------- */
+
+/* r_u[b] = user_mask_layer(user_embedder(user[b]))  (influentialRS.py:180). */
+int irs_pif(irs_ctx *ctx, const int64_t *dev_user, int32_t B, float *dev_r_u, void *stream);
+
+/* Full decoder over B sequences.
+ *  dev_seq   int64 [B, L] row-major, 1-based item ids, 0 = pad (not modified)
+ *  dev_user  int64 [B] (ignored for IRS_MASK_CAUSAL, may be NULL)
+ *  dev_x     float [B, L, d] out, may be NULL
+ *  dev_pos   int32 [B] row to extract per sequence, may be NULL
+ *  dev_xrows float [B, d] out: x[b, pos[b], :], may be NULL (with dev_pos)
+ *  dev_r_u   float [B] out, may be NULL */
+int irs_decode(irs_ctx *ctx, const int64_t *dev_seq, const int64_t *dev_user, int32_t B, float *dev_x,
+               const int32_t *dev_pos, float *dev_xrows, float *dev_r_u, void *stream);
+
+/* ---- scoring against the catalog shard (replaces `project`,
+ *      influentialRS.py:83/214, uRS.py:45/68, and the selections on it) ---
+ * Exact score of row m and local item j:
+ *   e = fmaf(x[d-1], W[j][d-1], ... fmaf(x[0], W[j][0], b[j]))   (float32, k ascending)
+ * identical bit for bit to oracle/oracle_score.c. */
+
+/* top-k per row (replaces softmax + topk(100), influentialRS.py:418-421; the
+ * softmax is monotone, so ids follow the logits).
+ *  dev_xrows float [M, d]
+ *  dev_val   float [M, k] out, exact scores, descending
+ *  dev_ids0  int64 [M, k] out, global 0-based ids (-1 where the shard has < k items)
+ *  dev_status int32 [M] out, IRS_ROW_* bits */
+int irs_score_topk(irs_ctx *ctx, const float *dev_xrows, int32_t M, int32_t k, int32_t sweep, float *dev_val,
+                   int64_t *dev_ids0, int32_t *dev_status, void *stream);
+
+/* Exact scores at chosen items (replaces prob_dict[j][end][item-1],
+ * evaluator.py:203-205, and the label lookup of influentialRS.py:386-388).
+ *  dev_ids0 int64 [M, g] global 0-based ids; entries outside this shard (or <0)
+ *  produce -inf so that an elementwise max over shards assembles the answer. */
+int irs_score_gather(irs_ctx *ctx, const float *dev_xrows, int32_t M, const int64_t *dev_ids0, int32_t g,
+                     float *dev_out, void *stream);
+
+/* count[m] = #{ local j not in excl[m] : (e_j, j) ranks before (ref_score[m], ref_id0[m]) }
+ * (replaces sort + history filter + nonzero, influentialRS.py:375-389,
+ * evaluator.py:121-131,266-286; rank = 1 + sum of count over shards).
+ *  dev_excl_ids0 int64 [M, n_excl] global 0-based ids, -1 = unused slot; duplicates allowed. */
+int irs_score_count_before(irs_ctx *ctx, const float *dev_xrows, int32_t M, const float *dev_ref_score,
+                           const int64_t *dev_ref_id0, const int64_t *dev_excl_ids0, int32_t n_excl,
+                           int64_t *dev_count, void *stream);
+
+/* Dense logits of the shard: out[m, j] for j in [0, n_local) with leading
+ * dimension ld (>= n_local); the API-compatible `forward()` output
+ * (influentialRS.py:214).  HBM-write bound by construction. */
+int irs_score_dense(irs_ctx *ctx, const float *dev_xrows, int32_t M, float *dev_out, int64_t ld, void *stream);
+
+/* Row-wise (max, sum exp(e - max)) over the shard (replaces Softmax /
+ * LogSoftmax over N, influentialRS.py:418, evaluator.py:195, and
+ * CrossEntropyLoss, evaluator.py:321).  Combine shards on the host side
+ * (max of maxes, rescaled sum). */
+int irs_score_lse(irs_ctx *ctx, const float *dev_xrows, int32_t M, float *dev_max, float *dev_sumexp, void *stream);
+
+/* Merge W per-shard top-k lists (after the RCCL all-gather) into
+ * the global top-k with the same total order.
+ *  dev_val_in float [W, M, k], dev_ids_in int64 [W, M, k] (ids -1 ignored) */
+int irs_merge_topk(irs_ctx *ctx, const float *dev_val_in, const int64_t *dev_ids_in, int32_t W, int32_t M, int32_t k,
+                   float *dev_val, int64_t *dev_ids0, void *stream);
+
+/* ---- one step of the persuasion-path search (replaces the per-row body of
+ *      IRSNN.get_seq_in_batch, influentialRS.py:419-450) ------------------
+ * For each row: drop candidates present in seq[b, :hep[b]+1], take the first
+ * survivor (greedy) or draw one of the first sample_k survivors with
+ * probability proportional to exp(val) (sample != 0; device counter RNG,
+ * distributional parity only), record it in paths[b, step], then grow the
+ * window (hep < L-2) or shift it left keeping the target at [L-1].
+ *  dev_seq  int64 [B, L] in/out     dev_hep int32 [B] in/out
+ *  dev_val  float [B, k], dev_ids0 int64 [B, k]: merged top-k (descending)
+ *  dev_paths float [B, path_ld] out (ids stored as float32 like the reference, :407)
+ *  dev_status int32 [B] in/out: IRS_ROW_NO_CANDIDATE is OR-ed in */
+int irs_path_step(irs_ctx *ctx, int64_t *dev_seq, int32_t *dev_hep, int32_t B, const float *dev_val,
+                  const int64_t *dev_ids0, int32_t k, int32_t step, float *dev_paths, int32_t path_ld, int32_t sample,
+                  int32_t sample_k, uint64_t seed, int32_t *dev_status, void *stream);
+
+/* Whole greedy/sampled path generation on ONE device holding the full catalog
+ * (world == 1): max_path_len x { decode, top-k, path step } enqueued on the
+ * stream; with use_graph != 0 one step is captured once into a hipGraph and
+ * replayed.  dev_seq is the working window (modified); dev_hep int32 [B]
+ * initial history end positions (L - gap_len - 2, per row). */
+int irs_generate_paths(irs_ctx *ctx, int64_t *dev_seq, const int64_t *dev_user, int32_t *dev_hep, int32_t B,
+                       int32_t max_path_len, int32_t k, int32_t sweep, int32_t sample, int32_t sample_k,
+                       uint64_t seed, int32_t use_graph, float *dev_paths, int32_t *dev_status, void *stream);
+
+/* ---- measurement hooks (bench.py only) ---------------------------------
+ * While enabled, every launch of the named kernel family is bracketed by HIP
+ * events on the launch stream; irs_prof_read() synchronises those events and
+ * returns launches and total milliseconds since the last reset. */
+#define IRS_PROF_NONE 0
+#define IRS_PROF_LINEAR 1  /* decoder fp32 MFMA GEMM */
+#define IRS_PROF_ATTN 2    /* decoder attention */
+#define IRS_PROF_SWEEP 3   /* catalog sweep (pre-pass + emit) */
+#define IRS_PROF_REFINE 4  /* candidate refine / exact re-score / sort */
+int irs_prof_enable(irs_ctx *ctx, int32_t family);
+int irs_prof_read(irs_ctx *ctx, int32_t *launches, double *total_ms, double *total_flops, double *total_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRS_HIP_H */

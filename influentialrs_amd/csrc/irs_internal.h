@@ -1,0 +1,162 @@
+// Internal declarations shared by the HIP translation units of libirs_hip.so.
+// gfx950 (CDNA4) only: wave = 64 lanes, MFMA 32x32 tiles, 160 KiB LDS per CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/irs_hip.h"
+
+#define IRS_MAX_LAYERS 16
+#define IRS_CAND_CAP 4096   // emitted candidates kept per row by the sweep
+#define IRS_REFINE_CAP 1024 // candidates exactly re-scored per row
+#define IRS_MAX_GROUPS 8192 // pre-pass group maxima per row (upper bound)
+
+struct irs_layer_w {
+    const float *sa_in_w, *sa_in_b, *sa_out_w, *sa_out_b;
+    const float *ca_in_w, *ca_in_b, *ca_out_w, *ca_out_b;
+    const float *l1_w, *l1_b, *l2_w, *l2_b;
+    const float *n1_w, *n1_b, *n2_w, *n2_b, *n3_w, *n3_b;
+};
+
+struct irs_prof_ev {
+    hipEvent_t a, b;
+};
+
+struct irs_ctx {
+    irs_dims dims;
+    irs_shard shard;
+    int64_t n_local; // items in this shard
+    int d_pad;       // d rounded up to 16/32/64/128/256
+    int KS;          // d_pad / 16 (bf16 MFMA k-steps)
+    int n_tiles;     // ceil(n_local / 32)
+    int max_seqs;    // sequences per decode call
+    int max_rows;    // scored rows per call
+    int m_pad_max;   // max_rows rounded up to 32
+
+    // bound weights (device)
+    const float *item_emb, *user_emb, *pe, *um_w, *um_b, *proj_w, *proj_b;
+    irs_layer_w layer[IRS_MAX_LAYERS];
+
+    // derived weights (device, in the caller's arena)
+    uint4 *wp;        // bf16 fragments [n_tiles][KS][64] x 16 B
+    float *bias_pad;  // [n_tiles*32], -inf beyond n_local
+    float *c_l;       // [n_layers][d] cross-attention constants
+    float *wnorm_max; // [1] max_j ||W_j||_2
+    bool finalized;
+
+    // workspace (device, caller-owned)
+    char *ws;
+    size_t ws_bytes;
+    // decoder activations
+    float *act_x, *act_y, *act_qkv, *act_ao, *act_h, *act_ru;
+    // scoring
+    uint4 *xb;          // packed bf16 rows [m_pad/32][KS][64] x 16 B
+    float *eps;         // [m_pad]
+    float *thr;         // [m_pad]
+    float *gm;          // [IRS_MAX_GROUPS][m_pad]
+    unsigned int *cand_cnt; // [m_pad]
+    unsigned long long *cand; // [m_pad][IRS_CAND_CAP]
+    float *lse_part;    // [lse_slots][m_pad][2]
+    int lse_slots;
+    float *ref_tmp;     // [m_pad]
+    // path generation scratch
+    float *xrows;       // [max_rows][d]
+    float *top_val;     // [max_rows][max_k]
+    int64_t *top_ids;   // [max_rows][max_k]
+    int32_t *row_status;// [max_rows]
+    int32_t *step_ctr;  // [1]
+    int32_t *pos_tmp;   // [max_seqs]
+
+    // graph cache for irs_generate_paths
+    hipGraphExec_t graph_exec;
+    int graph_B, graph_k, graph_sweep, graph_sample, graph_sample_k;
+    void *graph_seq, *graph_user, *graph_hep, *graph_paths, *graph_status;
+    uint64_t graph_seed;
+
+    // profiling
+    int prof_family;
+    irs_prof_ev *prof_ev;
+    int prof_n, prof_cap;
+    double prof_flops, prof_bytes;
+
+    char err[512];
+};
+
+#define IRS_CHECK_HIP(ctx, expr)                                                                         \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess) {                                                                          \
+            snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #expr,        \
+                     hipGetErrorString(_e));                                                             \
+            return IRS_E_HIP;                                                                            \
+        }                                                                                                \
+    } while (0)
+
+#define IRS_FAIL(ctx, code, ...)                                  \
+    do {                                                          \
+        snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__);    \
+        return (code);                                            \
+    } while (0)
+
+// profiling bracket helpers (no-ops unless the family is enabled)
+void irs_prof_begin(irs_ctx *ctx, int family, hipStream_t s);
+void irs_prof_end(irs_ctx *ctx, int family, hipStream_t s, double flops, double bytes);
+
+// ---- decoder.hip ----
+int irs_launch_pif(irs_ctx *ctx, const int64_t *user, int B, float *r_u, hipStream_t s);
+int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int B, float *x_out, const int32_t *pos,
+                      float *xrows, float *r_u_out, hipStream_t s);
+int irs_launch_cross_const(irs_ctx *ctx, hipStream_t s);
+
+// ---- score.hip ----
+int irs_launch_pack_w(irs_ctx *ctx, hipStream_t s);
+int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, float *val, int64_t *ids0,
+                    int32_t *status, hipStream_t s);
+int irs_launch_gather(irs_ctx *ctx, const float *xrows, int M, const int64_t *ids0, int g, float *out, hipStream_t s);
+int irs_launch_count_before(irs_ctx *ctx, const float *xrows, int M, const float *ref_score, const int64_t *ref_id0,
+                            const int64_t *excl, int n_excl, int64_t *count, hipStream_t s);
+int irs_launch_dense(irs_ctx *ctx, const float *xrows, int M, float *out, int64_t ld, hipStream_t s);
+int irs_launch_lse(irs_ctx *ctx, const float *xrows, int M, float *out_max, float *out_sum, hipStream_t s);
+
+// ---- path.hip ----
+int irs_launch_merge(irs_ctx *ctx, const float *val_in, const int64_t *ids_in, int W, int M, int k, float *val,
+                     int64_t *ids0, hipStream_t s);
+int irs_launch_path_step(irs_ctx *ctx, int64_t *seq, int32_t *hep, int B, const float *val, const int64_t *ids0, int k,
+                         int step, const int32_t *step_ptr, float *paths, int path_ld, int sample, int sample_k,
+                         uint64_t seed, int32_t *status, hipStream_t s);
+int irs_launch_inc(irs_ctx *ctx, int32_t *ctr, hipStream_t s);
+
+// ---- small device helpers ----
+#ifdef __HIPCC__
+// float -> unsigned key whose unsigned order equals float order; -0 folded onto +0
+// (identical to fkey() in oracle/oracle_score.c).
+__device__ __forceinline__ unsigned int irs_fkey(float f) {
+    unsigned int u = __float_as_uint(f);
+    if (u == 0x80000000u) u = 0u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float irs_unkey(unsigned int k) {
+    unsigned int u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(u);
+}
+// exact score: k-ascending float32 fma chain seeded with the bias
+__device__ __forceinline__ float irs_chain(const float *__restrict__ x, const float *__restrict__ w, float b, int d) {
+    float acc = b;
+    if ((d & 3) == 0 && ((((uintptr_t)w) & 15) == 0)) {
+        const float4 *w4 = reinterpret_cast<const float4 *>(w);
+        for (int k = 0; k < d / 4; ++k) {
+            float4 v = w4[k];
+            acc = __fmaf_rn(x[4 * k + 0], v.x, acc);
+            acc = __fmaf_rn(x[4 * k + 1], v.y, acc);
+            acc = __fmaf_rn(x[4 * k + 2], v.z, acc);
+            acc = __fmaf_rn(x[4 * k + 3], v.w, acc);
+        }
+    } else {
+        for (int k = 0; k < d; ++k) acc = __fmaf_rn(x[k], w[k], acc);
+    }
+    return acc;
+}
+#endif

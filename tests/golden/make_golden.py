@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by importing the UNMODIFIED reference.
+
+Runs only in the build container (where /root/reference is mounted read-only).
+The reference never travels: only the arrays written here (inputs + expected
+outputs) are committed under tests/golden/.  Weights are NOT stored -- both
+sides regenerate them from influentialrs_amd.synth (the build's own
+deterministic generator) and the reference receives them via load_state_dict.
+
+Harness-side shims for API drift between the reference's pinned torch 1.12 /
+numpy 1.23 and this image's torch 2.10 / numpy 2.2; no
+reference file is touched:
+  1. ReduceLROnPlateau(verbose=True) is rejected by torch 2.10 -> subclass
+     that swallows `verbose`.
+  2. `import wandb` (absent here) -> empty stub module (only needed when the
+     data_provider/pipeline modules are imported).
+  3. np.Inf alias.
+
+The published IRN only runs at batch size 1, so every IRN
+golden is produced by looping the reference at B=1.
+
+Usage:  python tests/golden/make_golden.py [case ...]   (default: all cases)
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+os.chdir("/tmp")
+
+import numpy as np
+import torch
+from torch.optim import lr_scheduler
+
+if not hasattr(np, "Inf"):
+    np.Inf = np.inf
+sys.modules.setdefault("wandb", types.ModuleType("wandb"))
+
+_RLROP = lr_scheduler.ReduceLROnPlateau
+
+
+class _RLROPCompat(_RLROP):
+    def __init__(self, *a, verbose=None, **k):
+        super().__init__(*a, **k)
+
+
+lr_scheduler.ReduceLROnPlateau = _RLROPCompat
+
+from model.influentialRS import InfluentialNet, IRSNN  # noqa: E402  (reference)
+from model.uRS import SampleNet  # noqa: E402
+from model.evaluator import Evaluator  # noqa: E402
+
+from influentialrs_amd import synth  # noqa: E402
+
+
+def _load(net, sd_np):
+    sd = {k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}
+    missing, unexpected = net.load_state_dict(sd, strict=True), None
+    return net
+
+
+def _pad_ragged(lst, fill=0):
+    n = max(len(a) for a in lst)
+    out = np.full((len(lst), n), fill, dtype=np.int64)
+    lens = np.zeros(len(lst), dtype=np.int64)
+    for i, a in enumerate(lst):
+        out[i, :len(a)] = a
+        lens[i] = len(a)
+    return out, lens
+
+
+def irn_case(name, cfg_name, n_users, seed=1234, max_path_len=20, full_logits=False, hist_users=None,
+             save_x_full=False):
+    cfg = synth.make_config(cfg_name)
+    sd = synth.irn_state_dict(cfg, seed)
+    torch.manual_seed(0)
+    net = _load(InfluentialNet(cfg), sd)
+    net.eval()
+    irn = IRSNN(cfg, net, "cpu")
+    irn.eval()
+    hist_n = hist_users or max(n_users, 8)
+    hists = synth.user_histories(hist_n, cfg.n_item, seed=7)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=11)[:n_users]
+    raws, seqs, users, targets, labels = synth.collate_eval_irs(rows, cfg.max_len, gap_len=0)
+    L = cfg.max_len
+    hep = L - 2
+    g = {}
+    g["seqs"], g["users"], g["targets"], g["labels"] = seqs, users, targets, labels
+    g["raw"], g["raw_len"] = _pad_ragged(raws)
+    r_us, x_rows, x_full, logits_hep, top_ids, top_vals, margins, probes, probe_ids = [], [], [], [], [], [], [], [], []
+    logits_full = []
+    hit_total, rr_all, paths_all, early_total = 0, [], [], 0
+    rng = np.random.default_rng(5)
+    with torch.no_grad():
+        for i in range(n_users):
+            s = torch.from_numpy(seqs[i:i + 1])
+            u = torch.from_numpy(users[i:i + 1])
+            t = torch.from_numpy(targets[i:i + 1])
+            lab = torch.from_numpy(labels[i:i + 1])
+            r_us.append(irn.get_pif_in_batch(s, u)[0])
+            x = net.decoding(s.clone(), u)[0].numpy()
+            x_rows.append(x[hep])
+            if save_x_full:
+                x_full.append(x)
+            lg = net.forward(s.clone(), u)[0].numpy()
+            if full_logits:
+                logits_full.append(lg)
+            row = lg[hep]
+            if cfg.n_item <= 4096:
+                logits_hep.append(row)
+            order = np.lexsort((np.arange(row.shape[0]), -row.astype(np.float64)))
+            k = min(101, row.shape[0])
+            top = order[:k]
+            top_ids.append(top[:100])
+            top_vals.append(row[top[:100]])
+            gaps = row[top[:-1]].astype(np.float64) - row[top[1:]].astype(np.float64)
+            margins.append(gaps.min())
+            pid = rng.choice(cfg.n_item, size=64, replace=False)
+            probe_ids.append(pid)
+            probes.append(row[pid])
+            hit, rr = irn.get_accuracy_metrics_in_batch([torch.from_numpy(raws[i])], s, u, t, lab, 20, 0, True)
+            hit_total += hit
+            rr_all.append(rr[0] if len(rr) else 0.0)
+            p, tt, hh, early = irn.get_seq_in_batch(s, u, t, max_path_len, 0, False, 3)
+            paths_all.append(p[0])
+            early_total += early
+    g["r_u"] = np.array(r_us, dtype=np.float32).reshape(-1)
+    g["x_hep"] = np.stack(x_rows)
+    if save_x_full:
+        g["x_full"] = np.stack(x_full)
+    if logits_hep:
+        g["logits_hep"] = np.stack(logits_hep)
+    if full_logits:
+        g["logits_full"] = np.stack(logits_full)
+    g["top100_ids0"] = np.stack(top_ids).astype(np.int64)
+    g["top100_vals"] = np.stack(top_vals)
+    g["min_margin_top101"] = np.array(margins)
+    g["probe_ids0"] = np.stack(probe_ids).astype(np.int64)
+    g["probe_vals"] = np.stack(probes)
+    g["hit_count"] = np.array(hit_total)
+    g["rr"] = np.array(rr_all)
+    g["paths"] = np.stack(paths_all)
+    g["n_early_success"] = np.array(early_total)
+    g["meta"] = np.array([cfg_name, str(seed), str(max_path_len), torch.__version__, str(hist_n)])
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **g)
+    print(f"[golden] {name}: users={n_users} margins(min)={min(margins):.3e} hit={hit_total} early={early_total}")
+
+
+def _eval_inputs(cfg, n_rows, seed, irn_cfg_name):
+    """Evaluator inputs in the DatasetEvalNN1 layout (data_provider.py:711-760)
+    built by the REFERENCE's own class from synthetic histories/paths/targets."""
+    sys.modules.setdefault("sklearn", __import__("sklearn"))
+    from data_provider import DatasetEvalNN1, DataLoaderEvalNN1  # reference
+    rng = np.random.default_rng(seed)
+    hists = synth.user_histories(max(n_rows, 8), cfg.n_item, seed=7)
+    histories, paths, targets = [], [], []
+    for i in range(n_rows):
+        h = hists[i][:-1]
+        keep = [3, cfg.max_len - 10, cfg.max_len + 7, cfg.max_len - 1][i % 4]
+        h = h[-max(keep, 1):]
+        hs = set(int(v) for v in h)
+        t = int(rng.integers(1, cfg.n_item + 1))
+        while t in hs:
+            t = int(rng.integers(1, cfg.n_item + 1))
+        plen = int(rng.integers(3, min(20, cfg.max_len // 2) + 1))
+        p = np.zeros(20, dtype=np.float32)
+        items = rng.choice(cfg.n_item, size=plen, replace=False) + 1
+        p[:plen] = items
+        if i % 3 == 0 and plen > 2:  # early success: target inside the path, tail zeroed
+            pos = int(rng.integers(1, plen))
+            p[pos] = t
+            p[pos + 1:] = 0
+        histories.append(h)
+        paths.append(p)
+        targets.append(t)
+    ds = DatasetEvalNN1(histories, np.stack(paths), np.array(targets, dtype=np.int64), seq_len=cfg.max_len)
+    dl = DataLoaderEvalNN1(ds, batch_size=n_rows, shuffle=False, num_workers=0)
+    h, d, t, sp, lp = next(iter(dl))
+    hp, hl = _pad_ragged(histories)
+    return (h, d, t, sp, lp), dict(in_histories=hp, in_histories_len=hl, in_paths=np.stack(paths),
+                                   in_targets=np.array(targets, dtype=np.int64))
+
+
+def eval_case(name, cfg_name, n_rows, seed=17):
+    cfg = synth.make_config(cfg_name)
+    sd = synth.irn_state_dict(cfg, seed, evaluator=True)
+    torch.manual_seed(0)
+    net = _load(SampleNet(cfg), sd)
+    net.eval()
+    ev = Evaluator(cfg, net, "cpu")
+    ev.eval()
+    (h, d, t, sp, lp), extra = _eval_inputs(cfg, n_rows, seed, cfg_name)
+    g = dict(extra)
+    g["histories"], g["new_seqs"], g["targets"] = h.numpy().copy(), d.numpy().copy(), t.numpy().copy()
+    g["start_pos"], g["l_paths"] = sp.numpy().copy(), lp.numpy().copy()
+    with torch.no_grad():
+        g["pp"] = np.array(ev.get_pp_in_batch(d, sp, lp))
+        irr, ir = ev.get_rr_increase_in_batch(h, d, t)
+        g["irr"], g["ir"] = irr, ir
+        tp, pp_, avg, ioi = ev.get_grad_in_batch(h.clone(), d, t, sp, lp)
+        g["t_probs"], g["p_probs"], g["avg_ps"], g["iois"] = tp, pp_, np.array(avg), np.array(ioi)
+        lg = net.forward(d[:, :-1])[0].numpy()
+        g["logits_row0_full"] = lg if cfg.n_item <= 512 else lg[:4]
+    g["meta"] = np.array([cfg_name, str(seed), torch.__version__])
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **g)
+    print(f"[golden] {name}: rows={n_rows} pp[0]={g['pp'][0]:.5f} ir={ir[:4]}")
+
+
+CASES = {
+    "irn_tiny": lambda: irn_case("irn_tiny", "tiny", 6, full_logits=True, save_x_full=True),
+    "irn_default": lambda: irn_case("irn_default", "default", 4),
+    "irn_c1": lambda: irn_case("irn_c1", "c1", 3),
+    "irn_c2": lambda: irn_case("irn_c2", "c2", 2),
+    "irn_c3": lambda: irn_case("irn_c3", "c3", 2, max_path_len=4, hist_users=8),
+    "eval_tiny": lambda: eval_case("eval_tiny", "eval_tiny", 8),
+    "eval_default": lambda: eval_case("eval_default", "eval_default", 6),
+}
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or list(CASES)
+    for c in which:
+        CASES[c]()
