@@ -6,7 +6,7 @@
  * path: its boundary is the Python class API of model/influentialRS.py
  * (SURVEY.md section 8b, row B1).  This ABI is therefore NEW and sits below
  * that class API; each entry point names the reference call site whose
- * arithmetic it replaces.  The Python front-end (influentialrs_amd/model/*)
+ * arithmetic it replaces.  The Python front-end (influentialrs_amd/model/)
  * keeps the reference's class/method signatures and calls these through
  * ctypes; INTEGRATION.md shows the binding a maintainer of the reference
  * would add.
@@ -56,6 +56,8 @@ extern "C" {
 #define IRS_SWEEP_BF16 0 /* bf16 MFMA filter with a proven error bound, then exact fp32
                             re-scoring of the survivors: results identical to IRS_SWEEP_F32 */
 #define IRS_SWEEP_F32 1  /* fp32 MFMA sweep (exact k-ordered fma chain) */
+#define IRS_SWEEP_EXHAUSTIVE 2 /* irs_score_topk only: every item through the exact VALU chain,
+                                  one workgroup per row (fallback kernel; yard-stick in tests) */
 
 /* per-row status bits written by the selection kernels */
 #define IRS_ROW_OK 0
@@ -76,9 +78,9 @@ typedef struct irs_dims {
     int32_t n_layers;
     int32_t u_dim;    /* u_emb_dim (0 for SampleNet) */
     int32_t mask_mode;/* IRS_MASK_* */
-    int32_t max_rows; /* upper bound on rows (sequences / scored rows) per call */
+    int32_t max_rows; /* upper bound on scored rows per call */
     int32_t max_k;    /* upper bound on k of irs_score_topk (reference: 100) */
-    int32_t reserved;
+    int32_t max_seqs; /* upper bound on sequences per irs_decode call (0 -> max_rows) */
 } irs_dims;
 
 /* item-dimension shard held by this context: rows

@@ -1,0 +1,57 @@
+"""Build libirs_hip.so (gfx950) in-tree with hipcc.  No torch types in the library:
+it is a plain C-ABI shared object (include/irs_hip.h) loaded with ctypes.
+
+    python -m influentialrs_amd.build [--force]
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+LIB = os.path.join(HERE, "libirs_hip.so")
+SOURCES = ["capi.hip", "decoder.hip", "score.hip", "path.hip"]
+HEADERS = [os.path.join(CSRC, "irs_internal.h"), os.path.join(os.path.dirname(HERE), "include", "irs_hip.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-but-set-variable", "-Wno-unused-variable", "-Wno-unused-value"]
+
+
+def _stale(out: str, deps) -> bool:
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src: str, force: bool) -> str:
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    path = os.path.join(CSRC, src)
+    if force or _stale(obj, [path] + HEADERS):
+        cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        if r.stderr.strip():
+            sys.stderr.write(r.stderr)
+    return obj
+
+
+def build_lib(force: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    if force or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv))

@@ -1,0 +1,521 @@
+// C ABI of libirs_hip.so (include/irs_hip.h): context, weight binding, workspace
+// planning, entry points, hipGraph-captured path generation, measurement hooks.
+#include <stdlib.h>
+
+#include <new>
+
+#include "irs_internal.h"
+
+int irs_launch_topk_exhaustive(irs_ctx *ctx, const float *xrows, int M, int k, float *val, int64_t *ids0,
+                               int32_t *status, hipStream_t s);
+
+static char g_create_err[512] = "";
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int irs_abi_version(void) { return IRS_ABI_VERSION; }
+
+extern "C" const char *irs_last_error(const irs_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
+
+extern "C" int irs_create(irs_ctx **out, const irs_dims *dims, const irs_shard *shard) {
+    if (!out || !dims) {
+        snprintf(g_create_err, sizeof(g_create_err), "irs_create: null argument");
+        return IRS_E_INVALID;
+    }
+    const irs_dims &D = *dims;
+#define BAD(...)                                                   \
+    do {                                                           \
+        snprintf(g_create_err, sizeof(g_create_err), __VA_ARGS__); \
+        return IRS_E_INVALID;                                      \
+    } while (0)
+    if (D.n_item < 1) BAD("n_item must be >= 1");
+    if (D.d < 2 || D.d > 256 || (D.d & 1)) BAD("emb_dim must be even and in [2, 256] (got %d)", D.d);
+    if (D.max_len < 2 || D.max_len > 256) BAD("max_len must be in [2, 256] (got %d)", D.max_len);
+    if (D.n_heads < 1 || D.d % D.n_heads) BAD("n_heads must divide emb_dim");
+    if (D.d / D.n_heads > 64) BAD("head dim > 64 unsupported");
+    if (D.n_layers < 1 || D.n_layers > IRS_MAX_LAYERS) BAD("n_layers out of range");
+    if (D.ffn_dim < 1) BAD("ffn_dim must be >= 1");
+    if (D.mask_mode != IRS_MASK_IRN && D.mask_mode != IRS_MASK_CAUSAL) BAD("bad mask_mode");
+    if (D.mask_mode == IRS_MASK_IRN && (D.u_dim < 1 || D.n_user < 1)) BAD("IRN mask needs user embeddings");
+    if (D.max_rows < 1) BAD("max_rows must be >= 1");
+    if (D.max_k < 1 || D.max_k > 1024) BAD("max_k must be in [1, 1024]");
+    irs_shard sh;
+    if (shard) sh = *shard;
+    else {
+        sh.rank = 0;
+        sh.world = 1;
+        sh.item_lo = 0;
+        sh.item_hi = D.n_item;
+    }
+    if (sh.item_lo < 0 || sh.item_hi > D.n_item || sh.item_lo >= sh.item_hi) BAD("bad item shard [%lld, %lld)", (long long)sh.item_lo, (long long)sh.item_hi);
+    if (sh.item_hi - sh.item_lo > 0x7FFFFFE0LL) BAD("shard too large");
+#undef BAD
+    irs_ctx *c = new (std::nothrow) irs_ctx();
+    if (!c) {
+        snprintf(g_create_err, sizeof(g_create_err), "out of host memory");
+        return IRS_E_INVALID;
+    }
+    memset(c, 0, sizeof(*c));
+    c->dims = D;
+    c->shard = sh;
+    c->n_local = sh.item_hi - sh.item_lo;
+    int dp = 16;
+    while (dp < D.d) dp <<= 1;
+    c->d_pad = dp;
+    c->KS = dp / 16;
+    c->n_tiles = (int)((c->n_local + 31) / 32);
+    c->max_rows = D.max_rows;
+    c->max_seqs = D.max_seqs > 0 ? D.max_seqs : D.max_rows;
+    c->m_pad_max = (c->max_rows + 31) & ~31;
+    c->lse_slots = 2048;
+    *out = c;
+    return IRS_OK;
+}
+
+extern "C" void irs_destroy(irs_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->graph_exec) hipGraphExecDestroy(ctx->graph_exec);
+    if (ctx->prof_ev) {
+        for (int i = 0; i < ctx->prof_cap; ++i) {
+            hipEventDestroy(ctx->prof_ev[i].a);
+            hipEventDestroy(ctx->prof_ev[i].b);
+        }
+        free(ctx->prof_ev);
+    }
+    delete ctx;
+}
+
+// ------------------------------------------------------------------ weights
+static bool ends_with(const char *s, const char *suf) {
+    size_t ls = strlen(s), lf = strlen(suf);
+    return ls >= lf && strcmp(s + ls - lf, suf) == 0;
+}
+
+extern "C" int irs_bind_weight(irs_ctx *ctx, const char *name, const float *p, int64_t numel) {
+    if (!ctx || !name || !p) return IRS_E_INVALID;
+    if (strncmp(name, "module.", 7) == 0) name += 7;
+    const irs_dims &D = ctx->dims;
+    const int64_t d = D.d, F = D.ffn_dim;
+    const float **slot = nullptr;
+    int64_t want = -1;
+    if (!strcmp(name, "item_embedder.weight") || !strcmp(name, "word_embedder.weight")) {
+        slot = &ctx->item_emb;
+        want = (D.n_item + 1) * d;
+    } else if (!strcmp(name, "user_embedder.weight")) {
+        slot = &ctx->user_emb;
+        want = D.n_user * D.u_dim;
+    } else if (!strcmp(name, "pos_embedder.pe")) {
+        slot = &ctx->pe;
+        want = -2; // >= max_len * d
+        if (numel < (int64_t)D.max_len * d) IRS_FAIL(ctx, IRS_E_INVALID, "pos_embedder.pe too small");
+    } else if (!strcmp(name, "user_mask_layer.weight")) {
+        slot = &ctx->um_w;
+        want = D.u_dim;
+    } else if (!strcmp(name, "user_mask_layer.bias")) {
+        slot = &ctx->um_b;
+        want = 1;
+    } else if (!strcmp(name, "project.weight")) {
+        slot = &ctx->proj_w;
+        want = ctx->n_local * d;
+    } else if (!strcmp(name, "project.bias")) {
+        slot = &ctx->proj_b;
+        want = ctx->n_local;
+    } else if (!strncmp(name, "decoder.layers.", 15)) {
+        char *end = nullptr;
+        long l = strtol(name + 15, &end, 10);
+        if (l < 0 || l >= D.n_layers || !end || *end != '.') IRS_FAIL(ctx, IRS_E_INVALID, "bad layer in '%s'", name);
+        const char *rest = end + 1;
+        irs_layer_w &w = ctx->layer[l];
+        struct { const char *n; const float **s; int64_t numel; } tab[] = {
+            {"self_attn.in_proj_weight", &w.sa_in_w, 3 * d * d}, {"self_attn.in_proj_bias", &w.sa_in_b, 3 * d},
+            {"self_attn.out_proj.weight", &w.sa_out_w, d * d},   {"self_attn.out_proj.bias", &w.sa_out_b, d},
+            {"multihead_attn.in_proj_weight", &w.ca_in_w, 3 * d * d}, {"multihead_attn.in_proj_bias", &w.ca_in_b, 3 * d},
+            {"multihead_attn.out_proj.weight", &w.ca_out_w, d * d},   {"multihead_attn.out_proj.bias", &w.ca_out_b, d},
+            {"linear1.weight", &w.l1_w, F * d}, {"linear1.bias", &w.l1_b, F},
+            {"linear2.weight", &w.l2_w, d * F}, {"linear2.bias", &w.l2_b, d},
+            {"norm1.weight", &w.n1_w, d}, {"norm1.bias", &w.n1_b, d},
+            {"norm2.weight", &w.n2_w, d}, {"norm2.bias", &w.n2_b, d},
+            {"norm3.weight", &w.n3_w, d}, {"norm3.bias", &w.n3_b, d},
+        };
+        for (auto &e : tab)
+            if (!strcmp(rest, e.n)) {
+                slot = e.s;
+                want = e.numel;
+            }
+    }
+    if (!slot) IRS_FAIL(ctx, IRS_E_INVALID, "unknown weight '%s'", name);
+    if (want >= 0 && numel != want) IRS_FAIL(ctx, IRS_E_INVALID, "weight '%s': numel %lld, expected %lld", name, (long long)numel, (long long)want);
+    *slot = p;
+    ctx->finalized = false;
+    (void)ends_with;
+    return IRS_OK;
+}
+
+static int check_bound(irs_ctx *ctx) {
+    const irs_dims &D = ctx->dims;
+    if (!ctx->item_emb || !ctx->pe || !ctx->proj_w || !ctx->proj_b) IRS_FAIL(ctx, IRS_E_STATE, "embedding / pe / project weights not bound");
+    if (D.mask_mode == IRS_MASK_IRN && (!ctx->user_emb || !ctx->um_w || !ctx->um_b)) IRS_FAIL(ctx, IRS_E_STATE, "user weights not bound");
+    for (int l = 0; l < D.n_layers; ++l) {
+        const irs_layer_w &w = ctx->layer[l];
+        const float *all[] = {w.sa_in_w, w.sa_in_b, w.sa_out_w, w.sa_out_b, w.ca_in_b, w.ca_out_w, w.ca_out_b, w.l1_w,
+                              w.l1_b, w.l2_w, w.l2_b, w.n1_w, w.n1_b, w.n2_w, w.n2_b, w.n3_w, w.n3_b};
+        for (auto p : all)
+            if (!p) IRS_FAIL(ctx, IRS_E_STATE, "decoder layer %d has unbound weights", l);
+    }
+    return IRS_OK;
+}
+
+static size_t derived_plan(const irs_ctx *ctx, size_t *o_wp, size_t *o_bias, size_t *o_cl, size_t *o_wn) {
+    size_t off = 0;
+    *o_wp = off;
+    off = align_up(off + (size_t)ctx->n_tiles * ctx->KS * 1024, 256);
+    *o_bias = off;
+    off = align_up(off + (size_t)ctx->n_tiles * 32 * sizeof(float), 256);
+    *o_cl = off;
+    off = align_up(off + (size_t)ctx->dims.n_layers * ctx->dims.d * sizeof(float), 256);
+    *o_wn = off;
+    off = align_up(off + 256, 256);
+    return off;
+}
+
+extern "C" size_t irs_derived_bytes(const irs_ctx *ctx) {
+    size_t a, b, c, d;
+    return ctx ? derived_plan(ctx, &a, &b, &c, &d) : 0;
+}
+
+extern "C" int irs_finalize_weights(irs_ctx *ctx, void *arena, size_t bytes, void *stream) {
+    if (!ctx || !arena) return IRS_E_INVALID;
+    int rc = check_bound(ctx);
+    if (rc) return rc;
+    size_t o_wp, o_bias, o_cl, o_wn;
+    size_t need = derived_plan(ctx, &o_wp, &o_bias, &o_cl, &o_wn);
+    if (bytes < need) IRS_FAIL(ctx, IRS_E_INVALID, "derived arena too small: %zu < %zu", bytes, need);
+    if (((uintptr_t)arena) & 255) IRS_FAIL(ctx, IRS_E_INVALID, "derived arena must be 256-byte aligned");
+    char *base = (char *)arena;
+    ctx->wp = (uint4 *)(base + o_wp);
+    ctx->bias_pad = (float *)(base + o_bias);
+    ctx->c_l = (float *)(base + o_cl);
+    ctx->wnorm_max = (float *)(base + o_wn);
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = irs_launch_pack_w(ctx, s))) return rc;
+    if ((rc = irs_launch_cross_const(ctx, s))) return rc;
+    ctx->finalized = true;
+    if (ctx->graph_exec) {
+        hipGraphExecDestroy(ctx->graph_exec);
+        ctx->graph_exec = nullptr;
+    }
+    return IRS_OK;
+}
+
+// ------------------------------------------------------------------ workspace
+struct ws_plan {
+    size_t x, y, qkv, ao, h, ru, xb, eps, thr, gm, cnt, cand, lse, ref, xrows, tval, tids, status, step, pos, total;
+};
+
+static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
+    const irs_dims &D = ctx->dims;
+    const size_t RL = (size_t)ctx->max_seqs * D.max_len;
+    const size_t mp = ctx->m_pad_max;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = align_up(off + bytes, 256);
+        return o;
+    };
+    p->x = take(RL * D.d * 4);
+    p->y = take(RL * D.d * 4);
+    p->qkv = take(RL * 3 * D.d * 4);
+    p->ao = take(RL * D.d * 4);
+    p->h = take(RL * D.ffn_dim * 4);
+    p->ru = take((size_t)ctx->max_seqs * 4);
+    p->xb = take(mp * ctx->d_pad * 2);
+    p->eps = take(mp * 4);
+    p->thr = take(mp * 4);
+    p->gm = take((size_t)IRS_MAX_GROUPS * mp * 4);
+    p->cnt = take(mp * 4);
+    p->cand = take(mp * (size_t)IRS_CAND_CAP * 8);
+    p->lse = take((size_t)ctx->lse_slots * mp * 8);
+    p->ref = take(mp * 4);
+    p->xrows = take((size_t)ctx->max_rows * D.d * 4);
+    p->tval = take((size_t)ctx->max_rows * D.max_k * 4);
+    p->tids = take((size_t)ctx->max_rows * D.max_k * 8);
+    p->status = take((size_t)ctx->max_rows * 4);
+    p->step = take(256);
+    p->pos = take((size_t)ctx->max_seqs * 4);
+    p->total = off;
+}
+
+extern "C" size_t irs_workspace_bytes(const irs_ctx *ctx) {
+    if (!ctx) return 0;
+    ws_plan p;
+    workspace_plan(ctx, &p);
+    return p.total;
+}
+
+extern "C" int irs_bind_workspace(irs_ctx *ctx, void *ws, size_t bytes) {
+    if (!ctx || !ws) return IRS_E_INVALID;
+    ws_plan p;
+    workspace_plan(ctx, &p);
+    if (bytes < p.total) IRS_FAIL(ctx, IRS_E_INVALID, "workspace too small: %zu < %zu", bytes, p.total);
+    if (((uintptr_t)ws) & 255) IRS_FAIL(ctx, IRS_E_INVALID, "workspace must be 256-byte aligned");
+    char *b = (char *)ws;
+    ctx->ws = b;
+    ctx->ws_bytes = bytes;
+    ctx->act_x = (float *)(b + p.x);
+    ctx->act_y = (float *)(b + p.y);
+    ctx->act_qkv = (float *)(b + p.qkv);
+    ctx->act_ao = (float *)(b + p.ao);
+    ctx->act_h = (float *)(b + p.h);
+    ctx->act_ru = (float *)(b + p.ru);
+    ctx->xb = (uint4 *)(b + p.xb);
+    ctx->eps = (float *)(b + p.eps);
+    ctx->thr = (float *)(b + p.thr);
+    ctx->gm = (float *)(b + p.gm);
+    ctx->cand_cnt = (unsigned int *)(b + p.cnt);
+    ctx->cand = (unsigned long long *)(b + p.cand);
+    ctx->lse_part = (float *)(b + p.lse);
+    ctx->ref_tmp = (float *)(b + p.ref);
+    ctx->xrows = (float *)(b + p.xrows);
+    ctx->top_val = (float *)(b + p.tval);
+    ctx->top_ids = (int64_t *)(b + p.tids);
+    ctx->row_status = (int32_t *)(b + p.status);
+    ctx->step_ctr = (int32_t *)(b + p.step);
+    ctx->pos_tmp = (int32_t *)(b + p.pos);
+    if (ctx->graph_exec) {
+        hipGraphExecDestroy(ctx->graph_exec);
+        ctx->graph_exec = nullptr;
+    }
+    return IRS_OK;
+}
+
+static int ready(irs_ctx *ctx) {
+    if (!ctx) return IRS_E_INVALID;
+    if (!ctx->finalized) IRS_FAIL(ctx, IRS_E_STATE, "weights not finalized (irs_finalize_weights)");
+    if (!ctx->ws) IRS_FAIL(ctx, IRS_E_STATE, "workspace not bound (irs_bind_workspace)");
+    return IRS_OK;
+}
+
+// ------------------------------------------------------------------ entry points
+extern "C" int irs_pif(irs_ctx *ctx, const int64_t *user, int32_t B, float *r_u, void *stream) {
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if (B < 1 || !r_u) IRS_FAIL(ctx, IRS_E_INVALID, "irs_pif: bad arguments");
+    if (ctx->dims.mask_mode == IRS_MASK_IRN && !user) IRS_FAIL(ctx, IRS_E_INVALID, "irs_pif: user is null");
+    return irs_launch_pif(ctx, user, B, r_u, (hipStream_t)stream);
+}
+
+extern "C" int irs_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int32_t B, float *x, const int32_t *pos,
+                          float *xrows, float *r_u, void *stream) {
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if (!seq || B < 1) IRS_FAIL(ctx, IRS_E_INVALID, "irs_decode: bad arguments");
+    if (B > ctx->max_seqs) IRS_FAIL(ctx, IRS_E_INVALID, "irs_decode: B=%d exceeds max_seqs=%d", B, ctx->max_seqs);
+    if (ctx->dims.mask_mode == IRS_MASK_IRN && !user) IRS_FAIL(ctx, IRS_E_INVALID, "irs_decode: user is null");
+    if ((pos == nullptr) != (xrows == nullptr)) IRS_FAIL(ctx, IRS_E_INVALID, "irs_decode: pos and xrows go together");
+    return irs_launch_decode(ctx, seq, user, B, x, pos, xrows, r_u, (hipStream_t)stream);
+}
+
+static int check_rows(irs_ctx *ctx, const char *fn, const void *xrows, int M) {
+    if (!xrows || M < 1) IRS_FAIL(ctx, IRS_E_INVALID, "%s: bad arguments", fn);
+    if (M > ctx->max_rows) IRS_FAIL(ctx, IRS_E_INVALID, "%s: M=%d exceeds max_rows=%d", fn, M, ctx->max_rows);
+    return IRS_OK;
+}
+
+extern "C" int irs_score_topk(irs_ctx *ctx, const float *xrows, int32_t M, int32_t k, int32_t sweep, float *val,
+                              int64_t *ids0, int32_t *status, void *stream) {
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if ((rc = check_rows(ctx, "irs_score_topk", xrows, M))) return rc;
+    if (k < 1 || k > ctx->dims.max_k || !val || !ids0 || !status) IRS_FAIL(ctx, IRS_E_INVALID, "irs_score_topk: bad k / outputs");
+    if (sweep == IRS_SWEEP_EXHAUSTIVE) return irs_launch_topk_exhaustive(ctx, xrows, M, k, val, ids0, status, (hipStream_t)stream);
+    if (sweep != IRS_SWEEP_BF16 && sweep != IRS_SWEEP_F32) IRS_FAIL(ctx, IRS_E_INVALID, "irs_score_topk: bad sweep");
+    return irs_launch_topk(ctx, xrows, M, k, sweep, val, ids0, status, (hipStream_t)stream);
+}
+
+extern "C" int irs_score_gather(irs_ctx *ctx, const float *xrows, int32_t M, const int64_t *ids0, int32_t g, float *out,
+                                void *stream) {
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if ((rc = check_rows(ctx, "irs_score_gather", xrows, M))) return rc;
+    if (!ids0 || g < 1 || !out) IRS_FAIL(ctx, IRS_E_INVALID, "irs_score_gather: bad arguments");
+    return irs_launch_gather(ctx, xrows, M, ids0, g, out, (hipStream_t)stream);
+}
+
+extern "C" int irs_score_count_before(irs_ctx *ctx, const float *xrows, int32_t M, const float *ref_score,
+                                      const int64_t *ref_id0, const int64_t *excl, int32_t n_excl, int64_t *count,
+                                      void *stream) {
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if ((rc = check_rows(ctx, "irs_score_count_before", xrows, M))) return rc;
+    if (!ref_score || !ref_id0 || !count || n_excl < 0) IRS_FAIL(ctx, IRS_E_INVALID, "irs_score_count_before: bad arguments");
+    return irs_launch_count_before(ctx, xrows, M, ref_score, ref_id0, excl, n_excl, count, (hipStream_t)stream);
+}
+
+extern "C" int irs_score_dense(irs_ctx *ctx, const float *xrows, int32_t M, float *out, int64_t ld, void *stream) {
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if ((rc = check_rows(ctx, "irs_score_dense", xrows, M))) return rc;
+    if (!out || ld < ctx->n_local) IRS_FAIL(ctx, IRS_E_INVALID, "irs_score_dense: bad out / ld");
+    return irs_launch_dense(ctx, xrows, M, out, ld, (hipStream_t)stream);
+}
+
+extern "C" int irs_score_lse(irs_ctx *ctx, const float *xrows, int32_t M, float *omax, float *osum, void *stream) {
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if ((rc = check_rows(ctx, "irs_score_lse", xrows, M))) return rc;
+    if (!omax || !osum) IRS_FAIL(ctx, IRS_E_INVALID, "irs_score_lse: null outputs");
+    return irs_launch_lse(ctx, xrows, M, omax, osum, (hipStream_t)stream);
+}
+
+extern "C" int irs_merge_topk(irs_ctx *ctx, const float *val_in, const int64_t *ids_in, int32_t W, int32_t M, int32_t k,
+                              float *val, int64_t *ids0, void *stream) {
+    if (!ctx) return IRS_E_INVALID;
+    if (!val_in || !ids_in || !val || !ids0 || W < 1 || M < 1 || k < 1) IRS_FAIL(ctx, IRS_E_INVALID, "irs_merge_topk: bad arguments");
+    return irs_launch_merge(ctx, val_in, ids_in, W, M, k, val, ids0, (hipStream_t)stream);
+}
+
+extern "C" int irs_path_step(irs_ctx *ctx, int64_t *seq, int32_t *hep, int32_t B, const float *val, const int64_t *ids0,
+                             int32_t k, int32_t step, float *paths, int32_t path_ld, int32_t sample, int32_t sample_k,
+                             uint64_t seed, int32_t *status, void *stream) {
+    if (!ctx) return IRS_E_INVALID;
+    if (!seq || !hep || !val || !ids0 || !paths || !status || B < 1 || k < 1 || step < 0 || step >= path_ld)
+        IRS_FAIL(ctx, IRS_E_INVALID, "irs_path_step: bad arguments");
+    return irs_launch_path_step(ctx, seq, hep, B, val, ids0, k, step, nullptr, paths, path_ld, sample, sample_k, seed,
+                                status, (hipStream_t)stream);
+}
+
+// one search step on one device: decode -> rows at hep -> top-k -> choose/update
+static int enqueue_step(irs_ctx *ctx, int64_t *seq, const int64_t *user, int32_t *hep, int B, int k, int sweep,
+                        int sample, int sample_k, uint64_t seed, float *paths, int path_ld, int32_t *status,
+                        hipStream_t s) {
+    int rc;
+    if ((rc = irs_launch_decode(ctx, seq, user, B, nullptr, hep, ctx->xrows, nullptr, s))) return rc;
+    if ((rc = irs_launch_topk(ctx, ctx->xrows, B, k, sweep, ctx->top_val, ctx->top_ids, ctx->row_status, s))) return rc;
+    if ((rc = irs_launch_path_step(ctx, seq, hep, B, ctx->top_val, ctx->top_ids, k, 0, ctx->step_ctr, paths, path_ld,
+                                   sample, sample_k, seed, status, s)))
+        return rc;
+    return irs_launch_inc(ctx, ctx->step_ctr, s);
+}
+
+extern "C" int irs_generate_paths(irs_ctx *ctx, int64_t *seq, const int64_t *user, int32_t *hep, int32_t B,
+                                  int32_t max_path_len, int32_t k, int32_t sweep, int32_t sample, int32_t sample_k,
+                                  uint64_t seed, int32_t use_graph, float *paths, int32_t *status, void *stream) {
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if (ctx->shard.world != 1) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "irs_generate_paths needs the whole catalog on one device");
+    if (!seq || !hep || !paths || !status || B < 1 || max_path_len < 1) IRS_FAIL(ctx, IRS_E_INVALID, "irs_generate_paths: bad arguments");
+    if (B > ctx->max_seqs || B > ctx->max_rows) IRS_FAIL(ctx, IRS_E_INVALID, "irs_generate_paths: B too large");
+    if (k < 1 || k > ctx->dims.max_k) IRS_FAIL(ctx, IRS_E_INVALID, "irs_generate_paths: bad k");
+    if (sweep != IRS_SWEEP_BF16 && sweep != IRS_SWEEP_F32) IRS_FAIL(ctx, IRS_E_INVALID, "irs_generate_paths: bad sweep");
+    hipStream_t s = (hipStream_t)stream;
+    IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->step_ctr, 0, sizeof(int32_t), s));
+    IRS_CHECK_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t) * B, s));
+    if (!use_graph) {
+        for (int i = 0; i < max_path_len; ++i)
+            if ((rc = enqueue_step(ctx, seq, user, hep, B, k, sweep, sample, sample_k, seed, paths, max_path_len, status, s)))
+                return rc;
+        return IRS_OK;
+    }
+    bool reuse = ctx->graph_exec && ctx->graph_B == B && ctx->graph_k == k && ctx->graph_sweep == sweep &&
+                 ctx->graph_sample == sample && ctx->graph_sample_k == sample_k && ctx->graph_seq == seq &&
+                 ctx->graph_user == user && ctx->graph_hep == hep && ctx->graph_paths == paths &&
+                 ctx->graph_status == status && ctx->graph_seed == seed && ctx->prof_family == IRS_PROF_NONE;
+    if (!reuse) {
+        if (ctx->graph_exec) {
+            hipGraphExecDestroy(ctx->graph_exec);
+            ctx->graph_exec = nullptr;
+        }
+        int saved_prof = ctx->prof_family;
+        ctx->prof_family = IRS_PROF_NONE; // event records are not captured
+        hipStream_t cs;
+        IRS_CHECK_HIP(ctx, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            rc = enqueue_step(ctx, seq, user, hep, B, k, sweep, sample, sample_k, seed, paths, max_path_len, status, cs);
+            hipError_t e2 = hipStreamEndCapture(cs, &graph);
+            if (rc == IRS_OK && e2 != hipSuccess) e = e2;
+        }
+        ctx->prof_family = saved_prof;
+        if (e != hipSuccess || rc != IRS_OK || !graph) {
+            hipStreamDestroy(cs);
+            if (graph) hipGraphDestroy(graph);
+            if (rc) return rc;
+            IRS_FAIL(ctx, IRS_E_HIP, "graph capture failed: %s", hipGetErrorString(e));
+        }
+        e = hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        hipStreamDestroy(cs);
+        if (e != hipSuccess) {
+            ctx->graph_exec = nullptr;
+            IRS_FAIL(ctx, IRS_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+        }
+        ctx->graph_B = B;
+        ctx->graph_k = k;
+        ctx->graph_sweep = sweep;
+        ctx->graph_sample = sample;
+        ctx->graph_sample_k = sample_k;
+        ctx->graph_seq = seq;
+        ctx->graph_user = (void *)user;
+        ctx->graph_hep = hep;
+        ctx->graph_paths = paths;
+        ctx->graph_status = status;
+        ctx->graph_seed = seed;
+    }
+    for (int i = 0; i < max_path_len; ++i) IRS_CHECK_HIP(ctx, hipGraphLaunch(ctx->graph_exec, s));
+    return IRS_OK;
+}
+
+// ------------------------------------------------------------------ profiling hooks
+void irs_prof_begin(irs_ctx *ctx, int family, hipStream_t s) {
+    if (ctx->prof_family != family) return;
+    if (ctx->prof_n == ctx->prof_cap) {
+        int ncap = ctx->prof_cap ? ctx->prof_cap * 2 : 256;
+        irs_prof_ev *n = (irs_prof_ev *)realloc(ctx->prof_ev, sizeof(irs_prof_ev) * ncap);
+        if (!n) return;
+        for (int i = ctx->prof_cap; i < ncap; ++i) {
+            hipEventCreate(&n[i].a);
+            hipEventCreate(&n[i].b);
+        }
+        ctx->prof_ev = n;
+        ctx->prof_cap = ncap;
+    }
+    hipEventRecord(ctx->prof_ev[ctx->prof_n].a, s);
+}
+
+void irs_prof_end(irs_ctx *ctx, int family, hipStream_t s, double flops, double bytes) {
+    if (ctx->prof_family != family) return;
+    if (ctx->prof_n >= ctx->prof_cap) return;
+    hipEventRecord(ctx->prof_ev[ctx->prof_n].b, s);
+    ctx->prof_n++;
+    ctx->prof_flops += flops;
+    ctx->prof_bytes += bytes;
+}
+
+extern "C" int irs_prof_enable(irs_ctx *ctx, int32_t family) {
+    if (!ctx) return IRS_E_INVALID;
+    ctx->prof_family = family;
+    ctx->prof_n = 0;
+    ctx->prof_flops = 0;
+    ctx->prof_bytes = 0;
+    return IRS_OK;
+}
+
+extern "C" int irs_prof_read(irs_ctx *ctx, int32_t *launches, double *total_ms, double *total_flops, double *total_bytes) {
+    if (!ctx) return IRS_E_INVALID;
+    double ms = 0;
+    for (int i = 0; i < ctx->prof_n; ++i) {
+        IRS_CHECK_HIP(ctx, hipEventSynchronize(ctx->prof_ev[i].b));
+        float t = 0;
+        IRS_CHECK_HIP(ctx, hipEventElapsedTime(&t, ctx->prof_ev[i].a, ctx->prof_ev[i].b));
+        ms += t;
+    }
+    if (launches) *launches = ctx->prof_n;
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = ctx->prof_flops;
+    if (total_bytes) *total_bytes = ctx->prof_bytes;
+    ctx->prof_n = 0;
+    ctx->prof_flops = 0;
+    ctx->prof_bytes = 0;
+    return IRS_OK;
+}

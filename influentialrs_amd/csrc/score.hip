@@ -1,0 +1,926 @@
+// Score-all-items contraction and the selections on it, gfx950.
+//
+// Replaces (reference, /root/reference):
+//   project = nn.Linear(d, n_item)          model/influentialRS.py:83, :214 ; model/uRS.py:45, :68
+//   softmax + topk(100) of one row          model/influentialRS.py:418-421
+//   sort + history filter + nonzero (rank)  model/influentialRS.py:375-389 ; model/evaluator.py:121-131,266-286
+//   log-softmax + scalar gathers            model/evaluator.py:195-205, 307-322
+//
+// Exact score (shared with oracle/oracle_score.c):
+//   e[m][j] = fmaf(x[m][d-1], W[j][d-1], ... fmaf(x[m][0], W[j][0], b[j]))   float32, k ascending
+//
+// top-k pipeline (irs_launch_topk), nothing of size M x N is ever materialised:
+//   1. k_prep_x      rows -> bf16 MFMA fragments + per-row error bound eps
+//   2. k_sweep PRE   approximate scores of a catalog prefix; only per-wave group maxima are written
+//   3. k_select_thr  T0 = k-th largest group maximum  (>= k items score >= T0)
+//   4. k_sweep EMIT  full catalog; (score, id) pairs with score >= T0 - 2 eps appended per row
+//   5. k_refine      A_k = k-th largest emitted approx score; survivors (>= A_k - 2 eps) are
+//                    re-scored with the exact chain and sorted by (score desc, id asc)
+//   6. k_exhaustive  rows whose buffers overflowed are redone exactly over the whole shard
+// With |approx - exact| <= eps every member of the exact top-k survives 4 and 5,
+// so the result equals the exhaustive exact top-k bit for bit ("Why the
+// bf16 filter is exact").  The fp32 sweep (IRS_SWEEP_F32) uses v_mfma_f32_32x32x2_f32,
+// which is itself the exact chain, with eps = 0.
+//
+// MFMA orientation: D[item][row] = W_tile[item][k] . x^T[k][row]; a lane owns one
+// scored row (column lane&31) and 16 items, so row-wise reductions (max, count,
+// log-sum-exp) are register-local.  W is streamed straight from HBM into
+// registers (pre-packed in fragment order: 1 KiB contiguous per wave load);
+// the row block x is staged once per workgroup in LDS.
+#include "irs_internal.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+#define MODE_PRE 0
+#define MODE_EMIT 1
+#define MODE_COUNT 2
+#define MODE_DENSE 3
+#define MODE_LSE 4
+
+struct SweepArgs {
+    // operands
+    const uint4 *wp;     // bf16 fragments [n_tiles][KS][64]
+    const float *w32;    // fp32 [n_local][d] (fp32 sweep)
+    const float *bias;   // [n_tiles*32], -inf beyond n_local
+    const uint4 *xb;     // bf16 fragments of the rows [UT][KS][64]
+    const float *x32;    // fp32 rows [M][d] (fp32 sweep)
+    int M, M_pad, UT, d;
+    int64_t n_local;
+    // tile range and decomposition
+    int tile_begin, tile_end, tiles_per_wave, n_strips, n_ublocks;
+    // outputs
+    float *gm;                   // PRE  [n_groups][M_pad]
+    const float *thr;            // EMIT [M_pad]
+    unsigned int *cnt;           // EMIT [M_pad]
+    unsigned long long *cand;    // EMIT [M_pad][cap]
+    int cap;
+    const float *ref_score;      // COUNT [M]
+    const int64_t *ref_id;       // COUNT [M] (local 0-based, may be out of range)
+    unsigned long long *count;   // COUNT [M]
+    float *dense;                // DENSE [M][ld]
+    int64_t ld;
+    float *lse_part;             // LSE [slots][M_pad][2]
+};
+
+__device__ __forceinline__ float max16(const f32x16 &a) {
+    float m0 = fmaxf(fmaxf(a[0], a[1]), a[2]);
+    float m1 = fmaxf(fmaxf(a[3], a[4]), a[5]);
+    float m2 = fmaxf(fmaxf(a[6], a[7]), a[8]);
+    float m3 = fmaxf(fmaxf(a[9], a[10]), a[11]);
+    float m4 = fmaxf(fmaxf(a[12], a[13]), a[14]);
+    return fmaxf(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)), fmaxf(m4, a[15]));
+}
+
+// workgroup -> (strip, ublock): the n_ublocks workgroups that stream the same
+// W strip get ids congruent mod 8, i.e. land on one XCD and share its L2.
+__device__ __forceinline__ bool sweep_map(const SweepArgs &a, int &strip, int &ublock) {
+    int id = blockIdx.x;
+    int xcd = id & 7, local = id >> 3;
+    ublock = local % a.n_ublocks;
+    strip = (local / a.n_ublocks) * 8 + xcd;
+    return strip < a.n_strips;
+}
+
+// ---- epilogues (lane = scored row `user`, regs = 16 items of tile `t`, half h)
+__device__ __forceinline__ void emit_candidates(const SweepArgs &a, const f32x16 &acc, float thr, int user, int t, int h) {
+    float m = max16(acc);
+    if (__any(m >= thr)) {
+        if (m >= thr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (acc[r] >= thr) {
+                    unsigned int item = (unsigned int)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                    unsigned int slot = atomicAdd(&a.cnt[user], 1u);
+                    if (slot < (unsigned int)a.cap)
+                        a.cand[(size_t)user * a.cap + slot] = ((unsigned long long)irs_fkey(acc[r]) << 32) | item;
+                }
+            }
+        }
+    }
+}
+
+// =============================== bf16 sweep ===============================
+template <int KS, int UB, int MODE>
+__global__ void __launch_bounds__(256, 2) k_sweep_bf16(SweepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4 *xs = reinterpret_cast<uint4 *>(smem); // [UB][KS][64]
+    int strip, ublock;
+    if (!sweep_map(a, strip, ublock)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int ut0 = ublock * UB;
+    const int ubc = min(UB, a.UT - ut0);
+    {
+        const uint4 *src = a.xb + (size_t)ut0 * KS * 64;
+        for (int i = tid; i < ubc * KS * 64; i += 256) xs[i] = src[i];
+    }
+    __syncthreads();
+    const int gw = strip * 4 + wave;
+    int t0 = a.tile_begin + gw * a.tiles_per_wave;
+    int t1 = min(t0 + a.tiles_per_wave, a.tile_end);
+
+    float aux[UB]; // PRE: running max; EMIT: threshold
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+        if (MODE == MODE_PRE) aux[u] = -INFINITY;
+        else aux[u] = (u < ubc) ? fmaxf(a.thr[(ut0 + u) * 32 + r], -3.0e38f) : INFINITY;
+    }
+    if (t0 < t1) {
+        uint4 an[KS];
+        float4 bn[4];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) an[ks] = a.wp[((size_t)t0 * KS + ks) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bn[q] = *reinterpret_cast<const float4 *>(a.bias + (size_t)t0 * 32 + 8 * q + 4 * h);
+        for (int t = t0; t < t1; ++t) {
+            uint4 ac[KS];
+            float4 bc[4];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) ac[ks] = an[ks];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bc[q] = bn[q];
+            if (t + 1 < t1) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) an[ks] = a.wp[((size_t)(t + 1) * KS + ks) * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    bn[q] = *reinterpret_cast<const float4 *>(a.bias + (size_t)(t + 1) * 32 + 8 * q + 4 * h);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (u < ubc) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[4 * q + 0] = bc[q].x;
+                        acc[4 * q + 1] = bc[q].y;
+                        acc[4 * q + 2] = bc[q].z;
+                        acc[4 * q + 3] = bc[q].w;
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        uint4 bv = xs[(u * KS + ks) * 64 + lane];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[ks]),
+                                                                      __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+                    }
+                    if (MODE == MODE_PRE) aux[u] = fmaxf(aux[u], max16(acc));
+                    else emit_candidates(a, acc, aux[u], (ut0 + u) * 32 + r, t, h);
+                }
+            }
+        }
+    }
+    if (MODE == MODE_PRE) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+            if (u < ubc) a.gm[(size_t)(gw * 2 + h) * a.M_pad + (ut0 + u) * 32 + r] = aux[u];
+    }
+}
+
+// =============================== fp32 sweep ===============================
+// v_mfma_f32_32x32x2_f32: lane (r, h) supplies A[r][k=h] and B[k=h][r]; one
+// instruction is fma(a_k1, b_k1, fma(a_k0, b_k0, C)), so issuing k pairs in
+// ascending order reproduces the exact chain.  LDS image of the rows:
+// xs4[u][q][lane] = float4 {x[row r][8q + 2t + h]}, t = 0..3.
+template <int KS, int UB, int MODE, bool VEC>
+__global__ void __launch_bounds__(256, 2) k_sweep_f32(SweepArgs a) {
+    constexpr int QN = 2 * KS; // float4 groups per row (d_pad / 8)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *xs4 = reinterpret_cast<float4 *>(smem); // [UB][QN][64]
+    int strip, ublock;
+    if (!sweep_map(a, strip, ublock)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int ut0 = ublock * UB;
+    const int ubc = min(UB, a.UT - ut0);
+    for (int i = tid; i < ubc * QN * 64; i += 256) {
+        int ln = i & 63, q = (i >> 6) % QN, u = (i >> 6) / QN;
+        int row = (ut0 + u) * 32 + (ln & 31), hh = ln >> 5;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < a.M) {
+            const float *xr = a.x32 + (size_t)row * a.d;
+            int k = 8 * q + hh;
+            if (k < a.d) v.x = xr[k];
+            if (k + 2 < a.d) v.y = xr[k + 2];
+            if (k + 4 < a.d) v.z = xr[k + 4];
+            if (k + 6 < a.d) v.w = xr[k + 6];
+        }
+        xs4[i] = v;
+    }
+    __syncthreads();
+    const int gw = strip * 4 + wave;
+    int t0 = a.tile_begin + gw * a.tiles_per_wave;
+    int t1 = min(t0 + a.tiles_per_wave, a.tile_end);
+
+    float aux[UB];        // PRE: running max; EMIT: thr; COUNT: ref score; LSE: running max
+    float aux2[UB];       // LSE: running sum
+    unsigned int cnt[UB]; // COUNT
+    long long refid[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+        int user = (ut0 + u) * 32 + r;
+        aux[u] = -INFINITY;
+        aux2[u] = 0.f;
+        cnt[u] = 0;
+        refid[u] = -1;
+        if (MODE == MODE_EMIT) aux[u] = (u < ubc) ? fmaxf(a.thr[user], -3.0e38f) : INFINITY;
+        if (MODE == MODE_COUNT) {
+            aux[u] = (u < ubc && user < a.M) ? a.ref_score[user] : INFINITY;
+            refid[u] = (u < ubc && user < a.M) ? (long long)a.ref_id[user] : -1;
+        }
+    }
+    for (int t = t0; t < t1; ++t) {
+        // A fragments for the whole tile
+        float4 af[QN];
+        const int64_t item = (int64_t)t * 32 + r;
+        if (VEC) {
+            const float *wr = a.w32 + (size_t)(item < a.n_local ? item : 0) * a.d;
+#pragma unroll
+            for (int q = 0; q < QN; ++q) {
+                float4 v0 = *reinterpret_cast<const float4 *>(wr + 8 * q);
+                float4 v1 = *reinterpret_cast<const float4 *>(wr + 8 * q + 4);
+                float4 s = h ? make_float4(v0.y, v0.w, v1.y, v1.w) : make_float4(v0.x, v0.z, v1.x, v1.z);
+                if (item >= a.n_local) s = make_float4(0.f, 0.f, 0.f, 0.f);
+                af[q] = s;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < QN; ++q) {
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (item < a.n_local) {
+                    const float *wr = a.w32 + (size_t)item * a.d;
+                    int k = 8 * q + h;
+                    if (k < a.d) s.x = wr[k];
+                    if (k + 2 < a.d) s.y = wr[k + 2];
+                    if (k + 4 < a.d) s.z = wr[k + 4];
+                    if (k + 6 < a.d) s.w = wr[k + 6];
+                }
+                af[q] = s;
+            }
+        }
+        float4 bc[4];
+        float bd = 0.f;
+        if (MODE == MODE_DENSE) bd = a.bias[(size_t)t * 32 + r];
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bc[q] = *reinterpret_cast<const float4 *>(a.bias + (size_t)t * 32 + 8 * q + 4 * h);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (u < ubc) {
+                f32x16 acc;
+                if (MODE == MODE_DENSE) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[i] = bd;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[4 * q + 0] = bc[q].x;
+                        acc[4 * q + 1] = bc[q].y;
+                        acc[4 * q + 2] = bc[q].z;
+                        acc[4 * q + 3] = bc[q].w;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < QN; ++q) {
+                    float4 bv = xs4[(u * QN + q) * 64 + lane];
+                    if (MODE == MODE_DENSE) { // D[row][item]: rows on registers, items on lanes
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.x, af[q].x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.y, af[q].y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.z, af[q].z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.w, af[q].w, acc, 0, 0, 0);
+                    } else {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].x, bv.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].y, bv.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].z, bv.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].w, bv.w, acc, 0, 0, 0);
+                    }
+                }
+                const int user = (ut0 + u) * 32 + r;
+                if (MODE == MODE_PRE) aux[u] = fmaxf(aux[u], max16(acc));
+                else if (MODE == MODE_EMIT) emit_candidates(a, acc, aux[u], user, t, h);
+                else if (MODE == MODE_COUNT) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        long long it = (long long)t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        bool before = acc[i] > aux[u] || (acc[i] == aux[u] && it < refid[u]);
+                        cnt[u] += (before && it < a.n_local) ? 1u : 0u;
+                    }
+                } else if (MODE == MODE_DENSE) {
+                    const int64_t col = (int64_t)t * 32 + r;
+                    if (col < a.n_local) {
+                        int row0 = (ut0 + u) * 32 + 4 * h;
+                        asm volatile("" : "+v"(row0)); // keep 128 hoisted row addresses out of registers
+                        float *dst = a.dense + (size_t)row0 * a.ld + col;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int dr = (i & 3) + 8 * (i >> 2);
+                            if (row0 + dr < a.M) dst[(size_t)dr * a.ld] = acc[i];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0); // one row tile's accumulators live at a time
+                } else if (MODE == MODE_LSE) {
+                    float m = fmaxf(aux[u], max16(acc));
+                    if (m > -INFINITY) {
+                        float s = aux2[u] * __expf(aux[u] - m);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) s += __expf(acc[i] - m);
+                        aux[u] = m;
+                        aux2[u] = s;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+        if (u >= ubc) continue;
+        const int user = (ut0 + u) * 32 + r;
+        if (MODE == MODE_PRE) a.gm[(size_t)(gw * 2 + h) * a.M_pad + user] = aux[u];
+        if (MODE == MODE_COUNT) {
+            if (user < a.M && cnt[u]) atomicAdd(&a.count[user], (unsigned long long)cnt[u]);
+        }
+        if (MODE == MODE_LSE) {
+            float *p = a.lse_part + ((size_t)(gw * 2 + h) * a.M_pad + user) * 2;
+            p[0] = aux[u];
+            p[1] = aux2[u];
+        }
+    }
+}
+
+// =============================== small kernels ===============================
+// 8 consecutive k of one row -> one 16-byte bf16 fragment piece (RNE, finite inputs)
+__device__ __forceinline__ uint4 pack8_bf16(const float *__restrict__ src, int k0, int d, bool row_ok, float &ss) {
+    unsigned int h[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = (row_ok && k0 + j < d) ? src[k0 + j] : 0.f;
+        ss += v * v;
+        unsigned int u = __float_as_uint(v);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        h[j] = u >> 16;
+    }
+    return make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+}
+
+// rows -> bf16 fragments + eps.  One wave per row of the padded row block;
+// lane l < 2*KS packs k = 8l .. 8l+7 (ks = l>>1, half = l&1).
+__global__ void __launch_bounds__(256) k_prep_x(const float *__restrict__ x, int M, int M_pad, int d, int KS,
+                                                uint4 *__restrict__ xb, float *__restrict__ eps,
+                                                const float *__restrict__ wnorm_max, float eps_factor) {
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (row >= M_pad) return;
+    const int ut = row >> 5, r = row & 31;
+    float ss = 0.f;
+    if (lane < 2 * KS) {
+        uint4 v = pack8_bf16(x + (size_t)row * d, 8 * lane, d, row < M, ss);
+        xb[((size_t)ut * KS + (lane >> 1)) * 64 + (lane & 1) * 32 + r] = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if (lane == 0) eps[row] = (row < M) ? sqrtf(ss) * wnorm_max[0] * eps_factor : 0.f;
+}
+
+__global__ void k_zero_eps(float *eps, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) eps[i] = 0.f;
+}
+
+// W -> bf16 fragments, padded bias, max row norm.  One wave per item row (padded).
+__global__ void __launch_bounds__(256) k_pack_w(const float *__restrict__ W, const float *__restrict__ b, int64_t n_local,
+                                                int n_tiles, int d, int KS, uint4 *__restrict__ wp,
+                                                float *__restrict__ bias_pad, unsigned int *__restrict__ wnorm_max_bits) {
+    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (row >= (int64_t)n_tiles * 32) return;
+    const int64_t t = row >> 5;
+    const int r = (int)(row & 31);
+    float ss = 0.f;
+    if (lane < 2 * KS) {
+        uint4 v = pack8_bf16(W + (size_t)row * d, 8 * lane, d, row < n_local, ss);
+        wp[((size_t)t * KS + (lane >> 1)) * 64 + (lane & 1) * 32 + r] = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if (lane == 0) {
+        bias_pad[row] = (row < n_local) ? b[row] : -INFINITY;
+        if (row < n_local) atomicMax(wnorm_max_bits, __float_as_uint(sqrtf(ss) * 1.0001f));
+    }
+}
+
+// T0 = k-th largest of gm[0..G)[row]; thr = T0 - 2 eps (or -inf when G < k).
+// 16 rows per workgroup, 8-bit radix select with per-row LDS histograms.
+__global__ void __launch_bounds__(256) k_select_thr(const float *__restrict__ gm, int G, int M, int M_pad, int k,
+                                                    const float *__restrict__ eps, float *__restrict__ thr) {
+    __shared__ unsigned int hist[16][256];
+    __shared__ unsigned int s_prefix[16], s_k[16];
+    const int tu = threadIdx.x & 15, tg = threadIdx.x >> 4;
+    const int row = blockIdx.x * 16 + tu;
+    if (threadIdx.x < 16) {
+        s_prefix[threadIdx.x] = 0;
+        s_k[threadIdx.x] = k;
+    }
+    if (G < k) {
+        int rr = blockIdx.x * 16 + threadIdx.x;
+        if (threadIdx.x < 16 && rr < M_pad) thr[rr] = (rr < M) ? -INFINITY : INFINITY;
+        return;
+    }
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int i = threadIdx.x; i < 16 * 256; i += 256) (&hist[0][0])[i] = 0;
+        __syncthreads();
+        const unsigned int prefix = s_prefix[tu];
+        if (row < M_pad) {
+            for (int g = tg; g < G; g += 16) {
+                unsigned int key = irs_fkey(gm[(size_t)g * M_pad + row]);
+                bool match = (pass == 0) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+                if (match) atomicAdd(&hist[tu][(key >> shift) & 255], 1u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            unsigned int need = s_k[threadIdx.x], cum = 0;
+            int bin = 255;
+            for (; bin > 0; --bin) {
+                unsigned int c = hist[threadIdx.x][bin];
+                if (cum + c >= need) break;
+                cum += c;
+            }
+            s_k[threadIdx.x] = need - cum;
+            s_prefix[threadIdx.x] |= ((unsigned int)bin) << shift;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 16) {
+        int rr = blockIdx.x * 16 + threadIdx.x;
+        if (rr < M_pad) thr[rr] = (rr < M) ? irs_unkey(s_prefix[threadIdx.x]) - 2.0f * eps[rr] : INFINITY;
+    }
+}
+
+// in-LDS bitonic sort, descending, n a power of two, 256 threads
+__device__ __forceinline__ void bitonic_desc(unsigned long long *keys, int n) {
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < n / 2; i += blockDim.x) {
+                int lo = 2 * i - (i & (stride - 1));
+                int hi = lo + stride;
+                bool desc = ((lo & size) == 0);
+                unsigned long long a = keys[lo], b = keys[hi];
+                if ((a < b) == desc) {
+                    keys[lo] = b;
+                    keys[hi] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// One workgroup per row: refine the emitted candidates, re-score exactly, sort, write top-k.
+__global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int d, const float *__restrict__ W,
+                                                const float *__restrict__ bias, const unsigned int *__restrict__ cnt,
+                                                const unsigned long long *__restrict__ cand, int cap,
+                                                const float *__restrict__ eps, int k, int64_t item_lo, int64_t n_local,
+                                                float *__restrict__ val, int64_t *__restrict__ ids,
+                                                int32_t *__restrict__ status) {
+    __shared__ unsigned long long ckeys[IRS_CAND_CAP];
+    __shared__ unsigned long long rkeys[IRS_REFINE_CAP];
+    __shared__ unsigned int hist[256];
+    __shared__ float xs[256];
+    __shared__ unsigned int s_prefix, s_k, s_nr;
+    const int row = blockIdx.x, tid = threadIdx.x;
+    unsigned int c = cnt[row];
+    if (c > (unsigned int)cap) { // emission overflow -> exhaustive kernel redoes the row
+        if (tid == 0) status[row] |= IRS_ROW_FALLBACK;
+        return;
+    }
+    for (int i = tid; i < (int)c; i += 256) ckeys[i] = cand[(size_t)row * cap + i];
+    for (int i = tid; i < d; i += 256) xs[i] = x[(size_t)row * d + i];
+    if (tid == 0) {
+        s_prefix = 0;
+        s_k = k;
+        s_nr = 0;
+    }
+    __syncthreads();
+    float thr2 = -INFINITY;
+    if (c >= (unsigned int)k) {
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            hist[tid] = 0;
+            __syncthreads();
+            const unsigned int prefix = s_prefix;
+            for (int i = tid; i < (int)c; i += 256) {
+                unsigned int key = (unsigned int)(ckeys[i] >> 32);
+                bool match = (pass == 0) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+                if (match) atomicAdd(&hist[(key >> shift) & 255], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned int need = s_k, cum = 0;
+                int bin = 255;
+                for (; bin > 0; --bin) {
+                    unsigned int h = hist[bin];
+                    if (cum + h >= need) break;
+                    cum += h;
+                }
+                s_k = need - cum;
+                s_prefix |= ((unsigned int)bin) << shift;
+            }
+            __syncthreads();
+        }
+        thr2 = irs_unkey(s_prefix) - 2.0f * eps[row];
+    }
+    // survivors
+    for (int i = tid; i < (int)c; i += 256) {
+        float a = irs_unkey((unsigned int)(ckeys[i] >> 32));
+        if (a >= thr2) {
+            unsigned int slot = atomicAdd(&s_nr, 1u);
+            if (slot < IRS_REFINE_CAP) rkeys[slot] = ckeys[i] & 0xFFFFFFFFull;
+        }
+    }
+    __syncthreads();
+    const unsigned int nr = s_nr;
+    if (nr > IRS_REFINE_CAP) {
+        if (tid == 0) status[row] |= IRS_ROW_FALLBACK;
+        return;
+    }
+    // exact re-score
+    for (int i = tid; i < (int)nr; i += 256) {
+        unsigned int j = (unsigned int)rkeys[i];
+        float e = irs_chain(xs, W + (size_t)j * d, bias[j], d);
+        rkeys[i] = ((unsigned long long)irs_fkey(e) << 32) | (0xFFFFFFFFu - j);
+    }
+    int n2 = 2;
+    while (n2 < (int)nr) n2 <<= 1;
+    for (int i = nr + tid; i < n2; i += 256) rkeys[i] = 0ull;
+    bitonic_desc(rkeys, n2);
+    for (int i = tid; i < k; i += 256) {
+        if (i < (int)nr) {
+            unsigned long long kk = rkeys[i];
+            val[(size_t)row * k + i] = irs_unkey((unsigned int)(kk >> 32));
+            ids[(size_t)row * k + i] = item_lo + (int64_t)(0xFFFFFFFFu - (unsigned int)kk);
+        } else {
+            val[(size_t)row * k + i] = -INFINITY;
+            ids[(size_t)row * k + i] = -1;
+        }
+    }
+    if (tid == 0 && (int)nr < k) status[row] |= IRS_ROW_FEWER_THAN_K;
+}
+
+// Exhaustive exact top-k of one row over the whole shard (fallback and GPU-side yard-stick).
+// Streams every item through the exact chain; keeps the best k by (score desc, id asc).
+#define EXH_BUF 2048
+__global__ void __launch_bounds__(256) k_exhaustive(const float *__restrict__ x, int d, const float *__restrict__ W,
+                                                    const float *__restrict__ bias, int64_t n_local, int64_t item_lo,
+                                                    int k, int only_flagged, float *__restrict__ val,
+                                                    int64_t *__restrict__ ids, int32_t *__restrict__ status) {
+    __shared__ unsigned long long buf[EXH_BUF];
+    __shared__ float xs[256];
+    __shared__ unsigned int s_n;
+    __shared__ unsigned long long s_thr;
+    const int row = blockIdx.x, tid = threadIdx.x;
+    if (only_flagged && !(status[row] & IRS_ROW_FALLBACK)) return;
+    for (int i = tid; i < d; i += 256) xs[i] = x[(size_t)row * d + i];
+    if (tid == 0) {
+        s_n = 0;
+        s_thr = 0ull;
+    }
+    __syncthreads();
+    for (int64_t base = 0; base < n_local; base += 256) {
+        int64_t j = base + tid;
+        if (j < n_local) {
+            float e = irs_chain(xs, W + (size_t)j * d, bias[j], d);
+            unsigned long long key = ((unsigned long long)irs_fkey(e) << 32) | (0xFFFFFFFFu - (unsigned int)j);
+            if (key > s_thr) {
+                unsigned int slot = atomicAdd(&s_n, 1u);
+                buf[slot] = key; // slot < EXH_BUF: compaction below keeps s_n <= EXH_BUF - 256 at loop top
+            }
+        }
+        __syncthreads();
+        if (s_n > EXH_BUF - 256) {
+            unsigned int n = s_n;
+            for (int i = n + tid; i < EXH_BUF; i += 256) buf[i] = 0ull;
+            bitonic_desc(buf, EXH_BUF);
+            if (tid == 0) {
+                s_n = (n < (unsigned int)k) ? n : k;
+                if (n >= (unsigned int)k) s_thr = buf[k - 1];
+            }
+            __syncthreads();
+        }
+    }
+    unsigned int n = s_n;
+    for (int i = n + tid; i < EXH_BUF; i += 256) buf[i] = 0ull;
+    bitonic_desc(buf, EXH_BUF);
+    for (int i = tid; i < k; i += 256) {
+        if (i < (int)n) {
+            unsigned long long kk = buf[i];
+            val[(size_t)row * k + i] = irs_unkey((unsigned int)(kk >> 32));
+            ids[(size_t)row * k + i] = item_lo + (int64_t)(0xFFFFFFFFu - (unsigned int)kk);
+        } else {
+            val[(size_t)row * k + i] = -INFINITY;
+            ids[(size_t)row * k + i] = -1;
+        }
+    }
+    if (tid == 0 && (int)n < k) status[row] |= IRS_ROW_FEWER_THAN_K;
+}
+
+// exact scores at chosen items; -inf outside the shard
+__global__ void __launch_bounds__(64) k_gather(const float *__restrict__ x, int d, const float *__restrict__ W,
+                                               const float *__restrict__ bias, int64_t item_lo, int64_t n_local,
+                                               const int64_t *__restrict__ ids0, int g, float *__restrict__ out) {
+    __shared__ float xs[256];
+    const int row = blockIdx.x;
+    for (int i = threadIdx.x; i < d; i += 64) xs[i] = x[(size_t)row * d + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < g; i += 64) {
+        int64_t j = ids0[(size_t)row * g + i] - item_lo;
+        float e = -INFINITY;
+        if (ids0[(size_t)row * g + i] >= 0 && j >= 0 && j < n_local) e = irs_chain(xs, W + (size_t)j * d, bias[j], d);
+        out[(size_t)row * g + i] = e;
+    }
+}
+
+// remove excluded items (history) that rank before the reference from count
+__global__ void __launch_bounds__(64) k_count_excl(const float *__restrict__ x, int d, const float *__restrict__ W,
+                                                   const float *__restrict__ bias, int64_t item_lo, int64_t n_local,
+                                                   const float *__restrict__ ref_score, const int64_t *__restrict__ ref_id0,
+                                                   const int64_t *__restrict__ excl, int n_excl,
+                                                   unsigned long long *__restrict__ count) {
+    __shared__ float xs[256];
+    const int row = blockIdx.x;
+    for (int i = threadIdx.x; i < d; i += 64) xs[i] = x[(size_t)row * d + i];
+    __syncthreads();
+    const float rs = ref_score[row];
+    const int64_t rid = ref_id0[row];
+    const int64_t *ex = excl + (size_t)row * n_excl;
+    unsigned int sub = 0;
+    for (int i = threadIdx.x; i < n_excl; i += 64) {
+        int64_t gid = ex[i];
+        int64_t j = gid - item_lo;
+        if (gid < 0 || j < 0 || j >= n_local || gid == rid) continue;
+        bool dup = false;
+        for (int q = 0; q < i; ++q)
+            if (ex[q] == gid) { dup = true; break; }
+        if (dup) continue;
+        float e = irs_chain(xs, W + (size_t)j * d, bias[j], d);
+        if (e > rs || (e == rs && gid < rid)) ++sub;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sub += __shfl_xor(sub, off, 64);
+    if (threadIdx.x == 0 && sub) atomicAdd(&count[row], (unsigned long long)(-(long long)sub));
+}
+
+__global__ void k_localize_ref(const int64_t *__restrict__ ref_id0, int64_t item_lo, int64_t *__restrict__ out, int M) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) out[i] = ref_id0[i] - item_lo; // may be negative / >= n_local: then only the score decides
+}
+
+__global__ void k_lse_reduce(const float *__restrict__ part, int slots, int M_pad, int M, float *__restrict__ out_max,
+                             float *__restrict__ out_sum) {
+    int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= M) return;
+    float m = -INFINITY;
+    for (int s = 0; s < slots; ++s) m = fmaxf(m, part[((size_t)s * M_pad + row) * 2]);
+    float acc = 0.f;
+    for (int s = 0; s < slots; ++s) {
+        float pm = part[((size_t)s * M_pad + row) * 2], ps = part[((size_t)s * M_pad + row) * 2 + 1];
+        if (pm > -INFINITY) acc += ps * __expf(pm - m);
+    }
+    out_max[row] = m;
+    out_sum[row] = acc;
+}
+
+// =============================== host side ===============================
+static inline int ub_bf16(int KS) { return KS >= 16 ? 4 : 8; }
+static inline int ub_f32(int KS) { return KS >= 16 ? 2 : KS >= 8 ? 4 : 8; }
+
+template <int MODE>
+static int launch_sweep_bf16(irs_ctx *ctx, SweepArgs &a, hipStream_t s) {
+    const int KS = ctx->KS, UB = ub_bf16(KS);
+    a.n_ublocks = (a.UT + UB - 1) / UB;
+    dim3 grid(((a.n_strips + 7) / 8) * 8 * a.n_ublocks);
+    size_t lds = (size_t)UB * KS * 1024;
+#define L_(KS_, UB_)                                                                                           \
+    hipLaunchKernelGGL((k_sweep_bf16<KS_, UB_, MODE>), grid, dim3(256), lds, s, a)
+    switch (KS) {
+    case 1: L_(1, 8); break;
+    case 2: L_(2, 8); break;
+    case 4: L_(4, 8); break;
+    case 8: L_(8, 8); break;
+    case 16: L_(16, 4); break;
+    default: IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "unsupported d_pad %d", ctx->d_pad);
+    }
+#undef L_
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}
+
+template <int MODE>
+static int launch_sweep_f32(irs_ctx *ctx, SweepArgs &a, hipStream_t s) {
+    const int KS = ctx->KS, UB = ub_f32(KS);
+    a.n_ublocks = (a.UT + UB - 1) / UB;
+    dim3 grid(((a.n_strips + 7) / 8) * 8 * a.n_ublocks);
+    size_t lds = (size_t)UB * KS * 2048;
+    const bool vec = (a.d % 8 == 0) && (a.d == KS * 16) && ((((uintptr_t)a.w32) & 15) == 0);
+#define L_(KS_, UB_)                                                                                           \
+    do {                                                                                                       \
+        if (vec) hipLaunchKernelGGL((k_sweep_f32<KS_, UB_, MODE, true>), grid, dim3(256), lds, s, a);          \
+        else hipLaunchKernelGGL((k_sweep_f32<KS_, UB_, MODE, false>), grid, dim3(256), lds, s, a);             \
+    } while (0)
+    switch (KS) {
+    case 1: L_(1, 8); break;
+    case 2: L_(2, 8); break;
+    case 4: L_(4, 8); break;
+    case 8: L_(8, 4); break;
+    case 16: L_(16, 2); break;
+    default: IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "unsupported d_pad %d", ctx->d_pad);
+    }
+#undef L_
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}
+
+static void sweep_common(irs_ctx *ctx, SweepArgs &a, const float *xrows, int M) {
+    memset(&a, 0, sizeof(a));
+    a.wp = ctx->wp;
+    a.w32 = ctx->proj_w;
+    a.bias = ctx->bias_pad;
+    a.xb = ctx->xb;
+    a.x32 = xrows;
+    a.M = M;
+    a.M_pad = (M + 31) & ~31;
+    a.UT = a.M_pad / 32;
+    a.d = ctx->dims.d;
+    a.n_local = ctx->n_local;
+    a.cap = IRS_CAND_CAP;
+}
+
+// choose tiles per wave so that the grid has >= ~2048 workgroups when the catalog allows it
+static void sweep_decompose(SweepArgs &a, int tile_begin, int tile_end, int n_ublocks_hint, int force_tpw) {
+    a.tile_begin = tile_begin;
+    a.tile_end = tile_end;
+    int nt = tile_end - tile_begin;
+    int tpw = force_tpw;
+    if (tpw <= 0) {
+        long long t = ((long long)nt * n_ublocks_hint) / (4LL * 2048);
+        tpw = (int)(t < 1 ? 1 : t > 16 ? 16 : t);
+    }
+    a.tiles_per_wave = tpw;
+    a.n_strips = (nt + 4 * tpw - 1) / (4 * tpw);
+    if (a.n_strips < 1) a.n_strips = 1;
+}
+
+int irs_launch_pack_w(irs_ctx *ctx, hipStream_t s) {
+    IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->wnorm_max, 0, sizeof(float), s));
+    int64_t rows = (int64_t)ctx->n_tiles * 32;
+    hipLaunchKernelGGL(k_pack_w, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, ctx->proj_w, ctx->proj_b,
+                       ctx->n_local, ctx->n_tiles, ctx->dims.d, ctx->KS, ctx->wp,
+                       ctx->bias_pad, reinterpret_cast<unsigned int *>(ctx->wnorm_max));
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}
+
+int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, float *val, int64_t *ids0,
+                    int32_t *status, hipStream_t s) {
+    SweepArgs a;
+    sweep_common(ctx, a, xrows, M);
+    const int M_pad = a.M_pad;
+    const int d = ctx->dims.d;
+    const int nt = ctx->n_tiles;
+    int rc;
+    IRS_CHECK_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t) * M, s));
+    IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->cand_cnt, 0, sizeof(unsigned int) * M_pad, s));
+    if (sweep == IRS_SWEEP_BF16) {
+        // |approx - exact| <= ||x|| * max||W_j|| * (2u + u^2 + accumulation), u = 2^-9
+        float eps_factor = 0.00390625f * 1.01f + (float)(ctx->d_pad + 8) * 2.384185791015625e-07f;
+        hipLaunchKernelGGL(k_prep_x, dim3((M_pad + 3) / 4), dim3(256), 0, s, xrows, M, M_pad, d, ctx->KS,
+                           ctx->xb, ctx->eps, ctx->wnorm_max, eps_factor);
+    } else {
+        hipLaunchKernelGGL(k_zero_eps, dim3((M_pad + 255) / 256), dim3(256), 0, s, ctx->eps, M_pad);
+    }
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    const int UBh = (sweep == IRS_SWEEP_BF16) ? ub_bf16(ctx->KS) : ub_f32(ctx->KS);
+    const int nub = (a.UT + UBh - 1) / UBh;
+
+    // pre-pass over a catalog prefix: >= 1024 tiles (32768 items) or 1/8 of the shard
+    int nt0 = nt / 8;
+    if (nt0 < 1024) nt0 = 1024;
+    if (nt0 > nt) nt0 = nt;
+    int tpw0 = (nt0 + 2047) / 2048; // -> at most ~4096 group maxima per row
+    sweep_decompose(a, 0, nt0, nub, tpw0);
+    int n_waves0 = a.n_strips * 4;
+    int G = 2 * n_waves0;
+    if (G > IRS_MAX_GROUPS) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "pre-pass groups %d > %d", G, IRS_MAX_GROUPS);
+    a.gm = ctx->gm;
+    irs_prof_begin(ctx, IRS_PROF_SWEEP, s);
+    if (sweep == IRS_SWEEP_BF16) rc = launch_sweep_bf16<MODE_PRE>(ctx, a, s);
+    else rc = launch_sweep_f32<MODE_PRE>(ctx, a, s);
+    irs_prof_end(ctx, IRS_PROF_SWEEP, s, 2.0 * d * (double)M * nt0 * 32.0,
+                 (double)nt0 * 32.0 * ctx->d_pad * (sweep == IRS_SWEEP_BF16 ? 2.0 : 4.0));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_select_thr, dim3((M_pad + 15) / 16), dim3(256), 0, s, ctx->gm, G, M, M_pad, k, ctx->eps, ctx->thr);
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+
+    // emission sweep over the whole shard
+    sweep_decompose(a, 0, nt, nub, 0);
+    a.thr = ctx->thr;
+    a.cnt = ctx->cand_cnt;
+    a.cand = ctx->cand;
+    irs_prof_begin(ctx, IRS_PROF_SWEEP, s);
+    if (sweep == IRS_SWEEP_BF16) rc = launch_sweep_bf16<MODE_EMIT>(ctx, a, s);
+    else rc = launch_sweep_f32<MODE_EMIT>(ctx, a, s);
+    irs_prof_end(ctx, IRS_PROF_SWEEP, s, 2.0 * d * (double)M * (double)ctx->n_local,
+                 (double)nt * 32.0 * ctx->d_pad * (sweep == IRS_SWEEP_BF16 ? 2.0 : 4.0));
+    if (rc) return rc;
+
+    irs_prof_begin(ctx, IRS_PROF_REFINE, s);
+    hipLaunchKernelGGL(k_refine, dim3(M), dim3(256), 0, s, xrows, d, ctx->proj_w, ctx->proj_b, ctx->cand_cnt, ctx->cand,
+                       IRS_CAND_CAP, ctx->eps, k, ctx->shard.item_lo, ctx->n_local, val, ids0, status);
+    irs_prof_end(ctx, IRS_PROF_REFINE, s, 0.0, 0.0);
+    hipLaunchKernelGGL(k_exhaustive, dim3(M), dim3(256), 0, s, xrows, d, ctx->proj_w, ctx->proj_b, ctx->n_local,
+                       ctx->shard.item_lo, k, 1, val, ids0, status);
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}
+
+// exhaustive exact top-k for every row (tests / yard-stick): sweep = -1 through the C ABI
+int irs_launch_topk_exhaustive(irs_ctx *ctx, const float *xrows, int M, int k, float *val, int64_t *ids0,
+                               int32_t *status, hipStream_t s) {
+    IRS_CHECK_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t) * M, s));
+    hipLaunchKernelGGL(k_exhaustive, dim3(M), dim3(256), 0, s, xrows, ctx->dims.d, ctx->proj_w, ctx->proj_b,
+                       ctx->n_local, ctx->shard.item_lo, k, 0, val, ids0, status);
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}
+
+int irs_launch_gather(irs_ctx *ctx, const float *xrows, int M, const int64_t *ids0, int g, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather, dim3(M), dim3(64), 0, s, xrows, ctx->dims.d, ctx->proj_w, ctx->proj_b,
+                       ctx->shard.item_lo, ctx->n_local, ids0, g, out);
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}
+
+int irs_launch_count_before(irs_ctx *ctx, const float *xrows, int M, const float *ref_score, const int64_t *ref_id0,
+                            const int64_t *excl, int n_excl, int64_t *count, hipStream_t s) {
+    SweepArgs a;
+    sweep_common(ctx, a, xrows, M);
+    IRS_CHECK_HIP(ctx, hipMemsetAsync(count, 0, sizeof(int64_t) * M, s));
+    int64_t *ref_local = reinterpret_cast<int64_t *>(ctx->cand); // scratch: [M] int64
+    hipLaunchKernelGGL(k_localize_ref, dim3((M + 255) / 256), dim3(256), 0, s, ref_id0, ctx->shard.item_lo, ref_local, M);
+    const int nub = (a.UT + ub_f32(ctx->KS) - 1) / ub_f32(ctx->KS);
+    sweep_decompose(a, 0, ctx->n_tiles, nub, 0);
+    a.ref_score = ref_score;
+    a.ref_id = ref_local;
+    a.count = reinterpret_cast<unsigned long long *>(count);
+    irs_prof_begin(ctx, IRS_PROF_SWEEP, s);
+    int rc = launch_sweep_f32<MODE_COUNT>(ctx, a, s);
+    irs_prof_end(ctx, IRS_PROF_SWEEP, s, 2.0 * ctx->dims.d * (double)M * (double)ctx->n_local,
+                 (double)ctx->n_local * ctx->dims.d * 4.0);
+    if (rc) return rc;
+    if (excl && n_excl > 0) {
+        hipLaunchKernelGGL(k_count_excl, dim3(M), dim3(64), 0, s, xrows, ctx->dims.d, ctx->proj_w, ctx->proj_b,
+                           ctx->shard.item_lo, ctx->n_local, ref_score, ref_id0, excl, n_excl,
+                           reinterpret_cast<unsigned long long *>(count));
+    }
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}
+
+int irs_launch_dense(irs_ctx *ctx, const float *xrows, int M, float *out, int64_t ld, hipStream_t s) {
+    SweepArgs a;
+    sweep_common(ctx, a, xrows, M);
+    const int nub = (a.UT + ub_f32(ctx->KS) - 1) / ub_f32(ctx->KS);
+    sweep_decompose(a, 0, ctx->n_tiles, nub, 0);
+    a.dense = out;
+    a.ld = ld;
+    irs_prof_begin(ctx, IRS_PROF_SWEEP, s);
+    int rc = launch_sweep_f32<MODE_DENSE>(ctx, a, s);
+    irs_prof_end(ctx, IRS_PROF_SWEEP, s, 2.0 * ctx->dims.d * (double)M * (double)ctx->n_local,
+                 (double)ctx->n_local * (ctx->dims.d + (double)M) * 4.0);
+    return rc;
+}
+
+int irs_launch_lse(irs_ctx *ctx, const float *xrows, int M, float *out_max, float *out_sum, hipStream_t s) {
+    SweepArgs a;
+    sweep_common(ctx, a, xrows, M);
+    const int nub = (a.UT + ub_f32(ctx->KS) - 1) / ub_f32(ctx->KS);
+    // bounded number of partial slots: tiles per wave from the slot budget
+    int max_waves = ctx->lse_slots / 2;
+    int tpw = (ctx->n_tiles + max_waves - 1) / max_waves;
+    if (tpw < 1) tpw = 1;
+    sweep_decompose(a, 0, ctx->n_tiles, nub, tpw);
+    int slots = a.n_strips * 4 * 2;
+    if (slots > ctx->lse_slots) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "lse slots %d > %d", slots, ctx->lse_slots);
+    a.lse_part = ctx->lse_part;
+    irs_prof_begin(ctx, IRS_PROF_SWEEP, s);
+    int rc = launch_sweep_f32<MODE_LSE>(ctx, a, s);
+    irs_prof_end(ctx, IRS_PROF_SWEEP, s, 2.0 * ctx->dims.d * (double)M * (double)ctx->n_local,
+                 (double)ctx->n_local * ctx->dims.d * 4.0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_lse_reduce, dim3((M + 255) / 256), dim3(256), 0, s, ctx->lse_part, slots, a.M_pad, M, out_max,
+                       out_sum);
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}

@@ -1,0 +1,237 @@
+"""Host-side engine: owns one irs_ctx (one device, one item shard), the derived
+weight arena and the workspace (as torch tensors: torch is only the allocator
+and stream provider here), and exposes the C-ABI calls on torch tensors.
+
+All methods enqueue work on torch's current stream for the engine's device and
+return device tensors; nothing synchronises unless the caller does.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (IRS_MASK_CAUSAL, IRS_MASK_IRN, IRS_SWEEP_BF16, IRS_SWEEP_EXHAUSTIVE, IRS_SWEEP_F32, IrsDims,
+                   IrsShard)
+
+
+class IrsError(RuntimeError):
+    pass
+
+
+def shard_bounds(n_item: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous item shard [lo, hi) of rank `rank` out of `world`, sizes
+    differing by at most one tile-aligned chunk: boundaries are multiples of 32
+    items so that every shard but the last is made of whole MFMA tiles."""
+    tiles = (n_item + 31) // 32
+    per, rem = divmod(tiles, world)
+    lo_t = rank * per + min(rank, rem)
+    hi_t = lo_t + per + (1 if rank < rem else 0)
+    return min(lo_t * 32, n_item), min(hi_t * 32, n_item)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Engine:
+    def __init__(self, *, n_item: int, n_user: int, d: int, max_len: int, n_heads: int, ffn_dim: int, n_layers: int,
+                 u_dim: int, mask_mode: int, device: torch.device, max_rows: int = 1024, max_seqs: int = 0,
+                 max_k: int = 100, rank: int = 0, world: int = 1):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise IrsError("the HIP engine needs a GPU device (no CPU fallback exists)")
+        lo, hi = shard_bounds(n_item, world, rank)
+        if hi <= lo:
+            raise IrsError(f"rank {rank} of {world} would hold an empty item shard of a {n_item}-item catalog")
+        self.item_lo, self.item_hi = lo, hi
+        self.n_local = hi - lo
+        self.n_item, self.d, self.L = n_item, d, max_len
+        self.max_rows, self.max_k = max_rows, max_k
+        self.max_seqs = max_seqs or max_rows
+        self.mask_mode = mask_mode
+        self.world, self.rank = world, rank
+        dims = IrsDims(n_item, n_user, d, max_len, n_heads, ffn_dim, n_layers, u_dim, mask_mode, max_rows, max_k,
+                       self.max_seqs)
+        shard = IrsShard(rank, world, lo, hi)
+        h = ctypes.c_void_p()
+        rc = self.lib.irs_create(ctypes.byref(h), ctypes.byref(dims), ctypes.byref(shard))
+        if rc != 0:
+            raise IrsError(f"irs_create failed ({rc}): {self.lib.irs_last_error(None).decode()}")
+        self.h = h
+        self._weights: Dict[str, torch.Tensor] = {}
+        with torch.cuda.device(self.device):
+            self._ws = torch.empty(self.lib.irs_workspace_bytes(self.h) + 256, dtype=torch.uint8, device=self.device)
+            self._check(self.lib.irs_bind_workspace(self.h, _ptr(self._ws), self._ws.numel()))
+        self._arena = None
+
+    # ------------------------------------------------------------------
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.irs_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise IrsError(f"libirs_hip error {rc}: {self.lib.irs_last_error(self.h).decode()}")
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, t: torch.Tensor, dtype) -> torch.Tensor:
+        if t.device != self.device:
+            raise IrsError(f"tensor on {t.device}, engine on {self.device}")
+        if t.dtype != dtype:
+            raise IrsError(f"tensor dtype {t.dtype}, expected {dtype}")
+        return t.contiguous()
+
+    # ------------------------------------------------------------------ weights
+    def bind_state_dict(self, sd: Dict[str, torch.Tensor]):
+        """Bind every tensor of a reference-keyed state_dict.
+        project.weight / project.bias may be given whole ([N, d] / [N]); the
+        local shard rows are sliced here (a view, no copy)."""
+        for name, t in sd.items():
+            key = name[7:] if name.startswith("module.") else name
+            if key.endswith("multihead_attn.in_proj_weight"):
+                pass  # bound for the key-set contract; only its bias slice matters (zero memory)
+            if key == "project.weight" and t.shape[0] == self.n_item and self.n_local != self.n_item:
+                t = t[self.item_lo:self.item_hi]
+            if key == "project.bias" and t.shape[0] == self.n_item and self.n_local != self.n_item:
+                t = t[self.item_lo:self.item_hi]
+            t = self._dev(t.detach(), torch.float32)
+            self._weights[key] = t  # keep alive
+            self._check(self.lib.irs_bind_weight(self.h, key.encode(), _ptr(t), t.numel()))
+        self.finalize()
+
+    def finalize(self):
+        with torch.cuda.device(self.device):
+            need = self.lib.irs_derived_bytes(self.h)
+            if self._arena is None or self._arena.numel() < need:
+                self._arena = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            self._check(self.lib.irs_finalize_weights(self.h, _ptr(self._arena), self._arena.numel(), self._stream()))
+
+    # ------------------------------------------------------------------ decoder
+    def pif(self, users: torch.Tensor) -> torch.Tensor:
+        users = self._dev(users, torch.int64)
+        out = torch.empty(users.shape[0], dtype=torch.float32, device=self.device)
+        self._check(self.lib.irs_pif(self.h, _ptr(users), users.shape[0], _ptr(out), self._stream()))
+        return out
+
+    def decode(self, seqs: torch.Tensor, users: Optional[torch.Tensor], *, want_x: bool = True,
+               pos: Optional[torch.Tensor] = None, want_r_u: bool = False):
+        """Returns (x[B,L,d] or None, xrows[B,d] or None, r_u[B] or None)."""
+        seqs = self._dev(seqs, torch.int64)
+        B, L = seqs.shape
+        if L != self.L:
+            raise IrsError(f"sequence length {L} != max_len {self.L}")
+        if users is not None:
+            users = self._dev(users, torch.int64)
+        x = torch.empty((B, L, self.d), dtype=torch.float32, device=self.device) if want_x else None
+        xr = None
+        if pos is not None:
+            pos = self._dev(pos, torch.int32)
+            xr = torch.empty((B, self.d), dtype=torch.float32, device=self.device)
+        ru = torch.empty(B, dtype=torch.float32, device=self.device) if want_r_u else None
+        self._check(self.lib.irs_decode(self.h, _ptr(seqs), _ptr(users), B, _ptr(x), _ptr(pos), _ptr(xr), _ptr(ru),
+                                        self._stream()))
+        return x, xr, ru
+
+    # ------------------------------------------------------------------ scoring
+    def score_topk(self, xrows: torch.Tensor, k: int = 100, sweep: int = IRS_SWEEP_BF16):
+        """(val[M,k] float32, ids0[M,k] int64 global 0-based, status[M] int32) of this shard."""
+        xrows = self._dev(xrows, torch.float32)
+        M = xrows.shape[0]
+        val = torch.empty((M, k), dtype=torch.float32, device=self.device)
+        ids = torch.empty((M, k), dtype=torch.int64, device=self.device)
+        st = torch.empty(M, dtype=torch.int32, device=self.device)
+        self._check(self.lib.irs_score_topk(self.h, _ptr(xrows), M, k, sweep, _ptr(val), _ptr(ids), _ptr(st),
+                                            self._stream()))
+        return val, ids, st
+
+    def score_gather(self, xrows: torch.Tensor, ids0: torch.Tensor) -> torch.Tensor:
+        xrows = self._dev(xrows, torch.float32)
+        ids0 = self._dev(ids0, torch.int64)
+        M, g = ids0.shape
+        out = torch.empty((M, g), dtype=torch.float32, device=self.device)
+        self._check(self.lib.irs_score_gather(self.h, _ptr(xrows), M, _ptr(ids0), g, _ptr(out), self._stream()))
+        return out
+
+    def score_count_before(self, xrows, ref_score, ref_id0, excl_ids0: Optional[torch.Tensor]) -> torch.Tensor:
+        xrows = self._dev(xrows, torch.float32)
+        ref_score = self._dev(ref_score, torch.float32)
+        ref_id0 = self._dev(ref_id0, torch.int64)
+        M = xrows.shape[0]
+        n_ex = 0
+        if excl_ids0 is not None:
+            excl_ids0 = self._dev(excl_ids0, torch.int64)
+            n_ex = excl_ids0.shape[1]
+        out = torch.empty(M, dtype=torch.int64, device=self.device)
+        self._check(self.lib.irs_score_count_before(self.h, _ptr(xrows), M, _ptr(ref_score), _ptr(ref_id0),
+                                                    _ptr(excl_ids0) if n_ex else None, n_ex, _ptr(out), self._stream()))
+        return out
+
+    def score_dense(self, xrows: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        xrows = self._dev(xrows, torch.float32)
+        M = xrows.shape[0]
+        if out is None:
+            out = torch.empty((M, self.n_local), dtype=torch.float32, device=self.device)
+        self._check(self.lib.irs_score_dense(self.h, _ptr(xrows), M, _ptr(out), out.stride(0), self._stream()))
+        return out
+
+    def score_lse(self, xrows: torch.Tensor):
+        xrows = self._dev(xrows, torch.float32)
+        M = xrows.shape[0]
+        mx = torch.empty(M, dtype=torch.float32, device=self.device)
+        sm = torch.empty(M, dtype=torch.float32, device=self.device)
+        self._check(self.lib.irs_score_lse(self.h, _ptr(xrows), M, _ptr(mx), _ptr(sm), self._stream()))
+        return mx, sm
+
+    def merge_topk(self, val_in: torch.Tensor, ids_in: torch.Tensor):
+        """[W, M, k] gathered per-shard lists -> global (val[M,k], ids0[M,k])."""
+        val_in = self._dev(val_in, torch.float32)
+        ids_in = self._dev(ids_in, torch.int64)
+        W, M, k = val_in.shape
+        val = torch.empty((M, k), dtype=torch.float32, device=self.device)
+        ids = torch.empty((M, k), dtype=torch.int64, device=self.device)
+        self._check(self.lib.irs_merge_topk(self.h, _ptr(val_in), _ptr(ids_in), W, M, k, _ptr(val), _ptr(ids),
+                                            self._stream()))
+        return val, ids
+
+    # ------------------------------------------------------------------ path search
+    def path_step(self, seqs, hep, val, ids0, step: int, paths, status, sample=False, sample_k=3, seed=0):
+        B = seqs.shape[0]
+        self._check(self.lib.irs_path_step(self.h, _ptr(seqs), _ptr(hep), B, _ptr(val), _ptr(ids0), val.shape[1], step,
+                                           _ptr(paths), paths.shape[1], int(sample), sample_k, seed, _ptr(status),
+                                           self._stream()))
+
+    def generate_paths(self, seqs: torch.Tensor, users: Optional[torch.Tensor], hep: torch.Tensor, max_path_len: int,
+                       k: int = 100, sweep: int = IRS_SWEEP_BF16, sample=False, sample_k=3, seed=0,
+                       use_graph: bool = False, paths: Optional[torch.Tensor] = None,
+                       status: Optional[torch.Tensor] = None):
+        """Runs the whole search loop on the device.  `seqs` and `hep` are the
+        working window state and are modified in place."""
+        B = seqs.shape[0]
+        if paths is None:
+            paths = torch.zeros((B, max_path_len), dtype=torch.float32, device=self.device)
+        if status is None:
+            status = torch.zeros(B, dtype=torch.int32, device=self.device)
+        self._check(self.lib.irs_generate_paths(self.h, _ptr(seqs), _ptr(users), _ptr(hep), B, max_path_len, k, sweep,
+                                                int(sample), sample_k, seed, int(use_graph), _ptr(paths), _ptr(status),
+                                                self._stream()))
+        return paths, status
+
+    # ------------------------------------------------------------------ measurement
+    def prof_enable(self, family: int):
+        self._check(self.lib.irs_prof_enable(self.h, family))
+
+    def prof_read(self):
+        n = ctypes.c_int32()
+        ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        self._check(self.lib.irs_prof_read(self.h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
+        return n.value, ms.value, fl.value, by.value

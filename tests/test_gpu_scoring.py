@@ -1,0 +1,157 @@
+"""-m gpu: the HIP scoring path (through the C ABI) against the oracle.
+Bar: bit-exact ids AND values for every selection (integer/index work and the
+fixed-order float chain), 1e-6 relative for log-sum-exp."""
+import numpy as np
+import pytest
+import torch
+
+from influentialrs_amd import synth
+from influentialrs_amd._lib import IRS_SWEEP_BF16, IRS_SWEEP_EXHAUSTIVE, IRS_SWEEP_F32
+from gpu_util import scoring_only_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _weights(n_item, d, seed):
+    g = np.random.default_rng(seed)
+    W = ((g.random((n_item, d), dtype=np.float32) * 2 - 1) / np.sqrt(d)).astype(np.float32)
+    b = (g.standard_normal(n_item) * 0.1).astype(np.float32)
+    return W, b
+
+
+def _rows(M, d, seed):
+    g = np.random.default_rng(seed + 100)
+    return g.standard_normal((M, d)).astype(np.float32)
+
+
+CASES = [  # (n_item, d, M, k)
+    (257, 16, 6, 100),
+    (100, 16, 3, 100),      # exactly k items
+    (57, 16, 2, 100),       # fewer than k items
+    (3415, 30, 5, 100),     # repo default d (not a multiple of 8)
+    (3415, 128, 33, 100),   # ml-1m shaped, ragged row count
+    (50_000, 64, 40, 100),
+    (200_003, 128, 9, 100),
+    (70_001, 256, 5, 32),
+]
+
+
+@pytest.mark.parametrize("n_item,d,M,k", CASES)
+@pytest.mark.parametrize("sweep", [IRS_SWEEP_BF16, IRS_SWEEP_F32, IRS_SWEEP_EXHAUSTIVE])
+def test_topk_bit_exact(oracle, n_item, d, M, k, sweep):
+    W, b = _weights(n_item, d, 1)
+    x = _rows(M, d, 2)
+    eng = scoring_only_engine(n_item, d, W, b, max_rows=max(M, 1))
+    val, ids, st = eng.score_topk(torch.from_numpy(x).cuda(), k, sweep)
+    torch.cuda.synchronize()
+    val, ids, st = val.cpu().numpy(), ids.cpu().numpy(), st.cpu().numpy()
+    for m in range(M):
+        s = oracle.score_chain(x[m], W, b)
+        ov, oi = oracle.topk(s, k)
+        n = len(oi)
+        assert np.array_equal(ids[m, :n], oi), f"row {m}: ids differ (sweep {sweep})"
+        assert np.array_equal(val[m, :n].view(np.uint32), ov.view(np.uint32)), f"row {m}: values differ"
+        if n < k:
+            assert (ids[m, n:] == -1).all() and np.isneginf(val[m, n:]).all()
+            assert st[m] & 4
+    if n_item >= k and sweep != IRS_SWEEP_EXHAUSTIVE:
+        assert (st & 1).sum() == 0, "unexpected fallback rows on benign data"
+
+
+def test_topk_ties_and_fallback(oracle):
+    """Massive exact ties (duplicate item rows, constant bias) overflow the
+    candidate buffers: the exhaustive kernel must take over and still return
+    the (score desc, id asc) order."""
+    n_item, d, M, k = 20_000, 32, 4, 100
+    W, b = _weights(n_item, d, 3)
+    W[:] = W[:7][np.arange(n_item) % 7]  # only 7 distinct rows
+    b[:] = 0.25
+    x = _rows(M, d, 4)
+    eng = scoring_only_engine(n_item, d, W, b, max_rows=M)
+    for sweep in (IRS_SWEEP_BF16, IRS_SWEEP_F32):
+        val, ids, st = eng.score_topk(torch.from_numpy(x).cuda(), k, sweep)
+        torch.cuda.synchronize()
+        assert (st.cpu().numpy() & 1).all(), "expected the fallback to trigger"
+        for m in range(M):
+            s = oracle.score_chain(x[m], W, b)
+            ov, oi = oracle.topk(s, k)
+            assert np.array_equal(ids[m].cpu().numpy(), oi)
+            assert np.array_equal(val[m].cpu().numpy().view(np.uint32), ov.view(np.uint32))
+
+
+@pytest.mark.parametrize("n_item,d,M", [(257, 16, 5), (3415, 30, 7), (3415, 128, 40), (40_000, 256, 3)])
+def test_dense_and_gather_bitwise(oracle, n_item, d, M):
+    """fp32 MFMA sweep == VALU chain == oracle chain, bit for bit."""
+    W, b = _weights(n_item, d, 5)
+    x = _rows(M, d, 6)
+    eng = scoring_only_engine(n_item, d, W, b, max_rows=M)
+    xt = torch.from_numpy(x).cuda()
+    dense = eng.score_dense(xt).cpu().numpy()
+    g = np.random.default_rng(0)
+    ids = g.integers(0, n_item, size=(M, 17)).astype(np.int64)
+    ids[0, 0] = -1
+    got = eng.score_gather(xt, torch.from_numpy(ids).cuda()).cpu().numpy()
+    for m in range(M):
+        s = oracle.score_chain(x[m], W, b)
+        assert np.array_equal(dense[m].view(np.uint32), s.view(np.uint32)), f"dense row {m}"
+        for j in range(17):
+            if ids[m, j] < 0:
+                assert np.isneginf(got[m, j])
+            else:
+                assert got[m, j].view(np.uint32) == s[ids[m, j]].view(np.uint32)
+
+
+@pytest.mark.parametrize("n_item,d,M", [(257, 16, 6), (3415, 128, 10), (60_000, 64, 4)])
+def test_count_before_matches_rank(oracle, n_item, d, M):
+    W, b = _weights(n_item, d, 7)
+    x = _rows(M, d, 8)
+    eng = scoring_only_engine(n_item, d, W, b, max_rows=M)
+    xt = torch.from_numpy(x).cuda()
+    g = np.random.default_rng(1)
+    labels = g.integers(0, n_item, size=M).astype(np.int64)
+    hist = g.integers(0, n_item, size=(M, 23)).astype(np.int64)
+    hist[:, 3] = hist[:, 4]  # duplicates
+    hist[:, 5] = -1          # unused slot
+    hist[1, 6] = labels[1]   # the label itself is never excluded by the count
+    ref = eng.score_gather(xt, torch.from_numpy(labels[:, None]).cuda())[:, 0].contiguous()
+    cnt = eng.score_count_before(xt, ref, torch.from_numpy(labels).cuda(), torch.from_numpy(hist).cuda()).cpu().numpy()
+    for m in range(M):
+        s = oracle.score_chain(x[m], W, b)
+        h = hist[m][hist[m] >= 0]
+        assert cnt[m] + 1 == oracle.rank_of(s, int(labels[m]), h), f"row {m}"
+
+
+@pytest.mark.parametrize("n_item,d,M", [(257, 16, 6), (3415, 128, 10), (100_000, 64, 3)])
+def test_lse(oracle, n_item, d, M):
+    W, b = _weights(n_item, d, 9)
+    x = _rows(M, d, 10)
+    eng = scoring_only_engine(n_item, d, W, b, max_rows=M)
+    mx, sm = eng.score_lse(torch.from_numpy(x).cuda())
+    mx, sm = mx.cpu().numpy(), sm.cpu().numpy()
+    for m in range(M):
+        s = oracle.score_chain(x[m], W, b)
+        om, osum = oracle.max_sumexp(s)
+        assert mx[m] == np.float32(om)
+        assert abs(sm[m] - osum) <= 2e-6 * osum  # float32 sum of N terms; tolerance 2e-6 relative
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_merge_equals_unsharded(oracle, world):
+    """Item-sharded top-k + merge == single-shard top-k, bit for bit."""
+    n_item, d, M, k = 30_011, 64, 12, 100
+    W, b = _weights(n_item, d, 11)
+    x = _rows(M, d, 12)
+    xt = torch.from_numpy(x).cuda()
+    vals, idss = [], []
+    for r in range(world):
+        eng = scoring_only_engine(n_item, d, W, b, max_rows=M, rank=r, world=world)
+        v, i, _ = eng.score_topk(xt, k, IRS_SWEEP_BF16)
+        vals.append(v)
+        idss.append(i)
+    mv, mi = eng.merge_topk(torch.stack(vals), torch.stack(idss))
+    mv, mi = mv.cpu().numpy(), mi.cpu().numpy()
+    for m in range(M):
+        s = oracle.score_chain(x[m], W, b)
+        ov, oi = oracle.topk(s, k)
+        assert np.array_equal(mi[m], oi)
+        assert np.array_equal(mv[m].view(np.uint32), ov.view(np.uint32))
