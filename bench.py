@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: one persuasion-path search STEP over a batch of users
+
+    step = decoder over B windows -> row at history end -> score against the whole
+           catalog -> top-100 -> window filter + greedy choice + window shift
+
+(IRSNN.get_seq_in_batch's loop body, reference model/influentialRS.py:412-450).
+Metric (BASELINE.json): scored user-item pairs/sec = users x n_item / time, whole job.
+Default workload = BASELINE.json configs[1]: ml-1m-shaped, d=128, L=200, H=4,
+6 layers, F=256, N=3415, synthetic weights and windows, inputs resident in HBM.
+
+    python bench.py                       # 1 GPU, C2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1 (weak scaling): every rank decodes its own B users, rows are all-gathered
+(RCCL), each rank scores all N*B rows against ITS item shard, per-shard top-100
+lists are all-gathered and merged identically on every rank.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from influentialrs_amd import synth  # noqa: E402
+from influentialrs_amd._lib import (IRS_MASK_IRN, IRS_PROF_ATTN, IRS_PROF_LINEAR, IRS_PROF_NONE,  # noqa: E402
+                                    IRS_PROF_REFINE, IRS_PROF_SWEEP, IRS_SWEEP_BF16, IRS_SWEEP_F32)
+from influentialrs_amd.engine import Engine  # noqa: E402
+
+PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (exact f32) dense peak
+PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA
+PEAK_HBM_GBS = 8000.0           # HBM3E spec
+
+
+def gpu_state_dict(cfg, device, seed=1234):
+    """Same init families as synth.irn_state_dict, generated on the device
+    (large catalogs: no host round trip)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    d, F, N = cfg.emb_dim, cfg.ffn_dim, cfg.n_item
+
+    def normal(*shape, std=1.0):
+        return torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * std
+
+    def uniform(*shape, bound):
+        return (torch.rand(*shape, generator=g, device=device, dtype=torch.float32) * 2 - 1) * bound
+
+    sd = {}
+    E = normal(N + 1, d)
+    E[0] = 0
+    sd["item_embedder.weight"] = E
+    sd["user_embedder.weight"] = normal(cfg.n_user, cfg.u_emb_dim)
+    sd["user_mask_layer.weight"] = uniform(1, cfg.u_emb_dim, bound=cfg.u_emb_dim ** -0.5)
+    sd["user_mask_layer.bias"] = normal(1, std=0.1)
+    sd["pos_embedder.pe"] = torch.from_numpy(synth.positional_encoding(d, cfg.max_len)).to(device)
+    sd["project.weight"] = uniform(N, d, bound=d ** -0.5)
+    sd["project.bias"] = normal(N, std=0.1)
+    xav = (6.0 / (4 * d)) ** 0.5
+    for l in range(cfg.n_layers):
+        p = f"decoder.layers.{l}."
+        for att in ("self_attn", "multihead_attn"):
+            sd[p + att + ".in_proj_weight"] = uniform(3 * d, d, bound=xav)
+            sd[p + att + ".in_proj_bias"] = normal(3 * d, std=0.1)
+            sd[p + att + ".out_proj.weight"] = uniform(d, d, bound=d ** -0.5)
+            sd[p + att + ".out_proj.bias"] = normal(d, std=0.1)
+        sd[p + "linear1.weight"] = uniform(F, d, bound=d ** -0.5)
+        sd[p + "linear1.bias"] = normal(F, std=0.1)
+        sd[p + "linear2.weight"] = uniform(d, F, bound=F ** -0.5)
+        sd[p + "linear2.bias"] = normal(d, std=0.1)
+        for n in ("norm1", "norm2", "norm3"):
+            sd[p + n + ".weight"] = 1.0 + normal(d, std=0.05)
+            sd[p + n + ".bias"] = normal(d, std=0.05)
+    return sd
+
+
+def gpu_windows(B, L, n_item, device, seed):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    seqs = torch.randint(1, n_item + 1, (B, L), generator=g, device=device, dtype=torch.int64)
+    hl = torch.randint(1, L, (B, 1), generator=g, device=device)
+    col = torch.arange(L, device=device)[None, :]
+    pad = col < (L - 1 - hl)
+    seqs[pad] = 0
+    return seqs
+
+
+class Job:
+    def __init__(self, args, rank, world, device):
+        self.args, self.rank, self.world, self.device = args, rank, world, device
+        self.cfg = synth.make_config(args.workload)
+        if args.n_item:
+            self.cfg.n_item = args.n_item
+        cfg = self.cfg
+        self.B = args.batch
+        self.k = 100
+        self.sweep = IRS_SWEEP_F32 if args.sweep == "f32" else IRS_SWEEP_BF16
+        rows = self.B * world
+        self.eng = Engine(n_item=cfg.n_item, n_user=cfg.n_user, d=cfg.emb_dim, max_len=cfg.max_len,
+                          n_heads=cfg.n_heads, ffn_dim=cfg.ffn_dim, n_layers=cfg.n_layers, u_dim=cfg.u_emb_dim,
+                          mask_mode=IRS_MASK_IRN, device=device, max_rows=rows, max_seqs=self.B, max_k=self.k,
+                          rank=rank, world=world)
+        if cfg.n_item <= 100_000:
+            sd = {k: torch.from_numpy(v).to(device) for k, v in synth.irn_state_dict(cfg, 1234).items()}
+        else:
+            sd = gpu_state_dict(cfg, device, 1234)
+        self.eng.bind_state_dict(sd)
+        self.seqs = gpu_windows(self.B, cfg.max_len, cfg.n_item, device, seed=100 + rank)
+        self.users = torch.randint(0, cfg.n_user, (self.B,), device=device, dtype=torch.int64)
+        self.hep = torch.full((self.B,), cfg.max_len - 2, dtype=torch.int32, device=device)
+        self.paths = torch.zeros((self.B, 1), dtype=torch.float32, device=device)
+        self.status = torch.zeros(self.B, dtype=torch.int32, device=device)
+        if world > 1:
+            self.x_all = torch.empty((rows, cfg.emb_dim), dtype=torch.float32, device=device)
+            self.v_all = torch.empty((world, rows, self.k), dtype=torch.float32, device=device)
+            self.i_all = torch.empty((world, rows, self.k), dtype=torch.int64, device=device)
+
+    def step(self):
+        eng = self.eng
+        _, xr, _ = eng.decode(self.seqs, self.users, want_x=False, pos=self.hep)
+        if self.world == 1:
+            val, ids, _ = eng.score_topk(xr, self.k, self.sweep)
+        else:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(self.x_all, xr)
+            v, i, _ = eng.score_topk(self.x_all, self.k, self.sweep)
+            dist.all_gather_into_tensor(self.v_all, v)
+            dist.all_gather_into_tensor(self.i_all, i)
+            mv, mi = eng.merge_topk(self.v_all, self.i_all)
+            lo = self.rank * self.B
+            val, ids = mv[lo:lo + self.B].contiguous(), mi[lo:lo + self.B].contiguous()
+        eng.path_step(self.seqs, self.hep, val, ids, 0, self.paths, self.status)
+
+
+def timed(job, steps, world):
+    import torch.distributed as dist
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=job.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def cpu_baseline(cfg, budget_s=20.0):
+    """The oracle (CPU restatement, 'port') timed on this box's host cores on a
+    bounded sample of the same workload: greedy path steps for a few users, one
+    user at a time (the only batch size the published IRN runs at), scoring the
+    consumed row only.  Checker code used as a yard-stick, never shipped."""
+    import subprocess
+    so = os.path.join(REPO, "oracle", "_build", "liboracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle")], stdout=subprocess.DEVNULL)
+    from oracle import oracle_np as O
+    sd = synth.irn_state_dict(cfg, 1234)
+    seqs = synth.random_windows(4, cfg.max_len, cfg.n_item, seed=3)
+    users = np.arange(4)
+    hep = cfg.max_len - 2
+    W, b = sd["project.weight"], sd["project.bias"]
+    done, t0 = 0, time.perf_counter()
+    while True:
+        for r in range(4):
+            x, _ = O.decode(sd, cfg, seqs[r], users[r])
+            s = O.score_chain(x[hep], W, b)
+            vals, ids0 = O.topk(s, 100)
+            nxt = O.select_next(ids0 + 1, vals, seqs[r][:hep + 1])
+            seqs[r][:-2] = seqs[r][1:-1].copy()
+            seqs[r][-2] = nxt
+            done += 1
+        if time.perf_counter() - t0 > budget_s or done >= 400:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done * cfg.n_item / dt, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{done} greedy path steps (4 users, B=1 loop, consumed row only) in {dt:.1f}s: numpy float32 "
+                      f"decoder (BLAS threads) + C fma-chain scoring/top-100 (OpenMP)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "default", "tiny"])
+    ap.add_argument("--batch", type=int, default=1024, help="users per rank per step")
+    ap.add_argument("--n-item", type=int, default=0, help="override the catalog size")
+    ap.add_argument("--sweep", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    job = Job(args, rank, world, device)
+    cfg = job.cfg
+    for _ in range(args.warmup):
+        job.step()
+    dt = timed(job, args.steps, world)
+    users_total = job.B * world
+    value = users_total * cfg.n_item * args.steps / dt
+
+    # second, instrumented pass: HIP events around every launch of each kernel family
+    fam = {}
+    for name, f in (("linear", IRS_PROF_LINEAR), ("attn", IRS_PROF_ATTN), ("sweep", IRS_PROF_SWEEP), ("refine", IRS_PROF_REFINE)):
+        job.eng.prof_enable(f)
+        for _ in range(args.steps):
+            job.step()
+        torch.cuda.synchronize()
+        n, ms, fl, by = job.eng.prof_read()
+        fam[name] = dict(launches=n, ms=ms, flops=fl, bytes=by)
+    job.eng.prof_enable(IRS_PROF_NONE)
+
+    out = None
+    if rank == 0:
+        dom = max(fam, key=lambda k: fam[k]["ms"])
+        f = fam[dom]
+        per_launch_ms = f["ms"] / max(f["launches"], 1)
+        if dom in ("linear", "attn"):
+            ach = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
+            roof = {"kernel": {"linear": "k_linear (decoder fp32 MFMA GEMM)", "attn": "k_attn (decoder attention, fp32 VALU)"}[dom],
+                    "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_F32_MATRIX_TFLOPS, "traffic": None}
+        else:
+            Mrows = users_total
+            if dom == "sweep" and Mrows >= 315 and job.sweep == IRS_SWEEP_BF16:
+                ach = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
+                roof = {"kernel": "k_sweep_bf16 (catalog sweep, bf16 MFMA)", "bound": "mfma", "achieved": ach,
+                        "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None}
+            else:
+                ach = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f["ms"] > 0 else 0.0
+                roof = {"kernel": f"k_{dom}", "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": ach / PEAK_HBM_GBS, "traffic": None}
+        roof["avg_launch_ms"] = per_launch_ms
+        roof["launches_per_step"] = f["launches"] / args.steps
+        roof["family_ms_per_step"] = {k: v["ms"] / args.steps for k, v in fam.items()}
+
+        lat = None
+        if not args.no_latency and world == 1:
+            # path-gen p50: one user, 20 greedy steps, hipGraph-replayed step
+            s1 = job.seqs[:1].clone()
+            u1 = job.users[:1].clone()
+            h1 = job.hep[:1].clone()
+            p1 = torch.zeros((1, 20), dtype=torch.float32, device=device)
+            st1 = torch.zeros(1, dtype=torch.int32, device=device)
+            ts = []
+            for it in range(35):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                job.eng.generate_paths(s1, u1, h1, 20, k=100, sweep=job.sweep, use_graph=True, paths=p1, status=st1)
+                torch.cuda.synchronize()
+                if it >= 5:
+                    ts.append((time.perf_counter() - t0) * 1e3)
+            lat = float(np.median(ts))
+
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(cfg)
+
+        out = {
+            "metric": "scored user-item pairs/sec (whole node)",
+            "value": value,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: n_item={cfg.n_item}, d={cfg.emb_dim}, L={cfg.max_len}, H={cfg.n_heads}, "
+                                   f"layers={cfg.n_layers}, ffn={cfg.ffn_dim}; one greedy path-search step",
+                       "users_per_step": users_total, "users_per_gpu": job.B, "top_k": 100,
+                       "sweep": args.sweep + (" filter + exact f32 re-score" if args.sweep == "bf16" else ""),
+                       "parallelism": "single GPU" if world == 1 else f"rows data-parallel + item-sharded x{world}, RCCL all-gather of rows and per-shard top-100"},
+            "path_gen_p50_ms_b1": lat,
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -73,6 +73,10 @@ def load() -> ctypes.CDLL:
         raise IrsLibraryError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
             "Build it with `python -m influentialrs_amd.build` or __graft_entry__.build().")
+    # One HIP runtime per process: torch ships its own libamdhip64 and must load it
+    # first so that this library's DT_NEEDED entry resolves to the same copy
+    # (two runtimes -> "no ROCm-capable device" in whichever came second).
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
