@@ -1,0 +1,90 @@
+"""Item-dimension sharding across the GPUs of one node.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Rank r
+holds rows [lo_r, hi_r) of project.weight / project.bias.  Per scoring call:
+
+    rows (data-parallel)  --all_gather-->  every rank has all rows
+    local sweep over the rank's item shard  ->  per-shard top-k / counts / (max, sumexp) / scores
+    --all_gather-->  identical deterministic combine on every rank
+
+so every rank advances the same windows with no further broadcast.  The payloads
+are tiny (M*k*12 bytes per rank), i.e. latency bound; nothing here is reduced
+at bandwidth scale.  The reference has no counterpart (it only knows
+nn.DataParallel, pipeline.py:43-44); this is the MI355X-native replacement.
+
+`scorer` is anything with the Engine scoring methods (score_topk, merge_topk,
+score_gather, score_count_before, score_lse); in the product it is an
+influentialrs_amd.engine.Engine.  The CPU rehearsal tests (gloo, world 2) pass
+an oracle-backed stand-in to exercise exactly this collective logic.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class ShardGroup:
+    def __init__(self, scorer, group: Optional["dist.ProcessGroup"] = None):
+        self.scorer = scorer
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+
+    # -- plumbing ---------------------------------------------------------
+    def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        """[...] -> [world, ...] (same shape on every rank)."""
+        t = t.contiguous()
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out.view(-1), t.view(-1), group=self.group)
+        return out
+
+    def gather_rows(self, local_rows: torch.Tensor) -> torch.Tensor:
+        """Rows decoded data-parallel -> all rows on every rank, rank-major."""
+        if self.world == 1:
+            return local_rows
+        g = self._all_gather(local_rows)
+        return g.view(-1, local_rows.shape[-1])
+
+    def my_slice(self, rows_per_rank: int) -> slice:
+        return slice(self.rank * rows_per_rank, (self.rank + 1) * rows_per_rank)
+
+    # -- combines ---------------------------------------------------------
+    def topk(self, xrows: torch.Tensor, k: int, sweep: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        val, ids, st = self.scorer.score_topk(xrows, k, sweep)
+        if self.world == 1:
+            return val, ids, st
+        v_all = self._all_gather(val)
+        i_all = self._all_gather(ids)
+        mv, mi = self.scorer.merge_topk(v_all, i_all)
+        # fallback bit is informational per shard; FEWER_THAN_K only if the merged list is short
+        st = (mi[:, -1] < 0).to(torch.int32) * 4
+        return mv, mi, st
+
+    def gather(self, xrows: torch.Tensor, ids0: torch.Tensor) -> torch.Tensor:
+        """Exact scores at global ids: each id lives in exactly one shard, the
+        others report -inf, so an elementwise max assembles the row."""
+        s = self.scorer.score_gather(xrows, ids0)
+        if self.world == 1:
+            return s
+        dist.all_reduce(s, op=dist.ReduceOp.MAX, group=self.group)
+        return s
+
+    def count_before(self, xrows, ref_score, ref_id0, excl_ids0) -> torch.Tensor:
+        c = self.scorer.score_count_before(xrows, ref_score, ref_id0, excl_ids0)
+        if self.world > 1:
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
+        return c
+
+    def lse(self, xrows: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Global (max, sum exp(e - max)) from per-shard pairs."""
+        m, s = self.scorer.score_lse(xrows)
+        if self.world == 1:
+            return m, s
+        gm = m.clone()
+        dist.all_reduce(gm, op=dist.ReduceOp.MAX, group=self.group)
+        s = s * torch.exp(m - gm)
+        s = torch.where(torch.isfinite(m), s, torch.zeros_like(s))
+        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
+        return gm, s

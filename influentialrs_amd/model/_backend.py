@@ -1,0 +1,97 @@
+"""Glue between the nn.Module front-ends and the HIP engine: keeps one Engine per
+network, (re)binds its parameters when they move or change, and offers the
+row-level operations the task handlers need.  No arithmetic of the hot path is
+done in torch here; torch supplies tensors, streams and collectives."""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .._lib import IRS_MASK_CAUSAL, IRS_MASK_IRN, IRS_SWEEP_BF16
+from ..dist import ShardGroup
+from ..engine import Engine, IrsError
+
+
+class HipBackend:
+    def __init__(self, net: nn.Module, mask_mode: int):
+        self.net = net
+        self.mask_mode = mask_mode
+        self.engine: Optional[Engine] = None
+        self._fp = None
+        self.group: Optional[ShardGroup] = None
+        self.sweep = IRS_SWEEP_BF16
+        self.rank, self.world = 0, 1
+
+    def set_sharding(self, rank: int, world: int):
+        """Item-dimension sharding over `world` ranks (torch.distributed must be
+        initialised by the caller when world > 1)."""
+        if (rank, world) != (self.rank, self.world):
+            self.rank, self.world = rank, world
+            self.engine = None
+
+    def _fingerprint(self):
+        return tuple((t.data_ptr(), t._version) for t in self.net.state_dict(keep_vars=True).values())
+
+    def get(self, n_seqs: int, n_rows: int) -> Engine:
+        net = self.net
+        dev = next(net.parameters()).device
+        if dev.type != "cuda":
+            raise IrsError("inference runs on the HIP engine only: move the network to a GPU "
+                           "(there is no CPU fallback in this package)")
+        need_new = (self.engine is None or self.engine.device != dev or self.engine.max_seqs < n_seqs
+                    or self.engine.max_rows < n_rows)
+        if need_new:
+            prev_s = self.engine.max_seqs if self.engine else 0
+            prev_r = self.engine.max_rows if self.engine else 0
+            self.engine = None
+            self.engine = Engine(
+                n_item=net.n_item, n_user=getattr(net, "n_user", 0), d=net.embed_dim, max_len=net.max_len,
+                n_heads=net.n_heads, ffn_dim=net.ffn_dim, n_layers=net.n_layers,
+                u_dim=getattr(net, "u_embed_dim", 0) if self.mask_mode == IRS_MASK_IRN else 0,
+                mask_mode=self.mask_mode, device=dev, max_rows=max(n_rows, prev_r, 64),
+                max_seqs=max(n_seqs, prev_s, 8), max_k=100, rank=self.rank, world=self.world)
+            self._fp = None
+            self.group = ShardGroup(self.engine) if self.world > 1 else None
+        fp = self._fingerprint()
+        if fp != self._fp:
+            sd = {k: v.detach() for k, v in net.state_dict(keep_vars=True).items() if v.dtype == torch.float32}
+            self.engine.bind_state_dict(sd)
+            self._fp = fp
+        return self.engine
+
+    # ---- row-level helpers (single shard or sharded group) ---------------
+    def topk(self, xrows, k=100):
+        if self.group is not None:
+            return self.group.topk(xrows, k, self.sweep)
+        return self.engine.score_topk(xrows, k, self.sweep)
+
+    def gather(self, xrows, ids0):
+        return self.group.gather(xrows, ids0) if self.group is not None else self.engine.score_gather(xrows, ids0)
+
+    def count_before(self, xrows, ref_score, ref_id0, excl):
+        if self.group is not None:
+            return self.group.count_before(xrows, ref_score, ref_id0, excl)
+        return self.engine.score_count_before(xrows, ref_score, ref_id0, excl)
+
+    def lse(self, xrows):
+        return self.group.lse(xrows) if self.group is not None else self.engine.score_lse(xrows)
+
+
+def pad_ragged_ids(lists: Sequence, device, minus: int = 1) -> torch.Tensor:
+    """List of 1-based id sequences -> int64 [B, n] of 0-based ids, -1 padded."""
+    n = max([len(a) for a in lists] + [1])
+    out = np.full((len(lists), n), -1, dtype=np.int64)
+    for i, a in enumerate(lists):
+        a = np.asarray(a.detach().cpu().numpy() if torch.is_tensor(a) else a, dtype=np.int64)
+        out[i, :len(a)] = a - minus
+    return torch.from_numpy(out).to(device)
+
+
+def make_scheduler(optimizer):
+    """ReduceLROnPlateau(factor=0.5, patience=4) as the reference builds it
+    (influentialRS.py:92-95); its `verbose=True` no longer exists in current torch."""
+    from torch.optim import lr_scheduler
+    return lr_scheduler.ReduceLROnPlateau(optimizer, factor=0.5, patience=4)

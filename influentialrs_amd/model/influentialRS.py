@@ -1,0 +1,263 @@
+"""MI355X-native counterpart of the reference's model/influentialRS.py.
+
+Same classes, constructor arguments, method names, argument meaning, return
+tuples and state_dict key set as the reference, so
+`pipeline.py` can import this module in place of `model.influentialRS`
+unchanged.  In eval mode every forward / scoring / path-search call runs on the
+hand-written gfx950 kernels behind include/irs_hip.h; there is no CPU
+fallback (IrsError if the network is not on a GPU).  Training mode keeps the
+stock PyTorch autograd modules (training is a "next" row).
+
+Behaviour pinned by the reference (file:line = /root/reference/model/influentialRS.py):
+  * mask semantics are the AS-CALLED ones (allowed = r_u, last column = 1.0,
+    :183-184 passing pi_factor into w_h), applied per row, so batches > 1 work
+    where the published code raises;
+  * logits index j <-> item id j+1 (:376, :422); pad id 0;
+  * ranking filters the full raw history (:372-379), path search filters the
+    current window (:423-427); rr skips rows whose label is filtered (:386);
+  * candidate width 100 (:421); all 100 in the window -> IndexError (:429);
+  * selection order is (score desc, id asc); torch's tie order is unspecified.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.optim as optim
+
+from .._lib import IRS_MASK_IRN, IRS_ROW_NO_CANDIDATE
+from ._backend import HipBackend, make_scheduler, pad_ragged_ids
+from .layers import PositionalEncoding, get_item_index
+
+
+class InfluentialNet(nn.Module):
+    """Influential Recommender Network (reference :22-216)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.PAD_ID = 0
+        self.item_embed_path = None
+        self.user_embed_path = None
+        self.n_item = config.n_item
+        self.n_user = config.n_user
+        self.use_u = False
+        self.max_len = config.max_len
+        self.n_layers = config.n_layers
+        self.n_heads = config.n_heads
+        self.embed_dim = config.emb_dim
+        self.u_embed_dim = config.u_emb_dim
+        self.ffn_dim = config.ffn_dim
+        self.dropout = config.dropout
+
+        self.item_embedder = nn.Embedding(self.n_item + 1, self.embed_dim, padding_idx=self.PAD_ID)
+        self.user_embedder = nn.Embedding(self.n_user, self.u_embed_dim)
+        self.pos_embedder = PositionalEncoding(self.embed_dim, self.max_len)
+        self.decoder = nn.TransformerDecoder(
+            decoder_layer=nn.TransformerDecoderLayer(d_model=self.embed_dim, nhead=self.n_heads,
+                                                     dim_feedforward=self.ffn_dim, dropout=self.dropout,
+                                                     activation="relu"),
+            num_layers=self.n_layers)
+        self.user_mask_layer = nn.Linear(self.u_embed_dim, 1)
+        self.project = nn.Linear(self.embed_dim, self.n_item)
+
+        self.optimizer = optim.Adam(filter(lambda x: x.requires_grad, self.parameters()), betas=(0.9, 0.98),
+                                    eps=1e-09, lr=config.lr1)
+        self.pla_lr_scheduler = make_scheduler(self.optimizer)
+        self._hip = HipBackend(self, IRS_MASK_IRN)
+
+    # ---- checkpoint contract: accept nn.DataParallel's "module." prefix (pipeline.py:140-142)
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    def shard_items(self, rank: int, world: int):
+        """Hold only rows [lo, hi) of the catalog on this GPU."""
+        self._hip.set_sharding(rank, world)
+
+    # ---- training-mode path: stock PyTorch autograd, per-row as-called mask
+    def _generate_square_subsequent_mask(self, size, pi_factor):
+        """[B*H, L, L] float mask: allowed = r_u[b], future = -inf, last column = 1.0
+        (the as-called semantics of reference :120-155 / :183-184, per row)."""
+        B = pi_factor.size(0)
+        dev = pi_factor.device
+        tril = torch.ones(size, size, device=dev).tril().bool()
+        m = torch.full((B, size, size), float("-inf"), device=dev)
+        m = torch.where(tril.unsqueeze(0), pi_factor.view(B, 1, 1).expand(B, size, size).float(), m)
+        m[:, :, -1] = 1.0
+        return torch.repeat_interleave(m, self.n_heads, dim=0)
+
+    def _decoding_autograd(self, dec_input_seq, user):
+        pad = dec_input_seq.eq(self.PAD_ID)
+        enc = torch.zeros(self.max_len, dec_input_seq.size(0), self.embed_dim, device=dec_input_seq.device)
+        x = self.item_embedder(dec_input_seq) * math.sqrt(self.embed_dim) + self.pos_embedder(dec_input_seq)
+        x = F.dropout(x, self.dropout, self.training).transpose(0, 1)
+        pi = self.user_mask_layer(self.user_embedder(user))
+        mask = self._generate_square_subsequent_mask(dec_input_seq.size(1), pi)
+        padf = torch.zeros_like(pad, dtype=torch.float32).masked_fill(pad, float("-inf"))
+        out = self.decoder(tgt=x, memory=enc, tgt_mask=mask, tgt_key_padding_mask=padf)
+        return out.transpose(0, 1), pi
+
+    # ---- reference API
+    def decoding(self, dec_input_seq, user, return_pi=False):
+        """[B, L] ids, [B] users -> [B, L, d] (and r_u [B, 1] if return_pi)."""
+        if self.training:
+            x, pi = self._decoding_autograd(dec_input_seq, user)
+        else:
+            eng = self._hip.get(dec_input_seq.size(0), 1)
+            x, _, ru = eng.decode(dec_input_seq, user, want_x=True, want_r_u=True)
+            pi = ru.view(-1, 1)
+        return (x, pi) if return_pi else x
+
+    def forward(self, dec_input_seq, user):
+        """[B, L, n_item] logits (reference :202-216).  The reference materialises
+        this tensor on every call; here it exists for API compatibility (and
+        training) -- the task handlers below never build it."""
+        if self.training:
+            x, _ = self._decoding_autograd(dec_input_seq, user)
+            return self.project(x)
+        B, L = dec_input_seq.shape
+        eng = self._hip.get(B, B * L)
+        if eng.world != 1:
+            raise RuntimeError("forward() materialises [B, L, n_item]; with item sharding use the IRSNN handlers")
+        x, _, _ = eng.decode(dec_input_seq, user, want_x=True)
+        return eng.score_dense(x.view(B * L, self.embed_dim)).view(B, L, self.n_item)
+
+    # rows of the decoder output at one position per sequence, without materialising [B, L, d] on the host side
+    def decode_rows(self, seqs, users, pos):
+        eng = self._hip.get(seqs.size(0), seqs.size(0))
+        _, xr, _ = eng.decode(seqs, users, want_x=False, pos=pos)
+        return xr
+
+
+class IRSNN(nn.Module):
+    """Task handler (reference :219-470)."""
+
+    def __init__(self, config, net, device):
+        super().__init__()
+        self.PAD_ID = 0
+        self.n_item = config.n_item
+        self.embed_dim = config.emb_dim
+        # pipeline.py:43-44,140-141 wraps the net in nn.DataParallel on multi-GPU hosts; the
+        # handlers need the module itself (the reference fails at :337 in that case)
+        self.net = net.module if isinstance(net, nn.DataParallel) else net
+        self.device = device
+        self.loss_function = nn.CrossEntropyLoss()
+        self.optimizer = optim.Adam(filter(lambda x: x.requires_grad, self.net.parameters()), betas=(0.9, 0.98),
+                                    eps=1e-09, lr=config.lr1)
+        self.pla_lr_scheduler = make_scheduler(self.optimizer)
+        self.softmax = nn.Softmax(dim=2)
+
+    # ---- training side (stock autograd; out of the inference hot path)
+    def _masked_loss(self, seqs, users):
+        output = self.net.forward(seqs.clone(), users)[:, :-1, :].contiguous().view(-1, self.n_item)
+        tgt = seqs[:, 1:].contiguous().view(-1)
+        mask = tgt.gt(self.PAD_ID)
+        return self.loss_function(output[mask], tgt[mask] - 1)
+
+    def get_loss_on_eval_data(self, seqs, users):
+        """Mean next-item cross entropy over non-pad targets (reference :252-276).
+        Eval mode: logits come from the HIP path; the loss reduction is torch."""
+        self.net.eval()
+        with torch.no_grad():
+            return self._masked_loss(seqs, users).item()
+
+    def train_batch(self, seqs, users):
+        """One Adam step (reference :278-310)."""
+        self.net.train()
+        loss = self._masked_loss(seqs, users)
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        return loss.item()
+
+    def _delete_item_in_history(self, tensor, indices):
+        return tensor[~tensor.unsqueeze(1).eq(indices).any(1)]
+
+    # ---- inference hot path
+    def get_pif_in_batch(self, seqs, users):
+        """r_u [B, 1] float32 (reference :325-338; the reference runs the whole
+        decoder to obtain it, here it is the two-op scalar it actually is)."""
+        self.net.eval()
+        eng = self.net._hip.get(seqs.size(0), 1)
+        return eng.pif(users).view(-1, 1).detach().cpu().numpy()
+
+    def get_accuracy_metrics_in_batch(self, raw, seqs, users, targets, labels, top_k=20, gap_len=20, use_h=True):
+        """(hit_count, rr array) -- Hit@top_k and reciprocal ranks (reference :340-390).
+        rank = 1 + #{items outside the raw history that precede the label}; no sort,
+        no [N, |hist|] boolean blow-up."""
+        self.net.eval()
+        B, L = seqs.shape
+        dev = seqs.device
+        hep = L - (gap_len + 1) - 1
+        pos = torch.full((B,), hep, dtype=torch.int32, device=dev)
+        xr = self.net.decode_rows(seqs.clone(), users, pos)
+        hip = self.net._hip
+        lab0 = labels.to(dev).to(torch.int64).view(B) - 1
+        excl = pad_ragged_ids(raw, dev) if use_h else None
+        if hip.world > 1:  # rows are data-parallel: every rank scores all rows against its item shard
+            g = hip.group
+            xr = g.gather_rows(xr)
+            lab0_all = g._all_gather(lab0).view(-1)
+            if excl is not None:
+                w = torch.tensor([excl.shape[1]], device=dev)
+                torch.distributed.all_reduce(w, op=torch.distributed.ReduceOp.MAX)
+                excl = F.pad(excl, (0, int(w.item()) - excl.shape[1]), value=-1)
+                excl = g._all_gather(excl).view(-1, excl.shape[1])
+            ref = hip.gather(xr, lab0_all.view(-1, 1))[:, 0].contiguous()
+            cnt = hip.count_before(xr, ref, lab0_all, excl)[g.my_slice(B)]
+        else:
+            ref = hip.gather(xr, lab0.view(B, 1))[:, 0].contiguous()
+            cnt = hip.count_before(xr, ref, lab0, excl)
+        ranks = (cnt + 1).cpu().numpy()
+        labels_np = labels.detach().cpu().numpy().reshape(-1)
+        hit_count, rr = 0, []
+        for i in range(B):
+            if use_h:
+                h = raw[i].detach().cpu().numpy() if torch.is_tensor(raw[i]) else np.asarray(raw[i])
+                if labels_np[i] in h:  # label filtered out: neither a hit nor an rr entry (:383-389)
+                    continue
+            if ranks[i] <= top_k:
+                hit_count += 1
+            rr.append(np.reciprocal(float(ranks[i])))
+        return hit_count, np.array(rr)
+
+    def get_seq_in_batch(self, seqs, users, targets, max_path_len=20, gap_len=20, sample=False, sample_k=3):
+        """Persuasion-path generation (reference :392-470): returns
+        (paths float32 [B, max_path_len], targets int64 [B], list of B history arrays, n_early_success)."""
+        self.net.eval()
+        B, L = seqs.shape
+        dev = seqs.device
+        hip = self.net._hip
+        work = seqs.clone()
+        hep = torch.full((B,), L - (gap_len + 1) - 1, dtype=torch.int32, device=dev)
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if sample else 0
+        if hip.world == 1:
+            eng = hip.get(B, B)
+            paths_t, status = eng.generate_paths(work, users, hep, max_path_len, k=100, sweep=hip.sweep,
+                                                 sample=sample, sample_k=sample_k, seed=seed, use_graph=False)
+        else:
+            eng = hip.get(B, B * hip.world)
+            paths_t = torch.zeros((B, max_path_len), dtype=torch.float32, device=dev)
+            status = torch.zeros(B, dtype=torch.int32, device=dev)
+            sl = hip.group.my_slice(B)
+            for i in range(max_path_len):
+                _, xr, _ = eng.decode(work, users, want_x=False, pos=hep)
+                allrows = hip.group.gather_rows(xr)
+                val, ids, _ = hip.group.topk(allrows, 100, hip.sweep)
+                eng.path_step(work, hep, val[sl].contiguous(), ids[sl].contiguous(), i, paths_t, status, sample, sample_k, seed)
+        if int((status & IRS_ROW_NO_CANDIDATE).sum().item()) > 0:
+            raise IndexError("index 0 is out of bounds: every top-100 candidate is already in the window "
+                             "(same condition as reference influentialRS.py:429)")
+        n_early_success = 0
+        paths = paths_t.detach().cpu().numpy()
+        targets = targets.detach().cpu().numpy()
+        histories = seqs[:, :-1].detach().cpu().numpy()
+        actual_history = []
+        for i in range(B):
+            pos = get_item_index(paths[i], targets[i])
+            if pos != -1:
+                n_early_success += 1
+                paths[i][pos + 1:] = 0
+            actual_history.append(histories[i][histories[i] != 0])
+        return paths, targets, actual_history, n_early_success

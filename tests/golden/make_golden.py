@@ -211,6 +211,36 @@ def eval_case(name, cfg_name, n_rows, seed=17):
     print(f"[golden] {name}: rows={n_rows} pp[0]={g['pp'][0]:.5f} ir={ir[:4]}")
 
 
+def contract_case():
+    """Input contract and checkpoint key set (section 5) from the
+    reference's own classes: DataLoaderEvalIRS._collate_fn (data_provider.py:591-617),
+    DatasetEvalNN1 (data_provider.py:711-760), InfluentialNet / SampleNet state_dict."""
+    from data_provider import DataLoaderEvalIRS, DatasetNN  # reference
+    g = {}
+    cfg = synth.make_config("default")
+    hists = synth.user_histories(12, cfg.n_item, seed=7)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=11)
+    for gap in (0, 5):
+        dl = DataLoaderEvalIRS(dataset=DatasetNN([list(r) for r in rows]), batch_size=len(rows), shuffle=False,
+                               num_workers=0, gap_len=gap, seq_len=cfg.max_len)
+        raw, seq, u, t, l = next(iter(dl))
+        g[f"collate_gap{gap}_seq"] = seq.numpy()
+        g[f"collate_gap{gap}_users"] = u.numpy()
+        g[f"collate_gap{gap}_targets"] = t.numpy()
+        g[f"collate_gap{gap}_labels"] = l.numpy()
+        g[f"collate_gap{gap}_raw"], g[f"collate_gap{gap}_raw_len"] = _pad_ragged([r.numpy() for r in raw])
+    tiny = synth.make_config("tiny")
+    net = InfluentialNet(tiny)
+    g["irn_keys"] = np.array(list(net.state_dict().keys()))
+    g["irn_shapes"] = np.array([",".join(map(str, v.shape)) for v in net.state_dict().values()])
+    et = synth.make_config("eval_tiny")
+    snet = SampleNet(et)
+    g["eval_keys"] = np.array(list(snet.state_dict().keys()))
+    g["eval_shapes"] = np.array([",".join(map(str, v.shape)) for v in snet.state_dict().values()])
+    np.savez_compressed(os.path.join(OUT, "contract.npz"), **g)
+    print("[golden] contract:", len(g["irn_keys"]), "irn keys,", len(g["eval_keys"]), "eval keys")
+
+
 CASES = {
     "irn_tiny": lambda: irn_case("irn_tiny", "tiny", 6, full_logits=True, save_x_full=True),
     "irn_default": lambda: irn_case("irn_default", "default", 4),
@@ -219,6 +249,7 @@ CASES = {
     "irn_c3": lambda: irn_case("irn_c3", "c3", 2, max_path_len=4, hist_users=8),
     "eval_tiny": lambda: eval_case("eval_tiny", "eval_tiny", 8),
     "eval_default": lambda: eval_case("eval_default", "eval_default", 6),
+    "contract": contract_case,
 }
 
 if __name__ == "__main__":

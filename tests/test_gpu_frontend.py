@@ -1,0 +1,115 @@
+"""-m gpu: the drop-in class API (InfluentialNet/IRSNN/SampleNet/Evaluator) on
+the HIP path against golden outputs of the reference's own methods.
+These tests read like calls to the reference (pipeline.py:187-217, :287-300)."""
+import numpy as np
+import pytest
+import torch
+
+from influentialrs_amd import synth
+from influentialrs_amd.model.evaluator import Evaluator
+from influentialrs_amd.model.influentialRS import IRSNN, InfluentialNet
+from influentialrs_amd.model.uRS import SampleNet
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _irn(cfgname):
+    cfg = synth.make_config(cfgname)
+    net = InfluentialNet(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.irn_state_dict(cfg, 1234).items()})
+    net.to(DEV)
+    irn = IRSNN(cfg, net, DEV)
+    irn.eval()
+    return cfg, net, irn
+
+
+@pytest.mark.parametrize("name,cfgname", [("irn_tiny", "tiny"), ("irn_default", "default"), ("irn_c1", "c1"), ("irn_c2", "c2")])
+def test_irsnn_handlers_match_reference(golden, name, cfgname):
+    g = golden(name)
+    cfg, net, irn = _irn(cfgname)
+    B = g["seqs"].shape[0]
+    raw = [torch.from_numpy(g["raw"][i, :g["raw_len"][i]]) for i in range(B)]
+    seq = torch.from_numpy(g["seqs"]).to(DEV)
+    u = torch.from_numpy(g["users"]).to(DEV)
+    t = torch.from_numpy(g["targets"]).to(DEV)
+    l = torch.from_numpy(g["labels"]).to(DEV)
+    with torch.no_grad():
+        seq_before = seq.clone()
+        r_u = irn.get_pif_in_batch(seq, u)
+        assert r_u.shape == (B, 1) and r_u.dtype == np.float32
+        assert np.abs(r_u[:, 0] - g["r_u"]).max() < 1e-6
+        hit, rr = irn.get_accuracy_metrics_in_batch(raw, seq, u, t, l, 20, 0, True)
+        assert hit == int(g["hit_count"])
+        ref_rr = g["rr"][g["rr"] > 0]
+        assert rr.shape == ref_rr.shape and np.array_equal(rr, ref_rr)  # ranks are integers: exact
+        P = int(g["meta"][2])
+        paths, tt, hh, early = irn.get_seq_in_batch(seq, u, t, P, 0, False, 3)
+        assert paths.dtype == np.float32 and paths.shape == (B, P)
+        assert np.array_equal(paths, g["paths"]) and early == int(g["n_early_success"])
+        assert np.array_equal(tt, g["targets"]) and tt.dtype == np.int64
+        for i in range(B):
+            h = g["seqs"][i, :-1]
+            assert np.array_equal(hh[i], h[h != 0])
+        assert torch.equal(seq, seq_before), "handlers must not modify the caller's seqs"
+
+
+def test_forward_api_materialises_reference_logits(golden):
+    g = golden("irn_tiny")
+    cfg, net, irn = _irn("tiny")
+    with torch.no_grad():
+        out = net(torch.from_numpy(g["seqs"]).to(DEV), torch.from_numpy(g["users"]).to(DEV))
+        assert out.shape == (g["seqs"].shape[0], cfg.max_len, cfg.n_item)
+        ref = g["logits_full"]
+        err = np.abs(out.cpu().numpy() - ref).max()
+        assert err <= 1e-3 * np.abs(ref).max() and err < 5e-5
+        x, pi = net.decoding(torch.from_numpy(g["seqs"]).to(DEV), torch.from_numpy(g["users"]).to(DEV), return_pi=True)
+        assert np.abs(x.cpu().numpy() - g["x_full"]).max() < 2e-5 and pi.shape == (g["seqs"].shape[0], 1)
+        loss = irn.get_loss_on_eval_data(torch.from_numpy(g["seqs"]).to(DEV), torch.from_numpy(g["users"]).to(DEV))
+        assert np.isfinite(loss)
+
+
+def test_early_success_is_trimmed_like_the_reference():
+    """Target = the item the model would pick at step 3 -> path tail zeroed, counted once
+    (influentialRS.py:459-467)."""
+    cfg, net, irn = _irn("tiny")
+    hists = synth.user_histories(8, cfg.n_item, seed=7)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=11)[:2]
+    raws, seqs, users, targets, labels = synth.collate_eval_irs(rows, cfg.max_len, gap_len=0)
+    seq, u, t = (torch.from_numpy(a).to(DEV) for a in (seqs, users, targets))
+    with torch.no_grad():
+        p0, _, _, e0 = irn.get_seq_in_batch(seq, u, t, 8, 0)
+        assert e0 == 0
+        # the target sits in the window's last slot and is filtered, so it cannot be picked:
+        # emulate an early success through the post-processing contract instead
+        t2 = torch.from_numpy(p0[:, 3].astype(np.int64)).to(DEV)
+        p1, tt, _, e1 = irn.get_seq_in_batch(seq, u, t2, 8, 0)
+    assert e1 == 2
+    assert np.array_equal(p1[:, :4], p0[:, :4]) and (p1[:, 4:] == 0).all()
+
+
+@pytest.mark.parametrize("name,cfgname", [("eval_tiny", "eval_tiny"), ("eval_default", "eval_default")])
+def test_evaluator_handlers_match_reference(golden, name, cfgname):
+    g = golden(name)
+    cfg = synth.make_config(cfgname)
+    net = SampleNet(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.irn_state_dict(cfg, 17, evaluator=True).items()})
+    net.to(DEV)
+    ev = Evaluator(cfg, net, DEV)
+    ev.eval()
+    h, d, t, sp, lp = (torch.from_numpy(g[k]).to(DEV) for k in ("histories", "new_seqs", "targets", "start_pos", "l_paths"))
+    with torch.no_grad():
+        pp = ev.get_pp_in_batch(d, sp, lp)
+        assert np.allclose(pp, g["pp"], rtol=1e-5, atol=1e-5)
+        irr, ir = ev.get_rr_increase_in_batch(h, d, t)
+        assert np.array_equal(ir, g["ir"]) and np.allclose(irr, g["irr"], atol=1e-12)
+        h_before = h.clone()
+        tp, ppb, avg, ioi = ev.get_grad_in_batch(h, d, t, sp, lp)
+        assert torch.equal(h, h_before)
+        assert np.allclose(tp, g["t_probs"], rtol=1e-5, atol=2e-5)
+        assert np.allclose(ppb, g["p_probs"], rtol=1e-5, atol=2e-5)
+        assert np.allclose(avg, g["avg_ps"], atol=2e-5) and np.allclose(ioi, g["iois"], atol=4e-5)
+        lg = net(d[:, :-1])
+        ref = g["logits_row0_full"]
+        got = lg[0].cpu().numpy() if ref.shape[0] == lg.shape[1] else lg[0, :4].cpu().numpy()
+        assert np.abs(got - ref).max() < 5e-5

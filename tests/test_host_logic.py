@@ -1,0 +1,106 @@
+"""not-gpu: host-side logic of the drop-in front-end: input contract, checkpoint
+key set, shard arithmetic, training-mode (autograd) semantics, error behaviour."""
+import numpy as np
+import pytest
+import torch
+
+from influentialrs_amd import synth
+from influentialrs_amd.engine import IrsError, shard_bounds
+from influentialrs_amd.model.influentialRS import IRSNN, InfluentialNet
+from influentialrs_amd.model.uRS import SampleNet
+from influentialrs_amd.model.evaluator import Evaluator
+from influentialrs_amd.model.layers import PositionalEncoding, get_end_index, get_item_index, get_start_index
+
+
+def test_collate_matches_reference_dataloader(golden):
+    """synth.collate_eval_irs == DataLoaderEvalIRS._collate_fn (data_provider.py:591-617)."""
+    g = golden("contract")
+    cfg = synth.make_config("default")
+    hists = synth.user_histories(12, cfg.n_item, seed=7)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=11)
+    for gap in (0, 5):
+        raws, seqs, users, targets, labels = synth.collate_eval_irs(rows, cfg.max_len, gap_len=gap)
+        assert np.array_equal(seqs, g[f"collate_gap{gap}_seq"])
+        assert np.array_equal(users, g[f"collate_gap{gap}_users"])
+        assert np.array_equal(targets, g[f"collate_gap{gap}_targets"])
+        assert np.array_equal(labels, g[f"collate_gap{gap}_labels"])
+        for i, r in enumerate(raws):
+            assert np.array_equal(r, g[f"collate_gap{gap}_raw"][i, :g[f"collate_gap{gap}_raw_len"][i]])
+
+
+def test_state_dict_key_set_is_the_reference_one(golden):
+    g = golden("contract")
+    net = InfluentialNet(synth.make_config("tiny"))
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(g["irn_keys"])
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == list(g["irn_shapes"])
+    snet = SampleNet(synth.make_config("eval_tiny"))
+    sd = snet.state_dict()
+    assert list(sd.keys()) == list(g["eval_keys"])
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == list(g["eval_shapes"])
+    # synthetic generator produces exactly that key set, and DataParallel-prefixed checkpoints load
+    cfg = synth.make_config("tiny")
+    w = synth.irn_state_dict(cfg, 1)
+    assert set(w) == set(g["irn_keys"])
+    net.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in w.items()})
+    assert torch.equal(net.project.bias, torch.from_numpy(w["project.bias"]))
+
+
+def test_positional_encoding_and_index_helpers():
+    pe = PositionalEncoding(16, 12)
+    assert np.allclose(pe.pe.numpy(), synth.positional_encoding(16, 12), atol=1e-7)
+    assert pe(torch.zeros(3, 5)).shape == (1, 5, 16)
+    s = np.array([4, 9, 2, 0, 0])
+    assert get_end_index(s) == 2 and get_end_index(np.array([1, 2])) == 1
+    assert get_start_index(np.array([0, 0, 5, 6])) == 2
+    assert get_item_index(s, 9) == 1 and get_item_index(s, 7) == -1
+
+
+def test_shard_bounds_partition_the_catalog():
+    for n in (1, 31, 32, 33, 3415, 1_000_000, 10_000_000):
+        for w in (1, 2, 3, 4, 8):
+            if (n + 31) // 32 < w:
+                continue
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert all(lo % 32 == 0 for lo, _ in b)
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 32 + 31
+
+
+def test_training_mode_is_autograd_with_per_row_as_called_mask(oracle):
+    """B > 1 in training mode (dropout 0): logits equal the oracle's per-row
+    as-called semantics (the published code raises for B > 1)."""
+    cfg = synth.make_config("tiny", dropout=0.0)
+    sd = synth.irn_state_dict(cfg, 1234)
+    net = InfluentialNet(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.train()
+    hists = synth.user_histories(8, cfg.n_item, seed=7)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=11)[:3]
+    raws, seqs, users, targets, labels = synth.collate_eval_irs(rows, cfg.max_len, gap_len=0)
+    out = net(torch.from_numpy(seqs), torch.from_numpy(users)).detach().numpy()
+    for i in range(3):
+        ref = oracle.forward_logits(sd, cfg, seqs[i], users[i], exact=False)
+        assert np.abs(out[i] - ref).max() < 2e-5
+    irn = IRSNN(cfg, net, "cpu")
+    l0 = irn.train_batch(torch.from_numpy(seqs), torch.from_numpy(users))
+    l1 = irn.train_batch(torch.from_numpy(seqs), torch.from_numpy(users))
+    assert np.isfinite(l0) and l1 < l0
+
+
+def test_eval_mode_needs_the_hip_engine():
+    cfg = synth.make_config("tiny")
+    net = InfluentialNet(cfg).eval()
+    seqs = torch.zeros((2, cfg.max_len), dtype=torch.int64)
+    seqs[:, -1] = 3
+    with pytest.raises(IrsError):
+        net(seqs, torch.zeros(2, dtype=torch.int64))
+    irn = IRSNN(cfg, torch.nn.DataParallel(net), "cpu")  # DataParallel is unwrapped (pipeline.py:43-44)
+    assert irn.net is net
+    with pytest.raises(IrsError):
+        irn.get_seq_in_batch(seqs, torch.zeros(2, dtype=torch.int64), torch.tensor([3, 3]), 2, 0)
+    ev = Evaluator(synth.make_config("eval_tiny"), SampleNet(synth.make_config("eval_tiny")).eval(), "cpu")
+    with pytest.raises(IrsError):
+        ev.get_pp_in_batch(torch.ones((2, 13), dtype=torch.int64), torch.tensor([3, 3]), torch.tensor([2, 2]))

@@ -1,0 +1,113 @@
+"""not-gpu: the CPU oracle (oracle/) pinned against golden vectors captured by
+importing the unmodified reference (tests/golden/make_golden.py).
+Tolerances: float32 vs float32 with different accumulation orders -> 5e-6 on
+decoder rows / logits (observed ~5e-7); ids exact where the recorded adjacent
+margin exceeds 1e-5; paths exact."""
+import numpy as np
+import pytest
+
+from influentialrs_amd import synth
+
+IRN = [("irn_tiny", "tiny"), ("irn_default", "default"), ("irn_c1", "c1"), ("irn_c2", "c2")]
+
+
+def _inputs(g):
+    B = g["seqs"].shape[0]
+    raws = [g["raw"][i, :g["raw_len"][i]] for i in range(B)]
+    return raws, g["seqs"], g["users"], g["targets"], g["labels"]
+
+
+@pytest.mark.parametrize("name,cfgname", IRN)
+def test_irn_decoder_logits_topk(oracle, golden, name, cfgname):
+    g = golden(name)
+    cfg = synth.make_config(cfgname)
+    sd = synth.irn_state_dict(cfg, 1234)
+    raws, seqs, users, targets, labels = _inputs(g)
+    B, L = seqs.shape
+    hep = L - 2
+    W, b = sd["project.weight"], sd["project.bias"]
+    for i in range(B):
+        x, ru = oracle.decode(sd, cfg, seqs[i], users[i])
+        assert abs(float(ru) - float(g["r_u"][i])) < 1e-6
+        assert np.abs(x[hep] - g["x_hep"][i]).max() < 5e-6
+        if "x_full" in g.files:
+            assert np.abs(x - g["x_full"][i]).max() < 5e-6
+        s = oracle.score_chain(x[hep], W, b)
+        assert np.abs(s[g["probe_ids0"][i]] - g["probe_vals"][i]).max() < 5e-6
+        if "logits_hep" in g.files:
+            assert np.abs(s - g["logits_hep"][i]).max() < 5e-6
+        v, ids = oracle.topk(s, 100)
+        assert np.abs(v - g["top100_vals"][i]).max() < 5e-6
+        if g["min_margin_top101"][i] > 1e-5:
+            assert np.array_equal(ids, g["top100_ids0"][i])
+    if "logits_full" in g.files:  # every row of forward(), tiny config
+        lg = oracle.forward_logits(sd, cfg, seqs[0], users[0])
+        assert np.abs(lg - g["logits_full"][0]).max() < 5e-6
+
+
+@pytest.mark.parametrize("name,cfgname", IRN)
+def test_irn_accuracy_and_paths(oracle, golden, name, cfgname):
+    g = golden(name)
+    cfg = synth.make_config(cfgname)
+    sd = synth.irn_state_dict(cfg, 1234)
+    raws, seqs, users, targets, labels = _inputs(g)
+    n = seqs.shape[0] if cfgname != "c2" else 1  # keep the CPU suite short
+    hit, rr, ranks = oracle.accuracy_metrics(sd, cfg, raws[:n], seqs[:n], users[:n], labels[:n], top_k=20, gap_len=0)
+    ref_rr = g["rr"][:n]
+    assert np.allclose(rr, ref_rr[ref_rr > 0], rtol=0, atol=1e-12)
+    if n == seqs.shape[0]:
+        assert hit == int(g["hit_count"])
+    P = int(g["meta"][2])
+    paths, tg, hs, ne = oracle.get_seq(sd, cfg, seqs[:n], users[:n], targets[:n], max_path_len=P)
+    assert np.array_equal(paths, g["paths"][:n])
+
+
+def test_irn_c3_million_items(oracle, golden):
+    """1M-item catalog: oracle top-100 and greedy steps against the reference."""
+    g = golden("irn_c3")
+    cfg = synth.make_config("c3")
+    sd = synth.irn_state_dict(cfg, 1234)
+    raws, seqs, users, targets, labels = _inputs(g)
+    hep = cfg.max_len - 2
+    x, _ = oracle.decode(sd, cfg, seqs[0], users[0])
+    assert np.abs(x[hep] - g["x_hep"][0]).max() < 5e-6
+    s = oracle.score_chain(x[hep], sd["project.weight"], sd["project.bias"])
+    v, ids = oracle.topk(s, 100)
+    assert np.abs(v - g["top100_vals"][0]).max() < 5e-6
+    if g["min_margin_top101"][0] > 1e-5:
+        assert np.array_equal(ids, g["top100_ids0"][0])
+    P = int(g["meta"][2])
+    paths, _, _, _ = oracle.get_seq(sd, cfg, seqs[:1], users[:1], targets[:1], max_path_len=P)
+    assert np.array_equal(paths, g["paths"][:1])
+
+
+@pytest.mark.parametrize("name,cfgname", [("eval_tiny", "eval_tiny"), ("eval_default", "eval_default")])
+def test_evaluator_metrics(oracle, golden, name, cfgname):
+    g = golden(name)
+    cfg = synth.make_config(cfgname)
+    sd = synth.irn_state_dict(cfg, 17, evaluator=True)
+    h, d, t, sp, lp = g["histories"], g["new_seqs"], g["targets"], g["start_pos"], g["l_paths"]
+    pp = oracle.eval_get_pp(sd, cfg, d, sp, lp)
+    assert np.allclose(pp, g["pp"], rtol=2e-6, atol=2e-6)
+    irr, ir = oracle.eval_get_rr_increase(sd, cfg, h, d, t)
+    assert np.array_equal(ir, g["ir"]) and np.allclose(irr, g["irr"], atol=1e-12)
+    tp, ppb, avg, ioi = oracle.eval_get_grad(sd, cfg, h, d, t, sp, lp)
+    assert np.allclose(tp, g["t_probs"], rtol=2e-6, atol=2e-6)
+    assert np.allclose(ppb, g["p_probs"], rtol=2e-6, atol=2e-6)
+    assert np.allclose(avg, g["avg_ps"], atol=5e-6) and np.allclose(ioi, g["iois"], atol=5e-6)
+
+
+def test_selection_definitions(oracle):
+    """top-k / rank total order (score desc, id asc), ties, -0 == +0, k > N."""
+    s = np.array([1.0, 3.0, 3.0, -0.0, 0.0, 2.0], dtype=np.float32)
+    v, i = oracle.topk(s, 4)
+    assert list(i) == [1, 2, 5, 0]
+    v, i = oracle.topk(s, 10)
+    assert list(i) == [1, 2, 5, 0, 3, 4]
+    assert oracle.rank_of(s, 2, []) == 2 and oracle.rank_of(s, 1, []) == 1
+    assert oracle.rank_of(s, 4, [1, 1, 7, -1]) == 5  # 2,5,0,3 precede 4 once item 1 is excluded
+    x = np.array([1.5, -2.0], dtype=np.float32)
+    W = np.array([[1.0, 1.0], [0.5, 0.25]], dtype=np.float32)
+    b = np.array([0.25, 0.0], dtype=np.float32)
+    assert list(oracle.score_chain(x, W, b)) == [-0.25, 0.25]
+    assert oracle.bf16_round(np.array([1.00390625], dtype=np.float32))[0] == 1.0  # ties to even
