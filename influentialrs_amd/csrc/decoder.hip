@@ -64,32 +64,48 @@ __global__ void k_cross_const(const float *__restrict__ Wo, const float *__restr
 }
 
 // ------------------------------------------------------------------ linear
-// Y[M,N] = act(X[M,K] . W[N,K]^T + bias[N]) (+ R[M,N]);  X, W, Y row-major.
-// 256 threads = 4 waves (2x2), wave tile 64x64 = 2x2 MFMA 32x32x2f32 tiles.
+// Y[M,N] = epilogue(X[M,K] . W[N,K]^T + bias[N]);  X, W, Y row-major fp32.
+// 256 threads = 4 waves (2x2); wave tile 64x64 = 2x2 v_mfma_f32_32x32x2_f32 tiles; block tile
+// 128x128, K staged in slabs of 32 through LDS (double buffered, rows padded to 36 floats so
+// that staging stores are 16-byte and fragment reads stay cheap next to 64-cycle MFMAs).
+// The accumulator tile is staged through the same LDS for a coalesced float4 epilogue:
+//   EPI_BIAS       y = acc + b (relu optional)
+//   EPI_RES_LN     z = acc + b + R;  y = LN(z; g1, b1);  if (c) y = LN(y + c; g2, b2)
+//                  (needs the whole row in the tile: N <= 128, grid.x == 1) -- this is
+//                  out-proj + LN1 + (x + c_l) + LN2, and FFN2 + LN3, of the post-norm layer.
 #define LIN_BM 128
 #define LIN_BN 128
-#define LIN_BK 16
-#define LIN_LD 17
+#define LIN_BK 32
+#define LIN_TLD 132
+#define EPI_BIAS 0
+#define EPI_RES_LN 1
 
+struct LinArgs {
+    const float *X, *W, *bias, *R;
+    float *Y;
+    int M, N, K;
+    int relu;
+    const float *g1, *b1, *c, *g2, *b2; // EPI_RES_LN
+};
+
+// LDS slab image: [128 rows][32 floats], 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7).
+// A wave's ds_read_b128 of (row = lane&31 (+const), chunk 2q + (lane>>5)) is then bank-conflict free,
+// and the staging stores are whole 16-byte chunks.  MFMA k-slots: for the 8 k of group q, half 0
+// supplies k = 8q + t and half 1 supplies k = 8q + 4 + t in step t (A and B agree, so any
+// assignment of k to slots is a valid contraction).
 template <bool VEC>
 __device__ __forceinline__ void lin_load_tile(const float *__restrict__ P, int rows, int K, int r0, int k0, int tid,
-                                              float4 (&v)[2]) {
+                                              float4 (&v)[4]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
         int idx = tid + i * 256;
-        int r = idx >> 2, c = (idx & 3) * 4;
+        int r = idx >> 3, c = (idx & 7) * 4;
         int gr = r0 + r, gk = k0 + c;
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gr < rows) {
             const float *p = P + (int64_t)gr * K + gk;
-            if (VEC) {
-                if (gk + 3 < K) t = *reinterpret_cast<const float4 *>(p);
-                else {
-                    if (gk < K) t.x = p[0];
-                    if (gk + 1 < K) t.y = p[1];
-                    if (gk + 2 < K) t.z = p[2];
-                }
-            } else {
+            if (VEC && gk + 3 < K) t = *reinterpret_cast<const float4 *>(p);
+            else {
                 if (gk < K) t.x = p[0];
                 if (gk + 1 < K) t.y = p[1];
                 if (gk + 2 < K) t.z = p[2];
@@ -100,86 +116,185 @@ __device__ __forceinline__ void lin_load_tile(const float *__restrict__ P, int r
     }
 }
 
-__device__ __forceinline__ void lin_store_tile(float (*S)[LIN_LD], int tid, const float4 (&v)[2]) {
+__device__ __forceinline__ void lin_store_tile(float *S, int tid, const float4 (&v)[4]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
         int idx = tid + i * 256;
-        int r = idx >> 2, c = (idx & 3) * 4;
-        S[r][c + 0] = v[i].x;
-        S[r][c + 1] = v[i].y;
-        S[r][c + 2] = v[i].z;
-        S[r][c + 3] = v[i].w;
+        int r = idx >> 3, c = idx & 7;
+        *reinterpret_cast<float4 *>(S + r * LIN_BK + ((c ^ ((r >> 1) & 7)) << 2)) = v[i];
     }
 }
 
-template <bool VEC, bool RELU>
-__global__ void __launch_bounds__(256) k_linear(const float *__restrict__ X, const float *__restrict__ W,
-                                                const float *__restrict__ bias, const float *__restrict__ R,
-                                                float *__restrict__ Y, int M, int N, int K) {
-    __shared__ float Xs[2][LIN_BM][LIN_LD];
-    __shared__ float Ws[2][LIN_BN][LIN_LD];
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <bool VEC, int EPI>
+__global__ void __launch_bounds__(256, 2) k_linear(LinArgs a) {
+    // staging: [stage][operand][128][32] floats = 65,536 B; reused as the [128][132] output tile (67,584 B)
+    __shared__ __attribute__((aligned(16))) float sm[LIN_BM * LIN_TLD];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lk = lane >> 5;
     const int n0 = blockIdx.x * LIN_BN, m0 = blockIdx.y * LIN_BM;
+    const int M = a.M, N = a.N, K = a.K;
+    auto Xs = [&](int st) { return sm + (st * 2 + 0) * LIN_BM * LIN_BK; };
+    auto Ws = [&](int st) { return sm + (st * 2 + 1) * LIN_BM * LIN_BK; };
 
     f32x16 acc[2][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 xv[2], wv[2];
-    lin_load_tile<VEC>(X, M, K, m0, 0, tid, xv);
-    lin_load_tile<VEC>(W, N, K, n0, 0, tid, wv);
-    lin_store_tile(Xs[0], tid, xv);
-    lin_store_tile(Ws[0], tid, wv);
+    // residual in C layout, issued before the K loop so its latency hides under the MFMAs
+    f32x16 res[2][2];
+    if (EPI == EPI_RES_LN) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int n = n0 + wc * 64 + tn * 32 + li;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    res[tm][tn][r] = (m < M && n < N) ? a.R[(int64_t)m * N + n] : 0.f;
+                }
+        }
+    }
+
+    float4 xv[4], wv[4];
+    lin_load_tile<VEC>(a.X, M, K, m0, 0, tid, xv);
+    lin_load_tile<VEC>(a.W, N, K, n0, 0, tid, wv);
+    lin_store_tile(Xs(0), tid, xv);
+    lin_store_tile(Ws(0), tid, wv);
     __syncthreads();
     const int nkt = (K + LIN_BK - 1) / LIN_BK;
+    const int sw = (li >> 1) & 7;
     int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) {
-            lin_load_tile<VEC>(X, M, K, m0, (kt + 1) * LIN_BK, tid, xv);
-            lin_load_tile<VEC>(W, N, K, n0, (kt + 1) * LIN_BK, tid, wv);
+            lin_load_tile<VEC>(a.X, M, K, m0, (kt + 1) * LIN_BK, tid, xv);
+            lin_load_tile<VEC>(a.W, N, K, n0, (kt + 1) * LIN_BK, tid, wv);
         }
+        const float *xa = Xs(cur) + (wr * 64 + li) * LIN_BK;
+        const float *wb = Ws(cur) + (wc * 64 + li) * LIN_BK;
 #pragma unroll
-        for (int ks = 0; ks < LIN_BK / 2; ++ks) {
-            float a0 = Xs[cur][wr * 64 + li][2 * ks + lk];
-            float a1 = Xs[cur][wr * 64 + 32 + li][2 * ks + lk];
-            float b0 = Ws[cur][wc * 64 + li][2 * ks + lk];
-            float b1 = Ws[cur][wc * 64 + 32 + li][2 * ks + lk];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int q = 0; q < LIN_BK / 8; ++q) {
+            const int off = ((2 * q + lk) ^ sw) << 2;
+            const float4 a0 = *reinterpret_cast<const float4 *>(xa + off);
+            const float4 a1 = *reinterpret_cast<const float4 *>(xa + 32 * LIN_BK + off);
+            const float4 b0 = *reinterpret_cast<const float4 *>(wb + off);
+            const float4 b1 = *reinterpret_cast<const float4 *>(wb + 32 * LIN_BK + off);
+#define LIN_STEP(E)                                                                       \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.E, b0.E, acc[0][0], 0, 0, 0);     \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.E, b1.E, acc[0][1], 0, 0, 0);     \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.E, b0.E, acc[1][0], 0, 0, 0);     \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.E, b1.E, acc[1][1], 0, 0, 0);
+            LIN_STEP(x) LIN_STEP(y) LIN_STEP(z) LIN_STEP(w)
+#undef LIN_STEP
         }
         if (kt + 1 < nkt) {
-            lin_store_tile(Xs[cur ^ 1], tid, xv);
-            lin_store_tile(Ws[cur ^ 1], tid, wv);
+            lin_store_tile(Xs(cur ^ 1), tid, xv);
+            lin_store_tile(Ws(cur ^ 1), tid, wv);
         }
         __syncthreads();
         cur ^= 1;
     }
-    // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // accumulators (+bias, +residual) -> LDS tile T[128][132]; C/D layout col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)
+    float *T = sm;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
-        int n = n0 + wc * 64 + tn * 32 + li;
-        if (n >= N) continue;
-        float bv = bias ? bias[n] : 0.f;
+        const int nl = wc * 64 + tn * 32 + li;
+        const float bv = (a.bias && n0 + nl < N) ? a.bias[n0 + nl] : 0.f;
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
+        for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int m = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (m < M) {
-                    float v = acc[tm][tn][r] + bv;
-                    if (RELU) v = fmaxf(v, 0.f);
-                    if (R) v += R[(int64_t)m * N + n];
-                    Y[(int64_t)m * N + n] = v;
+                const int ml = wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                float v = acc[tm][tn][r] + bv;
+                if (EPI == EPI_RES_LN) v += res[tm][tn][r];
+                if (EPI == EPI_BIAS && a.relu) v = fmaxf(v, 0.f);
+                T[ml * LIN_TLD + nl] = v;
+            }
+    }
+    __syncthreads();
+    if (EPI == EPI_BIAS) {
+        const bool vec_out = VEC && (N % 4 == 0);
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            int idx = tid + i * 256;
+            int r = idx >> 5, c = (idx & 31) * 4;
+            int gm = m0 + r, gn = n0 + c;
+            if (gm >= M || gn >= N) continue;
+            float4 v = *reinterpret_cast<const float4 *>(T + r * LIN_TLD + c);
+            if (a.R) { // residual (rows wider than one tile: LN runs as its own kernel)
+                const float *rp = a.R + (int64_t)gm * N + gn;
+                if (vec_out && gn + 3 < N) {
+                    float4 rv = *reinterpret_cast<const float4 *>(rp);
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                } else {
+                    v.x += rp[0];
+                    if (gn + 1 < N) v.y += rp[1];
+                    if (gn + 2 < N) v.z += rp[2];
+                    if (gn + 3 < N) v.w += rp[3];
                 }
+            }
+            float *dst = a.Y + (int64_t)gm * N + gn;
+            if (vec_out && gn + 3 < N) *reinterpret_cast<float4 *>(dst) = v;
+            else {
+                dst[0] = v.x;
+                if (gn + 1 < N) dst[1] = v.y;
+                if (gn + 2 < N) dst[2] = v.z;
+                if (gn + 3 < N) dst[3] = v.w;
+            }
+        }
+    } else {
+        // one wave per row, 32 rows per wave; lane owns columns 2*lane, 2*lane+1 (N <= 128); LDS only
+        const int c0 = 2 * lane;
+        const bool in0 = c0 < N, in1 = c0 + 1 < N;
+        const float invn = 1.0f / (float)N;
+        float g1a = in0 ? a.g1[c0] : 0.f, g1b = in1 ? a.g1[c0 + 1] : 0.f;
+        float b1a = in0 ? a.b1[c0] : 0.f, b1b = in1 ? a.b1[c0 + 1] : 0.f;
+        float ca = 0.f, cb = 0.f, g2a = 0.f, g2b = 0.f, b2a = 0.f, b2b = 0.f;
+        if (a.c) {
+            ca = in0 ? a.c[c0] : 0.f;
+            cb = in1 ? a.c[c0 + 1] : 0.f;
+            g2a = in0 ? a.g2[c0] : 0.f;
+            g2b = in1 ? a.g2[c0 + 1] : 0.f;
+            b2a = in0 ? a.b2[c0] : 0.f;
+            b2b = in1 ? a.b2[c0 + 1] : 0.f;
+        }
+#pragma unroll 4
+        for (int rr = 0; rr < 32; ++rr) {
+            const int r = wave * 32 + rr;
+            const int gm = m0 + r;
+            if (gm < M) {
+                float2 t = *reinterpret_cast<const float2 *>(T + r * LIN_TLD + c0);
+                float z0 = in0 ? t.x : 0.f;
+                float z1 = in1 ? t.y : 0.f;
+                float mu = wave_sum(z0 + z1) * invn;
+                float d0 = in0 ? z0 - mu : 0.f, d1 = in1 ? z1 - mu : 0.f;
+                float rstd = 1.0f / sqrtf(wave_sum(d0 * d0 + d1 * d1) * invn + 1e-5f);
+                float y0 = d0 * rstd * g1a + b1a, y1 = d1 * rstd * g1b + b1b;
+                if (a.c) {
+                    z0 = in0 ? y0 + ca : 0.f;
+                    z1 = in1 ? y1 + cb : 0.f;
+                    mu = wave_sum(z0 + z1) * invn;
+                    d0 = in0 ? z0 - mu : 0.f;
+                    d1 = in1 ? z1 - mu : 0.f;
+                    rstd = 1.0f / sqrtf(wave_sum(d0 * d0 + d1 * d1) * invn + 1e-5f);
+                    y0 = d0 * rstd * g2a + b2a;
+                    y1 = d1 * rstd * g2b + b2b;
+                }
+                float *Yr = a.Y + (int64_t)gm * N;
+                if (in0 && in1) *reinterpret_cast<float2 *>(Yr + c0) = make_float2(y0, y1);
+                else if (in0) Yr[c0] = y0;
             }
         }
     }
@@ -316,14 +431,403 @@ __global__ void __launch_bounds__(256) k_attn(const float *__restrict__ qkv, con
     }
 }
 
-// ------------------------------------------------------------------ layer norm
-// y = LN(z; g1, b1); if (c) y = LN(y + c; g2, b2).  One wave per row, d <= 512.
-__device__ __forceinline__ float wave_sum(float v) {
+// ------------------------------------------------------------------ linear + residual + LayerNorm (N <= 128)
+// y = LN(X W^T + b + R; g1, b1); if (c) y = LN(y + c; g2, b2)      -- out-proj + LN1 (+c_l, LN2), FFN2 + LN3.
+// Transposed MFMA orientation: D[n][m] = W_tile[n][k] . X^T[k][m], so a lane owns ONE token (column
+// lane&31) and a wave owns all 128 output columns of its 32 tokens (4 accumulators = 64 values per
+// lane, the other 64 in lane^32).  LayerNorm is then register-local: 64-term sums plus one xor-32
+// shuffle per statistic -- no LDS staging, no barrier, no per-row shuffle chains.
+// Workgroup = 4 waves = 128 tokens; W (all N rows) and X slabs of 32 k stream through the same
+// swizzled double-buffered LDS image as k_linear.
+__global__ void __launch_bounds__(256, 2) k_linear_ln(LinArgs a) {
+    __shared__ __attribute__((aligned(16))) float sm[2 * 2 * LIN_BM * LIN_BK + 6 * LIN_BN];
+    float *vecs = sm + 2 * 2 * LIN_BM * LIN_BK; // bias, g1, b1, c, g2, b2 (zero padded to 128)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int m0 = blockIdx.x * LIN_BM;
+    const int M = a.M, N = a.N, K = a.K;
+    const bool vecA = (K % 4 == 0) && ((((uintptr_t)a.X) & 15) == 0) && ((((uintptr_t)a.W) & 15) == 0);
+    auto Xs = [&](int st) { return sm + (st * 2 + 0) * LIN_BM * LIN_BK; };
+    auto Ws = [&](int st) { return sm + (st * 2 + 1) * LIN_BM * LIN_BK; };
+    if (tid < LIN_BN) {
+        const bool in = tid < N;
+        vecs[0 * LIN_BN + tid] = (in && a.bias) ? a.bias[tid] : 0.f;
+        vecs[1 * LIN_BN + tid] = in ? a.g1[tid] : 0.f;
+        vecs[2 * LIN_BN + tid] = in ? a.b1[tid] : 0.f;
+        vecs[3 * LIN_BN + tid] = (in && a.c) ? a.c[tid] : 0.f;
+        vecs[4 * LIN_BN + tid] = (in && a.c) ? a.g2[tid] : 0.f;
+        vecs[5 * LIN_BN + tid] = (in && a.c) ? a.b2[tid] : 0.f;
+    }
+    const int mt = m0 + wave * 32 + li; // this lane's token
+    const bool nvec = (N % 4 == 0) && ((((uintptr_t)a.R) & 15) == 0) && ((((uintptr_t)a.Y) & 15) == 0);
+
+    f32x16 acc[4];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tn][r] = 0.f;
+    // residual of this lane's token, C layout: register 4g+e of tile tn is column tn*32 + 8g + 4lk + e
+    float4 res[4][4];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = tn * 32 + 8 * g + 4 * lk;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (mt < M && n < N) {
+                const float *p = a.R + (int64_t)mt * N + n;
+                if (nvec && n + 3 < N) t = *reinterpret_cast<const float4 *>(p);
+                else {
+                    t.x = p[0];
+                    if (n + 1 < N) t.y = p[1];
+                    if (n + 2 < N) t.z = p[2];
+                    if (n + 3 < N) t.w = p[3];
+                }
+            }
+            res[tn][g] = t;
+        }
+
+    float4 xv[4], wv[4];
+    if (vecA) {
+        lin_load_tile<true>(a.X, M, K, m0, 0, tid, xv);
+        lin_load_tile<true>(a.W, N, K, 0, 0, tid, wv);
+    } else {
+        lin_load_tile<false>(a.X, M, K, m0, 0, tid, xv);
+        lin_load_tile<false>(a.W, N, K, 0, 0, tid, wv);
+    }
+    lin_store_tile(Xs(0), tid, xv);
+    lin_store_tile(Ws(0), tid, wv);
+    __syncthreads();
+    const int nkt = (K + LIN_BK - 1) / LIN_BK;
+    const int sw = (li >> 1) & 7;
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) {
+            if (vecA) {
+                lin_load_tile<true>(a.X, M, K, m0, (kt + 1) * LIN_BK, tid, xv);
+                lin_load_tile<true>(a.W, N, K, 0, (kt + 1) * LIN_BK, tid, wv);
+            } else {
+                lin_load_tile<false>(a.X, M, K, m0, (kt + 1) * LIN_BK, tid, xv);
+                lin_load_tile<false>(a.W, N, K, 0, (kt + 1) * LIN_BK, tid, wv);
+            }
+        }
+        const float *xb = Xs(cur) + (wave * 32 + li) * LIN_BK;
+        const float *wa = Ws(cur) + li * LIN_BK;
+#pragma unroll
+        for (int q = 0; q < LIN_BK / 8; ++q) {
+            const int off = ((2 * q + lk) ^ sw) << 2;
+            const float4 x4 = *reinterpret_cast<const float4 *>(xb + off);
+            const float4 w0 = *reinterpret_cast<const float4 *>(wa + off);
+            const float4 w1 = *reinterpret_cast<const float4 *>(wa + 32 * LIN_BK + off);
+            const float4 w2 = *reinterpret_cast<const float4 *>(wa + 64 * LIN_BK + off);
+            const float4 w3 = *reinterpret_cast<const float4 *>(wa + 96 * LIN_BK + off);
+#define LN_STEP(E)                                                                   \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.E, x4.E, acc[0], 0, 0, 0);      \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.E, x4.E, acc[1], 0, 0, 0);      \
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2.E, x4.E, acc[2], 0, 0, 0);      \
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w3.E, x4.E, acc[3], 0, 0, 0);
+            LN_STEP(x) LN_STEP(y) LN_STEP(z) LN_STEP(w)
+#undef LN_STEP
+        }
+        if (kt + 1 < nkt) {
+            lin_store_tile(Xs(cur ^ 1), tid, xv);
+            lin_store_tile(Ws(cur ^ 1), tid, wv);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // ---- register-local LayerNorm of this lane's token (64 of its N values here, 64 in lane^32)
+    const float invn = 1.0f / (float)N;
+    float sum = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = tn * 32 + 8 * g + 4 * lk;
+            const float4 bb = *reinterpret_cast<const float4 *>(vecs + n);
+            float z0 = acc[tn][4 * g + 0] + bb.x + res[tn][g].x;
+            float z1 = acc[tn][4 * g + 1] + bb.y + res[tn][g].y;
+            float z2 = acc[tn][4 * g + 2] + bb.z + res[tn][g].z;
+            float z3 = acc[tn][4 * g + 3] + bb.w + res[tn][g].w;
+            if (n >= N) z0 = 0.f;
+            if (n + 1 >= N) z1 = 0.f;
+            if (n + 2 >= N) z2 = 0.f;
+            if (n + 3 >= N) z3 = 0.f;
+            acc[tn][4 * g + 0] = z0;
+            acc[tn][4 * g + 1] = z1;
+            acc[tn][4 * g + 2] = z2;
+            acc[tn][4 * g + 3] = z3;
+            sum += (z0 + z1) + (z2 + z3);
+        }
+    auto stats = [&](float s1, float &mu, float &rstd) {
+        mu = (s1 + __shfl_xor(s1, 32, 64)) * invn;
+        float q = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const float dlt = (n < N) ? acc[tn][r] - mu : 0.f;
+                q += dlt * dlt;
+            }
+        rstd = 1.0f / sqrtf((q + __shfl_xor(q, 32, 64)) * invn + 1e-5f);
+    };
+    float mu, rstd;
+    stats(sum, mu, rstd);
+    const bool two = a.c != nullptr;
+    sum = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = tn * 32 + 8 * g + 4 * lk;
+            const float4 gg = *reinterpret_cast<const float4 *>(vecs + 1 * LIN_BN + n);
+            const float4 be = *reinterpret_cast<const float4 *>(vecs + 2 * LIN_BN + n);
+            const float4 cc = *reinterpret_cast<const float4 *>(vecs + 3 * LIN_BN + n);
+            float y0 = (acc[tn][4 * g + 0] - mu) * rstd * gg.x + be.x + cc.x;
+            float y1 = (acc[tn][4 * g + 1] - mu) * rstd * gg.y + be.y + cc.y;
+            float y2 = (acc[tn][4 * g + 2] - mu) * rstd * gg.z + be.z + cc.z;
+            float y3 = (acc[tn][4 * g + 3] - mu) * rstd * gg.w + be.w + cc.w;
+            if (n >= N) y0 = 0.f;
+            if (n + 1 >= N) y1 = 0.f;
+            if (n + 2 >= N) y2 = 0.f;
+            if (n + 3 >= N) y3 = 0.f;
+            acc[tn][4 * g + 0] = y0;
+            acc[tn][4 * g + 1] = y1;
+            acc[tn][4 * g + 2] = y2;
+            acc[tn][4 * g + 3] = y3;
+            sum += (y0 + y1) + (y2 + y3);
+        }
+    if (two) {
+        stats(sum, mu, rstd);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = tn * 32 + 8 * g + 4 * lk;
+                const float4 gg = *reinterpret_cast<const float4 *>(vecs + 4 * LIN_BN + n);
+                const float4 be = *reinterpret_cast<const float4 *>(vecs + 5 * LIN_BN + n);
+                acc[tn][4 * g + 0] = (acc[tn][4 * g + 0] - mu) * rstd * gg.x + be.x;
+                acc[tn][4 * g + 1] = (acc[tn][4 * g + 1] - mu) * rstd * gg.y + be.y;
+                acc[tn][4 * g + 2] = (acc[tn][4 * g + 2] - mu) * rstd * gg.z + be.z;
+                acc[tn][4 * g + 3] = (acc[tn][4 * g + 3] - mu) * rstd * gg.w + be.w;
+            }
+    }
+    if (mt < M) {
+        float *Yr = a.Y + (int64_t)mt * N;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = tn * 32 + 8 * g + 4 * lk;
+                if (n >= N) continue;
+                if (nvec && n + 3 < N)
+                    *reinterpret_cast<float4 *>(Yr + n) = make_float4(acc[tn][4 * g], acc[tn][4 * g + 1], acc[tn][4 * g + 2], acc[tn][4 * g + 3]);
+                else {
+                    Yr[n] = acc[tn][4 * g];
+                    if (n + 1 < N) Yr[n + 1] = acc[tn][4 * g + 1];
+                    if (n + 2 < N) Yr[n + 2] = acc[tn][4 * g + 2];
+                    if (n + 3 < N) Yr[n + 3] = acc[tn][4 * g + 3];
+                }
+            }
+    }
 }
 
+// ------------------------------------------------------------------ attention on fp32 MFMA
+// One workgroup per (head, sequence), 4 waves; K_h / V_h of the sequence in LDS.
+// A wave owns 32-query blocks.  Per (query block, key block):
+//   S^T[key][q] = K . Q^T            HDP/2 x v_mfma_f32_32x32x2_f32  (lane = query, regs = 16 keys)
+//   online softmax on the 16 registers (row max/sum are register-local; the two
+//   lane halves of a query are combined with one xor-32 shuffle)
+//   O^T[c][q] += V^T . P^T           16 MFMAs per 32 head columns; the B operand IS the S^T
+//   accumulator (register t of lane (q,kk) is key (t&3)+8(t>>2)+4kk of query q), so P never
+//   leaves registers.
+// MFMA k-slots of S^T: lane half kk supplies head column kk*HDP/2 + s in step s (contiguous
+// per lane -> float4 loads of Q).  Causal structure: key blocks kb <= qb only; a per-block
+// bitmask of masked keys (pads, keys >= L, the IRN target) lets fully masked blocks be skipped
+// and clean blocks take a mask-free path.  The IRN mask's target column (key L-1, +1.0,
+// visible to every query) seeds the online softmax with one VALU dot product per query.
+template <int HDP, bool V4>
+__global__ void __launch_bounds__(256) k_attn_mfma(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
+                                                   const float *__restrict__ r_u, float *__restrict__ out, int L,
+                                                   int d, int hd, int mask_mode) {
+    constexpr int HH = HDP / 2;               // MFMA k-steps of S^T; head columns per lane half
+    constexpr int VW = HDP < 32 ? 32 : HDP;   // V columns kept in LDS (zero padded)
+    constexpr int CT = VW / 32;               // 32-column tiles of O^T
+    constexpr int KLD = HDP + 1;              // padded K row stride (conflict-free column reads)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NB = (L + 31) / 32, Lp = NB * 32;
+    float *Vs = reinterpret_cast<float *>(smem);        // [Lp][VW]  (16-byte aligned rows)
+    float *Ks = Vs + (size_t)Lp * VW;                   // [Lp][KLD]
+    unsigned int *padbits = reinterpret_cast<unsigned int *>(Ks + (size_t)Lp * KLD); // [8]
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, kk = lane >> 5;
+    const int64_t base = (int64_t)b * L;
+    const int ld = 3 * d;
+    const bool irn = (mask_mode == IRS_MASK_IRN);
+    if (V4) {
+        constexpr int C4 = HDP / 4;
+        for (int idx = tid; idx < Lp * C4; idx += 256) {
+            int j = idx / C4, c = (idx % C4) * 4;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (j < L && c < hd) {
+                const float *row = qkv + (base + j) * ld + h * hd + c;
+                kv = *reinterpret_cast<const float4 *>(row + d);
+                vv = *reinterpret_cast<const float4 *>(row + 2 * d);
+            }
+            float *kd = Ks + (size_t)j * KLD + c;
+            kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+            *reinterpret_cast<float4 *>(Vs + (size_t)j * VW + c) = vv;
+        }
+        if (VW > HDP)
+            for (int idx = tid; idx < Lp * (VW - HDP); idx += 256) Vs[(size_t)(idx / (VW - HDP)) * VW + HDP + idx % (VW - HDP)] = 0.f;
+    } else {
+        for (int idx = tid; idx < Lp * VW; idx += 256) {
+            int j = idx / VW, c = idx % VW;
+            float kv = 0.f, vv = 0.f;
+            if (j < L && c < hd) {
+                const float *row = qkv + (base + j) * ld + h * hd + c;
+                kv = row[d];
+                vv = row[2 * d];
+            }
+            if (c < HDP) Ks[(size_t)j * KLD + c] = kv;
+            Vs[idx] = vv;
+        }
+    }
+    for (int kb = wave; kb < NB; kb += 4) { // masked-key bitmask of each key block
+        int j = kb * 32 + lq;
+        bool masked = (j >= L) || (seq[base + (j < L ? j : L - 1)] == 0) || (irn && j == L - 1);
+        unsigned long long bal = __ballot(masked);
+        if (lane == 0) padbits[kb] = (unsigned int)bal;
+    }
+    __syncthreads();
+    const float add_allowed = irn ? r_u[b] : 0.f;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const bool tgt_ok = irn && (seq[base + L - 1] != 0);
+
+    for (int pass = 0; pass < 2; ++pass) {
+        const int qb = pass == 0 ? wave : NB - 1 - wave;
+        if (qb >= NB || (pass == 1 && qb < 4)) continue;
+        const int qi = qb * 32 + lq; // this lane's query
+        // Q fragments (B operand of S^T): Q[qi][kk*HH + s] * scale
+        float qf[HH];
+        {
+            const float *qrow = qkv + (base + (qi < L ? qi : L - 1)) * ld + h * hd + kk * HH;
+            if (V4) {
+#pragma unroll
+                for (int s4 = 0; s4 < HH / 4; ++s4) {
+                    float4 t = (kk * HH + 4 * s4 < hd) ? *reinterpret_cast<const float4 *>(qrow + 4 * s4)
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                    qf[4 * s4 + 0] = t.x * scale;
+                    qf[4 * s4 + 1] = t.y * scale;
+                    qf[4 * s4 + 2] = t.z * scale;
+                    qf[4 * s4 + 3] = t.w * scale;
+                }
+            } else {
+#pragma unroll
+                for (int s2 = 0; s2 < HH; ++s2) qf[s2] = (kk * HH + s2 < hd) ? qrow[s2] * scale : 0.f;
+            }
+            if (qi >= L) {
+#pragma unroll
+                for (int s2 = 0; s2 < HH; ++s2) qf[s2] = 0.f;
+            }
+        }
+        float m = -INFINITY, l = 0.f;
+        f32x16 o[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+        if (tgt_ok) { // target column: s = q . K[L-1] + 1.0, p = 1
+            float part = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < HH; ++s2) part = __fmaf_rn(qf[s2], Ks[(size_t)(L - 1) * KLD + kk * HH + s2], part);
+            float st = part + __shfl_xor(part, 32, 64) + 1.0f;
+            m = st;
+            l = (kk == 0) ? 1.f : 0.f; // halves are summed at the end
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[ct][r] = Vs[(size_t)(L - 1) * VW + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk];
+        }
+        for (int kb = 0; kb <= qb; ++kb) {
+            const unsigned int pm = padbits[kb];
+            if (pm == 0xFFFFFFFFu) continue; // nothing visible in this key block (wave-uniform)
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            const float *kp = Ks + (size_t)(kb * 32 + lq) * KLD + kk * HH;
+#pragma unroll
+            for (int s2 = 0; s2 < HH; ++s2) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[s2], qf[s2], sacc, 0, 0, 0);
+            float mx = -INFINITY;
+            if (pm == 0u && kb < qb) { // clean off-diagonal block: no masking
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sacc[r] += add_allowed;
+                    mx = fmaxf(mx, sacc[r]);
+                }
+            } else {
+                const unsigned int pmk = pm >> (4 * kk);
+                const int qlim = (kb < qb) ? 64 : lq - 4 * kk; // key index (within block, minus 4kk) must be <= qlim
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ki = (r & 3) + 8 * (r >> 2); // + 4kk = key index within the block
+                    bool ok = !((pmk >> ki) & 1u) && (ki <= qlim);
+                    float v = ok ? sacc[r] + add_allowed : -INFINITY;
+                    sacc[r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m, mx);
+            const bool dead = (mn == -INFINITY);
+            const float alpha = dead ? 1.f : __expf(m - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pv = dead ? 0.f : __expf(sacc[r] - mn);
+                sacc[r] = pv;
+                ps += pv;
+            }
+            l = l * alpha + ps;
+            m = mn;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+                const float *vp = Vs + (size_t)(kb * 32 + 4 * kk) * VW + ct * 32 + lq; // A: V^T[c = lq][key]
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    o[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[((t & 3) + 8 * (t >> 2)) * VW], sacc[t], o[ct], 0, 0, 0);
+            }
+        }
+        const float lt = l + __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / lt; // 0 (fully masked) -> inf, 0 * inf = NaN like torch
+        if (qi < L) {
+            float *orow = out + (base + qi) * d + h * hd;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = ct * 32 + 8 * g + 4 * kk;
+                    if (V4) {
+                        if (c < hd)
+                            *reinterpret_cast<float4 *>(orow + c) = make_float4(o[ct][4 * g] * inv, o[ct][4 * g + 1] * inv,
+                                                                                 o[ct][4 * g + 2] * inv, o[ct][4 * g + 3] * inv);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (c + e < hd) orow[c + e] = o[ct][4 * g + e] * inv;
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ layer norm
+// y = LN(z; g1, b1); if (c) y = LN(y + c; g2, b2).  One wave per row, d <= 512.
 __global__ void __launch_bounds__(256) k_ln(const float *__restrict__ z, const float *__restrict__ g1,
                                             const float *__restrict__ b1, const float *__restrict__ c,
                                             const float *__restrict__ g2, const float *__restrict__ b2,
@@ -400,16 +904,19 @@ __global__ void k_gather_rows(const float *__restrict__ x, const int32_t *__rest
 
 // ------------------------------------------------------------------ host side
 static int launch_linear(irs_ctx *ctx, const float *X, const float *W, const float *bias, const float *R, float *Y,
-                         int M, int N, int K, bool relu, hipStream_t s) {
-    dim3 grid((N + LIN_BN - 1) / LIN_BN, (M + LIN_BM - 1) / LIN_BM);
-    bool vec = (K % 4 == 0) && ((((uintptr_t)X) & 15) == 0) && ((((uintptr_t)W) & 15) == 0);
+                         int M, int N, int K, bool relu, hipStream_t s, const float *g1 = nullptr,
+                         const float *b1 = nullptr, const float *c = nullptr, const float *g2 = nullptr,
+                         const float *b2 = nullptr) {
+    LinArgs a{X, W, bias, R, Y, M, N, K, relu ? 1 : 0, g1, b1, c, g2, b2};
     irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
-    if (vec) {
-        if (relu) hipLaunchKernelGGL((k_linear<true, true>), grid, dim3(256), 0, s, X, W, bias, R, Y, M, N, K);
-        else hipLaunchKernelGGL((k_linear<true, false>), grid, dim3(256), 0, s, X, W, bias, R, Y, M, N, K);
+    if (g1 != nullptr) { // fused residual + LayerNorm: whole rows per wave (N <= 128)
+        hipLaunchKernelGGL(k_linear_ln, dim3((M + LIN_BM - 1) / LIN_BM), dim3(256), 0, s, a);
     } else {
-        if (relu) hipLaunchKernelGGL((k_linear<false, true>), grid, dim3(256), 0, s, X, W, bias, R, Y, M, N, K);
-        else hipLaunchKernelGGL((k_linear<false, false>), grid, dim3(256), 0, s, X, W, bias, R, Y, M, N, K);
+        dim3 grid((N + LIN_BN - 1) / LIN_BN, (M + LIN_BM - 1) / LIN_BM);
+        bool vec = (K % 4 == 0) && ((((uintptr_t)X) & 15) == 0) && ((((uintptr_t)W) & 15) == 0) && ((((uintptr_t)Y) & 15) == 0) &&
+                   (!R || (((uintptr_t)R) & 15) == 0);
+        if (vec) hipLaunchKernelGGL((k_linear<true, EPI_BIAS>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_linear<false, EPI_BIAS>), grid, dim3(256), 0, s, a);
     }
     irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * M * (double)N * K,
                  4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)));
@@ -420,16 +927,25 @@ static int launch_linear(irs_ctx *ctx, const float *X, const float *W, const flo
 static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const float *r_u, float *out, int B,
                        hipStream_t s) {
     const int L = ctx->dims.max_len, d = ctx->dims.d, H = ctx->dims.n_heads, hd = d / H;
-    int HD = hd <= 8 ? 8 : hd <= 16 ? 16 : hd <= 32 ? 32 : 64;
-    size_t lds = (size_t)2 * L * HD * sizeof(float) + ((L + 15) & ~15);
+    const int HDP = hd <= 8 ? 8 : hd <= 16 ? 16 : hd <= 32 ? 32 : 64;
+    const int Lp = ((L + 31) / 32) * 32, VW = HDP < 32 ? 32 : HDP;
+    size_t lds = (size_t)Lp * (HDP + 1) * 4 + (size_t)Lp * VW * 4 + 64;
+    const bool v4 = (hd % 4 == 0) && (d % 4 == 0) && ((((uintptr_t)qkv) & 15) == 0) && ((((uintptr_t)out) & 15) == 0);
     dim3 grid(H, B);
+    const int mm = ctx->dims.mask_mode;
     irs_prof_begin(ctx, IRS_PROF_ATTN, s);
-    switch (HD) {
-    case 8: hipLaunchKernelGGL((k_attn<8>), grid, dim3(256), lds, s, qkv, seq, r_u, out, L, d, hd, ctx->dims.mask_mode); break;
-    case 16: hipLaunchKernelGGL((k_attn<16>), grid, dim3(256), lds, s, qkv, seq, r_u, out, L, d, hd, ctx->dims.mask_mode); break;
-    case 32: hipLaunchKernelGGL((k_attn<32>), grid, dim3(256), lds, s, qkv, seq, r_u, out, L, d, hd, ctx->dims.mask_mode); break;
-    default: hipLaunchKernelGGL((k_attn<64>), grid, dim3(256), lds, s, qkv, seq, r_u, out, L, d, hd, ctx->dims.mask_mode); break;
+#define A_(HDP_)                                                                                                   \
+    do {                                                                                                           \
+        if (v4) hipLaunchKernelGGL((k_attn_mfma<HDP_, true>), grid, dim3(256), lds, s, qkv, seq, r_u, out, L, d, hd, mm); \
+        else hipLaunchKernelGGL((k_attn_mfma<HDP_, false>), grid, dim3(256), lds, s, qkv, seq, r_u, out, L, d, hd, mm);   \
+    } while (0)
+    switch (HDP) {
+    case 8: A_(8); break;
+    case 16: A_(16); break;
+    case 32: A_(32); break;
+    default: A_(64); break;
     }
+#undef A_
     irs_prof_end(ctx, IRS_PROF_ATTN, s, 2.0 * B * (double)H * L * L * hd, 4.0 * 4.0 * B * (double)L * d);
     IRS_CHECK_HIP(ctx, hipGetLastError());
     return IRS_OK;
@@ -473,15 +989,26 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         // qkv = x W_in^T + b_in
         if ((rc = launch_linear(ctx, x, w.sa_in_w, w.sa_in_b, nullptr, ctx->act_qkv, rows, 3 * d, d, false, s))) return rc;
         if ((rc = launch_attn(ctx, ctx->act_qkv, seq, ctx->act_ru, ctx->act_ao, B, s))) return rc;
-        // y = x + ao W_o^T + b_o ; x = LN2(LN1(y) + c_l)
-        if ((rc = launch_linear(ctx, ctx->act_ao, w.sa_out_w, w.sa_out_b, x, y, rows, d, d, false, s))) return rc;
-        hipLaunchKernelGGL(k_ln, dim3((rows + 3) / 4), dim3(256), 0, s, y, w.n1_w, w.n1_b, ctx->c_l + (size_t)l * d,
-                           w.n2_w, w.n2_b, x, rows, d);
-        // h = relu(x W1^T + b1); y = x + h W2^T + b2; x = LN3(y)
-        if ((rc = launch_linear(ctx, x, w.l1_w, w.l1_b, nullptr, ctx->act_h, rows, F, d, true, s))) return rc;
-        if ((rc = launch_linear(ctx, ctx->act_h, w.l2_w, w.l2_b, x, y, rows, d, F, false, s))) return rc;
-        hipLaunchKernelGGL(k_ln, dim3((rows + 3) / 4), dim3(256), 0, s, y, w.n3_w, w.n3_b, (const float *)nullptr,
-                           (const float *)nullptr, (const float *)nullptr, x, rows, d);
+        const float *cl = ctx->c_l + (size_t)l * d;
+        if (d <= LIN_BN) {
+            // x <- LN2(LN1(x + ao W_o^T + b_o) + c_l), fused into the GEMM epilogue (in place is not safe: y)
+            if ((rc = launch_linear(ctx, ctx->act_ao, w.sa_out_w, w.sa_out_b, x, y, rows, d, d, false, s, w.n1_w, w.n1_b,
+                                    cl, w.n2_w, w.n2_b)))
+                return rc;
+            // h = relu(y W1^T + b1); x <- LN3(y + h W2^T + b2)
+            if ((rc = launch_linear(ctx, y, w.l1_w, w.l1_b, nullptr, ctx->act_h, rows, F, d, true, s))) return rc;
+            if ((rc = launch_linear(ctx, ctx->act_h, w.l2_w, w.l2_b, y, x, rows, d, F, false, s, w.n3_w, w.n3_b))) return rc;
+        } else {
+            // y = x + ao W_o^T + b_o ; x = LN2(LN1(y) + c_l)
+            if ((rc = launch_linear(ctx, ctx->act_ao, w.sa_out_w, w.sa_out_b, x, y, rows, d, d, false, s))) return rc;
+            hipLaunchKernelGGL(k_ln, dim3((rows + 3) / 4), dim3(256), 0, s, y, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, x,
+                               rows, d);
+            // h = relu(x W1^T + b1); y = x + h W2^T + b2; x = LN3(y)
+            if ((rc = launch_linear(ctx, x, w.l1_w, w.l1_b, nullptr, ctx->act_h, rows, F, d, true, s))) return rc;
+            if ((rc = launch_linear(ctx, ctx->act_h, w.l2_w, w.l2_b, x, y, rows, d, F, false, s))) return rc;
+            hipLaunchKernelGGL(k_ln, dim3((rows + 3) / 4), dim3(256), 0, s, y, w.n3_w, w.n3_b, (const float *)nullptr,
+                               (const float *)nullptr, (const float *)nullptr, x, rows, d);
+        }
         IRS_CHECK_HIP(ctx, hipGetLastError());
     }
     if (x_out) IRS_CHECK_HIP(ctx, hipMemcpyAsync(x_out, x, sizeof(float) * (size_t)rows * d, hipMemcpyDeviceToDevice, s));
