@@ -130,10 +130,10 @@ class Job:
             val, ids, _ = eng.score_topk(xr, self.k, self.sweep)
         else:
             import torch.distributed as dist
-            dist.all_gather_into_tensor(self.x_all, xr)
+            dist.all_gather_into_tensor(self.x_all.view(-1), xr.view(-1))
             v, i, _ = eng.score_topk(self.x_all, self.k, self.sweep)
-            dist.all_gather_into_tensor(self.v_all, v)
-            dist.all_gather_into_tensor(self.i_all, i)
+            dist.all_gather_into_tensor(self.v_all.view(-1), v.view(-1))
+            dist.all_gather_into_tensor(self.i_all.view(-1), i.view(-1))
             mv, mi = eng.merge_topk(self.v_all, self.i_all)
             lo = self.rank * self.B
             val, ids = mv[lo:lo + self.B].contiguous(), mi[lo:lo + self.B].contiguous()
@@ -203,6 +203,9 @@ def main():
     ap.add_argument("--sweep", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                    "the N > 1 code path with several ranks on ONE GPU)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -211,11 +214,14 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", 0 if args.same_device else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     job = Job(args, rank, world, device)
     cfg = job.cfg
