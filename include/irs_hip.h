@@ -208,6 +208,30 @@ int irs_generate_paths(irs_ctx *ctx, int64_t *dev_seq, const int64_t *dev_user, 
                        int32_t max_path_len, int32_t k, int32_t sweep, int32_t sample, int32_t sample_k,
                        uint64_t seed, int32_t use_graph, float *dev_paths, int32_t *dev_status, void *stream);
 
+/* ---- beam search over persuasion paths (BUILD-DEFINED: the reference has no beam
+ *      search -- SURVEY fact 4; BASELINE.json config 5).  Beam width W <= 32, path
+ *      length P <= 64.  W == 1 is the greedy search of irs_generate_paths id for id.
+ * One step for B users x W beams given each beam row's merged top-k (descending) and,
+ * for W > 1, its row-wise (max, sum exp) over the whole catalog:
+ *   candidates = first W window-survivors of every live beam, scored
+ *   cum + (val - max - log(sumexp)); best W by (score desc, parent asc, rank asc) survive.
+ * State is ping-ponged: *_in -> *_out ([B, W, ...] row-major; cum = -inf marks a dead beam). */
+int irs_beam_step(irs_ctx *ctx, const int64_t *dev_seq_in, const int32_t *dev_hep_in, const double *dev_cum_in,
+                  const float *dev_paths_in, const float *dev_val, const int64_t *dev_ids0, const float *dev_lse_max,
+                  const float *dev_lse_sum, int32_t B, int32_t W, int32_t k, int32_t step, int32_t P,
+                  int64_t *dev_seq_out, int32_t *dev_hep_out, double *dev_cum_out, float *dev_paths_out,
+                  int32_t *dev_status, void *stream);
+
+/* Whole beam search on ONE device holding the full catalog: P x { decode B*W windows, top-k,
+ * log-sum-exp, beam step } on the stream; use_graph != 0 captures a two-step hipGraph once and
+ * replays it.  Needs max_seqs >= B*W and max_rows >= B*W.
+ *  dev_seq0 int64 [B, L], dev_user int64 [B], dev_hep0 int32 [B]  (not modified)
+ *  dev_paths float [B, W, P] out (beam 0 = best), dev_scores double [B, W] out,
+ *  dev_seq_final int64 [B, W, L] out (may be NULL), dev_status int32 [B] out */
+int irs_beam_search(irs_ctx *ctx, const int64_t *dev_seq0, const int64_t *dev_user, const int32_t *dev_hep0, int32_t B,
+                    int32_t W, int32_t P, int32_t k, int32_t sweep, int32_t use_graph, float *dev_paths,
+                    double *dev_scores, int64_t *dev_seq_final, int32_t *dev_status, void *stream);
+
 /* ---- measurement hooks (bench.py only) ---------------------------------
  * While enabled, every launch of the named kernel family is bracketed by HIP
  * events on the launch stream; irs_prof_read() synchronises those events and

@@ -75,6 +75,7 @@ extern "C" int irs_create(irs_ctx **out, const irs_dims *dims, const irs_shard *
 extern "C" void irs_destroy(irs_ctx *ctx) {
     if (!ctx) return;
     if (ctx->graph_exec) hipGraphExecDestroy(ctx->graph_exec);
+    if (ctx->beam_graph) hipGraphExecDestroy(ctx->beam_graph);
     if (ctx->prof_ev) {
         for (int i = 0; i < ctx->prof_cap; ++i) {
             hipEventDestroy(ctx->prof_ev[i].a);
@@ -204,12 +205,17 @@ extern "C" int irs_finalize_weights(irs_ctx *ctx, void *arena, size_t bytes, voi
         hipGraphExecDestroy(ctx->graph_exec);
         ctx->graph_exec = nullptr;
     }
+    if (ctx->beam_graph) {
+        hipGraphExecDestroy(ctx->beam_graph);
+        ctx->beam_graph = nullptr;
+    }
     return IRS_OK;
 }
 
 // ------------------------------------------------------------------ workspace
 struct ws_plan {
-    size_t x, y, qkv, ao, h, ru, xb, eps, thr, gm, cnt, cand, lse, ref, xrows, tval, tids, status, step, pos, total;
+    size_t x, y, qkv, ao, h, ru, xb, eps, thr, gm, cnt, cand, lse, ref, xrows, tval, tids, status, step, pos;
+    size_t bseq[2], bhep[2], bcum[2], bpaths[2], buser, lmax, lsum, total;
 };
 
 static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
@@ -242,6 +248,15 @@ static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
     p->status = take((size_t)ctx->max_rows * 4);
     p->step = take(256);
     p->pos = take((size_t)ctx->max_seqs * 4);
+    for (int i = 0; i < 2; ++i) {
+        p->bseq[i] = take((size_t)ctx->max_seqs * D.max_len * 8);
+        p->bhep[i] = take((size_t)ctx->max_seqs * 4);
+        p->bcum[i] = take((size_t)ctx->max_seqs * 8);
+        p->bpaths[i] = take((size_t)ctx->max_seqs * IRS_MAX_PATH * 4);
+    }
+    p->buser = take((size_t)ctx->max_seqs * 8);
+    p->lmax = take((size_t)ctx->max_rows * 4);
+    p->lsum = take((size_t)ctx->max_rows * 4);
     p->total = off;
 }
 
@@ -281,6 +296,19 @@ extern "C" int irs_bind_workspace(irs_ctx *ctx, void *ws, size_t bytes) {
     ctx->row_status = (int32_t *)(b + p.status);
     ctx->step_ctr = (int32_t *)(b + p.step);
     ctx->pos_tmp = (int32_t *)(b + p.pos);
+    for (int i = 0; i < 2; ++i) {
+        ctx->bm_seq[i] = (int64_t *)(b + p.bseq[i]);
+        ctx->bm_hep[i] = (int32_t *)(b + p.bhep[i]);
+        ctx->bm_cum[i] = (double *)(b + p.bcum[i]);
+        ctx->bm_paths[i] = (float *)(b + p.bpaths[i]);
+    }
+    ctx->bm_user = (int64_t *)(b + p.buser);
+    ctx->lse_max = (float *)(b + p.lmax);
+    ctx->lse_sum = (float *)(b + p.lsum);
+    if (ctx->beam_graph) {
+        hipGraphExecDestroy(ctx->beam_graph);
+        ctx->beam_graph = nullptr;
+    }
     if (ctx->graph_exec) {
         hipGraphExecDestroy(ctx->graph_exec);
         ctx->graph_exec = nullptr;
@@ -463,6 +491,105 @@ extern "C" int irs_generate_paths(irs_ctx *ctx, int64_t *seq, const int64_t *use
         ctx->graph_seed = seed;
     }
     for (int i = 0; i < max_path_len; ++i) IRS_CHECK_HIP(ctx, hipGraphLaunch(ctx->graph_exec, s));
+    return IRS_OK;
+}
+
+// ------------------------------------------------------------------ beam search
+extern "C" int irs_beam_step(irs_ctx *ctx, const int64_t *seq_in, const int32_t *hep_in, const double *cum_in,
+                             const float *paths_in, const float *val, const int64_t *ids0, const float *lse_max,
+                             const float *lse_sum, int32_t B, int32_t W, int32_t k, int32_t step, int32_t P,
+                             int64_t *seq_out, int32_t *hep_out, double *cum_out, float *paths_out, int32_t *status,
+                             void *stream) {
+    if (!ctx) return IRS_E_INVALID;
+    if (!seq_in || !hep_in || !cum_in || !paths_in || !val || !ids0 || !seq_out || !hep_out || !cum_out || !paths_out ||
+        !status || B < 1 || W < 1 || k < 1 || P < 1 || step < 0 || step >= P)
+        IRS_FAIL(ctx, IRS_E_INVALID, "irs_beam_step: bad arguments");
+    if (W > 1 && (!lse_max || !lse_sum)) IRS_FAIL(ctx, IRS_E_INVALID, "irs_beam_step: W > 1 needs the row log-sum-exp");
+    return irs_launch_beam_step(ctx, seq_in, hep_in, cum_in, paths_in, val, ids0, W > 1 ? lse_max : nullptr,
+                                W > 1 ? lse_sum : nullptr, B, W, k, step, nullptr, P, seq_out, hep_out, cum_out,
+                                paths_out, status, (hipStream_t)stream);
+}
+
+static int enqueue_beam_step(irs_ctx *ctx, int in, int B, int W, int k, int sweep, int P, int32_t *status, hipStream_t s) {
+    const int out = in ^ 1, rows = B * W;
+    int rc;
+    if ((rc = irs_launch_decode(ctx, ctx->bm_seq[in], ctx->bm_user, rows, nullptr, ctx->bm_hep[in], ctx->xrows, nullptr, s))) return rc;
+    if ((rc = irs_launch_topk(ctx, ctx->xrows, rows, k, sweep, ctx->top_val, ctx->top_ids, ctx->row_status, s))) return rc;
+    if (W > 1 && (rc = irs_launch_lse(ctx, ctx->xrows, rows, ctx->lse_max, ctx->lse_sum, s))) return rc;
+    if ((rc = irs_launch_beam_step(ctx, ctx->bm_seq[in], ctx->bm_hep[in], ctx->bm_cum[in], ctx->bm_paths[in], ctx->top_val,
+                                   ctx->top_ids, W > 1 ? ctx->lse_max : nullptr, W > 1 ? ctx->lse_sum : nullptr, B, W, k, 0,
+                                   ctx->step_ctr, P, ctx->bm_seq[out], ctx->bm_hep[out], ctx->bm_cum[out],
+                                   ctx->bm_paths[out], status, s)))
+        return rc;
+    return irs_launch_inc(ctx, ctx->step_ctr, s);
+}
+
+extern "C" int irs_beam_search(irs_ctx *ctx, const int64_t *seq0, const int64_t *user, const int32_t *hep0, int32_t B,
+                               int32_t W, int32_t P, int32_t k, int32_t sweep, int32_t use_graph, float *paths,
+                               double *scores, int64_t *seq_final, int32_t *status, void *stream) {
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if (ctx->shard.world != 1) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "irs_beam_search needs the whole catalog on one device");
+    if (!seq0 || !hep0 || !paths || !scores || !status || B < 1) IRS_FAIL(ctx, IRS_E_INVALID, "irs_beam_search: bad arguments");
+    if (W < 1 || W > 32) IRS_FAIL(ctx, IRS_E_INVALID, "irs_beam_search: beam width must be in [1, 32]");
+    if (P < 1 || P > IRS_MAX_PATH) IRS_FAIL(ctx, IRS_E_INVALID, "irs_beam_search: path length must be in [1, %d]", IRS_MAX_PATH);
+    if ((int64_t)B * W > ctx->max_seqs || (int64_t)B * W > ctx->max_rows)
+        IRS_FAIL(ctx, IRS_E_INVALID, "irs_beam_search: B*W=%d exceeds max_seqs=%d / max_rows=%d", B * W, ctx->max_seqs, ctx->max_rows);
+    if (k < 1 || k > ctx->dims.max_k) IRS_FAIL(ctx, IRS_E_INVALID, "irs_beam_search: bad k");
+    if (sweep != IRS_SWEEP_BF16 && sweep != IRS_SWEEP_F32) IRS_FAIL(ctx, IRS_E_INVALID, "irs_beam_search: bad sweep");
+    if (ctx->dims.mask_mode == IRS_MASK_IRN && !user) IRS_FAIL(ctx, IRS_E_INVALID, "irs_beam_search: user is null");
+    hipStream_t s = (hipStream_t)stream;
+    IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->step_ctr, 0, sizeof(int32_t), s));
+    IRS_CHECK_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t) * B, s));
+    if ((rc = irs_launch_beam_init(ctx, seq0, user, hep0, B, W, P, ctx->bm_seq[0], ctx->bm_user, ctx->bm_hep[0],
+                                   ctx->bm_cum[0], ctx->bm_paths[0], s)))
+        return rc;
+    int done = 0;
+    if (use_graph && P >= 2 && ctx->prof_family == IRS_PROF_NONE) {
+        // NOTE: `status` is baked into the captured graph, so it is part of the cache key via its address below
+        static_assert(sizeof(void *) == 8, "64-bit only");
+        bool reuse = ctx->beam_graph && ctx->beam_B == B && ctx->beam_W == W && ctx->beam_k == k &&
+                     ctx->beam_sweep == sweep && ctx->beam_P == P && ctx->graph_status == (void *)status;
+        if (!reuse) {
+            if (ctx->beam_graph) {
+                hipGraphExecDestroy(ctx->beam_graph);
+                ctx->beam_graph = nullptr;
+            }
+            hipStream_t cs;
+            IRS_CHECK_HIP(ctx, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                rc = enqueue_beam_step(ctx, 0, B, W, k, sweep, P, status, cs);
+                if (rc == IRS_OK) rc = enqueue_beam_step(ctx, 1, B, W, k, sweep, P, status, cs);
+                hipError_t e2 = hipStreamEndCapture(cs, &graph);
+                if (rc == IRS_OK && e2 != hipSuccess) e = e2;
+            }
+            if (e == hipSuccess && rc == IRS_OK && graph) e = hipGraphInstantiate(&ctx->beam_graph, graph, nullptr, nullptr, 0);
+            if (graph) hipGraphDestroy(graph);
+            hipStreamDestroy(cs);
+            if (rc) return rc;
+            if (e != hipSuccess) {
+                ctx->beam_graph = nullptr;
+                IRS_FAIL(ctx, IRS_E_HIP, "beam graph capture failed: %s", hipGetErrorString(e));
+            }
+            ctx->beam_B = B;
+            ctx->beam_W = W;
+            ctx->beam_k = k;
+            ctx->beam_sweep = sweep;
+            ctx->beam_P = P;
+            ctx->graph_status = status;
+        }
+        for (; done + 2 <= P; done += 2) IRS_CHECK_HIP(ctx, hipGraphLaunch(ctx->beam_graph, s));
+    }
+    for (; done < P; ++done)
+        if ((rc = enqueue_beam_step(ctx, done & 1, B, W, k, sweep, P, status, s))) return rc;
+    const int fin = P & 1;
+    const size_t rows = (size_t)B * W;
+    IRS_CHECK_HIP(ctx, hipMemcpyAsync(paths, ctx->bm_paths[fin], rows * P * sizeof(float), hipMemcpyDeviceToDevice, s));
+    IRS_CHECK_HIP(ctx, hipMemcpyAsync(scores, ctx->bm_cum[fin], rows * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (seq_final)
+        IRS_CHECK_HIP(ctx, hipMemcpyAsync(seq_final, ctx->bm_seq[fin], rows * ctx->dims.max_len * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     return IRS_OK;
 }
 

@@ -13,6 +13,7 @@
 #define IRS_CAND_CAP 4096   // emitted candidates kept per row by the sweep
 #define IRS_REFINE_CAP 1024 // candidates exactly re-scored per row
 #define IRS_MAX_GROUPS 8192 // pre-pass group maxima per row (upper bound)
+#define IRS_MAX_PATH 64     // beam-search path length bound
 
 struct irs_layer_w {
     const float *sa_in_w, *sa_in_b, *sa_out_w, *sa_out_b;
@@ -69,6 +70,15 @@ struct irs_ctx {
     int32_t *row_status;// [max_rows]
     int32_t *step_ctr;  // [1]
     int32_t *pos_tmp;   // [max_seqs]
+    // beam-search state, ping-pong [2]
+    int64_t *bm_seq[2];  // [max_seqs][L]
+    int32_t *bm_hep[2];  // [max_seqs]
+    double *bm_cum[2];   // [max_seqs]
+    float *bm_paths[2];  // [max_seqs][IRS_MAX_PATH]
+    int64_t *bm_user;    // [max_seqs]
+    float *lse_max, *lse_sum; // [max_rows]
+    hipGraphExec_t beam_graph;
+    int beam_B, beam_W, beam_k, beam_sweep, beam_P;
 
     // graph cache for irs_generate_paths
     hipGraphExec_t graph_exec;
@@ -128,6 +138,13 @@ int irs_launch_path_step(irs_ctx *ctx, int64_t *seq, int32_t *hep, int B, const 
                          int step, const int32_t *step_ptr, float *paths, int path_ld, int sample, int sample_k,
                          uint64_t seed, int32_t *status, hipStream_t s);
 int irs_launch_inc(irs_ctx *ctx, int32_t *ctr, hipStream_t s);
+int irs_launch_beam_init(irs_ctx *ctx, const int64_t *seq0, const int64_t *user0, const int32_t *hep0, int B, int W,
+                         int P, int64_t *seq, int64_t *user, int32_t *hep, double *cum, float *paths, hipStream_t s);
+int irs_launch_beam_step(irs_ctx *ctx, const int64_t *seq_in, const int32_t *hep_in, const double *cum_in,
+                         const float *paths_in, const float *val, const int64_t *ids0, const float *lse_max,
+                         const float *lse_sum, int B, int W, int k, int step, const int32_t *step_ptr, int P,
+                         int64_t *seq_out, int32_t *hep_out, double *cum_out, float *paths_out, int32_t *status,
+                         hipStream_t s);
 
 // ---- small device helpers ----
 #ifdef __HIPCC__

@@ -151,6 +151,170 @@ __global__ void __launch_bounds__(256) k_merge(const float *__restrict__ val_in,
     }
 }
 
+// ------------------------------------------------------------------ beam search step
+// BUILD-DEFINED extension (the reference has no beam search; BASELINE config 5).
+// Per user: W beams, each a window + cumulative log-probability.  One step:
+//   for every live beam j: survivors = its top-k candidates (descending) not present in its
+//   window; the first W survivors become candidates with score cum[j] + log p(item | beam j),
+//   log p = e - max - log(sumexp) (row-wise log-softmax over the whole catalog);
+//   the best W candidates by (score desc, parent beam asc, rank within parent asc) become the
+//   new beams: window grown / shifted exactly like the greedy step, path extended.
+// W == 1 reduces to the greedy step of k_path_step bit for bit (the single live beam's first
+// survivor wins whatever its score; lse_* may then be null).
+// One workgroup (256 threads) per user; state is ping-ponged (in -> out).
+#define BEAM_MAXW 32
+__global__ void __launch_bounds__(256) k_beam_step(const int64_t *__restrict__ seq_in, const int32_t *__restrict__ hep_in,
+                                                   const double *__restrict__ cum_in, const float *__restrict__ paths_in,
+                                                   const float *__restrict__ val, const int64_t *__restrict__ ids0,
+                                                   const float *__restrict__ lse_max, const float *__restrict__ lse_sum,
+                                                   int W, int L, int k, int step_arg, const int32_t *__restrict__ step_ptr,
+                                                   int P, int64_t *__restrict__ seq_out, int32_t *__restrict__ hep_out,
+                                                   double *__restrict__ cum_out, float *__restrict__ paths_out,
+                                                   int32_t *__restrict__ status) {
+    __shared__ double c_score[BEAM_MAXW * BEAM_MAXW];
+    __shared__ int64_t c_item[BEAM_MAXW * BEAM_MAXW];
+    __shared__ int c_order[BEAM_MAXW * BEAM_MAXW];
+    __shared__ int c_count[BEAM_MAXW];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int step = step_ptr ? step_ptr[0] : step_arg;
+    const int WW = W * W;
+    for (int i = tid; i < WW; i += 256) {
+        c_score[i] = -INFINITY;
+        c_item[i] = 0;
+    }
+    __syncthreads();
+    // phase 1: survivors of every live beam (one wave per beam)
+    for (int j = wave; j < W; j += 4) {
+        const int row = b * W + j;
+        const double cj = cum_in[row];
+        int found = 0;
+        if (cj > -INFINITY) {
+            const int64_t *w = seq_in + (size_t)row * L;
+            const int wl = hep_in[row] + 1;
+            int64_t wv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int p = lane + 64 * i;
+                wv[i] = (p < wl && p < L) ? w[p] : (int64_t)-1;
+            }
+            double norm = 0.0;
+            if (lse_max) norm = (double)lse_max[row] + log((double)lse_sum[row]);
+            for (int c = 0; c < k && found < W; ++c) {
+                int64_t id0 = ids0[(size_t)row * k + c];
+                if (id0 < 0) break;
+                int64_t item = id0 + 1;
+                bool hit = false;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hit |= (wv[i] == item);
+                if (!__any(hit)) {
+                    if (lane == 0) {
+                        c_score[j * W + found] = cj + ((double)val[(size_t)row * k + c] - norm);
+                        c_item[j * W + found] = item;
+                    }
+                    ++found;
+                }
+            }
+            if (found == 0 && lane == 0) atomicOr(&status[b], IRS_ROW_NO_CANDIDATE);
+        }
+        if (lane == 0) c_count[j] = found;
+    }
+    __syncthreads();
+    // phase 2: order candidates by (score desc, index asc); index = parent * W + rank
+    int n2 = 2;
+    while (n2 < WW) n2 <<= 1;
+    for (int i = tid; i < n2; i += 256) c_order[i] = i;
+    // indices >= WW compare as -inf with a larger index: they sink to the end
+    auto before = [&](int x, int y) {
+        double sx = x < WW ? c_score[x] : -INFINITY, sy = y < WW ? c_score[y] : -INFINITY;
+        return sx > sy || (sx == sy && x < y);
+    };
+    for (int size = 2; size <= n2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = tid; i < n2 / 2; i += 256) {
+                int lo = 2 * i - (i & (stride - 1));
+                int hi = lo + stride;
+                bool asc = ((lo & size) == 0); // "ascending rank" = best first
+                int x = c_order[lo], y = c_order[hi];
+                if (before(y, x) == asc) {
+                    c_order[lo] = y;
+                    c_order[hi] = x;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // phase 3: materialise the new beams (one wave per new beam)
+    for (int t = wave; t < W; t += 4) {
+        const int ci = c_order[t];
+        const double sc = ci < WW ? c_score[ci] : -INFINITY;
+        const int orow = b * W + t;
+        int64_t *wo = seq_out + (size_t)orow * L;
+        float *po = paths_out + (size_t)orow * P;
+        if (!(sc > -INFINITY)) { // dead beam: keep a well-formed (copied) window, never selected again
+            const int64_t *wi = seq_in + (size_t)(b * W) * L;
+            for (int p = lane; p < L; p += 64) wo[p] = wi[p];
+            for (int p = lane; p < P; p += 64) po[p] = 0.f;
+            if (lane == 0) {
+                cum_out[orow] = -INFINITY;
+                hep_out[orow] = hep_in[b * W];
+            }
+            continue;
+        }
+        const int parent = ci / W;
+        const int prow = b * W + parent;
+        const int64_t item = c_item[ci];
+        const int64_t *wi = seq_in + (size_t)prow * L;
+        const float *pi = paths_in + (size_t)prow * P;
+        const int he = hep_in[prow];
+        if (he < L - 2) { // grow
+            for (int p = lane; p < L; p += 64) wo[p] = (p == he + 1) ? item : wi[p];
+            if (lane == 0) hep_out[orow] = he + 1;
+        } else { // shift, target stays last
+            for (int p = lane; p < L; p += 64) wo[p] = (p < L - 2) ? wi[p + 1] : (p == L - 2 ? item : wi[L - 1]);
+            if (lane == 0) hep_out[orow] = he;
+        }
+        for (int p = lane; p < P; p += 64) po[p] = (p < step) ? pi[p] : (p == step ? (float)item : 0.f);
+        if (lane == 0) cum_out[orow] = sc;
+    }
+}
+
+// beam state initialisation: beam 0 = the input window with score 0, others dead copies
+__global__ void k_beam_init(const int64_t *__restrict__ seq0, const int64_t *__restrict__ user0,
+                            const int32_t *__restrict__ hep0, int B, int W, int L, int P, int64_t *__restrict__ seq,
+                            int64_t *__restrict__ user, int32_t *__restrict__ hep, double *__restrict__ cum,
+                            float *__restrict__ paths) {
+    const int row = blockIdx.x; // b * W + j
+    const int b = row / W, j = row % W;
+    for (int p = threadIdx.x; p < L; p += blockDim.x) seq[(size_t)row * L + p] = seq0[(size_t)b * L + p];
+    for (int p = threadIdx.x; p < P; p += blockDim.x) paths[(size_t)row * P + p] = 0.f;
+    if (threadIdx.x == 0) {
+        user[row] = user0 ? user0[b] : 0;
+        hep[row] = hep0[b];
+        cum[row] = (j == 0) ? 0.0 : -INFINITY;
+    }
+}
+
+int irs_launch_beam_init(irs_ctx *ctx, const int64_t *seq0, const int64_t *user0, const int32_t *hep0, int B, int W,
+                         int P, int64_t *seq, int64_t *user, int32_t *hep, double *cum, float *paths, hipStream_t s) {
+    hipLaunchKernelGGL(k_beam_init, dim3(B * W), dim3(64), 0, s, seq0, user0, hep0, B, W, ctx->dims.max_len, P, seq,
+                       user, hep, cum, paths);
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}
+
+int irs_launch_beam_step(irs_ctx *ctx, const int64_t *seq_in, const int32_t *hep_in, const double *cum_in,
+                         const float *paths_in, const float *val, const int64_t *ids0, const float *lse_max,
+                         const float *lse_sum, int B, int W, int k, int step, const int32_t *step_ptr, int P,
+                         int64_t *seq_out, int32_t *hep_out, double *cum_out, float *paths_out, int32_t *status,
+                         hipStream_t s) {
+    if (W < 1 || W > BEAM_MAXW) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "beam width %d outside [1, %d]", W, BEAM_MAXW);
+    hipLaunchKernelGGL(k_beam_step, dim3(B), dim3(256), 0, s, seq_in, hep_in, cum_in, paths_in, val, ids0, lse_max,
+                       lse_sum, W, ctx->dims.max_len, k, step, step_ptr, P, seq_out, hep_out, cum_out, paths_out, status);
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}
+
 int irs_launch_merge(irs_ctx *ctx, const float *val_in, const int64_t *ids_in, int W, int M, int k, float *val,
                      int64_t *ids0, hipStream_t s) {
     if (W * k > 2048) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "merge of %d x %d entries exceeds 2048", W, k);

@@ -226,6 +226,34 @@ class Engine:
                                                 self._stream()))
         return paths, status
 
+    # ------------------------------------------------------------------ beam search (build-defined extension)
+    def beam_step(self, state_in, val, ids0, lse, step: int, state_out, status):
+        """One beam step; state = (seq[B,W,L] i64, hep[B,W] i32, cum[B,W] f64, paths[B,W,P] f32)."""
+        seq_i, hep_i, cum_i, paths_i = state_in
+        seq_o, hep_o, cum_o, paths_o = state_out
+        B, W, _ = seq_i.shape
+        lmax, lsum = lse if lse is not None else (None, None)
+        self._check(self.lib.irs_beam_step(self.h, _ptr(seq_i), _ptr(hep_i), _ptr(cum_i), _ptr(paths_i), _ptr(val),
+                                           _ptr(ids0), _ptr(lmax), _ptr(lsum), B, W, val.shape[1], step,
+                                           paths_i.shape[2], _ptr(seq_o), _ptr(hep_o), _ptr(cum_o), _ptr(paths_o),
+                                           _ptr(status), self._stream()))
+
+    def beam_search(self, seqs: torch.Tensor, users: Optional[torch.Tensor], hep: torch.Tensor, max_path_len: int,
+                    beam: int, k: int = 100, sweep: int = IRS_SWEEP_BF16, use_graph: bool = False,
+                    want_windows: bool = False):
+        """(paths[B,W,P] f32, scores[B,W] f64, status[B] i32[, windows[B,W,L]]); beam 0 is the best."""
+        seqs = self._dev(seqs, torch.int64)
+        hep = self._dev(hep, torch.int32)
+        B = seqs.shape[0]
+        paths = torch.zeros((B, beam, max_path_len), dtype=torch.float32, device=self.device)
+        scores = torch.zeros((B, beam), dtype=torch.float64, device=self.device)
+        status = torch.zeros(B, dtype=torch.int32, device=self.device)
+        fin = torch.empty((B, beam, self.L), dtype=torch.int64, device=self.device) if want_windows else None
+        self._check(self.lib.irs_beam_search(self.h, _ptr(seqs), _ptr(users), _ptr(hep), B, beam, max_path_len, k, sweep,
+                                             int(use_graph), _ptr(paths), _ptr(scores), _ptr(fin), _ptr(status),
+                                             self._stream()))
+        return (paths, scores, status, fin) if want_windows else (paths, scores, status)
+
     # ------------------------------------------------------------------ measurement
     def prof_enable(self, family: int):
         self._check(self.lib.irs_prof_enable(self.h, family))

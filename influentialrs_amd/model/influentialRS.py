@@ -222,9 +222,53 @@ class IRSNN(nn.Module):
             rr.append(np.reciprocal(float(ranks[i])))
         return hit_count, np.array(rr)
 
-    def get_seq_in_batch(self, seqs, users, targets, max_path_len=20, gap_len=20, sample=False, sample_k=3):
+    def _beam_paths(self, seqs, users, max_path_len, gap_len, beam_width):
+        """Best-beam paths [B, P] + status via the build-defined beam search (no reference
+        counterpart; beam_width == 1 equals the greedy search).  All beams and their
+        cumulative log-probabilities are kept in self.last_beams = (paths[B,W,P], scores[B,W])."""
+        B, L = seqs.shape
+        dev = seqs.device
+        hip = self.net._hip
+        W = beam_width
+        hep = torch.full((B,), L - (gap_len + 1) - 1, dtype=torch.int32, device=dev)
+        if hip.world == 1:
+            eng = hip.get(B * W, B * W)
+            paths, scores, status = eng.beam_search(seqs.contiguous(), users, hep, max_path_len, W, k=100, sweep=hip.sweep)
+        else:
+            eng = hip.get(B * W, B * W * hip.world)
+            g = hip.group
+
+            def mk():
+                return (torch.empty((B, W, L), dtype=torch.int64, device=dev), torch.empty((B, W), dtype=torch.int32, device=dev),
+                        torch.empty((B, W), dtype=torch.float64, device=dev),
+                        torch.zeros((B, W, max_path_len), dtype=torch.float32, device=dev))
+            st = [mk(), mk()]
+            st[0][0].copy_(seqs.unsqueeze(1).expand(B, W, L))
+            st[0][1].copy_(hep.unsqueeze(1).expand(B, W))
+            st[0][2].fill_(float("-inf"))
+            st[0][2][:, 0] = 0.0
+            urep = users.repeat_interleave(W).contiguous()
+            status = torch.zeros(B, dtype=torch.int32, device=dev)
+            sl = g.my_slice(B * W)
+            for i in range(max_path_len):
+                cur, nxt = st[i & 1], st[(i & 1) ^ 1]
+                _, xr, _ = eng.decode(cur[0].view(B * W, L), urep, want_x=False, pos=cur[1].view(-1))
+                allrows = g.gather_rows(xr)
+                val, ids, _ = g.topk(allrows, 100, hip.sweep)
+                lse = None
+                if W > 1:
+                    m, sm = g.lse(allrows)
+                    lse = (m[sl].contiguous(), sm[sl].contiguous())
+                eng.beam_step(cur, val[sl].contiguous(), ids[sl].contiguous(), lse, i, nxt, status)
+            paths, scores = st[max_path_len & 1][3], st[max_path_len & 1][2]
+        self.last_beams = (paths.detach().cpu().numpy(), scores.detach().cpu().numpy())
+        return paths[:, 0].contiguous(), status
+
+    def get_seq_in_batch(self, seqs, users, targets, max_path_len=20, gap_len=20, sample=False, sample_k=3,
+                         beam_width=1):
         """Persuasion-path generation (reference :392-470): returns
-        (paths float32 [B, max_path_len], targets int64 [B], list of B history arrays, n_early_success)."""
+        (paths float32 [B, max_path_len], targets int64 [B], list of B history arrays, n_early_success).
+        beam_width > 1 (extension, not in the reference) returns the best beam's path."""
         self.net.eval()
         B, L = seqs.shape
         dev = seqs.device
@@ -232,7 +276,9 @@ class IRSNN(nn.Module):
         work = seqs.clone()
         hep = torch.full((B,), L - (gap_len + 1) - 1, dtype=torch.int32, device=dev)
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if sample else 0
-        if hip.world == 1:
+        if beam_width > 1:
+            paths_t, status = self._beam_paths(work, users, max_path_len, gap_len, beam_width)
+        elif hip.world == 1:
             eng = hip.get(B, B)
             paths_t, status = eng.generate_paths(work, users, hep, max_path_len, k=100, sweep=hip.sweep,
                                                  sample=sample, sample_k=sample_k, seed=seed, use_graph=False)

@@ -337,6 +337,56 @@ def get_seq(sd, cfg, seqs: np.ndarray, users, targets, max_path_len=20, gap_len=
     return paths, tg, histories, n_early
 
 
+def beam_search(sd, cfg, seqs: np.ndarray, users, max_path_len=20, gap_len=0, beam=4, k_cand=100):
+    """BUILD-DEFINED beam search (the reference has none: SURVEY fact 4, row A9) -- the CPU
+    statement of influentialrs_amd/csrc/path.hip:k_beam_step, PARITY UNPINNED by the reference
+    for beam > 1; beam == 1 is get_seq() id for id.
+    Per step, every live beam contributes its first `beam` window-survivors of its top-k_cand,
+    scored cum + log-softmax(item); the best `beam` by (score desc, parent asc, rank asc) survive.
+    Returns (paths float32 [B, beam, P], scores float64 [B, beam])."""
+    seqs = np.asarray(seqs, dtype=np.int64)
+    B, L = seqs.shape
+    W, b = sd["project.weight"], sd["project.bias"]
+    paths = np.zeros((B, beam, max_path_len), dtype=np.float32)
+    scores = np.full((B, beam), -np.inf)
+    for r in range(B):
+        beams = [(0.0, seqs[r].copy(), L - (gap_len + 1) - 1, [])]
+        for step in range(max_path_len):
+            cands = []
+            for j, (cum, win, hep, path) in enumerate(beams):
+                x, _ = decode(sd, cfg, win, users[r])
+                s = score_chain(x[hep], W, b)
+                vals, ids0 = topk(s, k_cand)
+                norm = 0.0
+                if beam > 1:
+                    m, se = max_sumexp(s)
+                    norm = m + math.log(se)
+                present = np.isin(ids0 + 1, win[:hep + 1])
+                sv, si = vals[~present][:beam], (ids0 + 1)[~present][:beam]
+                for rank, (v, it) in enumerate(zip(sv, si)):
+                    cands.append((cum + (float(v) - norm), j, rank, int(it)))
+            cands.sort(key=lambda c: (-c[0], c[1], c[2]))
+            new = []
+            for sc, j, rank, it in cands[:beam]:
+                cum, win, hep, path = beams[j]
+                if hep < L - 2:
+                    nw = win.copy()
+                    nw[hep + 1] = it
+                    nh = hep + 1
+                else:
+                    nw = np.zeros(L, dtype=np.int64)
+                    nw[:-2] = win[1:-1]
+                    nw[-2] = it
+                    nw[-1] = win[-1]
+                    nh = hep
+                new.append((sc, nw, nh, path + [it]))
+            beams = new
+        for j, (sc, _, _, path) in enumerate(beams):
+            paths[r, j, :len(path)] = path
+            scores[r, j] = sc
+    return paths, scores
+
+
 # --------------------------------------------------------------------------
 # Evaluator side (SampleNet + Evaluator, model/uRS.py, model/evaluator.py)
 # --------------------------------------------------------------------------

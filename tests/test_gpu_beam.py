@@ -1,0 +1,78 @@
+"""-m gpu: beam search (build-defined extension, SURVEY row A9: no reference oracle;
+the CPU restatement oracle_np.beam_search is the yard-stick).  beam = 1 must equal the
+greedy search (and hence the reference goldens) id for id."""
+import numpy as np
+import pytest
+import torch
+
+from influentialrs_amd import synth
+from influentialrs_amd._lib import IRS_SWEEP_BF16, IRS_SWEEP_F32
+from influentialrs_amd.model.influentialRS import IRSNN, InfluentialNet
+from gpu_util import make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(cfgname, n):
+    cfg = synth.make_config(cfgname)
+    sd = synth.irn_state_dict(cfg, 1234)
+    hists = synth.user_histories(max(n, 8), cfg.n_item, seed=7)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=11)[:n]
+    raws, seqs, users, targets, labels = synth.collate_eval_irs(rows, cfg.max_len, gap_len=0)
+    return cfg, sd, seqs, users, targets
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_beam1_equals_greedy_and_reference(golden, use_graph):
+    g = golden("irn_default")
+    cfg = synth.make_config("default")
+    sd = synth.irn_state_dict(cfg, 1234)
+    eng = make_engine(cfg, sd, max_rows=8)
+    B, L = g["seqs"].shape
+    hep = torch.full((B,), L - 2, dtype=torch.int32, device="cuda")
+    P = int(g["meta"][2])
+    paths, scores, st = eng.beam_search(torch.from_numpy(g["seqs"]).cuda(), torch.from_numpy(g["users"]).cuda(), hep, P, 1,
+                                        use_graph=use_graph)
+    assert np.array_equal(paths[:, 0].cpu().numpy(), g["paths"])
+
+
+@pytest.mark.parametrize("cfgname,beam,P,use_graph", [("tiny", 4, 7, False), ("tiny", 4, 6, True), ("tiny", 32, 5, False),
+                                                      ("default", 3, 5, True)])
+def test_beam_matches_cpu_restatement(oracle, cfgname, beam, P, use_graph):
+    cfg, sd, seqs, users, targets = _setup(cfgname, 3)
+    B, L = seqs.shape
+    eng = make_engine(cfg, sd, max_rows=B * beam, max_seqs=B * beam)
+    hep = torch.full((B,), L - 2, dtype=torch.int32, device="cuda")
+    paths, scores, st, fin = eng.beam_search(torch.from_numpy(seqs).cuda(), torch.from_numpy(users).cuda(), hep, P, beam,
+                                             sweep=IRS_SWEEP_F32, use_graph=use_graph, want_windows=True)
+    paths, scores = paths.cpu().numpy(), scores.cpu().numpy()
+    op, osc = oracle.beam_search(sd, cfg, seqs, users, max_path_len=P, gap_len=0, beam=beam)
+    assert np.allclose(scores, osc, rtol=0, atol=2e-4), (scores, osc)
+    # ids exact wherever consecutive beam scores are separated by more than the float32 LSE noise
+    for b in range(B):
+        gaps = np.abs(np.diff(osc[b]))
+        n_safe = beam if len(gaps) == 0 or gaps.min() > 1e-4 else int(np.argmax(gaps <= 1e-4)) + 1
+        assert np.array_equal(paths[b, :n_safe], op[b, :n_safe]), (b, paths[b], op[b])
+    # scores are sorted, windows end with the path
+    assert (np.diff(scores, axis=1) <= 0).all()
+    w = fin.cpu().numpy()
+    n = min(P, L - 1)
+    assert np.array_equal(w[:, :, L - 1 - n:L - 1], paths[:, :, P - n:].astype(np.int64))
+
+
+def test_beam_frontend_kwarg():
+    cfg, sd, seqs, users, targets = _setup("tiny", 3)
+    net = InfluentialNet(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.to("cuda:0")
+    irn = IRSNN(cfg, net, "cuda:0").eval()
+    seq, u, t = (torch.from_numpy(a).cuda() for a in (seqs, users, targets))
+    with torch.no_grad():
+        p1, _, _, _ = irn.get_seq_in_batch(seq, u, t, 6, 0)
+        pb1, _, _, _ = irn.get_seq_in_batch(seq, u, t, 6, 0, beam_width=1)
+        pb4, _, hist, _ = irn.get_seq_in_batch(seq, u, t, 6, 0, beam_width=4)
+    assert np.array_equal(p1, pb1)
+    allp, alls = irn.last_beams
+    assert allp.shape == (3, 4, 6) and np.array_equal(allp[:, 0], pb4)
+    # the best beam's cumulative log-probability is at least the greedy path's
+    assert pb4.shape == p1.shape and len(hist) == 3
