@@ -238,7 +238,7 @@ static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
     p->eps = take(mp * 4);
     p->thr = take(mp * 4);
     p->gm = take((size_t)IRS_MAX_GROUPS * mp * 4);
-    p->cnt = take(mp * 4);
+    p->cnt = take(mp * (size_t)IRS_CAND_BUCKETS * 4);
     p->cand = take(mp * (size_t)IRS_CAND_CAP * 8);
     p->lse = take((size_t)ctx->lse_slots * mp * 8);
     p->ref = take(mp * 4);

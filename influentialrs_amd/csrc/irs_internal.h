@@ -10,7 +10,9 @@
 #include "../../include/irs_hip.h"
 
 #define IRS_MAX_LAYERS 16
-#define IRS_CAND_CAP 4096   // emitted candidates kept per row by the sweep
+#define IRS_CAND_BUCKETS 64 // candidate lists per row (bucket = item tile mod 64)
+#define IRS_CAND_SLOTS 64   // entries per bucket
+#define IRS_CAND_CAP (IRS_CAND_BUCKETS * IRS_CAND_SLOTS) // emitted candidates kept per row by the sweep
 #define IRS_REFINE_CAP 1024 // candidates exactly re-scored per row
 #define IRS_MAX_GROUPS 8192 // pre-pass group maxima per row (upper bound)
 #define IRS_MAX_PATH 64     // beam-search path length bound
@@ -58,7 +60,7 @@ struct irs_ctx {
     float *eps;         // [m_pad]
     float *thr;         // [m_pad]
     float *gm;          // [IRS_MAX_GROUPS][m_pad]
-    unsigned int *cand_cnt; // [m_pad]
+    unsigned int *cand_cnt; // [m_pad][IRS_CAND_BUCKETS]
     unsigned long long *cand; // [m_pad][IRS_CAND_CAP]
     float *lse_part;    // [lse_slots][m_pad][2]
     int lse_slots;

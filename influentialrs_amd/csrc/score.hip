@@ -49,11 +49,12 @@ struct SweepArgs {
     int64_t n_local;
     // tile range and decomposition
     int tile_begin, tile_end, tiles_per_wave, n_strips, n_ublocks;
+    int tile_stride; // PRE samples tiles tile_begin + i * tile_stride
     // outputs
     float *gm;                   // PRE  [n_groups][M_pad]
     const float *thr;            // EMIT [M_pad]
-    unsigned int *cnt;           // EMIT [M_pad]
-    unsigned long long *cand;    // EMIT [M_pad][cap]
+    unsigned int *cnt;           // EMIT [M_pad][IRS_CAND_BUCKETS]
+    unsigned long long *cand;    // EMIT [M_pad][IRS_CAND_BUCKETS][IRS_CAND_SLOTS]
     int cap;
     const float *ref_score;      // COUNT [M]
     const int64_t *ref_id;       // COUNT [M] (local 0-based, may be out of range)
@@ -83,22 +84,69 @@ __device__ __forceinline__ bool sweep_map(const SweepArgs &a, int &strip, int &u
 }
 
 // ---- epilogues (lane = scored row `user`, regs = 16 items of tile `t`, half h)
-__device__ __forceinline__ void emit_candidates(const SweepArgs &a, const f32x16 &acc, float thr, int user, int t, int h) {
+// Threshold hits are rare per element but frequent per tile, and a returning global atomic
+// inside a divergent branch costs a full memory round trip.  Hits therefore go to a small
+// wave-private LDS queue (LDS atomic) and are flushed 64 at a time, all global atomics of a
+// flush in flight together.
+#define EMIT_Q 128
+struct EmitQ {
+    unsigned long long *keys; // [EMIT_Q]
+    unsigned int *users;      // [EMIT_Q]
+    unsigned int *cnt;        // [1]
+};
+
+// candidate lists are bucketed by item tile (bucket = tile mod 64): 64 counters per row keep the
+// same-address atomic chains short, and interleaving tiles spreads any id-locality of the scores.
+__device__ __forceinline__ void emit_append_global(const SweepArgs &a, unsigned int user, unsigned long long key) {
+    const unsigned int bucket = (((unsigned int)key) >> 5) & (IRS_CAND_BUCKETS - 1);
+    const size_t cell = (size_t)user * IRS_CAND_BUCKETS + bucket;
+    unsigned int slot = atomicAdd(&a.cnt[cell], 1u);
+    if (slot < IRS_CAND_SLOTS) a.cand[cell * IRS_CAND_SLOTS + slot] = key;
+}
+
+__device__ __forceinline__ void emit_flush(const SweepArgs &a, const EmitQ &q, int lane) {
+    unsigned int n = __hip_atomic_load(q.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (n > EMIT_Q) n = EMIT_Q;
+    for (unsigned int i = lane; i < n; i += 64) emit_append_global(a, q.users[i], q.keys[i]);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __hip_atomic_store(q.cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void emit_candidates(const SweepArgs &a, const f32x16 &acc, float thr, int user, int t, int h,
+                                                const EmitQ &q, int lane) {
     float m = max16(acc);
-    if (__any(m >= thr)) {
-        if (m >= thr) {
+    if (!__any(m >= thr)) return;
+    if (__hip_atomic_load(q.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > EMIT_Q / 2) emit_flush(a, q, lane);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (acc[r] >= thr) {
-                    unsigned int item = (unsigned int)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
-                    unsigned int slot = atomicAdd(&a.cnt[user], 1u);
-                    if (slot < (unsigned int)a.cap)
-                        a.cand[(size_t)user * a.cap + slot] = ((unsigned long long)irs_fkey(acc[r]) << 32) | item;
+    for (int r = 0; r < 16; ++r) {
+        const bool hit = acc[r] >= thr;
+        if (__any(hit)) {
+            if (hit) {
+                const unsigned int item = (unsigned int)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                const unsigned long long key = ((unsigned long long)irs_fkey(acc[r]) << 32) | item;
+                unsigned int pos = atomicAdd(q.cnt, 1u);
+                if (pos < EMIT_Q) {
+                    q.keys[pos] = key;
+                    q.users[pos] = (unsigned int)user;
+                } else {
+                    emit_append_global(a, (unsigned int)user, key); // queue full (dense hits): direct append
                 }
             }
         }
     }
 }
+
+__device__ __forceinline__ EmitQ emit_queue(char *base, int wave) {
+    // per wave: 128 x 8 B keys, 128 x 4 B users, 16 B counter
+    char *p = base + wave * (EMIT_Q * 12 + 16);
+    EmitQ q;
+    q.keys = reinterpret_cast<unsigned long long *>(p);
+    q.users = reinterpret_cast<unsigned int *>(p + EMIT_Q * 8);
+    q.cnt = reinterpret_cast<unsigned int *>(p + EMIT_Q * 12);
+    return q;
+}
+#define EMIT_Q_BYTES (4 * (EMIT_Q * 12 + 16))
 
 // =============================== bf16 sweep ===============================
 template <int KS, int UB, int MODE>
@@ -111,14 +159,17 @@ __global__ void __launch_bounds__(256, 2) k_sweep_bf16(SweepArgs a) {
     const int r = lane & 31, h = lane >> 5;
     const int ut0 = ublock * UB;
     const int ubc = min(UB, a.UT - ut0);
+    const EmitQ eq = emit_queue(smem + (size_t)UB * KS * 1024, wave);
+    if (MODE == MODE_EMIT && lane == 0) *eq.cnt = 0u;
     {
         const uint4 *src = a.xb + (size_t)ut0 * KS * 64;
         for (int i = tid; i < ubc * KS * 64; i += 256) xs[i] = src[i];
     }
     __syncthreads();
     const int gw = strip * 4 + wave;
-    int t0 = a.tile_begin + gw * a.tiles_per_wave;
-    int t1 = min(t0 + a.tiles_per_wave, a.tile_end);
+    const int ts = a.tile_stride;
+    int t0 = a.tile_begin + gw * a.tiles_per_wave * ts;
+    int t1 = min(t0 + a.tiles_per_wave * ts, a.tile_end);
 
     float aux[UB]; // PRE: running max; EMIT: threshold
 #pragma unroll
@@ -133,19 +184,19 @@ __global__ void __launch_bounds__(256, 2) k_sweep_bf16(SweepArgs a) {
         for (int ks = 0; ks < KS; ++ks) an[ks] = a.wp[((size_t)t0 * KS + ks) * 64 + lane];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bn[q] = *reinterpret_cast<const float4 *>(a.bias + (size_t)t0 * 32 + 8 * q + 4 * h);
-        for (int t = t0; t < t1; ++t) {
+        for (int t = t0; t < t1; t += ts) {
             uint4 ac[KS];
             float4 bc[4];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) ac[ks] = an[ks];
 #pragma unroll
             for (int q = 0; q < 4; ++q) bc[q] = bn[q];
-            if (t + 1 < t1) {
+            if (t + ts < t1) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) an[ks] = a.wp[((size_t)(t + 1) * KS + ks) * 64 + lane];
+                for (int ks = 0; ks < KS; ++ks) an[ks] = a.wp[((size_t)(t + ts) * KS + ks) * 64 + lane];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    bn[q] = *reinterpret_cast<const float4 *>(a.bias + (size_t)(t + 1) * 32 + 8 * q + 4 * h);
+                    bn[q] = *reinterpret_cast<const float4 *>(a.bias + (size_t)(t + ts) * 32 + 8 * q + 4 * h);
             }
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
@@ -165,11 +216,12 @@ __global__ void __launch_bounds__(256, 2) k_sweep_bf16(SweepArgs a) {
                                                                       __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
                     }
                     if (MODE == MODE_PRE) aux[u] = fmaxf(aux[u], max16(acc));
-                    else emit_candidates(a, acc, aux[u], (ut0 + u) * 32 + r, t, h);
+                    else emit_candidates(a, acc, aux[u], (ut0 + u) * 32 + r, t, h, eq, lane);
                 }
             }
         }
     }
+    if (MODE == MODE_EMIT) emit_flush(a, eq, lane);
     if (MODE == MODE_PRE) {
 #pragma unroll
         for (int u = 0; u < UB; ++u)
@@ -193,6 +245,8 @@ __global__ void __launch_bounds__(256, 2) k_sweep_f32(SweepArgs a) {
     const int r = lane & 31, h = lane >> 5;
     const int ut0 = ublock * UB;
     const int ubc = min(UB, a.UT - ut0);
+    const EmitQ eq = emit_queue(smem + (size_t)UB * KS * 2048, wave);
+    if (MODE == MODE_EMIT && lane == 0) *eq.cnt = 0u;
     for (int i = tid; i < ubc * QN * 64; i += 256) {
         int ln = i & 63, q = (i >> 6) % QN, u = (i >> 6) / QN;
         int row = (ut0 + u) * 32 + (ln & 31), hh = ln >> 5;
@@ -209,8 +263,9 @@ __global__ void __launch_bounds__(256, 2) k_sweep_f32(SweepArgs a) {
     }
     __syncthreads();
     const int gw = strip * 4 + wave;
-    int t0 = a.tile_begin + gw * a.tiles_per_wave;
-    int t1 = min(t0 + a.tiles_per_wave, a.tile_end);
+    const int ts = a.tile_stride;
+    int t0 = a.tile_begin + gw * a.tiles_per_wave * ts;
+    int t1 = min(t0 + a.tiles_per_wave * ts, a.tile_end);
 
     float aux[UB];        // PRE: running max; EMIT: thr; COUNT: ref score; LSE: running max
     float aux2[UB];       // LSE: running sum
@@ -229,7 +284,7 @@ __global__ void __launch_bounds__(256, 2) k_sweep_f32(SweepArgs a) {
             refid[u] = (u < ubc && user < a.M) ? (long long)a.ref_id[user] : -1;
         }
     }
-    for (int t = t0; t < t1; ++t) {
+    for (int t = t0; t < t1; t += ts) {
         // A fragments for the whole tile
         float4 af[QN];
         const int64_t item = (int64_t)t * 32 + r;
@@ -298,7 +353,7 @@ __global__ void __launch_bounds__(256, 2) k_sweep_f32(SweepArgs a) {
                 }
                 const int user = (ut0 + u) * 32 + r;
                 if (MODE == MODE_PRE) aux[u] = fmaxf(aux[u], max16(acc));
-                else if (MODE == MODE_EMIT) emit_candidates(a, acc, aux[u], user, t, h);
+                else if (MODE == MODE_EMIT) emit_candidates(a, acc, aux[u], user, t, h, eq, lane);
                 else if (MODE == MODE_COUNT) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -332,6 +387,7 @@ __global__ void __launch_bounds__(256, 2) k_sweep_f32(SweepArgs a) {
             }
         }
     }
+    if (MODE == MODE_EMIT) emit_flush(a, eq, lane);
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
         if (u >= ubc) continue;
@@ -409,52 +465,74 @@ __global__ void __launch_bounds__(256) k_pack_w(const float *__restrict__ W, con
     }
 }
 
-// T0 = k-th largest of gm[0..G)[row]; thr = T0 - 2 eps (or -inf when G < k).
-// 16 rows per workgroup, 8-bit radix select with per-row LDS histograms.
-__global__ void __launch_bounds__(256) k_select_thr(const float *__restrict__ gm, int G, int M, int M_pad, int k,
-                                                    const float *__restrict__ eps, float *__restrict__ thr) {
-    __shared__ unsigned int hist[16][256];
-    __shared__ unsigned int s_prefix[16], s_k[16];
-    const int tu = threadIdx.x & 15, tg = threadIdx.x >> 4;
-    const int row = blockIdx.x * 16 + tu;
-    if (threadIdx.x < 16) {
-        s_prefix[threadIdx.x] = 0;
-        s_k[threadIdx.x] = k;
-    }
+// thr[row] = (k-th largest of gm[0..G)[row]) - 2 eps ; traw[row] = that order statistic itself
+// (-inf when G < k; +inf for padding rows so that they never emit).
+// 1024 threads = 32 rows x 32 threads per row; a wave's lanes read 32 consecutive rows of one group
+// (coalesced 128-byte lines of gm[G][M_pad]).  8-bit radix select, per-row LDS histograms; the 256-bin
+// scan of a row is done by its 32 threads (8 bins each + a 32-lane suffix sum).
+__global__ void __launch_bounds__(1024) k_select_thr(const float *__restrict__ gm, int G, int M, int M_pad, int k,
+                                                     const float *__restrict__ eps, float *__restrict__ thr,
+                                                     float *__restrict__ traw) {
+    __shared__ unsigned int hist[32][257];
+    __shared__ unsigned int s_prefix[32], s_k[32];
+    const int rl = threadIdx.x & 31, tq = threadIdx.x >> 5; // row within block, thread within row
+    const int row = blockIdx.x * 32 + rl;
     if (G < k) {
-        int rr = blockIdx.x * 16 + threadIdx.x;
-        if (threadIdx.x < 16 && rr < M_pad) thr[rr] = (rr < M) ? -INFINITY : INFINITY;
+        if (tq == 0 && row < M_pad) {
+            thr[row] = (row < M) ? -INFINITY : INFINITY;
+            traw[row] = (row < M) ? -INFINITY : INFINITY;
+        }
         return;
+    }
+    if (tq == 0) {
+        s_prefix[rl] = 0;
+        s_k[rl] = k;
     }
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
-        for (int i = threadIdx.x; i < 16 * 256; i += 256) (&hist[0][0])[i] = 0;
+        for (int i = threadIdx.x; i < 32 * 257; i += 1024) (&hist[0][0])[i] = 0;
         __syncthreads();
-        const unsigned int prefix = s_prefix[tu];
-        if (row < M_pad) {
-            for (int g = tg; g < G; g += 16) {
+        const unsigned int prefix = s_prefix[rl];
+        if (row < M) {
+            for (int g = tq; g < G; g += 32) {
                 unsigned int key = irs_fkey(gm[(size_t)g * M_pad + row]);
                 bool match = (pass == 0) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
-                if (match) atomicAdd(&hist[tu][(key >> shift) & 255], 1u);
+                if (match) atomicAdd(&hist[rl][(key >> shift) & 255], 1u);
             }
         }
         __syncthreads();
-        if (threadIdx.x < 16) {
-            unsigned int need = s_k[threadIdx.x], cum = 0;
-            int bin = 255;
-            for (; bin > 0; --bin) {
-                unsigned int c = hist[threadIdx.x][bin];
-                if (cum + c >= need) break;
-                cum += c;
+        // thread tq of row rl owns bins [8 tq, 8 tq + 8); find the bin where the descending cumulative count reaches need
+        {
+            const unsigned int need = s_k[rl];
+            unsigned int own = 0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) own += hist[rl][8 * tq + b];
+            // suffix sum over tq (threads of one row are 32 apart in threadIdx: go through LDS)
+            hist[rl][256] = 0; // unused pad word, keeps the row stride odd
+            __syncthreads();
+            __shared__ unsigned int part[32][33];
+            part[rl][tq] = own;
+            __syncthreads();
+            unsigned int above = 0; // count in bins owned by higher tq
+            for (int j = tq + 1; j < 32; ++j) above += part[rl][j];
+            if (above < need && above + own >= need) { // the target bin is mine
+                unsigned int cum = above;
+                int bin = 8 * tq + 7;
+                for (; bin > 8 * tq; --bin) {
+                    unsigned int c = hist[rl][bin];
+                    if (cum + c >= need) break;
+                    cum += c;
+                }
+                s_k[rl] = need - cum;
+                s_prefix[rl] = prefix | (((unsigned int)bin) << shift);
             }
-            s_k[threadIdx.x] = need - cum;
-            s_prefix[threadIdx.x] |= ((unsigned int)bin) << shift;
         }
         __syncthreads();
     }
-    if (threadIdx.x < 16) {
-        int rr = blockIdx.x * 16 + threadIdx.x;
-        if (rr < M_pad) thr[rr] = (rr < M) ? irs_unkey(s_prefix[threadIdx.x]) - 2.0f * eps[rr] : INFINITY;
+    if (tq == 0 && row < M_pad) {
+        const float t = irs_unkey(s_prefix[rl]);
+        thr[row] = (row < M) ? t - 2.0f * eps[row] : INFINITY;
+        traw[row] = (row < M) ? t : INFINITY;
     }
 }
 
@@ -478,32 +556,99 @@ __device__ __forceinline__ void bitonic_desc(unsigned long long *keys, int n) {
     __syncthreads();
 }
 
-// One workgroup per row: refine the emitted candidates, re-score exactly, sort, write top-k.
+// Wave-parallel search of the radix bin holding the `need`-th largest key: lane l owns bins
+// 4l..4l+3; an inclusive suffix sum over lanes (shuffles) replaces the serial 256-bin scan.
+// Executed by wave 0; returns (bin, need - count above bin) through the two shared words.
+__device__ __forceinline__ void radix_find_bin(const unsigned int *hist, unsigned int need, int lane, int shift,
+                                               unsigned int *s_prefix, unsigned int *s_k) {
+    const unsigned int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+    const unsigned int own = h0 + h1 + h2 + h3;
+    unsigned int suf = own; // inclusive suffix sum over lanes >= lane
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned int o = __shfl_down(suf, off, 64);
+        if (lane + off < 64) suf += o;
+    }
+    const unsigned int above = suf - own;
+    if (above < need && suf >= need) {
+        unsigned int cum = above;
+        int bin;
+        if (cum + h3 >= need) bin = 4 * lane + 3;
+        else {
+            cum += h3;
+            if (cum + h2 >= need) bin = 4 * lane + 2;
+            else {
+                cum += h2;
+                if (cum + h1 >= need) bin = 4 * lane + 1;
+                else {
+                    cum += h1;
+                    bin = 4 * lane;
+                }
+            }
+        }
+        *s_k = need - cum;
+        *s_prefix |= ((unsigned int)bin) << shift;
+    }
+}
+
+// One workgroup per row: gather the row's bucketed candidates, validate the emission threshold,
+// refine, re-score exactly, sort, write top-k.
 __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int d, const float *__restrict__ W,
                                                 const float *__restrict__ bias, const unsigned int *__restrict__ cnt,
-                                                const unsigned long long *__restrict__ cand, int cap,
-                                                const float *__restrict__ eps, int k, int64_t item_lo, int64_t n_local,
-                                                float *__restrict__ val, int64_t *__restrict__ ids,
-                                                int32_t *__restrict__ status) {
+                                                const unsigned long long *__restrict__ cand,
+                                                const float *__restrict__ eps, const float *__restrict__ traw, int k,
+                                                int64_t item_lo, int64_t n_local, float *__restrict__ val,
+                                                int64_t *__restrict__ ids, int32_t *__restrict__ status) {
     __shared__ unsigned long long ckeys[IRS_CAND_CAP];
     __shared__ unsigned long long rkeys[IRS_REFINE_CAP];
     __shared__ unsigned int hist[256];
     __shared__ float xs[256];
-    __shared__ unsigned int s_prefix, s_k, s_nr;
+    __shared__ unsigned int boff[IRS_CAND_BUCKETS + 1];
+    __shared__ unsigned int s_prefix, s_k, s_nr, s_above, s_over;
     const int row = blockIdx.x, tid = threadIdx.x;
-    unsigned int c = cnt[row];
-    if (c > (unsigned int)cap) { // emission overflow -> exhaustive kernel redoes the row
-        if (tid == 0) status[row] |= IRS_ROW_FALLBACK;
-        return;
-    }
-    for (int i = tid; i < (int)c; i += 256) ckeys[i] = cand[(size_t)row * cap + i];
-    for (int i = tid; i < d; i += 256) xs[i] = x[(size_t)row * d + i];
+    if (tid < IRS_CAND_BUCKETS) hist[tid] = cnt[(size_t)row * IRS_CAND_BUCKETS + tid];
+    __syncthreads();
     if (tid == 0) {
+        unsigned int off = 0, over = 0;
+        for (int b = 0; b < IRS_CAND_BUCKETS; ++b) {
+            unsigned int c = hist[b];
+            if (c > IRS_CAND_SLOTS) over = 1;
+            boff[b] = off;
+            off += (c > IRS_CAND_SLOTS) ? IRS_CAND_SLOTS : c;
+        }
+        boff[IRS_CAND_BUCKETS] = off;
+        s_over = over;
         s_prefix = 0;
         s_k = k;
         s_nr = 0;
+        s_above = 0;
     }
     __syncthreads();
+    if (s_over) { // a bucket overflowed -> the exhaustive kernel redoes the row
+        if (tid == 0) status[row] |= IRS_ROW_FALLBACK;
+        return;
+    }
+    const unsigned int c = boff[IRS_CAND_BUCKETS];
+    for (int idx = tid; idx < IRS_CAND_BUCKETS * IRS_CAND_SLOTS; idx += 256) {
+        const int b = idx / IRS_CAND_SLOTS, sl = idx % IRS_CAND_SLOTS;
+        if ((unsigned int)sl < boff[b + 1] - boff[b])
+            ckeys[boff[b] + sl] = cand[((size_t)row * IRS_CAND_BUCKETS + b) * IRS_CAND_SLOTS + sl];
+    }
+    for (int i = tid; i < d; i += 256) xs[i] = x[(size_t)row * d + i];
+    __syncthreads();
+    // validation of the (possibly speculative) emission threshold: at least k items must score >= traw,
+    // otherwise items between the true k-th score and the threshold may be missing
+    const float t1 = traw[row];
+    if (t1 > -INFINITY) {
+        unsigned int mine = 0;
+        for (int i = tid; i < (int)c; i += 256) mine += (irs_unkey((unsigned int)(ckeys[i] >> 32)) >= t1) ? 1u : 0u;
+        if (mine) atomicAdd(&s_above, mine);
+        __syncthreads();
+        if (s_above < (unsigned int)k) {
+            if (tid == 0) status[row] |= IRS_ROW_FALLBACK;
+            return;
+        }
+    }
     float thr2 = -INFINITY;
     if (c >= (unsigned int)k) {
         for (int pass = 0; pass < 4; ++pass) {
@@ -517,17 +662,7 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
                 if (match) atomicAdd(&hist[(key >> shift) & 255], 1u);
             }
             __syncthreads();
-            if (tid == 0) {
-                unsigned int need = s_k, cum = 0;
-                int bin = 255;
-                for (; bin > 0; --bin) {
-                    unsigned int h = hist[bin];
-                    if (cum + h >= need) break;
-                    cum += h;
-                }
-                s_k = need - cum;
-                s_prefix |= ((unsigned int)bin) << shift;
-            }
+            if (tid < 64) radix_find_bin(hist, s_k, tid, shift, &s_prefix, &s_k);
             __syncthreads();
         }
         thr2 = irs_unkey(s_prefix) - 2.0f * eps[row];
@@ -701,7 +836,7 @@ static int launch_sweep_bf16(irs_ctx *ctx, SweepArgs &a, hipStream_t s) {
     const int KS = ctx->KS, UB = ub_bf16(KS);
     a.n_ublocks = (a.UT + UB - 1) / UB;
     dim3 grid(((a.n_strips + 7) / 8) * 8 * a.n_ublocks);
-    size_t lds = (size_t)UB * KS * 1024;
+    size_t lds = (size_t)UB * KS * 1024 + EMIT_Q_BYTES;
 #define L_(KS_, UB_)                                                                                           \
     hipLaunchKernelGGL((k_sweep_bf16<KS_, UB_, MODE>), grid, dim3(256), lds, s, a)
     switch (KS) {
@@ -722,7 +857,7 @@ static int launch_sweep_f32(irs_ctx *ctx, SweepArgs &a, hipStream_t s) {
     const int KS = ctx->KS, UB = ub_f32(KS);
     a.n_ublocks = (a.UT + UB - 1) / UB;
     dim3 grid(((a.n_strips + 7) / 8) * 8 * a.n_ublocks);
-    size_t lds = (size_t)UB * KS * 2048;
+    size_t lds = (size_t)UB * KS * 2048 + EMIT_Q_BYTES;
     const bool vec = (a.d % 8 == 0) && (a.d == KS * 16) && ((((uintptr_t)a.w32) & 15) == 0);
 #define L_(KS_, UB_)                                                                                           \
     do {                                                                                                       \
@@ -758,10 +893,11 @@ static void sweep_common(irs_ctx *ctx, SweepArgs &a, const float *xrows, int M) 
 }
 
 // choose tiles per wave so that the grid has >= ~2048 workgroups when the catalog allows it
-static void sweep_decompose(SweepArgs &a, int tile_begin, int tile_end, int n_ublocks_hint, int force_tpw) {
+static void sweep_decompose(SweepArgs &a, int tile_begin, int tile_end, int n_ublocks_hint, int force_tpw, int stride = 1) {
     a.tile_begin = tile_begin;
     a.tile_end = tile_end;
-    int nt = tile_end - tile_begin;
+    a.tile_stride = stride;
+    int nt = (tile_end - tile_begin + stride - 1) / stride;
     int tpw = force_tpw;
     if (tpw <= 0) {
         long long t = ((long long)nt * n_ublocks_hint) / (4LL * 2048);
@@ -791,7 +927,7 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
     const int nt = ctx->n_tiles;
     int rc;
     IRS_CHECK_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t) * M, s));
-    IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->cand_cnt, 0, sizeof(unsigned int) * M_pad, s));
+    IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->cand_cnt, 0, sizeof(unsigned int) * (size_t)M_pad * IRS_CAND_BUCKETS, s));
     if (sweep == IRS_SWEEP_BF16) {
         // |approx - exact| <= ||x|| * max||W_j|| * (2u + u^2 + accumulation), u = 2^-9
         float eps_factor = 0.00390625f * 1.01f + (float)(ctx->d_pad + 8) * 2.384185791015625e-07f;
@@ -804,12 +940,14 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
     const int UBh = (sweep == IRS_SWEEP_BF16) ? ub_bf16(ctx->KS) : ub_f32(ctx->KS);
     const int nub = (a.UT + UBh - 1) / UBh;
 
-    // pre-pass over a catalog prefix: >= 1024 tiles (32768 items) or 1/8 of the shard
+    // pre-pass over a strided sample of item tiles: >= 1024 tiles (32768 items) or 1/8 of the shard
     int nt0 = nt / 8;
     if (nt0 < 1024) nt0 = 1024;
     if (nt0 > nt) nt0 = nt;
-    int tpw0 = (nt0 + 2047) / 2048; // -> at most ~4096 group maxima per row
-    sweep_decompose(a, 0, nt0, nub, tpw0);
+    const int stride = nt / nt0; // >= 1; sampled tiles 0, stride, 2 stride, ...
+    nt0 = (nt + stride - 1) / stride;
+    int tpw0 = (nt0 + 1023) / 1024; // -> at most ~2048 group maxima per row
+    sweep_decompose(a, 0, nt, nub, tpw0, stride);
     int n_waves0 = a.n_strips * 4;
     int G = 2 * n_waves0;
     if (G > IRS_MAX_GROUPS) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "pre-pass groups %d > %d", G, IRS_MAX_GROUPS);
@@ -820,7 +958,18 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
     irs_prof_end(ctx, IRS_PROF_SWEEP, s, 2.0 * d * (double)M * nt0 * 32.0,
                  (double)nt0 * 32.0 * ctx->d_pad * (sweep == IRS_SWEEP_BF16 ? 2.0 : 4.0));
     if (rc) return rc;
-    hipLaunchKernelGGL(k_select_thr, dim3((M_pad + 15) / 16), dim3(256), 0, s, ctx->gm, G, M, M_pad, k, ctx->eps, ctx->thr);
+    // Emission threshold = r-th largest sampled group maximum (minus 2 eps).  r = k is rigorous (>= k items
+    // score above it).  With a 1/stride sample, r ~ 3k/stride targets ~3k emitted items per row instead of
+    // ~k*stride; k_refine validates that >= k items really lie above it and otherwise hands the row to the
+    // exhaustive kernel, so the speculation can cost time but never correctness.
+    int r_sel = k;
+    if (stride > 1) {
+        r_sel = (3 * k + stride - 1) / stride;
+        if (r_sel < 8) r_sel = 8;
+        if (r_sel > k) r_sel = k;
+    }
+    hipLaunchKernelGGL(k_select_thr, dim3((M_pad + 31) / 32), dim3(1024), 0, s, ctx->gm, G, M, M_pad, r_sel, ctx->eps,
+                       ctx->thr, ctx->ref_tmp);
     IRS_CHECK_HIP(ctx, hipGetLastError());
 
     // emission sweep over the whole shard
@@ -837,7 +986,7 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
 
     irs_prof_begin(ctx, IRS_PROF_REFINE, s);
     hipLaunchKernelGGL(k_refine, dim3(M), dim3(256), 0, s, xrows, d, ctx->proj_w, ctx->proj_b, ctx->cand_cnt, ctx->cand,
-                       IRS_CAND_CAP, ctx->eps, k, ctx->shard.item_lo, ctx->n_local, val, ids0, status);
+                       ctx->eps, ctx->ref_tmp, k, ctx->shard.item_lo, ctx->n_local, val, ids0, status);
     irs_prof_end(ctx, IRS_PROF_REFINE, s, 0.0, 0.0);
     hipLaunchKernelGGL(k_exhaustive, dim3(M), dim3(256), 0, s, xrows, d, ctx->proj_w, ctx->proj_b, ctx->n_local,
                        ctx->shard.item_lo, k, 1, val, ids0, status);
