@@ -214,7 +214,7 @@ extern "C" int irs_finalize_weights(irs_ctx *ctx, void *arena, size_t bytes, voi
 
 // ------------------------------------------------------------------ workspace
 struct ws_plan {
-    size_t x, y, qkv, ao, h, ru, xb, eps, thr, gm, cnt, cand, lse, ref, xrows, tval, tids, status, step, pos;
+    size_t x, y, xf, yf, qkv, ao, h, ru, xb, eps, thr, gm, cnt, cand, lse, ref, xrows, tval, tids, status, step, pos;
     size_t bseq[2], bhep[2], bcum[2], bpaths[2], buser, lmax, lsum, total;
 };
 
@@ -230,6 +230,9 @@ static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
     };
     p->x = take(RL * D.d * 4);
     p->y = take(RL * D.d * 4);
+    const size_t RLf = ((RL + 127) / 128) * 128; // 128-token tiles x 128 padded columns
+    p->xf = take(RLf * 128 * 4);
+    p->yf = take(RLf * 128 * 4);
     p->qkv = take(RL * 3 * D.d * 4);
     p->ao = take(RL * D.d * 4);
     p->h = take(RL * D.ffn_dim * 4);
@@ -278,6 +281,8 @@ extern "C" int irs_bind_workspace(irs_ctx *ctx, void *ws, size_t bytes) {
     ctx->ws_bytes = bytes;
     ctx->act_x = (float *)(b + p.x);
     ctx->act_y = (float *)(b + p.y);
+    ctx->act_xf = (float *)(b + p.xf);
+    ctx->act_yf = (float *)(b + p.yf);
     ctx->act_qkv = (float *)(b + p.qkv);
     ctx->act_ao = (float *)(b + p.ao);
     ctx->act_h = (float *)(b + p.h);

@@ -75,17 +75,15 @@ __global__ void k_cross_const(const float *__restrict__ Wo, const float *__restr
 //                  out-proj + LN1 + (x + c_l) + LN2, and FFN2 + LN3, of the post-norm layer.
 #define LIN_BM 128
 #define LIN_BN 128
-#define LIN_BK 32
-#define LIN_TLD 132
-#define EPI_BIAS 0
-#define EPI_RES_LN 1
 
 struct LinArgs {
     const float *X, *W, *bias, *R;
     float *Y;
     int M, N, K;
     int relu;
-    const float *g1, *b1, *c, *g2, *b2; // EPI_RES_LN
+    const float *g1, *b1, *c, *g2, *b2; // fused LayerNorm parameters
+    const float *Rf; // residual in fragment-major layout (may be null -> row-major R is read, strided)
+    float *Yf;       // optional fragment-major copy of the output (next LN-GEMM's residual)
 };
 
 // LDS slab image: [128 rows][32 floats], 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7).
@@ -93,13 +91,14 @@ struct LinArgs {
 // and the staging stores are whole 16-byte chunks.  MFMA k-slots: for the 8 k of group q, half 0
 // supplies k = 8q + t and half 1 supplies k = 8q + 4 + t in step t (A and B agree, so any
 // assignment of k to slots is a valid contraction).
-template <bool VEC>
+template <bool VEC, int BK>
 __device__ __forceinline__ void lin_load_tile(const float *__restrict__ P, int rows, int K, int r0, int k0, int tid,
-                                              float4 (&v)[4]) {
+                                              float4 (&v)[BK / 8]) {
+    constexpr int CH = BK / 4; // 16-byte chunks per row
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < BK / 8; ++i) {
         int idx = tid + i * 256;
-        int r = idx >> 3, c = (idx & 7) * 4;
+        int r = idx / CH, c = (idx % CH) * 4;
         int gr = r0 + r, gk = k0 + c;
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gr < rows) {
@@ -116,12 +115,19 @@ __device__ __forceinline__ void lin_load_tile(const float *__restrict__ P, int r
     }
 }
 
-__device__ __forceinline__ void lin_store_tile(float *S, int tid, const float4 (&v)[4]) {
+// swizzle of the 16-byte chunk index: 128-byte rows (BK=32) use (row>>1)&7, 64-byte rows (BK=16) use (row>>2)&3;
+// both make a wave's ds_read_b128 of (row = lane&31, chunk 2q + (lane>>5)) bank-conflict free.
+template <int BK>
+__device__ __forceinline__ int lin_swz(int r) { return BK == 32 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
+
+template <int BK>
+__device__ __forceinline__ void lin_store_tile(float *S, int tid, const float4 (&v)[BK / 8]) {
+    constexpr int CH = BK / 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < BK / 8; ++i) {
         int idx = tid + i * 256;
-        int r = idx >> 3, c = idx & 7;
-        *reinterpret_cast<float4 *>(S + r * LIN_BK + ((c ^ ((r >> 1) & 7)) << 2)) = v[i];
+        int r = idx / CH, c = idx % CH;
+        *reinterpret_cast<float4 *>(S + r * BK + ((c ^ lin_swz<BK>(r)) << 2)) = v[i];
     }
 }
 
@@ -131,18 +137,18 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-template <bool VEC, int EPI>
-__global__ void __launch_bounds__(256, 2) k_linear(LinArgs a) {
-    // staging: [stage][operand][128][32] floats = 65,536 B; reused as the [128][132] output tile (67,584 B)
-    __shared__ __attribute__((aligned(16))) float sm[LIN_BM * LIN_TLD];
+template <bool VEC, int BK>
+__global__ void __launch_bounds__(256, BK == 16 ? 3 : 2) k_linear(LinArgs a) {
+    // staging: [stage][operand][128][BK] floats (BK=16: 32 KB, 124 VGPRs -> 4 workgroups per CU)
+    __shared__ __attribute__((aligned(16))) float sm[2 * 2 * LIN_BM * BK];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lk = lane >> 5;
     const int n0 = blockIdx.x * LIN_BN, m0 = blockIdx.y * LIN_BM;
     const int M = a.M, N = a.N, K = a.K;
-    auto Xs = [&](int st) { return sm + (st * 2 + 0) * LIN_BM * LIN_BK; };
-    auto Ws = [&](int st) { return sm + (st * 2 + 1) * LIN_BM * LIN_BK; };
+    auto Xs = [&](int st) { return sm + (st * 2 + 0) * LIN_BM * BK; };
+    auto Ws = [&](int st) { return sm + (st * 2 + 1) * LIN_BM * BK; };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -152,45 +158,29 @@ __global__ void __launch_bounds__(256, 2) k_linear(LinArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // residual in C layout, issued before the K loop so its latency hides under the MFMAs
-    f32x16 res[2][2];
-    if (EPI == EPI_RES_LN) {
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int n = n0 + wc * 64 + tn * 32 + li;
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    res[tm][tn][r] = (m < M && n < N) ? a.R[(int64_t)m * N + n] : 0.f;
-                }
-        }
-    }
-
-    float4 xv[4], wv[4];
-    lin_load_tile<VEC>(a.X, M, K, m0, 0, tid, xv);
-    lin_load_tile<VEC>(a.W, N, K, n0, 0, tid, wv);
-    lin_store_tile(Xs(0), tid, xv);
-    lin_store_tile(Ws(0), tid, wv);
+    float4 xv[BK / 8], wv[BK / 8];
+    lin_load_tile<VEC, BK>(a.X, M, K, m0, 0, tid, xv);
+    lin_load_tile<VEC, BK>(a.W, N, K, n0, 0, tid, wv);
+    lin_store_tile<BK>(Xs(0), tid, xv);
+    lin_store_tile<BK>(Ws(0), tid, wv);
     __syncthreads();
-    const int nkt = (K + LIN_BK - 1) / LIN_BK;
-    const int sw = (li >> 1) & 7;
+    const int nkt = (K + BK - 1) / BK;
+    const int sw = lin_swz<BK>(li);
     int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) {
-            lin_load_tile<VEC>(a.X, M, K, m0, (kt + 1) * LIN_BK, tid, xv);
-            lin_load_tile<VEC>(a.W, N, K, n0, (kt + 1) * LIN_BK, tid, wv);
+            lin_load_tile<VEC, BK>(a.X, M, K, m0, (kt + 1) * BK, tid, xv);
+            lin_load_tile<VEC, BK>(a.W, N, K, n0, (kt + 1) * BK, tid, wv);
         }
-        const float *xa = Xs(cur) + (wr * 64 + li) * LIN_BK;
-        const float *wb = Ws(cur) + (wc * 64 + li) * LIN_BK;
+        const float *xa = Xs(cur) + (wr * 64 + li) * BK;
+        const float *wb = Ws(cur) + (wc * 64 + li) * BK;
 #pragma unroll
-        for (int q = 0; q < LIN_BK / 8; ++q) {
+        for (int q = 0; q < BK / 8; ++q) {
             const int off = ((2 * q + lk) ^ sw) << 2;
             const float4 a0 = *reinterpret_cast<const float4 *>(xa + off);
-            const float4 a1 = *reinterpret_cast<const float4 *>(xa + 32 * LIN_BK + off);
+            const float4 a1 = *reinterpret_cast<const float4 *>(xa + 32 * BK + off);
             const float4 b0 = *reinterpret_cast<const float4 *>(wb + off);
-            const float4 b1 = *reinterpret_cast<const float4 *>(wb + 32 * LIN_BK + off);
+            const float4 b1 = *reinterpret_cast<const float4 *>(wb + 32 * BK + off);
 #define LIN_STEP(E)                                                                       \
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.E, b0.E, acc[0][0], 0, 0, 0);     \
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.E, b1.E, acc[0][1], 0, 0, 0);     \
@@ -200,234 +190,31 @@ __global__ void __launch_bounds__(256, 2) k_linear(LinArgs a) {
 #undef LIN_STEP
         }
         if (kt + 1 < nkt) {
-            lin_store_tile(Xs(cur ^ 1), tid, xv);
-            lin_store_tile(Ws(cur ^ 1), tid, wv);
+            lin_store_tile<BK>(Xs(cur ^ 1), tid, xv);
+            lin_store_tile<BK>(Ws(cur ^ 1), tid, wv);
         }
         __syncthreads();
         cur ^= 1;
     }
-    // accumulators (+bias, +residual) -> LDS tile T[128][132]; C/D layout col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)
-    float *T = sm;
+    // epilogue straight from registers: C/D layout col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5);
+    // one store instruction covers two 128-byte row segments
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
-        const int nl = wc * 64 + tn * 32 + li;
-        const float bv = (a.bias && n0 + nl < N) ? a.bias[n0 + nl] : 0.f;
+        const int n = n0 + wc * 64 + tn * 32 + li;
+        if (n >= N) continue;
+        const float bv = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ml = wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                float v = acc[tm][tn][r] + bv;
-                if (EPI == EPI_RES_LN) v += res[tm][tn][r];
-                if (EPI == EPI_BIAS && a.relu) v = fmaxf(v, 0.f);
-                T[ml * LIN_TLD + nl] = v;
-            }
-    }
-    __syncthreads();
-    if (EPI == EPI_BIAS) {
-        const bool vec_out = VEC && (N % 4 == 0);
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            int idx = tid + i * 256;
-            int r = idx >> 5, c = (idx & 31) * 4;
-            int gm = m0 + r, gn = n0 + c;
-            if (gm >= M || gn >= N) continue;
-            float4 v = *reinterpret_cast<const float4 *>(T + r * LIN_TLD + c);
-            if (a.R) { // residual (rows wider than one tile: LN runs as its own kernel)
-                const float *rp = a.R + (int64_t)gm * N + gn;
-                if (vec_out && gn + 3 < N) {
-                    float4 rv = *reinterpret_cast<const float4 *>(rp);
-                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-                } else {
-                    v.x += rp[0];
-                    if (gn + 1 < N) v.y += rp[1];
-                    if (gn + 2 < N) v.z += rp[2];
-                    if (gn + 3 < N) v.w += rp[3];
+                const int m = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m < M) {
+                    float v = acc[tm][tn][r] + bv;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (a.R) v += a.R[(int64_t)m * N + n];
+                    a.Y[(int64_t)m * N + n] = v;
                 }
             }
-            float *dst = a.Y + (int64_t)gm * N + gn;
-            if (vec_out && gn + 3 < N) *reinterpret_cast<float4 *>(dst) = v;
-            else {
-                dst[0] = v.x;
-                if (gn + 1 < N) dst[1] = v.y;
-                if (gn + 2 < N) dst[2] = v.z;
-                if (gn + 3 < N) dst[3] = v.w;
-            }
-        }
-    } else {
-        // one wave per row, 32 rows per wave; lane owns columns 2*lane, 2*lane+1 (N <= 128); LDS only
-        const int c0 = 2 * lane;
-        const bool in0 = c0 < N, in1 = c0 + 1 < N;
-        const float invn = 1.0f / (float)N;
-        float g1a = in0 ? a.g1[c0] : 0.f, g1b = in1 ? a.g1[c0 + 1] : 0.f;
-        float b1a = in0 ? a.b1[c0] : 0.f, b1b = in1 ? a.b1[c0 + 1] : 0.f;
-        float ca = 0.f, cb = 0.f, g2a = 0.f, g2b = 0.f, b2a = 0.f, b2b = 0.f;
-        if (a.c) {
-            ca = in0 ? a.c[c0] : 0.f;
-            cb = in1 ? a.c[c0 + 1] : 0.f;
-            g2a = in0 ? a.g2[c0] : 0.f;
-            g2b = in1 ? a.g2[c0 + 1] : 0.f;
-            b2a = in0 ? a.b2[c0] : 0.f;
-            b2b = in1 ? a.b2[c0 + 1] : 0.f;
-        }
-#pragma unroll 4
-        for (int rr = 0; rr < 32; ++rr) {
-            const int r = wave * 32 + rr;
-            const int gm = m0 + r;
-            if (gm < M) {
-                float2 t = *reinterpret_cast<const float2 *>(T + r * LIN_TLD + c0);
-                float z0 = in0 ? t.x : 0.f;
-                float z1 = in1 ? t.y : 0.f;
-                float mu = wave_sum(z0 + z1) * invn;
-                float d0 = in0 ? z0 - mu : 0.f, d1 = in1 ? z1 - mu : 0.f;
-                float rstd = 1.0f / sqrtf(wave_sum(d0 * d0 + d1 * d1) * invn + 1e-5f);
-                float y0 = d0 * rstd * g1a + b1a, y1 = d1 * rstd * g1b + b1b;
-                if (a.c) {
-                    z0 = in0 ? y0 + ca : 0.f;
-                    z1 = in1 ? y1 + cb : 0.f;
-                    mu = wave_sum(z0 + z1) * invn;
-                    d0 = in0 ? z0 - mu : 0.f;
-                    d1 = in1 ? z1 - mu : 0.f;
-                    rstd = 1.0f / sqrtf(wave_sum(d0 * d0 + d1 * d1) * invn + 1e-5f);
-                    y0 = d0 * rstd * g2a + b2a;
-                    y1 = d1 * rstd * g2b + b2b;
-                }
-                float *Yr = a.Y + (int64_t)gm * N;
-                if (in0 && in1) *reinterpret_cast<float2 *>(Yr + c0) = make_float2(y0, y1);
-                else if (in0) Yr[c0] = y0;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------ attention
-// One workgroup per (head, sequence).  K_h, V_h of the whole sequence staged in
-// LDS; one query row per thread (L <= 256); online softmax with the additive
-// mask evaluated in registers:
-//   IRN:    j == L-1 -> +1.0 (every row sees the target), j <= i -> + r_u, else -inf
-//   causal: j <= i -> 0, else -inf
-//   padded key (seq[j] == 0) -> -inf
-// A fully masked row yields NaN like torch's softmax over all -inf.
-template <int HD>
-__global__ void __launch_bounds__(256) k_attn(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
-                                              const float *__restrict__ r_u, float *__restrict__ out, int L, int d,
-                                              int hd, int mask_mode) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *Ks = reinterpret_cast<float *>(smem);
-    float *Vs = Ks + (size_t)L * HD;
-    unsigned char *pad = reinterpret_cast<unsigned char *>(Vs + (size_t)L * HD);
-    const int h = blockIdx.x, b = blockIdx.y;
-    const int tid = threadIdx.x;
-    const int64_t base = (int64_t)b * L;
-    const int ld = 3 * d;
-    for (int idx = tid; idx < L * HD; idx += 256) {
-        int j = idx / HD, c = idx % HD;
-        float kv = 0.f, vv = 0.f;
-        if (c < hd) {
-            const float *row = qkv + (base + j) * ld + h * hd + c;
-            kv = row[d];
-            vv = row[2 * d];
-        }
-        Ks[idx] = kv;
-        Vs[idx] = vv;
-    }
-    for (int j = tid; j < L; j += 256) pad[j] = (seq[base + j] == 0) ? 1 : 0;
-    __syncthreads();
-
-    const int i = tid;
-    const bool active = i < L;
-    const float scale = 1.0f / sqrtf((float)hd);
-    float q[HD], o[HD];
-#pragma unroll
-    for (int c = 0; c < HD; ++c) {
-        q[c] = (active && c < hd) ? qkv[(base + i) * ld + h * hd + c] * scale : 0.f;
-        o[c] = 0.f;
-    }
-    const float add_allowed = (mask_mode == IRS_MASK_IRN) ? r_u[b] : 0.f;
-    float m = -INFINITY, l = 0.f;
-    const int wave_first = tid & ~63;
-    int jend = wave_first + 63;
-    if (jend > L - 1) jend = L - 1;
-    const bool irn = (mask_mode == IRS_MASK_IRN);
-    // keys 0..jend (wave-uniform bound); in IRN mode key L-1 is handled after the loop
-    int jloop_end = irn ? (jend < L - 2 ? jend : L - 2) : jend;
-    if (wave_first < L) {
-        for (int j = 0; j <= jloop_end; ++j) {
-            const float4 *k4 = reinterpret_cast<const float4 *>(Ks + (size_t)j * HD);
-            float s = 0.f;
-#pragma unroll
-            for (int c4 = 0; c4 < HD / 4; ++c4) {
-                float4 kk = k4[c4];
-                s = __fmaf_rn(q[4 * c4 + 0], kk.x, s);
-                s = __fmaf_rn(q[4 * c4 + 1], kk.y, s);
-                s = __fmaf_rn(q[4 * c4 + 2], kk.z, s);
-                s = __fmaf_rn(q[4 * c4 + 3], kk.w, s);
-            }
-            bool valid = active && (j <= i) && !pad[j];
-            if (valid) {
-                s += add_allowed;
-                if (s > m) {
-                    float corr = __expf(m - s);
-                    l *= corr;
-#pragma unroll
-                    for (int c = 0; c < HD; ++c) o[c] *= corr;
-                    m = s;
-                }
-                float p = __expf(s - m);
-                l += p;
-                const float4 *v4 = reinterpret_cast<const float4 *>(Vs + (size_t)j * HD);
-#pragma unroll
-                for (int c4 = 0; c4 < HD / 4; ++c4) {
-                    float4 vv = v4[c4];
-                    o[4 * c4 + 0] = __fmaf_rn(p, vv.x, o[4 * c4 + 0]);
-                    o[4 * c4 + 1] = __fmaf_rn(p, vv.y, o[4 * c4 + 1]);
-                    o[4 * c4 + 2] = __fmaf_rn(p, vv.z, o[4 * c4 + 2]);
-                    o[4 * c4 + 3] = __fmaf_rn(p, vv.w, o[4 * c4 + 3]);
-                }
-            }
-        }
-        if (irn) {
-            const int j = L - 1;
-            const float4 *k4 = reinterpret_cast<const float4 *>(Ks + (size_t)j * HD);
-            float s = 0.f;
-#pragma unroll
-            for (int c4 = 0; c4 < HD / 4; ++c4) {
-                float4 kk = k4[c4];
-                s = __fmaf_rn(q[4 * c4 + 0], kk.x, s);
-                s = __fmaf_rn(q[4 * c4 + 1], kk.y, s);
-                s = __fmaf_rn(q[4 * c4 + 2], kk.z, s);
-                s = __fmaf_rn(q[4 * c4 + 3], kk.w, s);
-            }
-            bool valid = active && !pad[j];
-            if (valid) {
-                s += 1.0f;
-                if (s > m) {
-                    float corr = __expf(m - s);
-                    l *= corr;
-#pragma unroll
-                    for (int c = 0; c < HD; ++c) o[c] *= corr;
-                    m = s;
-                }
-                float p = __expf(s - m);
-                l += p;
-                const float4 *v4 = reinterpret_cast<const float4 *>(Vs + (size_t)j * HD);
-#pragma unroll
-                for (int c4 = 0; c4 < HD / 4; ++c4) {
-                    float4 vv = v4[c4];
-                    o[4 * c4 + 0] = __fmaf_rn(p, vv.x, o[4 * c4 + 0]);
-                    o[4 * c4 + 1] = __fmaf_rn(p, vv.y, o[4 * c4 + 1]);
-                    o[4 * c4 + 2] = __fmaf_rn(p, vv.z, o[4 * c4 + 2]);
-                    o[4 * c4 + 3] = __fmaf_rn(p, vv.w, o[4 * c4 + 3]);
-                }
-            }
-        }
-    }
-    if (active) {
-        float inv = 1.0f / l; // l == 0 (fully masked) -> inf * 0 = NaN, as torch
-        float *orow = out + (base + i) * d + h * hd;
-#pragma unroll
-        for (int c = 0; c < HD; ++c)
-            if (c < hd) orow[c] = o[c] * inv;
     }
 }
 
@@ -439,17 +226,18 @@ __global__ void __launch_bounds__(256) k_attn(const float *__restrict__ qkv, con
 // shuffle per statistic -- no LDS staging, no barrier, no per-row shuffle chains.
 // Workgroup = 4 waves = 128 tokens; W (all N rows) and X slabs of 32 k stream through the same
 // swizzled double-buffered LDS image as k_linear.
+template <int BK>
 __global__ void __launch_bounds__(256, 2) k_linear_ln(LinArgs a) {
-    __shared__ __attribute__((aligned(16))) float sm[2 * 2 * LIN_BM * LIN_BK + 6 * LIN_BN];
-    float *vecs = sm + 2 * 2 * LIN_BM * LIN_BK; // bias, g1, b1, c, g2, b2 (zero padded to 128)
+    __shared__ __attribute__((aligned(16))) float sm[2 * 2 * LIN_BM * BK + 6 * LIN_BN];
+    float *vecs = sm + 2 * 2 * LIN_BM * BK; // bias, g1, b1, c, g2, b2 (zero padded to 128)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lk = lane >> 5;
     const int m0 = blockIdx.x * LIN_BM;
     const int M = a.M, N = a.N, K = a.K;
     const bool vecA = (K % 4 == 0) && ((((uintptr_t)a.X) & 15) == 0) && ((((uintptr_t)a.W) & 15) == 0);
-    auto Xs = [&](int st) { return sm + (st * 2 + 0) * LIN_BM * LIN_BK; };
-    auto Ws = [&](int st) { return sm + (st * 2 + 1) * LIN_BM * LIN_BK; };
+    auto Xs = [&](int st) { return sm + (st * 2 + 0) * LIN_BM * BK; };
+    auto Ws = [&](int st) { return sm + (st * 2 + 1) * LIN_BM * BK; };
     if (tid < LIN_BN) {
         const bool in = tid < N;
         vecs[0 * LIN_BN + tid] = (in && a.bias) ? a.bias[tid] : 0.f;
@@ -462,20 +250,21 @@ __global__ void __launch_bounds__(256, 2) k_linear_ln(LinArgs a) {
     const int mt = m0 + wave * 32 + li; // this lane's token
     const bool nvec = (N % 4 == 0) && ((((uintptr_t)a.R) & 15) == 0) && ((((uintptr_t)a.Y) & 15) == 0);
 
+    // accumulators start from the residual of this lane's token (C layout: register 4g+e of tile tn is
+    // column tn*32 + 8g + 4lk + e); bias is added in the epilogue from LDS.  A fragment-major residual
+    // Rf[((token/32 * 4 + tn) * 4 + g) * 64 + lane] (float4) makes every wave load one contiguous KiB;
+    // the row-major fallback reads 16-byte pieces of 64 different rows per instruction.
     f32x16 acc[4];
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tn][r] = 0.f;
-    // residual of this lane's token, C layout: register 4g+e of tile tn is column tn*32 + 8g + 4lk + e
-    float4 res[4][4];
+    const int mtile = (m0 >> 5) + wave;
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = tn * 32 + 8 * g + 4 * lk;
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (mt < M && n < N) {
+            if (a.Rf) {
+                t = reinterpret_cast<const float4 *>(a.Rf)[((size_t)(mtile * 4 + tn) * 4 + g) * 64 + lane];
+            } else if (mt < M && n < N) {
                 const float *p = a.R + (int64_t)mt * N + n;
                 if (nvec && n + 3 < N) t = *reinterpret_cast<const float4 *>(p);
                 else {
@@ -485,43 +274,46 @@ __global__ void __launch_bounds__(256, 2) k_linear_ln(LinArgs a) {
                     if (n + 3 < N) t.w = p[3];
                 }
             }
-            res[tn][g] = t;
+            acc[tn][4 * g + 0] = t.x;
+            acc[tn][4 * g + 1] = t.y;
+            acc[tn][4 * g + 2] = t.z;
+            acc[tn][4 * g + 3] = t.w;
         }
 
-    float4 xv[4], wv[4];
+    float4 xv[BK / 8], wv[BK / 8];
     if (vecA) {
-        lin_load_tile<true>(a.X, M, K, m0, 0, tid, xv);
-        lin_load_tile<true>(a.W, N, K, 0, 0, tid, wv);
+        lin_load_tile<true, BK>(a.X, M, K, m0, 0, tid, xv);
+        lin_load_tile<true, BK>(a.W, N, K, 0, 0, tid, wv);
     } else {
-        lin_load_tile<false>(a.X, M, K, m0, 0, tid, xv);
-        lin_load_tile<false>(a.W, N, K, 0, 0, tid, wv);
+        lin_load_tile<false, BK>(a.X, M, K, m0, 0, tid, xv);
+        lin_load_tile<false, BK>(a.W, N, K, 0, 0, tid, wv);
     }
-    lin_store_tile(Xs(0), tid, xv);
-    lin_store_tile(Ws(0), tid, wv);
+    lin_store_tile<BK>(Xs(0), tid, xv);
+    lin_store_tile<BK>(Ws(0), tid, wv);
     __syncthreads();
-    const int nkt = (K + LIN_BK - 1) / LIN_BK;
-    const int sw = (li >> 1) & 7;
+    const int nkt = (K + BK - 1) / BK;
+    const int sw = lin_swz<BK>(li);
     int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) {
             if (vecA) {
-                lin_load_tile<true>(a.X, M, K, m0, (kt + 1) * LIN_BK, tid, xv);
-                lin_load_tile<true>(a.W, N, K, 0, (kt + 1) * LIN_BK, tid, wv);
+                lin_load_tile<true, BK>(a.X, M, K, m0, (kt + 1) * BK, tid, xv);
+                lin_load_tile<true, BK>(a.W, N, K, 0, (kt + 1) * BK, tid, wv);
             } else {
-                lin_load_tile<false>(a.X, M, K, m0, (kt + 1) * LIN_BK, tid, xv);
-                lin_load_tile<false>(a.W, N, K, 0, (kt + 1) * LIN_BK, tid, wv);
+                lin_load_tile<false, BK>(a.X, M, K, m0, (kt + 1) * BK, tid, xv);
+                lin_load_tile<false, BK>(a.W, N, K, 0, (kt + 1) * BK, tid, wv);
             }
         }
-        const float *xb = Xs(cur) + (wave * 32 + li) * LIN_BK;
-        const float *wa = Ws(cur) + li * LIN_BK;
+        const float *xb = Xs(cur) + (wave * 32 + li) * BK;
+        const float *wa = Ws(cur) + li * BK;
 #pragma unroll
-        for (int q = 0; q < LIN_BK / 8; ++q) {
+        for (int q = 0; q < BK / 8; ++q) {
             const int off = ((2 * q + lk) ^ sw) << 2;
             const float4 x4 = *reinterpret_cast<const float4 *>(xb + off);
             const float4 w0 = *reinterpret_cast<const float4 *>(wa + off);
-            const float4 w1 = *reinterpret_cast<const float4 *>(wa + 32 * LIN_BK + off);
-            const float4 w2 = *reinterpret_cast<const float4 *>(wa + 64 * LIN_BK + off);
-            const float4 w3 = *reinterpret_cast<const float4 *>(wa + 96 * LIN_BK + off);
+            const float4 w1 = *reinterpret_cast<const float4 *>(wa + 32 * BK + off);
+            const float4 w2 = *reinterpret_cast<const float4 *>(wa + 64 * BK + off);
+            const float4 w3 = *reinterpret_cast<const float4 *>(wa + 96 * BK + off);
 #define LN_STEP(E)                                                                   \
     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.E, x4.E, acc[0], 0, 0, 0);      \
     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.E, x4.E, acc[1], 0, 0, 0);      \
@@ -531,8 +323,8 @@ __global__ void __launch_bounds__(256, 2) k_linear_ln(LinArgs a) {
 #undef LN_STEP
         }
         if (kt + 1 < nkt) {
-            lin_store_tile(Xs(cur ^ 1), tid, xv);
-            lin_store_tile(Ws(cur ^ 1), tid, wv);
+            lin_store_tile<BK>(Xs(cur ^ 1), tid, xv);
+            lin_store_tile<BK>(Ws(cur ^ 1), tid, wv);
         }
         __syncthreads();
         cur ^= 1;
@@ -546,10 +338,10 @@ __global__ void __launch_bounds__(256, 2) k_linear_ln(LinArgs a) {
         for (int g = 0; g < 4; ++g) {
             const int n = tn * 32 + 8 * g + 4 * lk;
             const float4 bb = *reinterpret_cast<const float4 *>(vecs + n);
-            float z0 = acc[tn][4 * g + 0] + bb.x + res[tn][g].x;
-            float z1 = acc[tn][4 * g + 1] + bb.y + res[tn][g].y;
-            float z2 = acc[tn][4 * g + 2] + bb.z + res[tn][g].z;
-            float z3 = acc[tn][4 * g + 3] + bb.w + res[tn][g].w;
+            float z0 = acc[tn][4 * g + 0] + bb.x;
+            float z1 = acc[tn][4 * g + 1] + bb.y;
+            float z2 = acc[tn][4 * g + 2] + bb.z;
+            float z3 = acc[tn][4 * g + 3] + bb.w;
             if (n >= N) z0 = 0.f;
             if (n + 1 >= N) z1 = 0.f;
             if (n + 2 >= N) z2 = 0.f;
@@ -614,6 +406,14 @@ __global__ void __launch_bounds__(256, 2) k_linear_ln(LinArgs a) {
                 acc[tn][4 * g + 3] = (acc[tn][4 * g + 3] - mu) * rstd * gg.w + be.w;
             }
     }
+    if (a.Yf) { // fragment-major copy for the next LN-GEMM's residual (rows/cols beyond M/N are zeros)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                reinterpret_cast<float4 *>(a.Yf)[((size_t)(mtile * 4 + tn) * 4 + g) * 64 + lane] =
+                    make_float4(acc[tn][4 * g], acc[tn][4 * g + 1], acc[tn][4 * g + 2], acc[tn][4 * g + 3]);
+    }
     if (mt < M) {
         float *Yr = a.Y + (int64_t)mt * N;
 #pragma unroll
@@ -658,9 +458,11 @@ __global__ void __launch_bounds__(256) k_attn_mfma(const float *__restrict__ qkv
     constexpr int KLD = HDP + 1;              // padded K row stride (conflict-free column reads)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NB = (L + 31) / 32, Lp = NB * 32;
-    float *Vs = reinterpret_cast<float *>(smem);        // [Lp][VW]  (16-byte aligned rows)
-    float *Ks = Vs + (size_t)Lp * VW;                   // [Lp][KLD]
-    unsigned int *padbits = reinterpret_cast<unsigned int *>(Ks + (size_t)Lp * KLD); // [8]
+    // only the L real rows are kept (rows >= L are masked: reads clamp to row L-1), so that
+    // L = 200, hd = 32 fits three workgroups per CU
+    float *Vs = reinterpret_cast<float *>(smem);        // [L][VW]  (16-byte aligned rows)
+    float *Ks = Vs + (size_t)L * VW;                    // [L][KLD]
+    unsigned int *padbits = reinterpret_cast<unsigned int *>(Ks + (size_t)L * KLD); // [8]
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, kk = lane >> 5;
@@ -669,10 +471,10 @@ __global__ void __launch_bounds__(256) k_attn_mfma(const float *__restrict__ qkv
     const bool irn = (mask_mode == IRS_MASK_IRN);
     if (V4) {
         constexpr int C4 = HDP / 4;
-        for (int idx = tid; idx < Lp * C4; idx += 256) {
+        for (int idx = tid; idx < L * C4; idx += 256) {
             int j = idx / C4, c = (idx % C4) * 4;
             float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-            if (j < L && c < hd) {
+            if (c < hd) {
                 const float *row = qkv + (base + j) * ld + h * hd + c;
                 kv = *reinterpret_cast<const float4 *>(row + d);
                 vv = *reinterpret_cast<const float4 *>(row + 2 * d);
@@ -682,12 +484,12 @@ __global__ void __launch_bounds__(256) k_attn_mfma(const float *__restrict__ qkv
             *reinterpret_cast<float4 *>(Vs + (size_t)j * VW + c) = vv;
         }
         if (VW > HDP)
-            for (int idx = tid; idx < Lp * (VW - HDP); idx += 256) Vs[(size_t)(idx / (VW - HDP)) * VW + HDP + idx % (VW - HDP)] = 0.f;
+            for (int idx = tid; idx < L * (VW - HDP); idx += 256) Vs[(size_t)(idx / (VW - HDP)) * VW + HDP + idx % (VW - HDP)] = 0.f;
     } else {
-        for (int idx = tid; idx < Lp * VW; idx += 256) {
+        for (int idx = tid; idx < L * VW; idx += 256) {
             int j = idx / VW, c = idx % VW;
             float kv = 0.f, vv = 0.f;
-            if (j < L && c < hd) {
+            if (c < hd) {
                 const float *row = qkv + (base + j) * ld + h * hd + c;
                 kv = row[d];
                 vv = row[2 * d];
@@ -758,7 +560,7 @@ __global__ void __launch_bounds__(256) k_attn_mfma(const float *__restrict__ qkv
             f32x16 sacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-            const float *kp = Ks + (size_t)(kb * 32 + lq) * KLD + kk * HH;
+            const float *kp = Ks + (size_t)min(kb * 32 + lq, L - 1) * KLD + kk * HH;
 #pragma unroll
             for (int s2 = 0; s2 < HH; ++s2) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[s2], qf[s2], sacc, 0, 0, 0);
             float mx = -INFINITY;
@@ -797,10 +599,12 @@ __global__ void __launch_bounds__(256) k_attn_mfma(const float *__restrict__ qkv
             for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
-                const float *vp = Vs + (size_t)(kb * 32 + 4 * kk) * VW + ct * 32 + lq; // A: V^T[c = lq][key]
+                const float *vp = Vs + ct * 32 + lq; // A: V^T[c = lq][key]
+                const int key0 = kb * 32 + 4 * kk;
 #pragma unroll
                 for (int t = 0; t < 16; ++t)
-                    o[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[((t & 3) + 8 * (t >> 2)) * VW], sacc[t], o[ct], 0, 0, 0);
+                    o[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[(size_t)min(key0 + (t & 3) + 8 * (t >> 2), L - 1) * VW], sacc[t],
+                                                                 o[ct], 0, 0, 0);
             }
         }
         const float lt = l + __shfl_xor(l, 32, 64);
@@ -823,6 +627,68 @@ __global__ void __launch_bounds__(256) k_attn_mfma(const float *__restrict__ qkv
                     }
                 }
         }
+    }
+}
+
+// ------------------------------------------------------------------ single-query attention (last layer, rows-only decode)
+// Only row pos[b] of the last layer is consumed by the scoring step (the reference computes all L
+// rows and uses output[index][history_end_pos], influentialRS.py:374,421).  One wave per (sequence,
+// head): lanes over keys for the scores, lanes over head columns for P.V.  Same mask semantics as
+// k_attn_mfma.  out_rows[b][h*hd + c].
+__global__ void __launch_bounds__(64) k_attn_row(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
+                                                 const float *__restrict__ r_u, const int32_t *__restrict__ pos,
+                                                 float *__restrict__ out_rows, int L, int d, int hd, int mask_mode) {
+    __shared__ float p_s[256];
+    __shared__ float q_s[64];
+    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int64_t base = (int64_t)b * L;
+    const int ld = 3 * d;
+    int i = pos[b];
+    if (i < 0) i = 0;
+    if (i >= L) i = L - 1;
+    const bool irn = (mask_mode == IRS_MASK_IRN);
+    const float add_allowed = irn ? r_u[b] : 0.f;
+    const float scale = 1.0f / sqrtf((float)hd);
+    if (lane < hd) q_s[lane] = qkv[(base + i) * ld + h * hd + lane] * scale;
+    __syncthreads();
+    float sc[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int j = lane + 64 * t;
+        float s = -INFINITY;
+        if (j < L) {
+            const bool is_tgt = irn && (j == L - 1);
+            const bool ok = (seq[base + j] != 0) && (is_tgt || j <= i);
+            if (ok) {
+                const float *kr = qkv + (base + j) * ld + d + h * hd;
+                float acc = 0.f;
+                for (int c = 0; c < hd; ++c) acc = __fmaf_rn(q_s[c], kr[c], acc);
+                s = acc + (is_tgt ? 1.0f : add_allowed);
+            }
+        }
+        sc[t] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int j = lane + 64 * t;
+        float pv = (sc[t] == -INFINITY) ? 0.f : __expf(sc[t] - mx);
+        p_s[j] = pv;
+        sum += pv;
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    if (lane < hd) {
+        float o = 0.f;
+        for (int j = 0; j < L; ++j) {
+            const float pj = p_s[j];
+            if (pj != 0.f) o = __fmaf_rn(pj, qkv[(base + j) * ld + 2 * d + h * hd + lane], o);
+        }
+        out_rows[(int64_t)b * d + h * hd + lane] = o / sum; // sum == 0 (fully masked) -> NaN like torch
     }
 }
 
@@ -903,24 +769,33 @@ __global__ void k_gather_rows(const float *__restrict__ x, const int32_t *__rest
 }
 
 // ------------------------------------------------------------------ host side
+static int g_lin_bk = 16, g_ln_bk = 16; // K-slab depth (tools/gemm_lab.hip flips these to compare 16 vs 32)
 static int launch_linear(irs_ctx *ctx, const float *X, const float *W, const float *bias, const float *R, float *Y,
                          int M, int N, int K, bool relu, hipStream_t s, const float *g1 = nullptr,
                          const float *b1 = nullptr, const float *c = nullptr, const float *g2 = nullptr,
-                         const float *b2 = nullptr) {
-    LinArgs a{X, W, bias, R, Y, M, N, K, relu ? 1 : 0, g1, b1, c, g2, b2};
-    irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
+                         const float *b2 = nullptr, const float *Rf = nullptr, float *Yf = nullptr) {
+    LinArgs a{X, W, bias, R, Y, M, N, K, relu ? 1 : 0, g1, b1, c, g2, b2, Rf, Yf};
+    if (ctx) irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
     if (g1 != nullptr) { // fused residual + LayerNorm: whole rows per wave (N <= 128)
-        hipLaunchKernelGGL(k_linear_ln, dim3((M + LIN_BM - 1) / LIN_BM), dim3(256), 0, s, a);
+        dim3 grid((M + LIN_BM - 1) / LIN_BM);
+        if (g_ln_bk == 16) hipLaunchKernelGGL(k_linear_ln<16>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_linear_ln<32>, grid, dim3(256), 0, s, a);
     } else {
         dim3 grid((N + LIN_BN - 1) / LIN_BN, (M + LIN_BM - 1) / LIN_BM);
-        bool vec = (K % 4 == 0) && ((((uintptr_t)X) & 15) == 0) && ((((uintptr_t)W) & 15) == 0) && ((((uintptr_t)Y) & 15) == 0) &&
-                   (!R || (((uintptr_t)R) & 15) == 0);
-        if (vec) hipLaunchKernelGGL((k_linear<true, EPI_BIAS>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_linear<false, EPI_BIAS>), grid, dim3(256), 0, s, a);
+        bool vec = (K % 4 == 0) && ((((uintptr_t)X) & 15) == 0) && ((((uintptr_t)W) & 15) == 0);
+        if (g_lin_bk == 16) {
+            if (vec) hipLaunchKernelGGL((k_linear<true, 16>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_linear<false, 16>), grid, dim3(256), 0, s, a);
+        } else {
+            if (vec) hipLaunchKernelGGL((k_linear<true, 32>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_linear<false, 32>), grid, dim3(256), 0, s, a);
+        }
     }
-    irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * M * (double)N * K,
-                 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)));
-    IRS_CHECK_HIP(ctx, hipGetLastError());
+    if (ctx) {
+        irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * M * (double)N * K,
+                     4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)));
+        IRS_CHECK_HIP(ctx, hipGetLastError());
+    }
     return IRS_OK;
 }
 
@@ -929,7 +804,7 @@ static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const
     const int L = ctx->dims.max_len, d = ctx->dims.d, H = ctx->dims.n_heads, hd = d / H;
     const int HDP = hd <= 8 ? 8 : hd <= 16 ? 16 : hd <= 32 ? 32 : 64;
     const int Lp = ((L + 31) / 32) * 32, VW = HDP < 32 ? 32 : HDP;
-    size_t lds = (size_t)Lp * (HDP + 1) * 4 + (size_t)Lp * VW * 4 + 64;
+    size_t lds = (size_t)L * (HDP + 1) * 4 + (size_t)L * VW * 4 + 64;
     const bool v4 = (hd % 4 == 0) && (d % 4 == 0) && ((((uintptr_t)qkv) & 15) == 0) && ((((uintptr_t)out) & 15) == 0);
     dim3 grid(H, B);
     const int mm = ctx->dims.mask_mode;
@@ -984,20 +859,45 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     hipLaunchKernelGGL(k_embed, dim3((rows + 3) / 4), dim3(256), 0, s, seq, ctx->item_emb, ctx->pe, x, rows, L, d,
                        sqrtf((float)d), ctx->dims.n_item);
     IRS_CHECK_HIP(ctx, hipGetLastError());
+    // rows-only decode: the caller wants x[b, pos[b], :] only, so the LAST layer is evaluated for that one
+    // row per sequence (all earlier layers need every row: they feed the next layer's keys and values)
+    const bool rows_only = (x_out == nullptr) && pos && xrows && d <= LIN_BN && L >= 4;
     for (int l = 0; l < ctx->dims.n_layers; ++l) {
         const irs_layer_w &w = ctx->layer[l];
+        const bool last_rows = rows_only && (l + 1 == ctx->dims.n_layers);
         // qkv = x W_in^T + b_in
         if ((rc = launch_linear(ctx, x, w.sa_in_w, w.sa_in_b, nullptr, ctx->act_qkv, rows, 3 * d, d, false, s))) return rc;
-        if ((rc = launch_attn(ctx, ctx->act_qkv, seq, ctx->act_ru, ctx->act_ao, B, s))) return rc;
         const float *cl = ctx->c_l + (size_t)l * d;
+        if (last_rows) {
+            float *ao_r = ctx->act_ao;                 // [B, d] attention output rows
+            float *x_r = ctx->act_ao + (size_t)B * d;  // [B, d] residual rows x[b, pos[b]]
+            float *y_r = ctx->act_ao + (size_t)2 * B * d;
+            float *h_r = ctx->act_h;                   // [B, F]
+            irs_prof_begin(ctx, IRS_PROF_ATTN, s);
+            hipLaunchKernelGGL(k_attn_row, dim3(ctx->dims.n_heads, B), dim3(64), 0, s, ctx->act_qkv, seq, ctx->act_ru, pos,
+                               ao_r, L, d, d / ctx->dims.n_heads, ctx->dims.mask_mode);
+            irs_prof_end(ctx, IRS_PROF_ATTN, s, 4.0 * B * (double)L * d, 4.0 * 3.0 * B * (double)L * d);
+            hipLaunchKernelGGL(k_gather_rows, dim3(B), dim3(64), 0, s, x, pos, x_r, B, L, d);
+            if ((rc = launch_linear(ctx, ao_r, w.sa_out_w, w.sa_out_b, x_r, y_r, B, d, d, false, s, w.n1_w, w.n1_b, cl, w.n2_w,
+                                    w.n2_b)))
+                return rc;
+            if ((rc = launch_linear(ctx, y_r, w.l1_w, w.l1_b, nullptr, h_r, B, F, d, true, s))) return rc;
+            if ((rc = launch_linear(ctx, h_r, w.l2_w, w.l2_b, y_r, xrows, B, d, F, false, s, w.n3_w, w.n3_b))) return rc;
+            IRS_CHECK_HIP(ctx, hipGetLastError());
+            return IRS_OK;
+        }
+        if ((rc = launch_attn(ctx, ctx->act_qkv, seq, ctx->act_ru, ctx->act_ao, B, s))) return rc;
         if (d <= LIN_BN) {
-            // x <- LN2(LN1(x + ao W_o^T + b_o) + c_l), fused into the GEMM epilogue (in place is not safe: y)
+            // x <- LN2(LN1(x + ao W_o^T + b_o) + c_l), fused into the GEMM epilogue (y, not in place);
+            // residuals come from the fragment-major copy the previous LN-GEMM left (layer 0 reads row-major)
             if ((rc = launch_linear(ctx, ctx->act_ao, w.sa_out_w, w.sa_out_b, x, y, rows, d, d, false, s, w.n1_w, w.n1_b,
-                                    cl, w.n2_w, w.n2_b)))
+                                    cl, w.n2_w, w.n2_b, l > 0 ? ctx->act_xf : nullptr, ctx->act_yf)))
                 return rc;
             // h = relu(y W1^T + b1); x <- LN3(y + h W2^T + b2)
             if ((rc = launch_linear(ctx, y, w.l1_w, w.l1_b, nullptr, ctx->act_h, rows, F, d, true, s))) return rc;
-            if ((rc = launch_linear(ctx, ctx->act_h, w.l2_w, w.l2_b, y, x, rows, d, F, false, s, w.n3_w, w.n3_b))) return rc;
+            if ((rc = launch_linear(ctx, ctx->act_h, w.l2_w, w.l2_b, y, x, rows, d, F, false, s, w.n3_w, w.n3_b, nullptr,
+                                    nullptr, nullptr, ctx->act_yf, l + 1 < ctx->dims.n_layers ? ctx->act_xf : nullptr)))
+                return rc;
         } else {
             // y = x + ao W_o^T + b_o ; x = LN2(LN1(y) + c_l)
             if ((rc = launch_linear(ctx, ctx->act_ao, w.sa_out_w, w.sa_out_b, x, y, rows, d, d, false, s))) return rc;

@@ -55,6 +55,7 @@ struct irs_ctx {
     size_t ws_bytes;
     // decoder activations
     float *act_x, *act_y, *act_qkv, *act_ao, *act_h, *act_ru;
+    float *act_xf, *act_yf; // fragment-major copies of x / y (residual inputs of the LN-fused GEMMs)
     // scoring
     uint4 *xb;          // packed bf16 rows [m_pad/32][KS][64] x 16 B
     float *eps;         // [m_pad]

@@ -101,6 +101,28 @@ def test_paths_vs_reference_goldens(golden, name, cfgname, use_graph):
     assert np.array_equal(w[:, L - 1 - P:L - 1] if P < L - 1 else w[:, :L - 1], paths[:, -(L - 1):].astype(np.int64) if P >= L - 1 else paths.astype(np.int64))
 
 
+@pytest.mark.parametrize("cfgname", ["tiny", "default", "c2"])
+def test_rows_only_decode_equals_full_decode(cfgname):
+    """When only x[b, pos[b]] is requested the last layer is evaluated for that row alone
+    (single-query attention, B-row GEMMs): same values as the full decode to float32 noise."""
+    cfg = synth.make_config(cfgname)
+    sd = synth.irn_state_dict(cfg, 1234)
+    eng = make_engine(cfg, sd, max_rows=8)
+    hists = synth.user_histories(8, cfg.n_item, seed=7)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=11)[:5]
+    raws, seqs, users, targets, labels = synth.collate_eval_irs(rows, cfg.max_len, gap_len=2)
+    L = cfg.max_len
+    pos = torch.tensor([L - 4, L - 2, 3, L - 1, 0], dtype=torch.int32, device="cuda")
+    seq, u = torch.from_numpy(seqs).cuda(), torch.from_numpy(users).cuda()
+    x, xr_full, _ = eng.decode(seq, u, want_x=True, pos=pos)
+    _, xr, _ = eng.decode(seq, u, want_x=False, pos=pos)
+    ref = x[torch.arange(5), pos.long()]
+    assert torch.equal(xr_full, ref)
+    both = torch.isfinite(ref) & torch.isfinite(xr)
+    assert torch.equal(torch.isnan(ref), torch.isnan(xr))
+    assert (xr - ref)[both].abs().max().item() < 1e-5
+
+
 def test_path_grow_branch_and_errors(oracle):
     """gap_len > 0 exercises the grow branch (influentialRS.py:438-441); a window
     that swallows all k candidates raises IRS_ROW_NO_CANDIDATE."""

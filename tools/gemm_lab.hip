@@ -29,6 +29,7 @@ int main(int argc, char **argv) {
         {384, 128, false, false, "qkv    "}, {128, 128, true, false, "out+ln "}, {256, 128, false, true, "ffn1   "}, {128, 256, true, false, "ffn2+ln"}};
     float *X, *W, *B, *R, *Y, *G;
     CK(hipMalloc(&X, (size_t)M * 256 * 4)); CK(hipMalloc(&W, 384 * 256 * 4)); CK(hipMalloc(&B, 384 * 4));
+    float *Y2; CK(hipMalloc(&Y2, (size_t)M * 128 * 4));
     CK(hipMalloc(&R, (size_t)M * 384 * 4)); CK(hipMalloc(&Y, (size_t)M * 384 * 4)); CK(hipMalloc(&G, 384 * 4));
     std::vector<float> h((size_t)M * 256);
     for (auto &v : h) v = (rand() / (float)RAND_MAX) * 2 - 1;
@@ -38,14 +39,14 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(B, h.data(), 384 * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(G, h.data(), 384 * 4, hipMemcpyHostToDevice));
     for (auto &sh : shapes) {
-        LinArgs a{X, W, B, sh.ln ? R : nullptr, Y, M, sh.N, sh.K, sh.relu ? 1 : 0, sh.ln ? G : nullptr, G, sh.ln ? G : nullptr, G, G};
+        LinArgs a{X, W, B, sh.ln ? R : nullptr, Y, M, sh.N, sh.K, sh.relu ? 1 : 0, sh.ln ? G : nullptr, G, sh.ln ? G : nullptr, G, G, nullptr, nullptr};
+        LinArgs af = a; af.Rf = R; af.Yf = Y2;
         double gf = 2.0 * M * sh.N * sh.K / 1e9;
-        dim3 grid((sh.N + LIN_BN - 1) / LIN_BN, (M + LIN_BM - 1) / LIN_BM);
-        float ms = time_it([&] {
-            if (sh.ln) hipLaunchKernelGGL(k_linear_ln, dim3((M + LIN_BM - 1) / LIN_BM), dim3(256), 0, 0, a);
-            else hipLaunchKernelGGL((k_linear<true, EPI_BIAS>), grid, dim3(256), 0, 0, a);
-        }, 20);
-        printf("%s : %8.1f us  %6.1f TF\n", sh.name, ms * 1e3, gf / ms);
+        for (int bk : {32, 16}) {
+            g_lin_bk = bk; g_ln_bk = bk;
+            float ms = time_it([&] { launch_linear(nullptr, a.X, a.W, a.bias, a.R, a.Y, M, sh.N, sh.K, sh.relu, 0, a.g1, a.b1, a.c, a.g2, a.b2, nullptr, nullptr); }, 20);
+            printf("%s BK=%2d : %8.1f us  %6.1f TF\n", sh.name, bk, ms * 1e3, gf / ms);
+        }
     }
     CK(hipDeviceSynchronize());
     return 0;
