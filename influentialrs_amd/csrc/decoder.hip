@@ -434,6 +434,196 @@ __global__ void __launch_bounds__(256, 2) k_linear_ln(LinArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ small-M linear (latency path, few sequences)
+// With a few hundred rows the 128x128 tiling uses 2-6 workgroups of the 256 CUs.  Here one WAVE
+// owns one 32x32 output tile and loads its operands straight from L2 into MFMA-fragment registers
+// (lane (i, kk) reads 16-byte pieces k = 8q + 4kk of row i of X and of W): no LDS, no barriers,
+// M/32 x N/32 waves in flight.  K <= 256.
+template <bool LNV>
+__global__ void __launch_bounds__(256) k_linear_small(LinArgs a) {
+    __shared__ float part[2][4][32];      // LN variant: per-wave partial row statistics
+    __shared__ float vecs[LNV ? 6 * 128 : 4]; // LN variant: bias, g1, b1, c, g2, b2 (zero padded)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int M = a.M, N = a.N, K = a.K;
+    const int m0 = blockIdx.y * 32;
+    const int n0 = LNV ? wave * 32 : (blockIdx.x * 4 + wave) * 32;
+    const bool tile_ok = n0 < N; // whole-wave condition
+    const bool kvec = (K % 4 == 0) && ((((uintptr_t)a.X) & 15) == 0) && ((((uintptr_t)a.W) & 15) == 0);
+    if (LNV && tid < 128) {
+        const bool in = tid < N;
+        vecs[0 * 128 + tid] = (in && a.bias) ? a.bias[tid] : 0.f;
+        vecs[1 * 128 + tid] = in ? a.g1[tid] : 0.f;
+        vecs[2 * 128 + tid] = in ? a.b1[tid] : 0.f;
+        vecs[3 * 128 + tid] = (in && a.c) ? a.c[tid] : 0.f;
+        vecs[4 * 128 + tid] = (in && a.c) ? a.g2[tid] : 0.f;
+        vecs[5 * 128 + tid] = (in && a.c) ? a.b2[tid] : 0.f;
+    }
+    // LNV: D[n][m] (lane = token, A = W rows, B = X rows); else D[m][n] (lane = column)
+    const int xr = m0 + li, wr = n0 + li;
+    const float *xrow = a.X + (int64_t)(xr < M ? xr : 0) * K;
+    const float *wrow = a.W + (int64_t)(wr < N ? wr : 0) * K;
+    const int nq = (K + 7) / 8;
+    auto load_chunk = [&](int q0, float4 (&xf)[8], float4 (&wf)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k0 = 8 * (q0 + j) + 4 * lk;
+            float4 xt = make_float4(0.f, 0.f, 0.f, 0.f), wt = xt;
+            if (q0 + j < nq && k0 < K) {
+                if (kvec && k0 + 3 < K) {
+                    if (xr < M) xt = *reinterpret_cast<const float4 *>(xrow + k0);
+                    if (wr < N) wt = *reinterpret_cast<const float4 *>(wrow + k0);
+                } else {
+                    if (xr < M) {
+                        xt.x = xrow[k0];
+                        if (k0 + 1 < K) xt.y = xrow[k0 + 1];
+                        if (k0 + 2 < K) xt.z = xrow[k0 + 2];
+                        if (k0 + 3 < K) xt.w = xrow[k0 + 3];
+                    }
+                    if (wr < N) {
+                        wt.x = wrow[k0];
+                        if (k0 + 1 < K) wt.y = wrow[k0 + 1];
+                        if (k0 + 2 < K) wt.z = wrow[k0 + 2];
+                        if (k0 + 3 < K) wt.w = wrow[k0 + 3];
+                    }
+                }
+            }
+            xf[j] = xt;
+            wf[j] = wt;
+        }
+    };
+    auto mma_chunk = [&](f32x16 &acc, const float4 (&xf)[8], const float4 (&wf)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (LNV) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j].x, xf[j].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j].y, xf[j].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j].z, xf[j].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j].w, xf[j].w, acc, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[j].x, wf[j].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[j].y, wf[j].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[j].z, wf[j].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[j].w, wf[j].w, acc, 0, 0, 0);
+            }
+        }
+    };
+    // epilogue inputs issued before the K loop (independent of it)
+    float resv[16];
+    const int mt = m0 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        resv[r] = 0.f;
+        if (LNV) {
+            const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (n < N && mt < M) resv[r] = a.R[(int64_t)mt * N + n];
+        } else if (a.R) {
+            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lk, n = n0 + li;
+            if (m < M && n < N) resv[r] = a.R[(int64_t)m * N + n];
+        }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (tile_ok) { // two register sets: the next 64 k are in flight while the current 64 are multiplied
+        float4 xa[8], wa[8], xb[8], wb[8];
+        load_chunk(0, xa, wa);
+        for (int q0 = 0; q0 < nq; q0 += 16) {
+            if (q0 + 8 < nq) load_chunk(q0 + 8, xb, wb);
+            mma_chunk(acc, xa, wa);
+            if (q0 + 8 < nq) {
+                if (q0 + 16 < nq) load_chunk(q0 + 16, xa, wa);
+                mma_chunk(acc, xb, wb);
+            }
+        }
+    }
+    if (!LNV) {
+        const int n = n0 + li;
+        if (!tile_ok || n >= N) return;
+        const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (m < M) {
+                float v = acc[r] + bv;
+                if (a.relu) v = fmaxf(v, 0.f);
+                v += resv[r];
+                a.Y[(int64_t)m * N + n] = v;
+            }
+        }
+        return;
+    }
+    // ---- LN variant: lane = token m0 + li; registers = columns n0 + (r&3) + 8(r>>2) + 4lk of this wave's 32
+    __syncthreads(); // vecs
+    const float invn = 1.0f / (float)N;
+    float z[16];
+    float s1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        float v = 0.f;
+        if (n < N && mt < M) v = acc[r] + vecs[n] + resv[r];
+        z[r] = v;
+        s1 += v;
+    }
+    auto row_total = [&](float v, int slot) { // sum over the 128 columns of each token (4 waves x 2 lane halves)
+        v += __shfl_xor(v, 32, 64);
+        if (lk == 0) part[slot][wave][li] = v;
+        __syncthreads();
+        float t = part[slot][0][li] + part[slot][1][li] + part[slot][2][li] + part[slot][3][li];
+        __syncthreads();
+        return t;
+    };
+    float mu = row_total(s1, 0) * invn;
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const float dlt = (n < N) ? z[r] - mu : 0.f;
+        q += dlt * dlt;
+    }
+    float rstd = 1.0f / sqrtf(row_total(q, 1) * invn + 1e-5f);
+    s1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        float y = 0.f;
+        if (n < N) y = (z[r] - mu) * rstd * vecs[128 + n] + vecs[256 + n] + vecs[384 + n];
+        z[r] = y;
+        s1 += y;
+    }
+    if (a.c) {
+        mu = row_total(s1, 0) * invn;
+        q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const float dlt = (n < N) ? z[r] - mu : 0.f;
+            q += dlt * dlt;
+        }
+        rstd = 1.0f / sqrtf(row_total(q, 1) * invn + 1e-5f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (n < N) z[r] = (z[r] - mu) * rstd * vecs[512 + n] + vecs[640 + n];
+        }
+    }
+    if (mt < M) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + 8 * g + 4 * lk;
+            float *dst = a.Y + (int64_t)mt * N + n;
+            if ((N % 4 == 0) && n + 3 < N && ((((uintptr_t)a.Y) & 15) == 0))
+                *reinterpret_cast<float4 *>(dst) = make_float4(z[4 * g], z[4 * g + 1], z[4 * g + 2], z[4 * g + 3]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < N) dst[e] = z[4 * g + e];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ attention on fp32 MFMA
 // One workgroup per (head, sequence), 4 waves; K_h / V_h of the sequence in LDS.
 // A wave owns 32-query blocks.  Per (query block, key block):
@@ -663,7 +853,17 @@ __global__ void __launch_bounds__(64) k_attn_row(const float *__restrict__ qkv, 
             if (ok) {
                 const float *kr = qkv + (base + j) * ld + d + h * hd;
                 float acc = 0.f;
-                for (int c = 0; c < hd; ++c) acc = __fmaf_rn(q_s[c], kr[c], acc);
+                if ((hd & 3) == 0 && (d & 3) == 0 && ((((uintptr_t)qkv) & 15) == 0)) {
+                    for (int c = 0; c < hd; c += 4) {
+                        const float4 k4 = *reinterpret_cast<const float4 *>(kr + c);
+                        acc = __fmaf_rn(q_s[c], k4.x, acc);
+                        acc = __fmaf_rn(q_s[c + 1], k4.y, acc);
+                        acc = __fmaf_rn(q_s[c + 2], k4.z, acc);
+                        acc = __fmaf_rn(q_s[c + 3], k4.w, acc);
+                    }
+                } else {
+                    for (int c = 0; c < hd; ++c) acc = __fmaf_rn(q_s[c], kr[c], acc);
+                }
                 s = acc + (is_tgt ? 1.0f : add_allowed);
             }
         }
@@ -682,13 +882,20 @@ __global__ void __launch_bounds__(64) k_attn_row(const float *__restrict__ qkv, 
     }
     sum = wave_sum(sum);
     __syncthreads();
-    if (lane < hd) {
-        float o = 0.f;
-        for (int j = 0; j < L; ++j) {
-            const float pj = p_s[j];
-            if (pj != 0.f) o = __fmaf_rn(pj, qkv[(base + j) * ld + 2 * d + h * hd + lane], o);
+    // P.V: lane = (key parity group, column); independent coalesced loads, two partial sums combined at the end
+    {
+        const int c = lane & 31, half = lane >> 5;
+        const int nc = hd > 32 ? 2 : 1; // hd <= 64: up to two column passes
+        for (int cp = 0; cp < nc; ++cp) {
+            const int col = cp * 32 + c;
+            float o = 0.f;
+            if (col < hd) {
+                const float *vcol = qkv + base * ld + 2 * d + h * hd + col;
+                for (int j = half; j < L; j += 2) o = __fmaf_rn(p_s[j], vcol[(int64_t)j * ld], o);
+            }
+            o += __shfl_xor(o, 32, 64);
+            if (half == 0 && col < hd) out_rows[(int64_t)b * d + h * hd + col] = o / sum; // sum == 0 -> NaN like torch
         }
-        out_rows[(int64_t)b * d + h * hd + lane] = o / sum; // sum == 0 (fully masked) -> NaN like torch
     }
 }
 
@@ -776,7 +983,10 @@ static int launch_linear(irs_ctx *ctx, const float *X, const float *W, const flo
                          const float *b2 = nullptr, const float *Rf = nullptr, float *Yf = nullptr) {
     LinArgs a{X, W, bias, R, Y, M, N, K, relu ? 1 : 0, g1, b1, c, g2, b2, Rf, Yf};
     if (ctx) irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
-    if (g1 != nullptr) { // fused residual + LayerNorm: whole rows per wave (N <= 128)
+    if (M <= 2048 && K <= 256) { // latency path: one wave per 32x32 tile, operands straight from L2
+        if (g1 != nullptr) hipLaunchKernelGGL(k_linear_small<true>, dim3(1, (M + 31) / 32), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_linear_small<false>, dim3((N + 127) / 128, (M + 31) / 32), dim3(256), 0, s, a);
+    } else if (g1 != nullptr) { // fused residual + LayerNorm: whole rows per wave (N <= 128)
         dim3 grid((M + LIN_BM - 1) / LIN_BM);
         if (g_ln_bk == 16) hipLaunchKernelGGL(k_linear_ln<16>, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(k_linear_ln<32>, grid, dim3(256), 0, s, a);
