@@ -63,6 +63,102 @@ __global__ void k_cross_const(const float *__restrict__ Wo, const float *__restr
     c[i] = acc + bo[i];
 }
 
+// ------------------------------------------------------------------ packed (pad-free) decode plan
+// Pad tokens are masked as keys and their rows are never consumed, yet they are ~half of an ml-1m-shaped
+// batch (pre-padded windows, data_provider.py:591-617).  When only row pos[b] of every sequence is wanted,
+// the decoder runs on the PACKED valid tokens: tok_row[m'] = b*L + t for every t with seq[b,t] != 0 (plus
+// t = pos[b] itself), in (b, t) order; cnt[b] / off[b] delimit sequence b; qrow[b] is the packed index of
+// (b, pos[b]); m_dev[0] = total.  Causality is order-preserving, so every kernel just works on shorter
+// sequences.
+// Three small kernels: count (one wave per sequence, ballots), scan (one workgroup), fill (one wave per sequence).
+__device__ __forceinline__ bool plan_valid(const int64_t *__restrict__ sq, int t, int L, int p) {
+    return t < L && (sq[t] != 0 || t == p);
+}
+
+__global__ void __launch_bounds__(256) k_plan_count(const int64_t *__restrict__ seq, const int32_t *__restrict__ pos, int B,
+                                                    int L, int32_t *__restrict__ cnt) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    int p = pos[b];
+    p = p < 0 ? 0 : (p >= L ? L - 1 : p);
+    const int64_t *sq = seq + (int64_t)b * L;
+    int n = 0;
+    for (int t0 = 0; t0 < L; t0 += 64) n += __popcll(__ballot(plan_valid(sq, t0 + lane, L, p)));
+    if (lane == 0) cnt[b] = n;
+}
+
+__global__ void __launch_bounds__(1024) k_plan_scan(const int32_t *__restrict__ cnt, int B, int32_t *__restrict__ off,
+                                                    int32_t *__restrict__ m_dev) {
+    __shared__ int s_scan[1024];
+    __shared__ int s_base;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < B; b0 += 1024) {
+        const int b = b0 + tid;
+        const int n = (b < B) ? cnt[b] : 0;
+        s_scan[tid] = n;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) { // inclusive Hillis-Steele scan
+            int v = (tid >= o) ? s_scan[tid - o] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        const int base = s_base;
+        if (b < B) off[b] = base + s_scan[tid] - n;
+        __syncthreads();
+        if (tid == 1023) s_base = base + s_scan[1023];
+        __syncthreads();
+    }
+    if (tid == 0) m_dev[0] = s_base;
+}
+
+__global__ void __launch_bounds__(256) k_plan_fill(const int64_t *__restrict__ seq, const int32_t *__restrict__ pos, int B,
+                                                   int L, const int32_t *__restrict__ off, int32_t *__restrict__ qrow,
+                                                   int32_t *__restrict__ tok_row) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    int p = pos[b];
+    p = p < 0 ? 0 : (p >= L ? L - 1 : p);
+    const int64_t *sq = seq + (int64_t)b * L;
+    int o = off[b];
+    for (int t0 = 0; t0 < L; t0 += 64) {
+        const int t = t0 + lane;
+        const bool v = plan_valid(sq, t, L, p);
+        const unsigned long long m = __ballot(v);
+        if (v) {
+            const int idx = o + __popcll(m & ((1ull << lane) - 1ull));
+            tok_row[idx] = b * L + t;
+            if (t == p) qrow[b] = idx;
+        }
+        o += __popcll(m);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_embed_packed(const int64_t *__restrict__ seq, const float *__restrict__ E,
+                                                      const float *__restrict__ pe, float *__restrict__ x,
+                                                      const int32_t *__restrict__ tok_row, const int32_t *__restrict__ m_dev,
+                                                      int L, int d, float sqrtd, int64_t n_item) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= m_dev[0]) return;
+    const int orig = tok_row[row];
+    int64_t id = seq[orig];
+    if (id < 0) id = 0;
+    if (id > n_item) id = n_item;
+    const float *e = E + id * (int64_t)d;
+    const float *p = pe + (int64_t)(orig % L) * d;
+    float *o = x + (int64_t)row * d;
+    for (int c = lane; c < d; c += 64) o[c] = __fadd_rn(__fmul_rn(e[c], sqrtd), p[c]);
+}
+
+__global__ void k_gather_rows_idx(const float *__restrict__ x, const int32_t *__restrict__ rowidx, float *__restrict__ out,
+                                  int d) {
+    const float *src = x + (int64_t)rowidx[blockIdx.x] * d;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) out[(int64_t)blockIdx.x * d + c] = src[c];
+}
+
 // ------------------------------------------------------------------ linear
 // Y[M,N] = epilogue(X[M,K] . W[N,K]^T + bias[N]);  X, W, Y row-major fp32.
 // 256 threads = 4 waves (2x2); wave tile 64x64 = 2x2 v_mfma_f32_32x32x2_f32 tiles; block tile
@@ -84,6 +180,7 @@ struct LinArgs {
     const float *g1, *b1, *c, *g2, *b2; // fused LayerNorm parameters
     const float *Rf; // residual in fragment-major layout (may be null -> row-major R is read, strided)
     float *Yf;       // optional fragment-major copy of the output (next LN-GEMM's residual)
+    const int32_t *m_dev; // optional device-side row count (packed decode): rows >= *m_dev do not exist
 };
 
 // LDS slab image: [128 rows][32 floats], 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7).
@@ -146,7 +243,8 @@ __global__ void __launch_bounds__(256, BK == 16 ? 3 : 2) k_linear(LinArgs a) {
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lk = lane >> 5;
     const int n0 = blockIdx.x * LIN_BN, m0 = blockIdx.y * LIN_BM;
-    const int M = a.M, N = a.N, K = a.K;
+    const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M, N = a.N, K = a.K;
+    if (m0 >= M) return;
     auto Xs = [&](int st) { return sm + (st * 2 + 0) * LIN_BM * BK; };
     auto Ws = [&](int st) { return sm + (st * 2 + 1) * LIN_BM * BK; };
 
@@ -234,7 +332,8 @@ __global__ void __launch_bounds__(256, 2) k_linear_ln(LinArgs a) {
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lk = lane >> 5;
     const int m0 = blockIdx.x * LIN_BM;
-    const int M = a.M, N = a.N, K = a.K;
+    const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M, N = a.N, K = a.K;
+    if (m0 >= M) return;
     const bool vecA = (K % 4 == 0) && ((((uintptr_t)a.X) & 15) == 0) && ((((uintptr_t)a.W) & 15) == 0);
     auto Xs = [&](int st) { return sm + (st * 2 + 0) * LIN_BM * BK; };
     auto Ws = [&](int st) { return sm + (st * 2 + 1) * LIN_BM * BK; };
@@ -445,8 +544,9 @@ __global__ void __launch_bounds__(256) k_linear_small(LinArgs a) {
     __shared__ float vecs[LNV ? 6 * 128 : 4]; // LN variant: bias, g1, b1, c, g2, b2 (zero padded)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lk = lane >> 5;
-    const int M = a.M, N = a.N, K = a.K;
+    const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M, N = a.N, K = a.K;
     const int m0 = blockIdx.y * 32;
+    if (m0 >= M) return;
     const int n0 = LNV ? wave * 32 : (blockIdx.x * 4 + wave) * 32;
     const bool tile_ok = n0 < N; // whole-wave condition
     const bool kvec = (K % 4 == 0) && ((((uintptr_t)a.X) & 15) == 0) && ((((uintptr_t)a.W) & 15) == 0);
@@ -640,23 +740,26 @@ __global__ void __launch_bounds__(256) k_linear_small(LinArgs a) {
 // visible to every query) seeds the online softmax with one VALU dot product per query.
 template <int HDP, bool V4>
 __global__ void __launch_bounds__(256) k_attn_mfma(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
-                                                   const float *__restrict__ r_u, float *__restrict__ out, int L,
-                                                   int d, int hd, int mask_mode) {
+                                                   const float *__restrict__ r_u, float *__restrict__ out, int Lmax,
+                                                   int d, int hd, int mask_mode, const int32_t *__restrict__ off,
+                                                   const int32_t *__restrict__ cnt, const int32_t *__restrict__ tok_row) {
     constexpr int HH = HDP / 2;               // MFMA k-steps of S^T; head columns per lane half
     constexpr int VW = HDP < 32 ? 32 : HDP;   // V columns kept in LDS (zero padded)
     constexpr int CT = VW / 32;               // 32-column tiles of O^T
     constexpr int KLD = HDP + 1;              // padded K row stride (conflict-free column reads)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int NB = (L + 31) / 32, Lp = NB * 32;
+    // packed decode: sequence b owns rows [off[b], off[b] + cnt[b]) of the packed token list (order preserving)
+    const int L = cnt ? cnt[blockIdx.y] : Lmax;
+    const int NB = (L + 31) / 32;
     // only the L real rows are kept (rows >= L are masked: reads clamp to row L-1), so that
     // L = 200, hd = 32 fits three workgroups per CU
     float *Vs = reinterpret_cast<float *>(smem);        // [L][VW]  (16-byte aligned rows)
-    float *Ks = Vs + (size_t)L * VW;                    // [L][KLD]
-    unsigned int *padbits = reinterpret_cast<unsigned int *>(Ks + (size_t)L * KLD); // [8]
+    float *Ks = Vs + (size_t)Lmax * VW;                 // [L][KLD]
+    unsigned int *padbits = reinterpret_cast<unsigned int *>(Ks + (size_t)Lmax * KLD); // [8]
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, kk = lane >> 5;
-    const int64_t base = (int64_t)b * L;
+    const int64_t base = off ? (int64_t)off[b] : (int64_t)b * Lmax;
     const int ld = 3 * d;
     const bool irn = (mask_mode == IRS_MASK_IRN);
     if (V4) {
@@ -690,14 +793,16 @@ __global__ void __launch_bounds__(256) k_attn_mfma(const float *__restrict__ qkv
     }
     for (int kb = wave; kb < NB; kb += 4) { // masked-key bitmask of each key block
         int j = kb * 32 + lq;
-        bool masked = (j >= L) || (seq[base + (j < L ? j : L - 1)] == 0) || (irn && j == L - 1);
+        const int64_t jr = base + (j < L ? j : L - 1);
+        bool masked = (j >= L) || (seq[tok_row ? (int64_t)tok_row[jr] : jr] == 0) || (irn && j == L - 1);
         unsigned long long bal = __ballot(masked);
         if (lane == 0) padbits[kb] = (unsigned int)bal;
     }
     __syncthreads();
     const float add_allowed = irn ? r_u[b] : 0.f;
     const float scale = 1.0f / sqrtf((float)hd);
-    const bool tgt_ok = irn && (seq[base + L - 1] != 0);
+    // the target (original position Lmax-1, never a pad when present) is the last row of the sequence
+    const bool tgt_ok = irn && (seq[(int64_t)b * Lmax + Lmax - 1] != 0);
 
     for (int pass = 0; pass < 2; ++pass) {
         const int qb = pass == 0 ? wave : NB - 1 - wave;
@@ -827,15 +932,19 @@ __global__ void __launch_bounds__(256) k_attn_mfma(const float *__restrict__ qkv
 // k_attn_mfma.  out_rows[b][h*hd + c].
 __global__ void __launch_bounds__(64) k_attn_row(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
                                                  const float *__restrict__ r_u, const int32_t *__restrict__ pos,
-                                                 float *__restrict__ out_rows, int L, int d, int hd, int mask_mode) {
+                                                 float *__restrict__ out_rows, int Lmax, int d, int hd, int mask_mode,
+                                                 const int32_t *__restrict__ off, const int32_t *__restrict__ cnt,
+                                                 const int32_t *__restrict__ tok_row, const int32_t *__restrict__ qrow) {
     __shared__ float p_s[256];
     __shared__ float q_s[64];
     const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-    const int64_t base = (int64_t)b * L;
+    const int L = cnt ? cnt[b] : Lmax;
+    const int64_t base = off ? (int64_t)off[b] : (int64_t)b * Lmax;
     const int ld = 3 * d;
-    int i = pos[b];
+    int i = qrow ? qrow[b] - (int)base : pos[b]; // query row within the sequence
     if (i < 0) i = 0;
     if (i >= L) i = L - 1;
+    const bool has_tgt = (seq[(int64_t)b * Lmax + Lmax - 1] != 0);
     const bool irn = (mask_mode == IRS_MASK_IRN);
     const float add_allowed = irn ? r_u[b] : 0.f;
     const float scale = 1.0f / sqrtf((float)hd);
@@ -848,8 +957,9 @@ __global__ void __launch_bounds__(64) k_attn_row(const float *__restrict__ qkv, 
         const int j = lane + 64 * t;
         float s = -INFINITY;
         if (j < L) {
-            const bool is_tgt = irn && (j == L - 1);
-            const bool ok = (seq[base + j] != 0) && (is_tgt || j <= i);
+            const bool is_tgt = irn && has_tgt && (j == L - 1);
+            const int64_t jr = base + j;
+            const bool ok = (seq[tok_row ? (int64_t)tok_row[jr] : jr] != 0) && (is_tgt || j <= i);
             if (ok) {
                 const float *kr = qkv + (base + j) * ld + d + h * hd;
                 float acc = 0.f;
@@ -980,8 +1090,9 @@ static int g_lin_bk = 16, g_ln_bk = 16; // K-slab depth (tools/gemm_lab.hip flip
 static int launch_linear(irs_ctx *ctx, const float *X, const float *W, const float *bias, const float *R, float *Y,
                          int M, int N, int K, bool relu, hipStream_t s, const float *g1 = nullptr,
                          const float *b1 = nullptr, const float *c = nullptr, const float *g2 = nullptr,
-                         const float *b2 = nullptr, const float *Rf = nullptr, float *Yf = nullptr) {
-    LinArgs a{X, W, bias, R, Y, M, N, K, relu ? 1 : 0, g1, b1, c, g2, b2, Rf, Yf};
+                         const float *b2 = nullptr, const float *Rf = nullptr, float *Yf = nullptr,
+                         const int32_t *m_dev = nullptr) {
+    LinArgs a{X, W, bias, R, Y, M, N, K, relu ? 1 : 0, g1, b1, c, g2, b2, Rf, Yf, m_dev};
     if (ctx) irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
     if (M <= 2048 && K <= 256) { // latency path: one wave per 32x32 tile, operands straight from L2
         if (g1 != nullptr) hipLaunchKernelGGL(k_linear_small<true>, dim3(1, (M + 31) / 32), dim3(256), 0, s, a);
@@ -1010,7 +1121,8 @@ static int launch_linear(irs_ctx *ctx, const float *X, const float *W, const flo
 }
 
 static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const float *r_u, float *out, int B,
-                       hipStream_t s) {
+                       hipStream_t s, const int32_t *off = nullptr, const int32_t *cnt = nullptr,
+                       const int32_t *tok_row = nullptr) {
     const int L = ctx->dims.max_len, d = ctx->dims.d, H = ctx->dims.n_heads, hd = d / H;
     const int HDP = hd <= 8 ? 8 : hd <= 16 ? 16 : hd <= 32 ? 32 : 64;
     const int Lp = ((L + 31) / 32) * 32, VW = HDP < 32 ? 32 : HDP;
@@ -1021,8 +1133,8 @@ static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const
     irs_prof_begin(ctx, IRS_PROF_ATTN, s);
 #define A_(HDP_)                                                                                                   \
     do {                                                                                                           \
-        if (v4) hipLaunchKernelGGL((k_attn_mfma<HDP_, true>), grid, dim3(256), lds, s, qkv, seq, r_u, out, L, d, hd, mm); \
-        else hipLaunchKernelGGL((k_attn_mfma<HDP_, false>), grid, dim3(256), lds, s, qkv, seq, r_u, out, L, d, hd, mm);   \
+        if (v4) hipLaunchKernelGGL((k_attn_mfma<HDP_, true>), grid, dim3(256), lds, s, qkv, seq, r_u, out, L, d, hd, mm, off, cnt, tok_row); \
+        else hipLaunchKernelGGL((k_attn_mfma<HDP_, false>), grid, dim3(256), lds, s, qkv, seq, r_u, out, L, d, hd, mm, off, cnt, tok_row);   \
     } while (0)
     switch (HDP) {
     case 8: A_(8); break;
@@ -1066,17 +1178,36 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     if ((rc = irs_launch_pif(ctx, user, B, ctx->act_ru, s)) != IRS_OK) return rc;
     if (r_u_out) IRS_CHECK_HIP(ctx, hipMemcpyAsync(r_u_out, ctx->act_ru, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
     float *x = ctx->act_x, *y = ctx->act_y;
-    hipLaunchKernelGGL(k_embed, dim3((rows + 3) / 4), dim3(256), 0, s, seq, ctx->item_emb, ctx->pe, x, rows, L, d,
-                       sqrtf((float)d), ctx->dims.n_item);
-    IRS_CHECK_HIP(ctx, hipGetLastError());
-    // rows-only decode: the caller wants x[b, pos[b], :] only, so the LAST layer is evaluated for that one
-    // row per sequence (all earlier layers need every row: they feed the next layer's keys and values)
+    // rows-only decode: the caller wants x[b, pos[b], :] only.  Then (1) the decoder runs on the PACKED
+    // non-pad tokens (k_plan), every kernel clamping its row count to the device-side total, and (2) the
+    // LAST layer is evaluated for the one consumed row per sequence (all earlier layers need every valid
+    // row: they feed the next layer's keys and values).
     const bool rows_only = (x_out == nullptr) && pos && xrows && d <= LIN_BN && L >= 4;
+    const int32_t *off = nullptr, *cnt = nullptr, *tok = nullptr, *qrow = nullptr, *m_dev = nullptr;
+    if (rows_only) {
+        hipLaunchKernelGGL(k_plan_count, dim3((B + 3) / 4), dim3(256), 0, s, seq, pos, B, L, ctx->seq_cnt);
+        hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, s, ctx->seq_cnt, B, ctx->seq_off, ctx->m_dev);
+        hipLaunchKernelGGL(k_plan_fill, dim3((B + 3) / 4), dim3(256), 0, s, seq, pos, B, L, ctx->seq_off, ctx->seq_qrow,
+                           ctx->tok_row);
+        off = ctx->seq_off;
+        cnt = ctx->seq_cnt;
+        tok = ctx->tok_row;
+        qrow = ctx->seq_qrow;
+        m_dev = ctx->m_dev;
+        hipLaunchKernelGGL(k_embed_packed, dim3((rows + 3) / 4), dim3(256), 0, s, seq, ctx->item_emb, ctx->pe, x, tok, m_dev,
+                           L, d, sqrtf((float)d), ctx->dims.n_item);
+    } else {
+        hipLaunchKernelGGL(k_embed, dim3((rows + 3) / 4), dim3(256), 0, s, seq, ctx->item_emb, ctx->pe, x, rows, L, d,
+                           sqrtf((float)d), ctx->dims.n_item);
+    }
+    IRS_CHECK_HIP(ctx, hipGetLastError());
     for (int l = 0; l < ctx->dims.n_layers; ++l) {
         const irs_layer_w &w = ctx->layer[l];
         const bool last_rows = rows_only && (l + 1 == ctx->dims.n_layers);
         // qkv = x W_in^T + b_in
-        if ((rc = launch_linear(ctx, x, w.sa_in_w, w.sa_in_b, nullptr, ctx->act_qkv, rows, 3 * d, d, false, s))) return rc;
+        if ((rc = launch_linear(ctx, x, w.sa_in_w, w.sa_in_b, nullptr, ctx->act_qkv, rows, 3 * d, d, false, s, nullptr, nullptr,
+                                nullptr, nullptr, nullptr, nullptr, nullptr, m_dev)))
+            return rc;
         const float *cl = ctx->c_l + (size_t)l * d;
         if (last_rows) {
             float *ao_r = ctx->act_ao;                 // [B, d] attention output rows
@@ -1085,9 +1216,9 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             float *h_r = ctx->act_h;                   // [B, F]
             irs_prof_begin(ctx, IRS_PROF_ATTN, s);
             hipLaunchKernelGGL(k_attn_row, dim3(ctx->dims.n_heads, B), dim3(64), 0, s, ctx->act_qkv, seq, ctx->act_ru, pos,
-                               ao_r, L, d, d / ctx->dims.n_heads, ctx->dims.mask_mode);
+                               ao_r, L, d, d / ctx->dims.n_heads, ctx->dims.mask_mode, off, cnt, tok, qrow);
             irs_prof_end(ctx, IRS_PROF_ATTN, s, 4.0 * B * (double)L * d, 4.0 * 3.0 * B * (double)L * d);
-            hipLaunchKernelGGL(k_gather_rows, dim3(B), dim3(64), 0, s, x, pos, x_r, B, L, d);
+            hipLaunchKernelGGL(k_gather_rows_idx, dim3(B), dim3(64), 0, s, x, qrow, x_r, d);
             if ((rc = launch_linear(ctx, ao_r, w.sa_out_w, w.sa_out_b, x_r, y_r, B, d, d, false, s, w.n1_w, w.n1_b, cl, w.n2_w,
                                     w.n2_b)))
                 return rc;
@@ -1096,17 +1227,19 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             IRS_CHECK_HIP(ctx, hipGetLastError());
             return IRS_OK;
         }
-        if ((rc = launch_attn(ctx, ctx->act_qkv, seq, ctx->act_ru, ctx->act_ao, B, s))) return rc;
+        if ((rc = launch_attn(ctx, ctx->act_qkv, seq, ctx->act_ru, ctx->act_ao, B, s, off, cnt, tok))) return rc;
         if (d <= LIN_BN) {
             // x <- LN2(LN1(x + ao W_o^T + b_o) + c_l), fused into the GEMM epilogue (y, not in place);
             // residuals come from the fragment-major copy the previous LN-GEMM left (layer 0 reads row-major)
             if ((rc = launch_linear(ctx, ctx->act_ao, w.sa_out_w, w.sa_out_b, x, y, rows, d, d, false, s, w.n1_w, w.n1_b,
-                                    cl, w.n2_w, w.n2_b, l > 0 ? ctx->act_xf : nullptr, ctx->act_yf)))
+                                    cl, w.n2_w, w.n2_b, l > 0 ? ctx->act_xf : nullptr, ctx->act_yf, m_dev)))
                 return rc;
             // h = relu(y W1^T + b1); x <- LN3(y + h W2^T + b2)
-            if ((rc = launch_linear(ctx, y, w.l1_w, w.l1_b, nullptr, ctx->act_h, rows, F, d, true, s))) return rc;
+            if ((rc = launch_linear(ctx, y, w.l1_w, w.l1_b, nullptr, ctx->act_h, rows, F, d, true, s, nullptr, nullptr, nullptr,
+                                    nullptr, nullptr, nullptr, nullptr, m_dev)))
+                return rc;
             if ((rc = launch_linear(ctx, ctx->act_h, w.l2_w, w.l2_b, y, x, rows, d, F, false, s, w.n3_w, w.n3_b, nullptr,
-                                    nullptr, nullptr, ctx->act_yf, l + 1 < ctx->dims.n_layers ? ctx->act_xf : nullptr)))
+                                    nullptr, nullptr, ctx->act_yf, l + 1 < ctx->dims.n_layers ? ctx->act_xf : nullptr, m_dev)))
                 return rc;
         } else {
             // y = x + ao W_o^T + b_o ; x = LN2(LN1(y) + c_l)

@@ -56,6 +56,10 @@ struct irs_ctx {
     // decoder activations
     float *act_x, *act_y, *act_qkv, *act_ao, *act_h, *act_ru;
     float *act_xf, *act_yf; // fragment-major copies of x / y (residual inputs of the LN-fused GEMMs)
+    // packed (pad-free) decode plan
+    int32_t *tok_row;  // [max_seqs * L] packed index -> b*L + t
+    int32_t *seq_cnt, *seq_off, *seq_qrow; // [max_seqs]
+    int32_t *m_dev;    // [1] number of packed rows
     // scoring
     uint4 *xb;          // packed bf16 rows [m_pad/32][KS][64] x 16 B
     float *eps;         // [m_pad]
