@@ -133,8 +133,11 @@ class Job:
         self.status = torch.zeros(self.B, dtype=torch.int32, device=device)
         if world > 1:
             self.x_all = torch.empty((rows, cfg.emb_dim), dtype=torch.float32, device=device)
-            self.v_all = torch.empty((world, rows, self.k), dtype=torch.float32, device=device)
-            self.i_all = torch.empty((world, rows, self.k), dtype=torch.int64, device=device)
+            # exchange of per-shard top-k lists: each rank only needs the lists of ITS rows -> all_to_all of
+            # [world, B, k] (score f32 + id i32) instead of all-gathering every row's list on every rank
+            self.v_recv = torch.empty((world, self.B, self.k), dtype=torch.float32, device=device)
+            self.i_recv = torch.empty((world, self.B, self.k), dtype=torch.int32, device=device)
+            self.exchange = args.exchange
 
     def step(self):
         eng = self.eng
@@ -144,12 +147,20 @@ class Job:
         else:
             import torch.distributed as dist
             dist.all_gather_into_tensor(self.x_all.view(-1), xr.view(-1))
-            v, i, _ = eng.score_topk(self.x_all, self.k, self.sweep)
-            dist.all_gather_into_tensor(self.v_all.view(-1), v.view(-1))
-            dist.all_gather_into_tensor(self.i_all.view(-1), i.view(-1))
-            mv, mi = eng.merge_topk(self.v_all, self.i_all)
-            lo = self.rank * self.B
-            val, ids = mv[lo:lo + self.B].contiguous(), mi[lo:lo + self.B].contiguous()
+            v, i, _ = eng.score_topk(self.x_all, self.k, self.sweep)  # all rows x this rank's item shard
+            i32 = i.to(torch.int32)
+            if self.exchange == "all_to_all":
+                dist.all_to_all_single(self.v_recv.view(-1), v.view(-1))
+                dist.all_to_all_single(self.i_recv.view(-1), i32.view(-1))
+            else:  # rehearsal backends without all_to_all: gather everything, keep the own slice
+                vg = torch.empty((self.world,) + tuple(v.shape), dtype=v.dtype, device=v.device)
+                ig = torch.empty((self.world,) + tuple(i32.shape), dtype=i32.dtype, device=v.device)
+                dist.all_gather_into_tensor(vg.view(-1), v.view(-1))
+                dist.all_gather_into_tensor(ig.view(-1), i32.view(-1))
+                lo = self.rank * self.B
+                self.v_recv.copy_(vg[:, lo:lo + self.B])
+                self.i_recv.copy_(ig[:, lo:lo + self.B])
+            val, ids = eng.merge_topk(self.v_recv, self.i_recv.to(torch.int64))
         eng.path_step(self.seqs, self.hep, val, ids, 0, self.paths, self.status)
 
 
@@ -211,7 +222,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "default", "tiny"])
-    ap.add_argument("--batch", type=int, default=1024, help="users per rank per step")
+    ap.add_argument("--batch", type=int, default=4096, help="users per rank per step")
     ap.add_argument("--n-item", type=int, default=0, help="override the catalog size")
     ap.add_argument("--sweep", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -219,8 +230,12 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N > 1 code path with several ranks on ONE GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--exchange", default=None, choices=["all_to_all", "all_gather"],
+                    help="how per-shard top-k lists travel (default: all_to_all on nccl, all_gather otherwise)")
     args = ap.parse_args()
 
+    if args.exchange is None:
+        args.exchange = "all_to_all" if args.backend == "nccl" else "all_gather"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -326,7 +341,7 @@ def main():
                                   "(packed rows), results identical",
                        "packed_row_fraction": fam["linear"]["packed_fraction"],
                        "sweep": args.sweep + (" filter + exact f32 re-score" if args.sweep == "bf16" else ""),
-                       "parallelism": "single GPU" if world == 1 else f"rows data-parallel + item-sharded x{world}, RCCL all-gather of rows and per-shard top-100"},
+                       "parallelism": "single GPU" if world == 1 else f"rows data-parallel + item-sharded x{world}: RCCL all-gather of rows, {args.exchange} of per-shard top-100"},
             "path_gen_p50_ms_b1": lat,
             "roofline": roof,
             "cpu_baseline": cpu,
