@@ -188,27 +188,35 @@ struct LinArgs {
 // and the staging stores are whole 16-byte chunks.  MFMA k-slots: for the 8 k of group q, half 0
 // supplies k = 8q + t and half 1 supplies k = 8q + 4 + t in step t (A and B agree, so any
 // assignment of k to slots is a valid contraction).
-template <bool VEC, int BK>
+// FULL = aligned operands and K a multiple of the slab depth: unconditional 16-byte loads.  Rows beyond
+// `rows` are clamped to the last row (their products land in output rows / columns that are never stored),
+// so the loader has no branches and no per-load waits.  !FULL = fully guarded generic path.
+template <bool FULL, int BK>
 __device__ __forceinline__ void lin_load_tile(const float *__restrict__ P, int rows, int K, int r0, int k0, int tid,
                                               float4 (&v)[BK / 8]) {
     constexpr int CH = BK / 4; // 16-byte chunks per row
 #pragma unroll
     for (int i = 0; i < BK / 8; ++i) {
-        int idx = tid + i * 256;
-        int r = idx / CH, c = (idx % CH) * 4;
-        int gr = r0 + r, gk = k0 + c;
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gr < rows) {
-            const float *p = P + (int64_t)gr * K + gk;
-            if (VEC && gk + 3 < K) t = *reinterpret_cast<const float4 *>(p);
-            else {
+        const int idx = tid + i * 256;
+        const int r = idx / CH, c = (idx % CH) * 4;
+        if (FULL) {
+            const int gr = min(r0 + r, rows - 1);
+            const float *p = P + (int64_t)gr * K + k0 + c;
+            float4 t;
+            t.x = p[0], t.y = p[1], t.z = p[2], t.w = p[3];
+            v[i] = t;
+        } else {
+            const int gr = r0 + r, gk = k0 + c;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gr < rows) {
+                const float *p = P + (int64_t)gr * K + gk;
                 if (gk < K) t.x = p[0];
                 if (gk + 1 < K) t.y = p[1];
                 if (gk + 2 < K) t.z = p[2];
                 if (gk + 3 < K) t.w = p[3];
             }
+            v[i] = t;
         }
-        v[i] = t;
     }
 }
 
@@ -234,8 +242,8 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-template <bool VEC, int BK>
-__global__ void __launch_bounds__(256, BK == 16 ? 3 : 2) k_linear(LinArgs a) {
+template <bool FULL, int BK>
+__global__ void __launch_bounds__(256, BK == 16 ? 4 : 2) k_linear(LinArgs a) {
     // staging: [stage][operand][128][BK] floats (BK=16: 32 KB, 124 VGPRs -> 4 workgroups per CU)
     __shared__ __attribute__((aligned(16))) float sm[2 * 2 * LIN_BM * BK];
     const int tid = threadIdx.x;
@@ -257,8 +265,8 @@ __global__ void __launch_bounds__(256, BK == 16 ? 3 : 2) k_linear(LinArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 xv[BK / 8], wv[BK / 8];
-    lin_load_tile<VEC, BK>(a.X, M, K, m0, 0, tid, xv);
-    lin_load_tile<VEC, BK>(a.W, N, K, n0, 0, tid, wv);
+    lin_load_tile<FULL, BK>(a.X, M, K, m0, 0, tid, xv);
+    lin_load_tile<FULL, BK>(a.W, N, K, n0, 0, tid, wv);
     lin_store_tile<BK>(Xs(0), tid, xv);
     lin_store_tile<BK>(Ws(0), tid, wv);
     __syncthreads();
@@ -267,8 +275,8 @@ __global__ void __launch_bounds__(256, BK == 16 ? 3 : 2) k_linear(LinArgs a) {
     int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) {
-            lin_load_tile<VEC, BK>(a.X, M, K, m0, (kt + 1) * BK, tid, xv);
-            lin_load_tile<VEC, BK>(a.W, N, K, n0, (kt + 1) * BK, tid, wv);
+            lin_load_tile<FULL, BK>(a.X, M, K, m0, (kt + 1) * BK, tid, xv);
+            lin_load_tile<FULL, BK>(a.W, N, K, n0, (kt + 1) * BK, tid, wv);
         }
         const float *xa = Xs(cur) + (wr * 64 + li) * BK;
         const float *wb = Ws(cur) + (wc * 64 + li) * BK;
@@ -324,8 +332,9 @@ __global__ void __launch_bounds__(256, BK == 16 ? 3 : 2) k_linear(LinArgs a) {
 // shuffle per statistic -- no LDS staging, no barrier, no per-row shuffle chains.
 // Workgroup = 4 waves = 128 tokens; W (all N rows) and X slabs of 32 k stream through the same
 // swizzled double-buffered LDS image as k_linear.
-template <int BK>
-__global__ void __launch_bounds__(256, 2) k_linear_ln(LinArgs a) {
+// FULL = N == 128, K a multiple of BK, every operand 16-byte aligned (host-checked): no guards anywhere.
+template <int BK, bool FULL>
+__global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(LinArgs a) {
     __shared__ __attribute__((aligned(16))) float sm[2 * 2 * LIN_BM * BK + 6 * LIN_BN];
     float *vecs = sm + 2 * 2 * LIN_BM * BK; // bias, g1, b1, c, g2, b2 (zero padded to 128)
     const int tid = threadIdx.x;
@@ -334,7 +343,6 @@ __global__ void __launch_bounds__(256, 2) k_linear_ln(LinArgs a) {
     const int m0 = blockIdx.x * LIN_BM;
     const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M, N = a.N, K = a.K;
     if (m0 >= M) return;
-    const bool vecA = (K % 4 == 0) && ((((uintptr_t)a.X) & 15) == 0) && ((((uintptr_t)a.W) & 15) == 0);
     auto Xs = [&](int st) { return sm + (st * 2 + 0) * LIN_BM * BK; };
     auto Ws = [&](int st) { return sm + (st * 2 + 1) * LIN_BM * BK; };
     if (tid < LIN_BN) {
@@ -347,7 +355,6 @@ __global__ void __launch_bounds__(256, 2) k_linear_ln(LinArgs a) {
         vecs[5 * LIN_BN + tid] = (in && a.c) ? a.b2[tid] : 0.f;
     }
     const int mt = m0 + wave * 32 + li; // this lane's token
-    const bool nvec = (N % 4 == 0) && ((((uintptr_t)a.R) & 15) == 0) && ((((uintptr_t)a.Y) & 15) == 0);
 
     // accumulators start from the residual of this lane's token (C layout: register 4g+e of tile tn is
     // column tn*32 + 8g + 4lk + e); bias is added in the epilogue from LDS.  A fragment-major residual
@@ -355,38 +362,53 @@ __global__ void __launch_bounds__(256, 2) k_linear_ln(LinArgs a) {
     // the row-major fallback reads 16-byte pieces of 64 different rows per instruction.
     f32x16 acc[4];
     const int mtile = (m0 >> 5) + wave;
+    if (a.Rf) { // 16 unconditional, perfectly coalesced loads
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = tn * 32 + 8 * g + 4 * lk;
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.Rf) {
-                t = reinterpret_cast<const float4 *>(a.Rf)[((size_t)(mtile * 4 + tn) * 4 + g) * 64 + lane];
-            } else if (mt < M && n < N) {
-                const float *p = a.R + (int64_t)mt * N + n;
-                if (nvec && n + 3 < N) t = *reinterpret_cast<const float4 *>(p);
-                else {
+            for (int g = 0; g < 4; ++g) {
+                const float4 t = reinterpret_cast<const float4 *>(a.Rf)[((size_t)(mtile * 4 + tn) * 4 + g) * 64 + lane];
+                acc[tn][4 * g + 0] = t.x;
+                acc[tn][4 * g + 1] = t.y;
+                acc[tn][4 * g + 2] = t.z;
+                acc[tn][4 * g + 3] = t.w;
+            }
+    } else if (FULL) { // full rows: unconditional loads from a clamped row (rows >= M are never stored)
+        const float *rrow = a.R + (int64_t)min(mt, M - 1) * N;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t = *reinterpret_cast<const float4 *>(rrow + tn * 32 + 8 * g + 4 * lk);
+                acc[tn][4 * g + 0] = t.x;
+                acc[tn][4 * g + 1] = t.y;
+                acc[tn][4 * g + 2] = t.z;
+                acc[tn][4 * g + 3] = t.w;
+            }
+    } else {
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = tn * 32 + 8 * g + 4 * lk;
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (mt < M && n < N) {
+                    const float *p = a.R + (int64_t)mt * N + n;
                     t.x = p[0];
                     if (n + 1 < N) t.y = p[1];
                     if (n + 2 < N) t.z = p[2];
                     if (n + 3 < N) t.w = p[3];
                 }
+                acc[tn][4 * g + 0] = t.x;
+                acc[tn][4 * g + 1] = t.y;
+                acc[tn][4 * g + 2] = t.z;
+                acc[tn][4 * g + 3] = t.w;
             }
-            acc[tn][4 * g + 0] = t.x;
-            acc[tn][4 * g + 1] = t.y;
-            acc[tn][4 * g + 2] = t.z;
-            acc[tn][4 * g + 3] = t.w;
-        }
+    }
 
     float4 xv[BK / 8], wv[BK / 8];
-    if (vecA) {
-        lin_load_tile<true, BK>(a.X, M, K, m0, 0, tid, xv);
-        lin_load_tile<true, BK>(a.W, N, K, 0, 0, tid, wv);
-    } else {
-        lin_load_tile<false, BK>(a.X, M, K, m0, 0, tid, xv);
-        lin_load_tile<false, BK>(a.W, N, K, 0, 0, tid, wv);
-    }
+    lin_load_tile<FULL, BK>(a.X, M, K, m0, 0, tid, xv);
+    lin_load_tile<FULL, BK>(a.W, N, K, 0, 0, tid, wv);
     lin_store_tile<BK>(Xs(0), tid, xv);
     lin_store_tile<BK>(Ws(0), tid, wv);
     __syncthreads();
@@ -395,13 +417,8 @@ __global__ void __launch_bounds__(256, 2) k_linear_ln(LinArgs a) {
     int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) {
-            if (vecA) {
-                lin_load_tile<true, BK>(a.X, M, K, m0, (kt + 1) * BK, tid, xv);
-                lin_load_tile<true, BK>(a.W, N, K, 0, (kt + 1) * BK, tid, wv);
-            } else {
-                lin_load_tile<false, BK>(a.X, M, K, m0, (kt + 1) * BK, tid, xv);
-                lin_load_tile<false, BK>(a.W, N, K, 0, (kt + 1) * BK, tid, wv);
-            }
+            lin_load_tile<FULL, BK>(a.X, M, K, m0, (kt + 1) * BK, tid, xv);
+            lin_load_tile<FULL, BK>(a.W, N, K, 0, (kt + 1) * BK, tid, wv);
         }
         const float *xb = Xs(cur) + (wave * 32 + li) * BK;
         const float *wa = Ws(cur) + li * BK;
@@ -513,7 +530,15 @@ __global__ void __launch_bounds__(256, 2) k_linear_ln(LinArgs a) {
                 reinterpret_cast<float4 *>(a.Yf)[((size_t)(mtile * 4 + tn) * 4 + g) * 64 + lane] =
                     make_float4(acc[tn][4 * g], acc[tn][4 * g + 1], acc[tn][4 * g + 2], acc[tn][4 * g + 3]);
     }
-    if (mt < M) {
+    if (FULL && mt < M) {
+        float *Yr = a.Y + (int64_t)mt * N;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4 *>(Yr + tn * 32 + 8 * g + 4 * lk) =
+                    make_float4(acc[tn][4 * g], acc[tn][4 * g + 1], acc[tn][4 * g + 2], acc[tn][4 * g + 3]);
+    } else if (!FULL && mt < M) {
         float *Yr = a.Y + (int64_t)mt * N;
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
@@ -521,7 +546,7 @@ __global__ void __launch_bounds__(256, 2) k_linear_ln(LinArgs a) {
             for (int g = 0; g < 4; ++g) {
                 const int n = tn * 32 + 8 * g + 4 * lk;
                 if (n >= N) continue;
-                if (nvec && n + 3 < N)
+                if (false)
                     *reinterpret_cast<float4 *>(Yr + n) = make_float4(acc[tn][4 * g], acc[tn][4 * g + 1], acc[tn][4 * g + 2], acc[tn][4 * g + 3]);
                 else {
                     Yr[n] = acc[tn][4 * g];
@@ -1094,21 +1119,30 @@ static int launch_linear(irs_ctx *ctx, const float *X, const float *W, const flo
                          const int32_t *m_dev = nullptr) {
     LinArgs a{X, W, bias, R, Y, M, N, K, relu ? 1 : 0, g1, b1, c, g2, b2, Rf, Yf, m_dev};
     if (ctx) irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
+    auto al16 = [](const void *p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; };
     if (M <= 2048 && K <= 256) { // latency path: one wave per 32x32 tile, operands straight from L2
         if (g1 != nullptr) hipLaunchKernelGGL(k_linear_small<true>, dim3(1, (M + 31) / 32), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(k_linear_small<false>, dim3((N + 127) / 128, (M + 31) / 32), dim3(256), 0, s, a);
     } else if (g1 != nullptr) { // fused residual + LayerNorm: whole rows per wave (N <= 128)
         dim3 grid((M + LIN_BM - 1) / LIN_BM);
-        if (g_ln_bk == 16) hipLaunchKernelGGL(k_linear_ln<16>, grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(k_linear_ln<32>, grid, dim3(256), 0, s, a);
+        const int bk = g_ln_bk;
+        const bool full = (N == LIN_BN) && (K % bk == 0) && al16(X) && al16(W) && al16(R) && al16(Y) && al16(Rf) && al16(Yf);
+        if (bk == 16) {
+            if (full) hipLaunchKernelGGL((k_linear_ln<16, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_linear_ln<16, false>), grid, dim3(256), 0, s, a);
+        } else {
+            if (full) hipLaunchKernelGGL((k_linear_ln<32, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_linear_ln<32, false>), grid, dim3(256), 0, s, a);
+        }
     } else {
         dim3 grid((N + LIN_BN - 1) / LIN_BN, (M + LIN_BM - 1) / LIN_BM);
-        bool vec = (K % 4 == 0) && ((((uintptr_t)X) & 15) == 0) && ((((uintptr_t)W) & 15) == 0);
-        if (g_lin_bk == 16) {
-            if (vec) hipLaunchKernelGGL((k_linear<true, 16>), grid, dim3(256), 0, s, a);
+        const int bk = g_lin_bk;
+        const bool full = (K % bk == 0) && al16(X) && al16(W);
+        if (bk == 16) {
+            if (full) hipLaunchKernelGGL((k_linear<true, 16>), grid, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((k_linear<false, 16>), grid, dim3(256), 0, s, a);
         } else {
-            if (vec) hipLaunchKernelGGL((k_linear<true, 32>), grid, dim3(256), 0, s, a);
+            if (full) hipLaunchKernelGGL((k_linear<true, 32>), grid, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((k_linear<false, 32>), grid, dim3(256), 0, s, a);
         }
     }
