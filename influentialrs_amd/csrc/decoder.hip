@@ -181,6 +181,7 @@ struct LinArgs {
     const float *Rf; // residual in fragment-major layout (may be null -> row-major R is read, strided)
     float *Yf;       // optional fragment-major copy of the output (next LN-GEMM's residual)
     const int32_t *m_dev; // optional device-side row count (packed decode): rows >= *m_dev do not exist
+    int slots;            // workgroups of this kernel the device holds at once (k_linear's work-unit split)
 };
 
 // LDS slab image: [128 rows][32 floats], 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7).
@@ -242,17 +243,31 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// One workgroup owns 128 rows and walks every 128-column block of the output: the (column block, k-slab)
+// steps form ONE software pipeline, so the global-load latency of a block's first slab and the store tail of
+// the previous block hide behind MFMA work instead of costing a prologue/epilogue bubble per output tile,
+// and the X rows are re-read from the workgroup's own L2 (same XCD) rather than by workgroups on other XCDs.
 template <bool FULL, int BK>
 __global__ void __launch_bounds__(256, BK == 16 ? 4 : 2) k_linear(LinArgs a) {
-    // staging: [stage][operand][128][BK] floats (BK=16: 32 KB, 124 VGPRs -> 4 workgroups per CU)
+    // staging: [stage][operand][128][BK] floats (BK=16: 32 KB, <=128 VGPRs -> 4 workgroups per CU)
     __shared__ __attribute__((aligned(16))) float sm[2 * 2 * LIN_BM * BK];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lk = lane >> 5;
-    const int n0 = blockIdx.x * LIN_BN, m0 = blockIdx.y * LIN_BM;
     const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M, N = a.N, K = a.K;
-    if (m0 >= M) return;
+    // work units: the first `full` workgroups (whole rounds of the device's resident slots) own a 128-row block
+    // and all of its column blocks; the remaining row blocks are cut into one-column-block units, so the last,
+    // partially filled round costs 1/ntn of a full one
+    const int ntn = (N + LIN_BN - 1) / LIN_BN, ntm = (M + LIN_BM - 1) / LIN_BM;
+    const int full = (ntm / a.slots) * a.slots;
+    int mt = blockIdx.x, nb = 0, ne = ntn;
+    if ((int)blockIdx.x >= full) {
+        const int u = blockIdx.x - full;
+        mt = full + u / ntn, nb = u % ntn, ne = nb + 1;
+    }
+    if (mt >= ntm) return;
+    const int m0 = mt * LIN_BM;
     auto Xs = [&](int st) { return sm + (st * 2 + 0) * LIN_BM * BK; };
     auto Ws = [&](int st) { return sm + (st * 2 + 1) * LIN_BM * BK; };
 
@@ -266,17 +281,21 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : 2) k_linear(LinArgs a) {
 
     float4 xv[BK / 8], wv[BK / 8];
     lin_load_tile<FULL, BK>(a.X, M, K, m0, 0, tid, xv);
-    lin_load_tile<FULL, BK>(a.W, N, K, n0, 0, tid, wv);
+    lin_load_tile<FULL, BK>(a.W, N, K, nb * LIN_BN, 0, tid, wv);
     lin_store_tile<BK>(Xs(0), tid, xv);
     lin_store_tile<BK>(Ws(0), tid, wv);
     __syncthreads();
     const int nkt = (K + BK - 1) / BK;
+    const int nsteps = (ne - nb) * nkt;
     const int sw = lin_swz<BK>(li);
-    int cur = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) {
-            lin_load_tile<FULL, BK>(a.X, M, K, m0, (kt + 1) * BK, tid, xv);
-            lin_load_tile<FULL, BK>(a.W, N, K, n0, (kt + 1) * BK, tid, wv);
+    int cur = 0, kt = 0, n0 = nb * LIN_BN;
+    for (int s = 0; s < nsteps; ++s) {
+        int kt1 = kt + 1, n1 = n0;
+        if (kt1 == nkt) kt1 = 0, n1 = n0 + LIN_BN;
+        const bool more = s + 1 < nsteps;
+        if (more) {
+            lin_load_tile<FULL, BK>(a.X, M, K, m0, kt1 * BK, tid, xv);
+            lin_load_tile<FULL, BK>(a.W, N, K, n1, kt1 * BK, tid, wv);
         }
         const float *xa = Xs(cur) + (wr * 64 + li) * BK;
         const float *wb = Ws(cur) + (wc * 64 + li) * BK;
@@ -295,32 +314,60 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : 2) k_linear(LinArgs a) {
             LIN_STEP(x) LIN_STEP(y) LIN_STEP(z) LIN_STEP(w)
 #undef LIN_STEP
         }
-        if (kt + 1 < nkt) {
+        if (kt == nkt - 1) {
+            // epilogue straight from registers: C/D layout col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5);
+            // one store instruction covers two 128-byte row segments.  The row base is made opaque so the
+            // 64 output addresses are formed here, not hoisted out of the pipeline loop into live registers.
+            int mrow = m0 + wr * 64 + 4 * lk;
+            asm volatile("" : "+v"(mrow));
+            const bool interior = (m0 + LIN_BM <= M) && (n0 + LIN_BN <= N) && a.R == nullptr;
+            if (interior) { // workgroup-uniform: no per-element masks, no loads -> 64 back-to-back stores
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    const int n = n0 + wc * 64 + tn * 32 + li;
+                    const float bv = a.bias ? a.bias[n] : 0.f;
+                    float *yp = a.Y + (int64_t)mrow * N + n;
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int dm = tm * 32 + (r & 3) + 8 * (r >> 2);
+                            float v = acc[tm][tn][r] + bv;
+                            v = a.relu ? fmaxf(v, 0.f) : v;
+                            yp[(int64_t)dm * N] = v;
+                            acc[tm][tn][r] = 0.f;
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    const int n = n0 + wc * 64 + tn * 32 + li;
+                    const bool nin = n < N;
+                    const float bv = (nin && a.bias) ? a.bias[n] : 0.f;
+                    const int64_t col = (int64_t)mrow * N + n;
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int dm = tm * 32 + (r & 3) + 8 * (r >> 2);
+                            if (nin && mrow + dm < M) {
+                                float v = acc[tm][tn][r] + bv;
+                                if (a.relu) v = fmaxf(v, 0.f);
+                                if (a.R) v += a.R[col + (int64_t)dm * N];
+                                a.Y[col + (int64_t)dm * N] = v;
+                            }
+                            acc[tm][tn][r] = 0.f;
+                        }
+                }
+            }
+        }
+        if (more) {
             lin_store_tile<BK>(Xs(cur ^ 1), tid, xv);
             lin_store_tile<BK>(Ws(cur ^ 1), tid, wv);
         }
         __syncthreads();
         cur ^= 1;
-    }
-    // epilogue straight from registers: C/D layout col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5);
-    // one store instruction covers two 128-byte row segments
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        const int n = n0 + wc * 64 + tn * 32 + li;
-        if (n >= N) continue;
-        const float bv = a.bias ? a.bias[n] : 0.f;
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (m < M) {
-                    float v = acc[tm][tn][r] + bv;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (a.R) v += a.R[(int64_t)m * N + n];
-                    a.Y[(int64_t)m * N + n] = v;
-                }
-            }
+        kt = kt1, n0 = n1;
     }
 }
 
@@ -1135,8 +1182,18 @@ static int launch_linear(irs_ctx *ctx, const float *X, const float *W, const flo
             else hipLaunchKernelGGL((k_linear_ln<32, false>), grid, dim3(256), 0, s, a);
         }
     } else {
-        dim3 grid((N + LIN_BN - 1) / LIN_BN, (M + LIN_BM - 1) / LIN_BM);
         const int bk = g_lin_bk;
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+                n_cu = 256;
+        }
+        a.slots = n_cu * (bk == 16 ? 4 : 2); // matches the kernels' launch bounds
+        const int ntm = (M + LIN_BM - 1) / LIN_BM, ntn = (N + LIN_BN - 1) / LIN_BN;
+        // exact unit count when M is known here, its upper bound over any device-side M otherwise
+        dim3 grid(m_dev ? ntm + (a.slots - 1) * (ntn - 1) : (ntm / a.slots) * a.slots + (ntm % a.slots) * ntn);
         const bool full = (K % bk == 0) && al16(X) && al16(W);
         if (bk == 16) {
             if (full) hipLaunchKernelGGL((k_linear<true, 16>), grid, dim3(256), 0, s, a);

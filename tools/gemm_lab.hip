@@ -23,8 +23,33 @@ static float time_it(std::function<void()> f, int reps) {
     return ms / reps;
 }
 
+// fp32 MFMA issue-rate probe: no memory traffic, NACC independent accumulator tiles per wave.
+template <int NACC>
+__global__ void __launch_bounds__(256) k_mfma_peak(float *out, int iters) {
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    f16v acc[NACC];
+    for (int i = 0; i < NACC; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float sum = 0.f;
+    for (int i = 0; i < NACC; ++i) for (int j = 0; j < 16; ++j) sum += acc[i][j];
+    if (sum == 12345.f) out[0] = sum;
+}
+
 int main(int argc, char **argv) {
     int M = argc > 1 ? atoi(argv[1]) : 204800;
+    {
+        float *o; CK(hipMalloc(&o, 4));
+        const int iters = 4096;
+        for (int wgs : {256, 512, 1024, 2048}) {
+            float ms = time_it([&] { hipLaunchKernelGGL(k_mfma_peak<4>, dim3(wgs), dim3(256), 0, 0, o, iters); }, 5);
+            double tf = (double)wgs * 4 * iters * 4 * 4096.0 / (ms * 1e-3) / 1e12;
+            printf("mfma f32 32x32x2 peak probe: %4d WGs x 4 waves, 4 acc: %8.1f us  %6.1f TF\n", wgs, ms * 1e3, tf);
+        }
+    }
     struct Shape { int N, K; bool ln, relu; const char *name; } shapes[] = {
         {384, 128, false, false, "qkv    "}, {128, 128, true, false, "out+ln "}, {256, 128, false, true, "ffn1   "}, {128, 256, true, false, "ffn2+ln"}};
     float *X, *W, *B, *R, *Y, *G;
