@@ -159,6 +159,49 @@ __global__ void k_gather_rows_idx(const float *__restrict__ x, const int32_t *__
     for (int c = threadIdx.x; c < d; c += blockDim.x) out[(int64_t)blockIdx.x * d + c] = src[c];
 }
 
+// Fragment-major embed (see frag_index below): one wave per 32-token tile; per (column group) every lane
+// reads 16 bytes of its token's item row and of its position row and the wave stores one contiguous KiB.
+// Rows beyond the packed / total count and columns beyond d are written as zeros.
+__global__ void __launch_bounds__(256) k_embed_frag(const int64_t *__restrict__ seq, const float *__restrict__ E,
+                                                    const float *__restrict__ pe, float *__restrict__ xf,
+                                                    const int32_t *__restrict__ tok_row, const int32_t *__restrict__ m_dev,
+                                                    int rows, int L, int d, float sqrtd, int64_t n_item) {
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5;
+    const int M = m_dev ? min(rows, m_dev[0]) : rows;
+    if (tile * 32 >= M) return;
+    const int row = tile * 32 + li;
+    const bool live = row < M;
+    const int orig = live ? (tok_row ? tok_row[row] : row) : 0;
+    int64_t id = live ? seq[orig] : 0;
+    if (id < 0) id = 0;
+    if (id > n_item) id = n_item;
+    const float *e = E + id * (int64_t)d;
+    const float *p = pe + (int64_t)(orig % L) * d;
+    float4 *o = reinterpret_cast<float4 *>(xf) + (size_t)tile * 16 * 64 + lane;
+#pragma unroll 4
+    for (int c = 0; c < 16; ++c) { // c = tn * 4 + g
+        const int n = (c >> 2) * 32 + (c & 3) * 8 + 4 * lk;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live && n < d) { // d is a multiple of 4 on this path
+            v.x = __fadd_rn(__fmul_rn(e[n + 0], sqrtd), p[n + 0]);
+            v.y = __fadd_rn(__fmul_rn(e[n + 1], sqrtd), p[n + 1]);
+            v.z = __fadd_rn(__fmul_rn(e[n + 2], sqrtd), p[n + 2]);
+            v.w = __fadd_rn(__fmul_rn(e[n + 3], sqrtd), p[n + 3]);
+        }
+        o[c * 64] = v;
+    }
+}
+
+// out[b, :] = act[rowidx[b], :] read from the fragment-major layout
+__global__ void k_gather_rows_frag(const float *__restrict__ xf, const int32_t *__restrict__ rowidx,
+                                   float *__restrict__ out, int d) {
+    const int row = rowidx[blockIdx.x];
+    for (int c = threadIdx.x; c < d; c += blockDim.x)
+        out[(int64_t)blockIdx.x * d + c] =
+            xf[(((size_t)(row >> 5) * 4 + (c >> 5)) * 4 + ((c >> 3) & 3)) * 256 + ((c >> 2) & 1) * 128 + (row & 31) * 4 + (c & 3)];
+}
+
 // ------------------------------------------------------------------ linear
 // Y[M,N] = epilogue(X[M,K] . W[N,K]^T + bias[N]);  X, W, Y row-major fp32.
 // 256 threads = 4 waves (2x2); wave tile 64x64 = 2x2 v_mfma_f32_32x32x2_f32 tiles; block tile
@@ -182,6 +225,7 @@ struct LinArgs {
     float *Yf;       // optional fragment-major copy of the output (next LN-GEMM's residual)
     const int32_t *m_dev; // optional device-side row count (packed decode): rows >= *m_dev do not exist
     int slots;            // workgroups of this kernel the device holds at once (k_linear's work-unit split)
+    const float *Xf;      // X operand in fragment-major layout (K <= 128); X is then unused
 };
 
 // LDS slab image: [128 rows][32 floats], 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7).
@@ -237,6 +281,42 @@ __device__ __forceinline__ void lin_store_tile(float *S, int tid, const float4 (
     }
 }
 
+// Fragment-major activations ("xf" layout): tokens in tiles of 32, 128 (zero-padded) columns per token,
+//   float4 index = ((tile * 4 + tn) * 4 + g) * 64 + lk * 32 + li   holds   act[tile*32 + li][tn*32 + 8g + 4lk + 0..3].
+// It is the register image of the transposed MFMA C layout (a lane owns a token), so the LN-fused GEMMs write
+// it and read their residual from it with contiguous 1 KiB wave accesses, and a [32 tokens][8 k] piece of a
+// k-slab is one contiguous KiB too: the GEMM loaders below read it as the X operand, which is why no
+// row-major copy of x / y exists between the layers.
+__device__ __forceinline__ size_t frag_index(int token, int n) {
+    return (((size_t)(token >> 5) * 4 + (n >> 5)) * 4 + ((n >> 3) & 3)) * 256 + ((n >> 2) & 1) * 128 + (token & 31) * 4 + (n & 3);
+}
+
+template <int BK>
+__device__ __forceinline__ void lin_load_tile_frag(const float *__restrict__ Pf, int m0, int k0, int tid,
+                                                   float4 (&v)[BK / 8]) {
+#pragma unroll
+    for (int i = 0; i < BK / 8; ++i) {
+        const int idx = tid + i * 256;
+        const int t = idx / (8 * BK), j = idx % (8 * BK); // 32-token tile of the 128-row block, float4 within its slab
+        const int kk = k0 + 8 * (j >> 6);
+        const float *p = Pf + ((((size_t)((m0 >> 5) + t) * 4 + (kk >> 5)) * 4 + ((kk >> 3) & 3)) * 64 + (j & 63)) * 4;
+        float4 q;
+        q.x = p[0], q.y = p[1], q.z = p[2], q.w = p[3];
+        v[i] = q;
+    }
+}
+
+template <int BK>
+__device__ __forceinline__ void lin_store_tile_frag(float *S, int tid, const float4 (&v)[BK / 8]) {
+#pragma unroll
+    for (int i = 0; i < BK / 8; ++i) {
+        const int idx = tid + i * 256;
+        const int t = idx / (8 * BK), j = idx % (8 * BK);
+        const int r = t * 32 + (j & 31), c = 2 * (j >> 6) + ((j >> 5) & 1);
+        *reinterpret_cast<float4 *>(S + r * BK + ((c ^ lin_swz<BK>(r)) << 2)) = v[i];
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -247,7 +327,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // steps form ONE software pipeline, so the global-load latency of a block's first slab and the store tail of
 // the previous block hide behind MFMA work instead of costing a prologue/epilogue bubble per output tile,
 // and the X rows are re-read from the workgroup's own L2 (same XCD) rather than by workgroups on other XCDs.
-template <bool FULL, int BK>
+// XF = the X operand comes from the fragment-major layout (a.Xf) instead of row-major a.X.
+template <bool FULL, int BK, bool XF>
 __global__ void __launch_bounds__(256, BK == 16 ? 4 : 2) k_linear(LinArgs a) {
     // staging: [stage][operand][128][BK] floats (BK=16: 32 KB, <=128 VGPRs -> 4 workgroups per CU)
     __shared__ __attribute__((aligned(16))) float sm[2 * 2 * LIN_BM * BK];
@@ -280,9 +361,11 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : 2) k_linear(LinArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 xv[BK / 8], wv[BK / 8];
-    lin_load_tile<FULL, BK>(a.X, M, K, m0, 0, tid, xv);
+    if (XF) lin_load_tile_frag<BK>(a.Xf, m0, 0, tid, xv);
+    else lin_load_tile<FULL, BK>(a.X, M, K, m0, 0, tid, xv);
     lin_load_tile<FULL, BK>(a.W, N, K, nb * LIN_BN, 0, tid, wv);
-    lin_store_tile<BK>(Xs(0), tid, xv);
+    if (XF) lin_store_tile_frag<BK>(Xs(0), tid, xv);
+    else lin_store_tile<BK>(Xs(0), tid, xv);
     lin_store_tile<BK>(Ws(0), tid, wv);
     __syncthreads();
     const int nkt = (K + BK - 1) / BK;
@@ -294,7 +377,8 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : 2) k_linear(LinArgs a) {
         if (kt1 == nkt) kt1 = 0, n1 = n0 + LIN_BN;
         const bool more = s + 1 < nsteps;
         if (more) {
-            lin_load_tile<FULL, BK>(a.X, M, K, m0, kt1 * BK, tid, xv);
+            if (XF) lin_load_tile_frag<BK>(a.Xf, m0, kt1 * BK, tid, xv);
+            else lin_load_tile<FULL, BK>(a.X, M, K, m0, kt1 * BK, tid, xv);
             lin_load_tile<FULL, BK>(a.W, N, K, n1, kt1 * BK, tid, wv);
         }
         const float *xa = Xs(cur) + (wr * 64 + li) * BK;
@@ -362,7 +446,8 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : 2) k_linear(LinArgs a) {
             }
         }
         if (more) {
-            lin_store_tile<BK>(Xs(cur ^ 1), tid, xv);
+            if (XF) lin_store_tile_frag<BK>(Xs(cur ^ 1), tid, xv);
+            else lin_store_tile<BK>(Xs(cur ^ 1), tid, xv);
             lin_store_tile<BK>(Ws(cur ^ 1), tid, wv);
         }
         __syncthreads();
@@ -380,7 +465,7 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : 2) k_linear(LinArgs a) {
 // Workgroup = 4 waves = 128 tokens; W (all N rows) and X slabs of 32 k stream through the same
 // swizzled double-buffered LDS image as k_linear.
 // FULL = N == 128, K a multiple of BK, every operand 16-byte aligned (host-checked): no guards anywhere.
-template <int BK, bool FULL>
+template <int BK, bool FULL, bool XF>
 __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(LinArgs a) {
     __shared__ __attribute__((aligned(16))) float sm[2 * 2 * LIN_BM * BK + 6 * LIN_BN];
     float *vecs = sm + 2 * 2 * LIN_BM * BK; // bias, g1, b1, c, g2, b2 (zero padded to 128)
@@ -454,9 +539,11 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(L
     }
 
     float4 xv[BK / 8], wv[BK / 8];
-    lin_load_tile<FULL, BK>(a.X, M, K, m0, 0, tid, xv);
+    if (XF) lin_load_tile_frag<BK>(a.Xf, m0, 0, tid, xv);
+    else lin_load_tile<FULL, BK>(a.X, M, K, m0, 0, tid, xv);
     lin_load_tile<FULL, BK>(a.W, N, K, 0, 0, tid, wv);
-    lin_store_tile<BK>(Xs(0), tid, xv);
+    if (XF) lin_store_tile_frag<BK>(Xs(0), tid, xv);
+    else lin_store_tile<BK>(Xs(0), tid, xv);
     lin_store_tile<BK>(Ws(0), tid, wv);
     __syncthreads();
     const int nkt = (K + BK - 1) / BK;
@@ -464,7 +551,8 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(L
     int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) {
-            lin_load_tile<FULL, BK>(a.X, M, K, m0, (kt + 1) * BK, tid, xv);
+            if (XF) lin_load_tile_frag<BK>(a.Xf, m0, (kt + 1) * BK, tid, xv);
+            else lin_load_tile<FULL, BK>(a.X, M, K, m0, (kt + 1) * BK, tid, xv);
             lin_load_tile<FULL, BK>(a.W, N, K, 0, (kt + 1) * BK, tid, wv);
         }
         const float *xb = Xs(cur) + (wave * 32 + li) * BK;
@@ -486,7 +574,8 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(L
 #undef LN_STEP
         }
         if (kt + 1 < nkt) {
-            lin_store_tile<BK>(Xs(cur ^ 1), tid, xv);
+            if (XF) lin_store_tile_frag<BK>(Xs(cur ^ 1), tid, xv);
+            else lin_store_tile<BK>(Xs(cur ^ 1), tid, xv);
             lin_store_tile<BK>(Ws(cur ^ 1), tid, wv);
         }
         __syncthreads();
@@ -577,7 +666,7 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(L
                 reinterpret_cast<float4 *>(a.Yf)[((size_t)(mtile * 4 + tn) * 4 + g) * 64 + lane] =
                     make_float4(acc[tn][4 * g], acc[tn][4 * g + 1], acc[tn][4 * g + 2], acc[tn][4 * g + 3]);
     }
-    if (FULL && mt < M) {
+    if (FULL && a.Y && mt < M) {
         float *Yr = a.Y + (int64_t)mt * N;
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
@@ -585,7 +674,7 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(L
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<float4 *>(Yr + tn * 32 + 8 * g + 4 * lk) =
                     make_float4(acc[tn][4 * g], acc[tn][4 * g + 1], acc[tn][4 * g + 2], acc[tn][4 * g + 3]);
-    } else if (!FULL && mt < M) {
+    } else if (!FULL && a.Y && mt < M) {
         float *Yr = a.Y + (int64_t)mt * N;
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
@@ -1163,8 +1252,12 @@ static int launch_linear(irs_ctx *ctx, const float *X, const float *W, const flo
                          int M, int N, int K, bool relu, hipStream_t s, const float *g1 = nullptr,
                          const float *b1 = nullptr, const float *c = nullptr, const float *g2 = nullptr,
                          const float *b2 = nullptr, const float *Rf = nullptr, float *Yf = nullptr,
-                         const int32_t *m_dev = nullptr) {
-    LinArgs a{X, W, bias, R, Y, M, N, K, relu ? 1 : 0, g1, b1, c, g2, b2, Rf, Yf, m_dev};
+                         const int32_t *m_dev = nullptr, const float *Xf = nullptr) {
+    LinArgs a{X, W, bias, R, Y, M, N, K, relu ? 1 : 0, g1, b1, c, g2, b2, Rf, Yf, m_dev, 0, Xf};
+    if (Xf && !(K <= 128 && K % 32 == 0 && M > 2048)) {
+        if (ctx) snprintf(ctx->err, sizeof(ctx->err), "launch_linear: fragment-major X needs K <= 128, K %% 32 == 0, M > 2048");
+        return IRS_E_INVALID;
+    }
     if (ctx) irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
     auto al16 = [](const void *p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; };
     if (M <= 2048 && K <= 256) { // latency path: one wave per 32x32 tile, operands straight from L2
@@ -1174,12 +1267,18 @@ static int launch_linear(irs_ctx *ctx, const float *X, const float *W, const flo
         dim3 grid((M + LIN_BM - 1) / LIN_BM);
         const int bk = g_ln_bk;
         const bool full = (N == LIN_BN) && (K % bk == 0) && al16(X) && al16(W) && al16(R) && al16(Y) && al16(Rf) && al16(Yf);
+        if (Xf && !(full && al16(Xf))) {
+            if (ctx) snprintf(ctx->err, sizeof(ctx->err), "launch_linear: fragment-major X needs the aligned N == 128 case");
+            return IRS_E_INVALID;
+        }
         if (bk == 16) {
-            if (full) hipLaunchKernelGGL((k_linear_ln<16, true>), grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((k_linear_ln<16, false>), grid, dim3(256), 0, s, a);
+            if (Xf) hipLaunchKernelGGL((k_linear_ln<16, true, true>), grid, dim3(256), 0, s, a);
+            else if (full) hipLaunchKernelGGL((k_linear_ln<16, true, false>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_linear_ln<16, false, false>), grid, dim3(256), 0, s, a);
         } else {
-            if (full) hipLaunchKernelGGL((k_linear_ln<32, true>), grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((k_linear_ln<32, false>), grid, dim3(256), 0, s, a);
+            if (Xf) hipLaunchKernelGGL((k_linear_ln<32, true, true>), grid, dim3(256), 0, s, a);
+            else if (full) hipLaunchKernelGGL((k_linear_ln<32, true, false>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_linear_ln<32, false, false>), grid, dim3(256), 0, s, a);
         }
     } else {
         const int bk = g_lin_bk;
@@ -1195,12 +1294,18 @@ static int launch_linear(irs_ctx *ctx, const float *X, const float *W, const flo
         // exact unit count when M is known here, its upper bound over any device-side M otherwise
         dim3 grid(m_dev ? ntm + (a.slots - 1) * (ntn - 1) : (ntm / a.slots) * a.slots + (ntm % a.slots) * ntn);
         const bool full = (K % bk == 0) && al16(X) && al16(W);
+        if (Xf && !(full && al16(Xf))) {
+            if (ctx) snprintf(ctx->err, sizeof(ctx->err), "launch_linear: fragment-major X needs aligned operands");
+            return IRS_E_INVALID;
+        }
         if (bk == 16) {
-            if (full) hipLaunchKernelGGL((k_linear<true, 16>), grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((k_linear<false, 16>), grid, dim3(256), 0, s, a);
+            if (Xf) hipLaunchKernelGGL((k_linear<true, 16, true>), grid, dim3(256), 0, s, a);
+            else if (full) hipLaunchKernelGGL((k_linear<true, 16, false>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_linear<false, 16, false>), grid, dim3(256), 0, s, a);
         } else {
-            if (full) hipLaunchKernelGGL((k_linear<true, 32>), grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((k_linear<false, 32>), grid, dim3(256), 0, s, a);
+            if (Xf) hipLaunchKernelGGL((k_linear<true, 32, true>), grid, dim3(256), 0, s, a);
+            else if (full) hipLaunchKernelGGL((k_linear<true, 32, false>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_linear<false, 32, false>), grid, dim3(256), 0, s, a);
         }
     }
     if (ctx) {
@@ -1275,6 +1380,10 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     // row: they feed the next layer's keys and values).
     const bool rows_only = (x_out == nullptr) && pos && xrows && d <= LIN_BN && L >= 4;
     const int32_t *off = nullptr, *cnt = nullptr, *tok = nullptr, *qrow = nullptr, *m_dev = nullptr;
+    // throughput shapes keep x / y ONLY in the fragment-major layout between the layers (see frag_index): the
+    // LN-fused GEMMs write it, read their residual from it, and the QKV / FFN1 GEMMs load it as their X operand
+    const bool frag = d <= LIN_BN && d % 32 == 0 && rows > 2048;
+    float *xf = ctx->act_xf, *yf = ctx->act_yf;
     if (rows_only) {
         hipLaunchKernelGGL(k_plan_count, dim3((B + 3) / 4), dim3(256), 0, s, seq, pos, B, L, ctx->seq_cnt);
         hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, s, ctx->seq_cnt, B, ctx->seq_off, ctx->m_dev);
@@ -1285,19 +1394,23 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         tok = ctx->tok_row;
         qrow = ctx->seq_qrow;
         m_dev = ctx->m_dev;
+    }
+    if (frag)
+        hipLaunchKernelGGL(k_embed_frag, dim3((rows + 127) / 128), dim3(256), 0, s, seq, ctx->item_emb, ctx->pe, xf, tok, m_dev,
+                           rows, L, d, sqrtf((float)d), ctx->dims.n_item);
+    else if (rows_only)
         hipLaunchKernelGGL(k_embed_packed, dim3((rows + 3) / 4), dim3(256), 0, s, seq, ctx->item_emb, ctx->pe, x, tok, m_dev,
                            L, d, sqrtf((float)d), ctx->dims.n_item);
-    } else {
+    else
         hipLaunchKernelGGL(k_embed, dim3((rows + 3) / 4), dim3(256), 0, s, seq, ctx->item_emb, ctx->pe, x, rows, L, d,
                            sqrtf((float)d), ctx->dims.n_item);
-    }
     IRS_CHECK_HIP(ctx, hipGetLastError());
     for (int l = 0; l < ctx->dims.n_layers; ++l) {
         const irs_layer_w &w = ctx->layer[l];
         const bool last_rows = rows_only && (l + 1 == ctx->dims.n_layers);
         // qkv = x W_in^T + b_in
         if ((rc = launch_linear(ctx, x, w.sa_in_w, w.sa_in_b, nullptr, ctx->act_qkv, rows, 3 * d, d, false, s, nullptr, nullptr,
-                                nullptr, nullptr, nullptr, nullptr, nullptr, m_dev)))
+                                nullptr, nullptr, nullptr, nullptr, nullptr, m_dev, frag ? xf : nullptr)))
             return rc;
         const float *cl = ctx->c_l + (size_t)l * d;
         if (last_rows) {
@@ -1309,7 +1422,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             hipLaunchKernelGGL(k_attn_row, dim3(ctx->dims.n_heads, B), dim3(64), 0, s, ctx->act_qkv, seq, ctx->act_ru, pos,
                                ao_r, L, d, d / ctx->dims.n_heads, ctx->dims.mask_mode, off, cnt, tok, qrow);
             irs_prof_end(ctx, IRS_PROF_ATTN, s, 4.0 * B * (double)L * d, 4.0 * 3.0 * B * (double)L * d);
-            hipLaunchKernelGGL(k_gather_rows_idx, dim3(B), dim3(64), 0, s, x, qrow, x_r, d);
+            if (frag) hipLaunchKernelGGL(k_gather_rows_frag, dim3(B), dim3(64), 0, s, xf, qrow, x_r, d);
+            else hipLaunchKernelGGL(k_gather_rows_idx, dim3(B), dim3(64), 0, s, x, qrow, x_r, d);
             if ((rc = launch_linear(ctx, ao_r, w.sa_out_w, w.sa_out_b, x_r, y_r, B, d, d, false, s, w.n1_w, w.n1_b, cl, w.n2_w,
                                     w.n2_b)))
                 return rc;
@@ -1319,18 +1433,31 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             return IRS_OK;
         }
         if ((rc = launch_attn(ctx, ctx->act_qkv, seq, ctx->act_ru, ctx->act_ao, B, s, off, cnt, tok))) return rc;
-        if (d <= LIN_BN) {
-            // x <- LN2(LN1(x + ao W_o^T + b_o) + c_l), fused into the GEMM epilogue (y, not in place);
-            // residuals come from the fragment-major copy the previous LN-GEMM left (layer 0 reads row-major)
+        if (frag) {
+            const bool last = l + 1 == ctx->dims.n_layers;
+            // y <- LN2(LN1(x + ao W_o^T + b_o) + c_l): residual from xf, result to yf only
+            if ((rc = launch_linear(ctx, ctx->act_ao, w.sa_out_w, w.sa_out_b, nullptr, nullptr, rows, d, d, false, s, w.n1_w,
+                                    w.n1_b, cl, w.n2_w, w.n2_b, xf, yf, m_dev)))
+                return rc;
+            // h = relu(y W1^T + b1) with y read from yf; x <- LN3(y + h W2^T + b2) back into xf (the last
+            // layer of a full decode writes the row-major x the caller receives instead)
+            if ((rc = launch_linear(ctx, nullptr, w.l1_w, w.l1_b, nullptr, ctx->act_h, rows, F, d, true, s, nullptr, nullptr,
+                                    nullptr, nullptr, nullptr, nullptr, nullptr, m_dev, yf)))
+                return rc;
+            if ((rc = launch_linear(ctx, ctx->act_h, w.l2_w, w.l2_b, nullptr, last ? x : nullptr, rows, d, F, false, s, w.n3_w,
+                                    w.n3_b, nullptr, nullptr, nullptr, yf, last ? nullptr : xf, m_dev)))
+                return rc;
+        } else if (d <= LIN_BN) {
+            // x <- LN2(LN1(x + ao W_o^T + b_o) + c_l), fused into the GEMM epilogue (y, not in place)
             if ((rc = launch_linear(ctx, ctx->act_ao, w.sa_out_w, w.sa_out_b, x, y, rows, d, d, false, s, w.n1_w, w.n1_b,
-                                    cl, w.n2_w, w.n2_b, l > 0 ? ctx->act_xf : nullptr, ctx->act_yf, m_dev)))
+                                    cl, w.n2_w, w.n2_b, nullptr, nullptr, m_dev)))
                 return rc;
             // h = relu(y W1^T + b1); x <- LN3(y + h W2^T + b2)
             if ((rc = launch_linear(ctx, y, w.l1_w, w.l1_b, nullptr, ctx->act_h, rows, F, d, true, s, nullptr, nullptr, nullptr,
                                     nullptr, nullptr, nullptr, nullptr, m_dev)))
                 return rc;
             if ((rc = launch_linear(ctx, ctx->act_h, w.l2_w, w.l2_b, y, x, rows, d, F, false, s, w.n3_w, w.n3_b, nullptr,
-                                    nullptr, nullptr, ctx->act_yf, l + 1 < ctx->dims.n_layers ? ctx->act_xf : nullptr, m_dev)))
+                                    nullptr, nullptr, nullptr, nullptr, m_dev)))
                 return rc;
         } else {
             // y = x + ao W_o^T + b_o ; x = LN2(LN1(y) + c_l)

@@ -182,3 +182,44 @@ def test_sampled_paths_distribution():
     assert set(got) <= set(si)
     freq = np.array([(got == s).mean() for s in si])
     assert np.abs(freq - p).max() < 0.08, (freq, p)
+
+
+@pytest.mark.parametrize("cfgname,B", [("c2", 24), ("default", 80)])
+def test_throughput_shape_decode_matches_small_batches_and_oracle(oracle, cfgname, B):
+    """More than 2048 token rows per call switches the decoder to its throughput kernels (128-row MFMA tiles,
+    activations kept fragment-major between the layers, packed rows when only x[b, pos[b]] is wanted).  The
+    same sequences decoded eight at a time go through the small-batch kernels the goldens pin; both, and the
+    numpy oracle on a few sequences, must agree to float32 accumulation noise."""
+    cfg = synth.make_config(cfgname)
+    L = cfg.max_len
+    assert B * L > 2048
+    sd = synth.irn_state_dict(cfg, 4321)
+    eng = make_engine(cfg, sd, max_rows=B, max_seqs=B)
+    hists = synth.user_histories(B, cfg.n_item, seed=17)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=19)
+    raws, seqs, users, targets, labels = synth.collate_eval_irs(rows, L, gap_len=1)
+    seqs[1, :] = 0          # an all-pad window
+    seqs[1, -1] = targets[1]
+    seqs[2, : L // 2] = seqs[2, L - L // 2:]  # a full window (no padding at all)
+    seqs[2, seqs[2] == 0] = 1
+    pos = np.full(B, L - 2, dtype=np.int32)
+    pos[3], pos[4], pos[5] = 0, L - 1, L // 2
+    seq, u, p = torch.from_numpy(seqs).cuda(), torch.from_numpy(users).cuda(), torch.from_numpy(pos).cuda()
+    x_big, xr_big_full, _ = eng.decode(seq, u, want_x=True, pos=p)
+    _, xr_big, _ = eng.decode(seq, u, want_x=False, pos=p)
+    assert torch.equal(xr_big_full, x_big[torch.arange(B), p.long()])
+    x_small = torch.cat([eng.decode(seq[i:i + 8], u[i:i + 8], want_x=True)[0] for i in range(0, B, 8)])
+
+    def close(a, b):
+        assert torch.equal(torch.isnan(a), torch.isnan(b))
+        ok = torch.isfinite(a) & torch.isfinite(b)
+        assert (a - b)[ok].abs().max().item() < X_TOL
+
+    close(x_big, x_small)
+    close(xr_big, x_small[torch.arange(B), p.long()])
+    for b in (0, 2, 5):
+        ref = oracle.decode(sd, cfg, seqs[b], int(users[b]))[0]
+        got = x_big[b].cpu().numpy()
+        ok = np.isfinite(ref) & np.isfinite(got)
+        assert np.array_equal(np.isnan(ref), np.isnan(got))
+        assert np.abs(ref - got)[ok].max() < X_TOL
