@@ -694,6 +694,207 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(L
     }
 }
 
+// ------------------------------------------------------------------ fused feed-forward block (d = 128, F = 256)
+// xf <- LN3(y + relu(y W1^T + b1) W2^T + b2)        reference: nn.TransformerDecoderLayer._ff_block + norm3
+// The [tokens][F] hidden activation never leaves the registers: in the transposed orientation a wave owns 32
+// tokens; GEMM 1 leaves h^T[f][token] in 8 accumulator tiles (lane = token, 64+64 of the 256 f values in the
+// lane pair), bias + relu are applied in place, and because the MFMA C layout of a tile is a valid B-operand
+// layout (register 4g+e of tile ft <-> k-pair {32ft+8g+e, 32ft+8g+4+e}) those registers feed GEMM 2 directly,
+// whose A operand (W2) is read from LDS in the same chunk order every other GEMM here uses.  y is read from the
+// fragment-major layout as GEMM 1's B operand (contiguous KiB per wave) and again as the residual that seeds
+// GEMM 2's accumulators.  HBM traffic per token: 512 B in, 512 B out -- the unfused pair moved 3.5x that.
+// Workgroup = 4 waves = 128 tokens; W1 / W2 k-slabs of 16 stream through one double-buffered LDS image
+// (24 pipeline steps: 8 of [256][16] for W1, 16 of [128][16] for W2).
+struct FfnArgs {
+    const float *Yf, *W1, *b1, *W2, *b2, *g, *b;
+    float *Xf; // fragment-major output (may be null)
+    float *Y;  // row-major output [M][128] (may be null)
+    int M;
+    const int32_t *m_dev;
+};
+
+__global__ void __launch_bounds__(256, 2) k_ffn_ln(FfnArgs a) {
+    constexpr int D = 128, F = 256, BK = 16;
+    __shared__ __attribute__((aligned(16))) float sm[2 * F * BK + F + 3 * D];
+    float *vecs = sm + 2 * F * BK; // b1[256], b2[128], g[128], b[128]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int m0 = blockIdx.x * 128;
+    const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M;
+    if (m0 >= M) return;
+    vecs[tid] = a.b1[tid];
+    if (tid < D) {
+        vecs[F + tid] = a.b2[tid];
+        vecs[F + D + tid] = a.g[tid];
+        vecs[F + 2 * D + tid] = a.b[tid];
+    }
+    const int mtile = (m0 >> 5) + wave;
+    const int mt = m0 + wave * 32 + li; // this lane's token
+    const float4 *yfrag = reinterpret_cast<const float4 *>(a.Yf) + (size_t)mtile * 16 * 64 + lane; // + (tn*4+g)*64
+
+    // slab loaders: step t < 8 -> W1[:, 16t .. 16t+15] (256 rows), t >= 8 -> W2[:, 16(t-8) ..] (128 rows)
+    float4 wv[4];
+    auto load_slab = [&](int t) {
+        if (t < 8) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + i * 256;
+                const float *p = a.W1 + (size_t)(idx >> 2) * D + t * BK + (idx & 3) * 4;
+                wv[i] = make_float4(p[0], p[1], p[2], p[3]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + i * 256;
+                const float *p = a.W2 + (size_t)(idx >> 2) * F + (t - 8) * BK + (idx & 3) * 4;
+                wv[i] = make_float4(p[0], p[1], p[2], p[3]);
+            }
+        }
+    };
+    auto store_slab = [&](int t, float *S) {
+        const int n = t < 8 ? 4 : 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < n) {
+                const int idx = tid + i * 256;
+                const int r = idx >> 2, c = idx & 3;
+                *reinterpret_cast<float4 *>(S + r * BK + ((c ^ lin_swz<BK>(r)) << 2)) = wv[i];
+            }
+    };
+    const int sw = lin_swz<BK>(li);
+
+    f32x16 h[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[i][r] = 0.f;
+
+    load_slab(0);
+    float4 yv[2], yn[2];
+    yv[0] = yfrag[0];
+    yv[1] = yfrag[64];
+    store_slab(0, sm);
+    __syncthreads();
+    int cur = 0;
+    // ---- GEMM 1: h^T = W1 y^T
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        load_slab(t + 1);
+        if (t + 1 < 8) {
+            yn[0] = yfrag[(2 * (t + 1)) * 64];
+            yn[1] = yfrag[(2 * (t + 1) + 1) * 64];
+        }
+        const float *wa = sm + cur * F * BK + li * BK;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int off = ((2 * q + lk) ^ sw) << 2;
+            const float4 x4 = yv[q];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float4 w[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = *reinterpret_cast<const float4 *>(wa + (half * 4 + i) * 32 * BK + off);
+#define FFN_STEP(E)                                                                                         \
+    h[half * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0].E, x4.E, h[half * 4 + 0], 0, 0, 0);         \
+    h[half * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1].E, x4.E, h[half * 4 + 1], 0, 0, 0);         \
+    h[half * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2].E, x4.E, h[half * 4 + 2], 0, 0, 0);         \
+    h[half * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3].E, x4.E, h[half * 4 + 3], 0, 0, 0);
+                FFN_STEP(x) FFN_STEP(y) FFN_STEP(z) FFN_STEP(w)
+#undef FFN_STEP
+            }
+        }
+        store_slab(t + 1, sm + (cur ^ 1) * F * BK);
+        __syncthreads();
+        cur ^= 1;
+        yv[0] = yn[0];
+        yv[1] = yn[1];
+    }
+    // ---- h = relu(h + b1) in place
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bb = *reinterpret_cast<const float4 *>(vecs + ft * 32 + 8 * g + 4 * lk);
+            h[ft][4 * g + 0] = fmaxf(h[ft][4 * g + 0] + bb.x, 0.f);
+            h[ft][4 * g + 1] = fmaxf(h[ft][4 * g + 1] + bb.y, 0.f);
+            h[ft][4 * g + 2] = fmaxf(h[ft][4 * g + 2] + bb.z, 0.f);
+            h[ft][4 * g + 3] = fmaxf(h[ft][4 * g + 3] + bb.w, 0.f);
+        }
+    // ---- GEMM 2 accumulators start from the residual y of this lane's token
+    f32x16 acc[4];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 t4 = yfrag[(tn * 4 + g) * 64];
+            acc[tn][4 * g + 0] = t4.x;
+            acc[tn][4 * g + 1] = t4.y;
+            acc[tn][4 * g + 2] = t4.z;
+            acc[tn][4 * g + 3] = t4.w;
+        }
+    // ---- GEMM 2: out^T = W2 h^T ; slab s covers f = 16s .. 16s+15 = tile ft = s/2, groups g = 2(s&1) + q
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+        if (s2 + 1 < 16) load_slab(8 + s2 + 1);
+        const float *wa = sm + cur * F * BK + li * BK;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int off = ((2 * q + lk) ^ sw) << 2;
+            const int ft = s2 >> 1, g = 2 * (s2 & 1) + q;
+            float4 w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = *reinterpret_cast<const float4 *>(wa + i * 32 * BK + off);
+#define FFN_STEP2(E, R)                                                                                \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0].E, h[ft][4 * g + R], acc[0], 0, 0, 0);          \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1].E, h[ft][4 * g + R], acc[1], 0, 0, 0);          \
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2].E, h[ft][4 * g + R], acc[2], 0, 0, 0);          \
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3].E, h[ft][4 * g + R], acc[3], 0, 0, 0);
+            FFN_STEP2(x, 0) FFN_STEP2(y, 1) FFN_STEP2(z, 2) FFN_STEP2(w, 3)
+#undef FFN_STEP2
+        }
+        if (s2 + 1 < 16) store_slab(8 + s2 + 1, sm + (cur ^ 1) * F * BK);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // ---- + b2, register-local LayerNorm (64 of the 128 values here, 64 in lane^32), stores
+    const float invn = 1.0f / (float)D;
+    float sum = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bb = *reinterpret_cast<const float4 *>(vecs + F + tn * 32 + 8 * g + 4 * lk);
+            acc[tn][4 * g + 0] += bb.x;
+            acc[tn][4 * g + 1] += bb.y;
+            acc[tn][4 * g + 2] += bb.z;
+            acc[tn][4 * g + 3] += bb.w;
+            sum += (acc[tn][4 * g + 0] + acc[tn][4 * g + 1]) + (acc[tn][4 * g + 2] + acc[tn][4 * g + 3]);
+        }
+    const float mu = (sum + __shfl_xor(sum, 32, 64)) * invn;
+    float qs = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float dlt = acc[tn][r] - mu;
+            qs += dlt * dlt;
+        }
+    const float rstd = 1.0f / sqrtf((qs + __shfl_xor(qs, 32, 64)) * invn + 1e-5f);
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = tn * 32 + 8 * g + 4 * lk;
+            const float4 gg = *reinterpret_cast<const float4 *>(vecs + F + D + n);
+            const float4 be = *reinterpret_cast<const float4 *>(vecs + F + 2 * D + n);
+            const float4 o = make_float4((acc[tn][4 * g + 0] - mu) * rstd * gg.x + be.x, (acc[tn][4 * g + 1] - mu) * rstd * gg.y + be.y,
+                                         (acc[tn][4 * g + 2] - mu) * rstd * gg.z + be.z, (acc[tn][4 * g + 3] - mu) * rstd * gg.w + be.w);
+            if (a.Xf) reinterpret_cast<float4 *>(a.Xf)[((size_t)(mtile * 4 + tn) * 4 + g) * 64 + lane] = o;
+            if (a.Y && mt < M) *reinterpret_cast<float4 *>(a.Y + (int64_t)mt * D + n) = o;
+        }
+}
+
 // ------------------------------------------------------------------ small-M linear (latency path, few sequences)
 // With a few hundred rows the 128x128 tiling uses 2-6 workgroups of the 256 CUs.  Here one WAVE
 // owns one 32x32 output tile and loads its operands straight from L2 into MFMA-fragment registers
@@ -1439,14 +1640,21 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             if ((rc = launch_linear(ctx, ctx->act_ao, w.sa_out_w, w.sa_out_b, nullptr, nullptr, rows, d, d, false, s, w.n1_w,
                                     w.n1_b, cl, w.n2_w, w.n2_b, xf, yf, m_dev)))
                 return rc;
-            // h = relu(y W1^T + b1) with y read from yf; x <- LN3(y + h W2^T + b2) back into xf (the last
-            // layer of a full decode writes the row-major x the caller receives instead)
-            if ((rc = launch_linear(ctx, nullptr, w.l1_w, w.l1_b, nullptr, ctx->act_h, rows, F, d, true, s, nullptr, nullptr,
-                                    nullptr, nullptr, nullptr, nullptr, nullptr, m_dev, yf)))
-                return rc;
-            if ((rc = launch_linear(ctx, ctx->act_h, w.l2_w, w.l2_b, nullptr, last ? x : nullptr, rows, d, F, false, s, w.n3_w,
-                                    w.n3_b, nullptr, nullptr, nullptr, yf, last ? nullptr : xf, m_dev)))
-                return rc;
+            // x <- LN3(y + relu(y W1^T + b1) W2^T + b2) back into xf (the last layer of a full decode writes the
+            // row-major x the caller receives instead); d = 128, F = 256 runs as one kernel with h in registers
+            if (d == 128 && F == 256) {
+                FfnArgs fa{yf, w.l1_w, w.l1_b, w.l2_w, w.l2_b, w.n3_w, w.n3_b, last ? nullptr : xf, last ? x : nullptr, rows, m_dev};
+                irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
+                hipLaunchKernelGGL(k_ffn_ln, dim3((rows + 127) / 128), dim3(256), 0, s, fa);
+                irs_prof_end(ctx, IRS_PROF_LINEAR, s, 4.0 * rows * (double)d * F, 8.0 * rows * (double)d);
+            } else {
+                if ((rc = launch_linear(ctx, nullptr, w.l1_w, w.l1_b, nullptr, ctx->act_h, rows, F, d, true, s, nullptr, nullptr,
+                                        nullptr, nullptr, nullptr, nullptr, nullptr, m_dev, yf)))
+                    return rc;
+                if ((rc = launch_linear(ctx, ctx->act_h, w.l2_w, w.l2_b, nullptr, last ? x : nullptr, rows, d, F, false, s, w.n3_w,
+                                        w.n3_b, nullptr, nullptr, nullptr, yf, last ? nullptr : xf, m_dev)))
+                    return rc;
+            }
         } else if (d <= LIN_BN) {
             // x <- LN2(LN1(x + ao W_o^T + b_o) + c_l), fused into the GEMM epilogue (y, not in place)
             if ((rc = launch_linear(ctx, ctx->act_ao, w.sa_out_w, w.sa_out_b, x, y, rows, d, d, false, s, w.n1_w, w.n1_b,

@@ -73,6 +73,11 @@ int main(int argc, char **argv) {
             printf("%s BK=%2d : %8.1f us  %6.1f TF\n", sh.name, bk, ms * 1e3, gf / ms);
         }
     }
+    {   // fused FFN block (fragment-major in/out): compare with ffn1 + ffn2+ln above
+        FfnArgs fa{R, W, B, W, B, G, G, Y, nullptr, M, nullptr};
+        float ms = time_it([&] { hipLaunchKernelGGL(k_ffn_ln, dim3((M + 127) / 128), dim3(256), 0, 0, fa); }, 20);
+        printf("ffn fused     : %8.1f us  %6.1f TF\n", ms * 1e3, 4.0 * M * 128 * 256 / 1e9 / ms);
+    }
     CK(hipDeviceSynchronize());
     return 0;
 }
