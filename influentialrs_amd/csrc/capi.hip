@@ -215,7 +215,7 @@ extern "C" int irs_finalize_weights(irs_ctx *ctx, void *arena, size_t bytes, voi
 // ------------------------------------------------------------------ workspace
 struct ws_plan {
     size_t x, y, xf, yf, qkv, ao, h, ru, xb, eps, thr, gm, cnt, cand, lse, ref, xrows, tval, tids, status, step, pos;
-    size_t bseq[2], bhep[2], bcum[2], bpaths[2], buser, lmax, lsum, tokrow, scnt, soff, sqrow, mdev, total;
+    size_t bseq[2], bhep[2], bcum[2], bpaths[2], buser, lmax, lsum, tokrow, scnt, soff, sqrow, spadq, mdev, total;
 };
 
 static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
@@ -264,6 +264,7 @@ static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
     p->scnt = take((size_t)ctx->max_seqs * 4);
     p->soff = take((size_t)ctx->max_seqs * 4);
     p->sqrow = take((size_t)ctx->max_seqs * 4);
+    p->spadq = take((size_t)ctx->max_seqs * 4);
     p->mdev = take(256);
     p->total = off;
 }
@@ -319,6 +320,7 @@ extern "C" int irs_bind_workspace(irs_ctx *ctx, void *ws, size_t bytes) {
     ctx->seq_cnt = (int32_t *)(b + p.scnt);
     ctx->seq_off = (int32_t *)(b + p.soff);
     ctx->seq_qrow = (int32_t *)(b + p.sqrow);
+    ctx->seq_padq = (int32_t *)(b + p.spadq);
     ctx->m_dev = (int32_t *)(b + p.mdev);
     if (ctx->beam_graph) {
         hipGraphExecDestroy(ctx->beam_graph);

@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(1024) k_plan_scan(const int32_t *__restrict__ 
 
 __global__ void __launch_bounds__(256) k_plan_fill(const int64_t *__restrict__ seq, const int32_t *__restrict__ pos, int B,
                                                    int L, const int32_t *__restrict__ off, int32_t *__restrict__ qrow,
-                                                   int32_t *__restrict__ tok_row) {
+                                                   int32_t *__restrict__ tok_row, int32_t *__restrict__ padq) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= B) return;
     int p = pos[b];
@@ -130,7 +130,10 @@ __global__ void __launch_bounds__(256) k_plan_fill(const int64_t *__restrict__ s
         if (v) {
             const int idx = o + __popcll(m & ((1ull << lane) - 1ull));
             tok_row[idx] = b * L + t;
-            if (t == p) qrow[b] = idx;
+            if (t == p) {
+                qrow[b] = idx;
+                padq[b] = (sq[t] == 0) ? idx - off[b] : -1; // the only pad a packed sequence can hold
+            }
         }
         o += __popcll(m);
     }
@@ -1287,6 +1290,259 @@ __global__ void __launch_bounds__(256) k_attn_mfma(const float *__restrict__ qkv
     }
 }
 
+// ------------------------------------------------------------------ attention, head dim 32, 16-query blocks
+// Same mathematics and masks as k_attn_mfma, restructured around v_mfma_f32_16x16x4_f32 for the throughput
+// shapes: a causal sequence of L tokens has only ceil(L/32) 32-query blocks, too few and too unequal to keep
+// four waves busy (L = 132: costs 1..5 key blocks -> the longest wave does 6 of 15), and half of every
+// diagonal 32x32 block is masked.  With 16-query blocks x 16-key tiles the causal waste halves and a greedy
+// longest-first assignment of the blocks to the waves balances to ~90 %.
+//   S^T[key][q] = K . Q^T : lane (q = lane%16, gq = lane/16) holds Q[q][8gq .. 8gq+7] (B operand) and reads
+//                 K[key][8gq .. 8gq+7] as two ds_read_b128 (A operand); C register r <-> key 4gq + r
+//   O^T[c][q] += V^T . P^T: the S accumulator is the B operand (register j <-> key 4gq + j); the A operand
+//                 V^T[c][4gq .. 4gq+3] is ONE ds_read_b128 from the transposed V image
+// A query block keeps ALL its score tiles in registers (<= MAXT tiles of 4 registers): the softmax is two-pass
+// (one max / shuffle pair per query block, no running rescale), the score tiles are independent MFMA chains and
+// P.V runs on four accumulators -- the online form's per-tile shuffle + rescale chain was the critical path.
+// LDS: K [L][32] with the 16-byte chunk index XOR (key&7)^((key>>3)&1), V^T [32][S] with S = 8 mod 16 floats --
+// both conflict-free for the four 16-lane groups ds_read_b128 is serviced in.  Keys in [L, 16 ceil(L/16)) of
+// the last tile carry p = 0; their K rows are zero-filled, their V^T columns are zero-filled up to S (a column
+// index >= S aliases the next row's first keys: finite values times 0).
+__device__ __forceinline__ int attn16_vstride(int Lmax) {
+    int S = (Lmax + 7) & ~7;
+    if ((S & 15) != 8) S += 8;
+    return S;
+}
+
+template <int MAXT>
+__global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
+                                                const float *__restrict__ r_u, float *__restrict__ out, int Lmax, int d,
+                                                int mask_mode, const int32_t *__restrict__ off,
+                                                const int32_t *__restrict__ cnt, const int32_t *__restrict__ padq) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    constexpr int HD = 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int L = cnt ? cnt[blockIdx.y] : Lmax;
+    const int S = attn16_vstride(Lmax);
+    float *Vt = reinterpret_cast<float *>(smem);                 // [32][S]
+    float *Ks = Vt + 32 * S;                                     // [Lmax rounded to 16][32], swizzled chunks
+    unsigned int *padbits = reinterpret_cast<unsigned int *>(Ks + (size_t)((Lmax + 15) & ~15) * HD); // [ceil(L/32)]
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 15, gq = lane >> 4;
+    const int64_t base = off ? (int64_t)off[b] : (int64_t)b * Lmax;
+    const int ld = 3 * d;
+    const bool irn = (mask_mode == IRS_MASK_IRN);
+    const int L16 = (L + 15) & ~15, NB16 = L16 >> 4;
+    // K / V of this (sequence, head) -> LDS.  32 consecutive lanes take 32 consecutive keys of one 16-byte
+    // column chunk: conflict-free ds_write_b128 (K) and ds_write_b32 (V^T).  ALL global loads are issued
+    // before the first LDS store (one memory round trip per workgroup, not one per 32 keys).
+    {
+        float4 kv[MAXT / 2], vv[MAXT / 2];
+        const int jl = tid & 31, c4 = (tid >> 5) & 7;
+#pragma unroll
+        for (int it = 0; it < MAXT / 2; ++it) {
+            const int j = jl + 32 * it;
+            kv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vv[it] = kv[it];
+            if (j < L) {
+                const float *row = qkv + (base + j) * ld + h * HD + 4 * c4;
+                kv[it] = *reinterpret_cast<const float4 *>(row + d);
+                vv[it] = *reinterpret_cast<const float4 *>(row + 2 * d);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < MAXT / 2; ++it) {
+            const int j = jl + 32 * it;
+            if (j < L16) {
+                *reinterpret_cast<float4 *>(Ks + j * HD + ((c4 ^ (j & 7) ^ ((j >> 3) & 1)) << 2)) = kv[it];
+                if (j < S) {
+                    Vt[(4 * c4 + 0) * S + j] = vv[it].x;
+                    Vt[(4 * c4 + 1) * S + j] = vv[it].y;
+                    Vt[(4 * c4 + 2) * S + j] = vv[it].z;
+                    Vt[(4 * c4 + 3) * S + j] = vv[it].w;
+                }
+            }
+        }
+    }
+    // masked-key bitmask of each 32-key block.  A packed sequence holds no pads except possibly its pos token
+    // (index padq[b], recorded by the plan): no global loads on that path.
+    const int pq = padq ? padq[b] : -1;
+    for (int kb = wave; kb < (L + 31) / 32; kb += 4) {
+        const int j = kb * 32 + (lane & 31);
+        bool masked = (j >= L) || (irn && j == L - 1);
+        if (padq) masked = masked || (j == pq);
+        else masked = masked || (seq[base + (j < L ? j : L - 1)] == 0);
+        const unsigned long long bal = __ballot(masked);
+        if (lane == 0) padbits[kb] = (unsigned int)bal;
+    }
+    __syncthreads();
+    // Scores are kept in the log2 domain (Q is pre-scaled by log2(e)/sqrt(hd), p = exp2(s - m)), and the IRN
+    // mask's "+ r_u on every allowed key" is applied as "- r_u on the target column" instead (softmax is
+    // shift-invariant over the unmasked keys): two VALU operations per score fewer.
+    const float LOG2E = 1.4426950408889634f;
+    const float tgt_add = irn ? (1.0f - r_u[b]) * LOG2E : 0.f;
+    const float scale = LOG2E / sqrtf((float)HD);
+    const bool tgt_ok = irn && (seq[(int64_t)b * Lmax + Lmax - 1] != 0);
+
+    // longest-first assignment of the 16-query blocks (block qb costs qb + 1 key tiles) to the 4 waves
+    unsigned int mine = 0;
+    {
+        int load[4] = {0, 0, 0, 0};
+        for (int qb = NB16 - 1; qb >= 0; --qb) {
+            int w = 0;
+            if (load[1] < load[w]) w = 1;
+            if (load[2] < load[w]) w = 2;
+            if (load[3] < load[w]) w = 3;
+            load[w] += qb + 1;
+            if (w == wave) mine |= 1u << qb;
+        }
+    }
+    while (mine) {
+        const int qb = 31 - __builtin_clz(mine);
+        mine &= ~(1u << qb);
+        const int qi = qb * 16 + lq; // this lane's query
+        float qf[8];
+        {
+            const float *qrow = qkv + (base + (qi < L ? qi : L - 1)) * ld + h * HD + 8 * gq;
+            const float4 t0 = *reinterpret_cast<const float4 *>(qrow), t1 = *reinterpret_cast<const float4 *>(qrow + 4);
+            const float sc = qi < L ? scale : 0.f;
+            qf[0] = t0.x * sc, qf[1] = t0.y * sc, qf[2] = t0.z * sc, qf[3] = t0.w * sc;
+            qf[4] = t1.x * sc, qf[5] = t1.y * sc, qf[6] = t1.z * sc, qf[7] = t1.w * sc;
+        }
+        // ---- pass 1: every visible score tile of this query block, masked, with the running maximum
+        f32x4 sacc[MAXT];
+        float mx = -INFINITY;
+        auto score_tile = [&](int kt, f32x4 &sa) {
+            const int key = kt * 16 + lq;
+            const float *kr = Ks + key * HD;
+            const int sw = (key & 7) ^ ((key >> 3) & 1);
+            const float4 k0 = *reinterpret_cast<const float4 *>(kr + (((2 * gq) ^ sw) << 2));
+            const float4 k1 = *reinterpret_cast<const float4 *>(kr + (((2 * gq + 1) ^ sw) << 2));
+            sa = {0.f, 0.f, 0.f, 0.f};
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.x, qf[0], sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.y, qf[1], sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.z, qf[2], sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.w, qf[3], sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.x, qf[4], sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.y, qf[5], sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.z, qf[6], sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.w, qf[7], sa, 0, 0, 0);
+        };
+        auto mask_tile = [&](int kt, unsigned int pm, f32x4 &sa) {
+            if (pm == 0u && kt < qb) { // clean off-diagonal tile: no masking
+                mx = fmaxf(fmaxf(mx, sa[0]), fmaxf(sa[1], fmaxf(sa[2], sa[3])));
+            } else {
+                const unsigned int pmk = pm >> (4 * gq);
+                const int qlim = (kt < qb) ? 64 : lq - 4 * gq; // key index within the tile, minus 4gq, must be <= qlim
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = !((pmk >> r) & 1u) && (r <= qlim);
+                    const float v = ok ? sa[r] : -INFINITY;
+                    sa[r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        };
+        unsigned int live = 0; // tiles with at least one unmasked key (wave-uniform)
+#pragma unroll
+        for (int kp = 0; kp < MAXT / 2; ++kp) {
+            const int k0t = 2 * kp, k1t = 2 * kp + 1;
+            const unsigned int pw = (k0t <= qb) ? padbits[kp] : 0xFFFFFFFFu;
+            const unsigned int pm0 = pw & 0xFFFFu, pm1 = pw >> 16;
+            const bool do0 = pm0 != 0xFFFFu, do1 = (k1t <= qb) && pm1 != 0xFFFFu;
+            if (do0 && do1) { // two independent MFMA chains
+                score_tile(k0t, sacc[k0t]);
+                score_tile(k1t, sacc[k1t]);
+                mask_tile(k0t, pm0, sacc[k0t]);
+                mask_tile(k1t, pm1, sacc[k1t]);
+                live |= 3u << k0t;
+            } else if (do0) {
+                score_tile(k0t, sacc[k0t]);
+                mask_tile(k0t, pm0, sacc[k0t]);
+                live |= 1u << k0t;
+            } else if (do1) {
+                score_tile(k1t, sacc[k1t]);
+                mask_tile(k1t, pm1, sacc[k1t]);
+                live |= 2u << k0t;
+            }
+        }
+        // ---- the IRN target column (key L-1, +1.0, visible to every query): s = q . K[L-1] + 1.0
+        float st = -INFINITY;
+        if (tgt_ok) {
+            const int jt = L - 1;
+            const float *kr = Ks + jt * HD;
+            const int sw = (jt & 7) ^ ((jt >> 3) & 1);
+            const float4 k0 = *reinterpret_cast<const float4 *>(kr + (((2 * gq) ^ sw) << 2));
+            const float4 k1 = *reinterpret_cast<const float4 *>(kr + (((2 * gq + 1) ^ sw) << 2));
+            float part = qf[0] * k0.x;
+            part = __fmaf_rn(qf[1], k0.y, part);
+            part = __fmaf_rn(qf[2], k0.z, part);
+            part = __fmaf_rn(qf[3], k0.w, part);
+            part = __fmaf_rn(qf[4], k1.x, part);
+            part = __fmaf_rn(qf[5], k1.y, part);
+            part = __fmaf_rn(qf[6], k1.z, part);
+            part = __fmaf_rn(qf[7], k1.w, part);
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            st = part + tgt_add;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float m = fmaxf(mx, st);
+        if (m == -INFINITY) m = 0.f; // nothing visible: every exp2(-inf - 0) is 0, l = 0 -> NaN row like torch
+        // ---- pass 2: p = exp(s - m), O^T += V^T P^T on four accumulators (tile parity x column tile)
+        float l = 0.f;
+        f32x4 o[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[i][ct][r] = 0.f;
+        if (tgt_ok) {
+            const float pt = __builtin_amdgcn_exp2f(st - m);
+            l = (gq == 0) ? pt : 0.f; // the four lanes of a query are summed at the end
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[0][ct][r] = pt * Vt[(16 * ct + 4 * gq + r) * S + L - 1];
+        }
+#pragma unroll
+        for (int kt = 0; kt < MAXT; ++kt) {
+            if ((live >> kt) & 1u) { // wave-uniform; tiles beyond qb are never live
+                f32x4 pa;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(sacc[kt][r] - m);
+                    pa[r] = pv;
+                    l += pv;
+                }
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const float4 v4 = *reinterpret_cast<const float4 *>(Vt + (16 * ct + lq) * S + kt * 16 + 4 * gq);
+                    f32x4 oo = o[kt & 1][ct];
+                    oo = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.x, pa[0], oo, 0, 0, 0);
+                    oo = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.y, pa[1], oo, 0, 0, 0);
+                    oo = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.z, pa[2], oo, 0, 0, 0);
+                    oo = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.w, pa[3], oo, 0, 0, 0);
+                    o[kt & 1][ct] = oo;
+                }
+            }
+        }
+        float lt = l + __shfl_xor(l, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        const float inv = 1.0f / lt; // 0 (fully masked) -> inf, 0 * inf = NaN like torch
+        if (qi < L) {
+            float *orow = out + (base + qi) * d + h * HD + 4 * gq;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                *reinterpret_cast<float4 *>(orow + 16 * ct) =
+                    make_float4((o[0][ct][0] + o[1][ct][0]) * inv, (o[0][ct][1] + o[1][ct][1]) * inv,
+                                (o[0][ct][2] + o[1][ct][2]) * inv, (o[0][ct][3] + o[1][ct][3]) * inv);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ single-query attention (last layer, rows-only decode)
 // Only row pos[b] of the last layer is consumed by the scoring step (the reference computes all L
 // rows and uses output[index][history_end_pos], influentialRS.py:374,421).  One wave per (sequence,
@@ -1517,6 +1773,8 @@ static int launch_linear(irs_ctx *ctx, const float *X, const float *W, const flo
     return IRS_OK;
 }
 
+static int g_attn16 = 1; // 16-query-block attention kernel for head dim 32 (0: k_attn_mfma everywhere)
+
 static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const float *r_u, float *out, int B,
                        hipStream_t s, const int32_t *off = nullptr, const int32_t *cnt = nullptr,
                        const int32_t *tok_row = nullptr) {
@@ -1528,6 +1786,16 @@ static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const
     dim3 grid(H, B);
     const int mm = ctx->dims.mask_mode;
     irs_prof_begin(ctx, IRS_PROF_ATTN, s);
+    if (hd == 32 && v4 && L <= 256 && g_attn16) {
+        int S16 = (L + 7) & ~7; // attn16_vstride
+        if ((S16 & 15) != 8) S16 += 8;
+        const size_t lds16 = (size_t)32 * S16 * 4 + (size_t)((L + 15) & ~15) * 32 * 4 + 64;
+        hipLaunchKernelGGL(k_attn16<16>, grid, dim3(256), lds16, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
+                           tok_row ? ctx->seq_padq : nullptr);
+        irs_prof_end(ctx, IRS_PROF_ATTN, s, 2.0 * B * (double)H * L * L * hd, 4.0 * 4.0 * B * (double)L * d);
+        IRS_CHECK_HIP(ctx, hipGetLastError());
+        return IRS_OK;
+    }
 #define A_(HDP_)                                                                                                   \
     do {                                                                                                           \
         if (v4) hipLaunchKernelGGL((k_attn_mfma<HDP_, true>), grid, dim3(256), lds, s, qkv, seq, r_u, out, L, d, hd, mm, off, cnt, tok_row); \
@@ -1589,7 +1857,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         hipLaunchKernelGGL(k_plan_count, dim3((B + 3) / 4), dim3(256), 0, s, seq, pos, B, L, ctx->seq_cnt);
         hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, s, ctx->seq_cnt, B, ctx->seq_off, ctx->m_dev);
         hipLaunchKernelGGL(k_plan_fill, dim3((B + 3) / 4), dim3(256), 0, s, seq, pos, B, L, ctx->seq_off, ctx->seq_qrow,
-                           ctx->tok_row);
+                           ctx->tok_row, ctx->seq_padq);
         off = ctx->seq_off;
         cnt = ctx->seq_cnt;
         tok = ctx->tok_row;

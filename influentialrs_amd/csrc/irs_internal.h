@@ -59,6 +59,7 @@ struct irs_ctx {
     // packed (pad-free) decode plan
     int32_t *tok_row;  // [max_seqs * L] packed index -> b*L + t
     int32_t *seq_cnt, *seq_off, *seq_qrow; // [max_seqs]
+    int32_t *seq_padq; // [max_seqs] index within the packed sequence of the one pad token it may hold (pos), or -1
     int32_t *m_dev;    // [1] number of packed rows
     // scoring
     uint4 *xb;          // packed bf16 rows [m_pad/32][KS][64] x 16 B
