@@ -15,6 +15,8 @@ reference file is touched:
   2. `import wandb` (absent here) -> empty stub module (only needed when the
      data_provider/pipeline modules are imported).
   3. np.Inf alias.
+  4. np.save of a ragged list (pipeline.py:244 `histories`) is rejected by numpy >= 1.24 -> retried as an
+     object array (harness case only).
 
 The published IRN only runs at batch size 1, so every IRN
 golden is produced by looping the reference at B=1.
@@ -241,6 +243,92 @@ def contract_case():
     print("[golden] contract:", len(g["irn_keys"]), "irn keys,", len(g["eval_keys"]), "eval keys")
 
 
+def harness_case():
+    """the reference's UNMODIFIED pipeline.test_model (pipeline.py:151-247) and
+    pipeline.evaluate_prob (:250-331) run end to end on CPU, at the only batch size the published IRN
+    supports (1), from checkpoints written in the reference's own format.  `dp` is a stub whose
+    get_random_evaluate_data returns synthetic rows in the reference's row layout
+    [new_seq, user_id, random_target, label] (data_provider.py:398-449).  Stored: the inputs, the printed
+    aggregates and the six result arrays."""
+    import contextlib
+    import io
+    import re
+    import tempfile
+    import pipeline  # reference, unmodified
+    tmp = tempfile.mkdtemp(dir="/tmp")
+    os.chdir(tmp)
+    cfg = synth.make_config("tiny")
+    ecfg = synth.make_config("eval_tiny")
+    n_users, max_path_len = 10, 6
+    for k, v in dict(model_store_path=tmp + "/", dataset="syn", method="IRN", use_train=False, gap_len=0, batch_size=1,
+                     top_k=20, use_h=True, max_path_len=max_path_len, sample=False, sample_k=3, use_wandb=False).items():
+        setattr(cfg, k, v)
+    ecfg.batch_size = 4
+    os.makedirs(os.path.join(tmp, "syn"))
+    torch.manual_seed(0)
+    net = _load(InfluentialNet(cfg), synth.irn_state_dict(cfg, 1234))
+    irn = IRSNN(cfg, net, "cpu")
+    torch.save({"epoch": 3, "state_dict": net.state_dict(), "optimizer": irn.optimizer.state_dict()},
+               os.path.join(tmp, "syn", "irn_params.pth.tar"))
+    snet = _load(SampleNet(ecfg), synth.irn_state_dict(ecfg, 17, evaluator=True))
+    ev = Evaluator(ecfg, snet, "cpu")
+    torch.save({"epoch": 3, "state_dict": snet.state_dict(), "optimizer": ev.optimizer.state_dict()},
+               os.path.join(tmp, "syn", "eval_params.pth.tar"))
+    hists = synth.user_histories(n_users, cfg.n_item, seed=7)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=11)
+
+    class _DP:
+        def get_random_evaluate_data(self, **kw):
+            return [list(r) for r in rows]
+
+    orig_save = np.save
+
+    def save_ragged(file, arr, *a, **k):
+        try:
+            return orig_save(file, arr, *a, **k)
+        except ValueError:
+            o = np.empty(len(arr), dtype=object)
+            for i, x in enumerate(arr):
+                o[i] = x
+            return orig_save(file, o, *a, **k)
+
+    pipeline.np.save = save_ragged
+    buf = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(buf):
+            pipeline.test_model(cfg, _DP(), device="cpu")
+            pipeline.evaluate_prob(cfg, dict(vars(ecfg)), _DP(), device="cpu")
+    finally:
+        pipeline.np.save = orig_save
+    out = buf.getvalue()
+
+    def grab(label):
+        return float(re.search(re.escape(label) + r": (-?[0-9.eE+-]+|nan|inf)", out).group(1))
+
+    g = {}
+    g["in_raw"], g["in_raw_len"] = _pad_ragged([r[0] for r in rows])
+    g["in_users"] = np.array([r[1] for r in rows], dtype=np.int64)
+    g["in_targets"] = np.array([r[2] for r in rows], dtype=np.int64)
+    g["in_labels"] = np.array([r[3] for r in rows], dtype=np.int64)
+    g["max_path_len"] = np.array(max_path_len)
+    g["printed"] = np.array([grab("Hit rate"), grab("MRR"), grab("Early Success"), grab("Early Success Rate"),
+                             grab("The perplexity"), grab("The increase of interest"),
+                             grab("The increase of reverse ranking"), grab("The increase of ranking"),
+                             grab("The average acceptance probability")])
+    rd = os.path.join(tmp, "results", "syn", "IRN")
+    g["paths"] = np.load(os.path.join(rd, "paths_d_%d.npy" % max_path_len))
+    g["targets"] = np.load(os.path.join(rd, "targets_d_%d.npy" % max_path_len))
+    g["r_u"] = np.load(os.path.join(rd, "r_u.npy"))
+    h = np.load(os.path.join(rd, "histories.npy"), allow_pickle=True)
+    g["histories"], g["histories_len"] = _pad_ragged([np.asarray(x) for x in h])
+    g["p_probs"] = np.load(os.path.join(rd, "p_probs.npy"))
+    g["t_probs"] = np.load(os.path.join(rd, "t_probs.npy"))
+    g["dtypes"] = np.array([str(g[k].dtype) for k in ("paths", "targets", "r_u", "p_probs", "t_probs")])
+    g["meta"] = np.array(["tiny", "eval_tiny", torch.__version__])
+    np.savez_compressed(os.path.join(OUT, "harness_tiny.npz"), **g)
+    print("[golden] harness_tiny: printed =", g["printed"], "paths", g["paths"].shape, g["paths"].dtype)
+
+
 CASES = {
     "irn_tiny": lambda: irn_case("irn_tiny", "tiny", 6, full_logits=True, save_x_full=True),
     "irn_default": lambda: irn_case("irn_default", "default", 4),
@@ -250,6 +338,7 @@ CASES = {
     "eval_tiny": lambda: eval_case("eval_tiny", "eval_tiny", 8),
     "eval_default": lambda: eval_case("eval_default", "eval_default", 6),
     "contract": contract_case,
+    "harness_tiny": harness_case,
 }
 
 if __name__ == "__main__":
