@@ -184,6 +184,24 @@ int irs_score_lse(irs_ctx *ctx, const float *dev_xrows, int32_t M, float *dev_ma
 int irs_merge_topk(irs_ctx *ctx, const float *dev_val_in, const int64_t *dev_ids_in, int32_t W, int32_t M, int32_t k,
                    float *dev_val, int64_t *dev_ids0, void *stream);
 
+/* ---- evaluation batch construction on the device (replaces the per-user Python of
+ *      DataProvider.get_random_evaluate_data, data_provider.py:398-449, and
+ *      DataLoaderEvalIRS._collate_fn, data_provider.py:591-617) -------------
+ * User b's events are dev_items[dev_offsets[b] .. dev_offsets[b+1]) (1-based ids, oldest first).
+ *   label[b]  = the last event; history = all events before it; raw window = its last raw_len items
+ *   target[b] = dev_targets_in[b] when given, else a uniformly random member of [1, n_item] (or of
+ *               dev_pool[0 .. n_pool), the reference's `popular_item` restriction) that is absent from the raw
+ *               window -- device counter RNG keyed by (seed, b): distributional parity with random.sample
+ *   seq[b]    = [0 .. 0, last (L - gap_len - 1) raw items, gap_len zeros, target],  L = max_len
+ *  dev_seq int64 [B, L], dev_target / dev_label int64 [B] out
+ *  dev_raw int64 [B, raw_len] out, right-aligned zero-padded raw windows, dev_raw_n int32 [B] their lengths (both may be NULL)
+ *  dev_status int32 [B] in/out (may be NULL): IRS_ROW_NO_CANDIDATE is OR-ed in when no target was found
+ * Needs L - gap_len - 1 >= 1 (the reference's slice arithmetic is only meaningful there). */
+int irs_build_eval_batch(irs_ctx *ctx, const int64_t *dev_items, const int64_t *dev_offsets, int32_t B, int32_t raw_len,
+                         int32_t gap_len, const int64_t *dev_targets_in, const int64_t *dev_pool, int64_t n_pool,
+                         uint64_t seed, int64_t *dev_seq, int64_t *dev_target, int64_t *dev_label, int64_t *dev_raw,
+                         int32_t *dev_raw_n, int32_t *dev_status, void *stream);
+
 /* ---- one step of the persuasion-path search (replaces the per-row body of
  *      IRSNN.get_seq_in_batch, influentialRS.py:419-450) ------------------
  * For each row: drop candidates present in seq[b, :hep[b]+1], take the first

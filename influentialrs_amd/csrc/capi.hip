@@ -419,6 +419,17 @@ extern "C" int irs_merge_topk(irs_ctx *ctx, const float *val_in, const int64_t *
     return irs_launch_merge(ctx, val_in, ids_in, W, M, k, val, ids0, (hipStream_t)stream);
 }
 
+extern "C" int irs_build_eval_batch(irs_ctx *ctx, const int64_t *items, const int64_t *offsets, int32_t B, int32_t raw_len,
+                                    int32_t gap_len, const int64_t *targets_in, const int64_t *pool, int64_t n_pool,
+                                    uint64_t seed, int64_t *seq, int64_t *target, int64_t *label, int64_t *raw,
+                                    int32_t *raw_n, int32_t *status, void *stream) {
+    if (!ctx) return IRS_E_INVALID;
+    if (!items || !offsets || !seq || !target || !label || B < 1 || raw_len < 1 || gap_len < 0 || (pool && n_pool < 1))
+        IRS_FAIL(ctx, IRS_E_INVALID, "irs_build_eval_batch: bad arguments");
+    return irs_launch_build_eval_batch(ctx, items, offsets, B, raw_len, gap_len, targets_in, pool, n_pool, seed, seq, target,
+                                       label, raw, raw_n, status, (hipStream_t)stream);
+}
+
 extern "C" int irs_path_step(irs_ctx *ctx, int64_t *seq, int32_t *hep, int32_t B, const float *val, const int64_t *ids0,
                              int32_t k, int32_t step, float *paths, int32_t path_ld, int32_t sample, int32_t sample_k,
                              uint64_t seed, int32_t *status, void *stream) {

@@ -154,6 +154,11 @@ int irs_launch_beam_step(irs_ctx *ctx, const int64_t *seq_in, const int32_t *hep
                          int64_t *seq_out, int32_t *hep_out, double *cum_out, float *paths_out, int32_t *status,
                          hipStream_t s);
 
+int irs_launch_build_eval_batch(irs_ctx *ctx, const int64_t *items, const int64_t *offsets, int B, int raw_len, int gap_len,
+                                const int64_t *targets_in, const int64_t *pool, int64_t n_pool, uint64_t seed, int64_t *seq,
+                                int64_t *target, int64_t *label, int64_t *raw, int32_t *raw_n, int32_t *status,
+                                hipStream_t s);
+
 // ---- small device helpers ----
 #ifdef __HIPCC__
 // float -> unsigned key whose unsigned order equals float order; -0 folded onto +0

@@ -337,3 +337,76 @@ int irs_launch_inc(irs_ctx *ctx, int32_t *ctr, hipStream_t s) {
     IRS_CHECK_HIP(ctx, hipGetLastError());
     return IRS_OK;
 }
+
+// ------------------------------------------------------------------ evaluation batch on the device
+// Replaces the per-user Python of DataProvider.get_random_evaluate_data (data_provider.py:398-449: history =
+// all but the last event, label = the last event, target = a random item absent from the last raw_len
+// history items) and DataLoaderEvalIRS._collate_fn (:591-617: pre-padded window, gap zeros, target last).
+// One wave per user.  The target is drawn by rejection from a counter RNG (splitmix64 of (seed, user,
+// attempt)) over [1, n_item] or over an explicit candidate pool (the reference's `popular_item` set):
+// distributional parity with random.sample, exact parity of everything else.
+__global__ void __launch_bounds__(64) k_build_eval_batch(const int64_t *__restrict__ items, const int64_t *__restrict__ offsets,
+                                                         int B, int L, int raw_len, int gap_len, int64_t n_item,
+                                                         const int64_t *__restrict__ targets_in, const int64_t *__restrict__ pool,
+                                                         int64_t n_pool, unsigned long long seed, int64_t *__restrict__ seq,
+                                                         int64_t *__restrict__ target, int64_t *__restrict__ label,
+                                                         int64_t *__restrict__ raw, int32_t *__restrict__ raw_n,
+                                                         int32_t *__restrict__ status) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int64_t lo = offsets[b], hi = offsets[b + 1];
+    const int64_t n_hist = hi - lo - 1;                       // history = all but the last event
+    const int rn = (int)(n_hist < raw_len ? (n_hist < 0 ? 0 : n_hist) : raw_len);
+    const int64_t *rw = items + lo + (n_hist - rn);           // the raw window, oldest first
+    int64_t tgt = 0;
+    if (targets_in) {
+        tgt = targets_in[b];
+    } else {
+        const int64_t space = pool ? n_pool : n_item;
+        bool found = false;
+        for (int attempt = 0; attempt < 256 && !found; ++attempt) {
+            unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)b * 2654435761ull + (unsigned long long)attempt + 1ull);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z = z ^ (z >> 31);
+            const unsigned long long pick = __umul64hi(z, (unsigned long long)space); // uniform in [0, space)
+            const int64_t cand = pool ? pool[pick] : (int64_t)pick + 1;
+            bool hit = false;
+            for (int i = lane; i < rn; i += 64) hit |= (rw[i] == cand);
+            if (!__any(hit)) {
+                tgt = cand;
+                found = true;
+            }
+        }
+        if (!found && lane == 0 && status) status[b] |= IRS_ROW_NO_CANDIDATE;
+    }
+    const int l_history = L - gap_len - 1;
+    const int nh = rn < l_history ? rn : l_history;           // seq[-l_history:] of the raw window
+    const int start = L - nh - gap_len - 1;
+    int64_t *row = seq + (int64_t)b * L;
+    for (int t = lane; t < L; t += 64) {
+        int64_t v = 0;
+        if (t >= start && t < start + nh) v = rw[rn - nh + (t - start)];
+        if (t == L - 1) v = tgt;
+        row[t] = v;
+    }
+    if (raw)
+        for (int i = lane; i < raw_len; i += 64) raw[(int64_t)b * raw_len + i] = (i >= raw_len - rn) ? rw[i - (raw_len - rn)] : 0;
+    if (lane == 0) {
+        target[b] = tgt;
+        label[b] = (hi > lo) ? items[hi - 1] : 0;
+        if (raw_n) raw_n[b] = rn;
+    }
+}
+
+int irs_launch_build_eval_batch(irs_ctx *ctx, const int64_t *items, const int64_t *offsets, int B, int raw_len, int gap_len,
+                                const int64_t *targets_in, const int64_t *pool, int64_t n_pool, uint64_t seed, int64_t *seq,
+                                int64_t *target, int64_t *label, int64_t *raw, int32_t *raw_n, int32_t *status,
+                                hipStream_t s) {
+    const int L = ctx->dims.max_len;
+    if (L - gap_len - 1 < 1) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "gap_len %d leaves no history slot in a window of %d", gap_len, L);
+    hipLaunchKernelGGL(k_build_eval_batch, dim3(B), dim3(64), 0, s, items, offsets, B, L, raw_len, gap_len,
+                       (int64_t)ctx->dims.n_item, targets_in, pool, n_pool, (unsigned long long)seed, seq, target, label, raw,
+                       raw_n, status);
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}

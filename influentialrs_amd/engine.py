@@ -203,6 +203,31 @@ class Engine:
                                             self._stream()))
         return val, ids
 
+    # ------------------------------------------------------------------ evaluation batch (device-side loader)
+    def build_eval_batch(self, items: torch.Tensor, offsets: torch.Tensor, *, raw_len: int = 100, gap_len: int = 0,
+                         targets: Optional[torch.Tensor] = None, pool: Optional[torch.Tensor] = None, seed: int = 0):
+        """get_random_evaluate_data + DataLoaderEvalIRS._collate_fn on the device (data_provider.py:398-449,
+        591-617).  `items` int64 [total] / `offsets` int64 [B+1]: every user's events, oldest first.
+        Returns (seq[B,L], targets[B], labels[B], raw[B,raw_len] right-aligned, raw_n[B] int32, status[B] int32)."""
+        items = self._dev(items, torch.int64)
+        offsets = self._dev(offsets, torch.int64)
+        B = offsets.shape[0] - 1
+        if targets is not None:
+            targets = self._dev(targets, torch.int64)
+        if pool is not None:
+            pool = self._dev(pool, torch.int64)
+        seq = torch.empty((B, self.L), dtype=torch.int64, device=self.device)
+        tgt = torch.empty(B, dtype=torch.int64, device=self.device)
+        lab = torch.empty(B, dtype=torch.int64, device=self.device)
+        raw = torch.empty((B, raw_len), dtype=torch.int64, device=self.device)
+        raw_n = torch.empty(B, dtype=torch.int32, device=self.device)
+        status = torch.zeros(B, dtype=torch.int32, device=self.device)
+        self._check(self.lib.irs_build_eval_batch(self.h, _ptr(items), _ptr(offsets), B, raw_len, gap_len, _ptr(targets),
+                                                  _ptr(pool), 0 if pool is None else pool.shape[0], seed & (2 ** 64 - 1),
+                                                  _ptr(seq), _ptr(tgt), _ptr(lab), _ptr(raw), _ptr(raw_n), _ptr(status),
+                                                  self._stream()))
+        return seq, tgt, lab, raw, raw_n, status
+
     # ------------------------------------------------------------------ path search
     def path_step(self, seqs, hep, val, ids0, step: int, paths, status, sample=False, sample_k=3, seed=0):
         B = seqs.shape[0]

@@ -113,3 +113,46 @@ def test_evaluator_handlers_match_reference(golden, name, cfgname):
         ref = g["logits_row0_full"]
         got = lg[0].cpu().numpy() if ref.shape[0] == lg.shape[1] else lg[0, :4].cpu().numpy()
         assert np.abs(got - ref).max() < 5e-5
+
+
+def test_device_eval_batch_matches_reference_loader_layout(golden):
+    """irs_build_eval_batch against the reference loader's own output (contract golden:
+    DataLoaderEvalIRS._collate_fn over rows built the way get_random_evaluate_data builds them), for gap 0 and 5;
+    then the sampled targets: absent from the raw window, inside the catalog / the pool, seed-reproducible,
+    spread over the catalog."""
+    from gpu_util import make_engine
+    g = golden("contract")
+    cfg = synth.make_config("default")
+    eng = make_engine(cfg, synth.irn_state_dict(cfg, 1234), max_rows=16)
+    hists = synth.user_histories(12, cfg.n_item, seed=7)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=11)
+    items = torch.from_numpy(np.concatenate(hists).astype(np.int64)).to(DEV)
+    offsets = torch.from_numpy(np.concatenate([[0], np.cumsum([len(h) for h in hists])]).astype(np.int64)).to(DEV)
+    given = torch.from_numpy(np.array([r[2] for r in rows], dtype=np.int64)).to(DEV)
+    for gap in (0, 5):
+        seq, tgt, lab, raw, raw_n, st = eng.build_eval_batch(items, offsets, raw_len=100, gap_len=gap, targets=given)
+        assert np.array_equal(seq.cpu().numpy(), g[f"collate_gap{gap}_seq"])
+        assert np.array_equal(tgt.cpu().numpy(), g[f"collate_gap{gap}_targets"])
+        assert np.array_equal(lab.cpu().numpy(), g[f"collate_gap{gap}_labels"])
+        rn = raw_n.cpu().numpy()
+        assert np.array_equal(rn, g[f"collate_gap{gap}_raw_len"])
+        for i in range(len(rows)):
+            assert np.array_equal(raw[i, 100 - rn[i]:].cpu().numpy(), g[f"collate_gap{gap}_raw"][i, :rn[i]])
+            assert not raw[i, :100 - rn[i]].any()
+        assert not st.any()
+    # sampled targets
+    big = synth.user_histories(2048, cfg.n_item, seed=23)
+    items = torch.from_numpy(np.concatenate(big).astype(np.int64)).to(DEV)
+    offsets = torch.from_numpy(np.concatenate([[0], np.cumsum([len(h) for h in big])]).astype(np.int64)).to(DEV)
+    eng2 = make_engine(cfg, synth.irn_state_dict(cfg, 1234), max_rows=2048, max_seqs=2048)
+    seq, tgt, lab, raw, raw_n, st = eng2.build_eval_batch(items, offsets, seed=5)
+    t = tgt.cpu().numpy()
+    assert t.min() >= 1 and t.max() <= cfg.n_item and not st.any()
+    for i, h in enumerate(big):
+        assert t[i] not in set(h[:-1][-100:].tolist()) and lab[i].item() == h[-1] and seq[i, -1].item() == t[i]
+    assert torch.equal(tgt, eng2.build_eval_batch(items, offsets, seed=5)[1])
+    assert not torch.equal(tgt, eng2.build_eval_batch(items, offsets, seed=6)[1])
+    assert len(np.unique(t)) > 1200 and abs(t.mean() - cfg.n_item / 2) < 0.06 * cfg.n_item  # uniform over the catalog
+    pool = torch.arange(1, 41, dtype=torch.int64, device=DEV)
+    tp = eng2.build_eval_batch(items, offsets, seed=5, pool=pool)[1].cpu().numpy()
+    assert tp.min() >= 1 and tp.max() <= 40
