@@ -1333,6 +1333,30 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
     const int ld = 3 * d;
     const bool irn = (mask_mode == IRS_MASK_IRN);
     const int L16 = (L + 15) & ~15, NB16 = L16 >> 4;
+    // longest-first assignment of the 16-query blocks (block qb costs qb + 1 key tiles) to the 4 waves
+    unsigned int mine = 0;
+    {
+        int load[4] = {0, 0, 0, 0};
+        for (int qb = NB16 - 1; qb >= 0; --qb) {
+            int w = 0;
+            if (load[1] < load[w]) w = 1;
+            if (load[2] < load[w]) w = 2;
+            if (load[3] < load[w]) w = 3;
+            load[w] += qb + 1;
+            if (w == wave) mine |= 1u << qb;
+        }
+    }
+    // Q of a query block: lane (q, gq) holds Q[q][8gq .. 8gq+7]; the next block's rows are requested one block
+    // ahead (the first one before the K / V fill) so their latency is never exposed
+    auto load_q = [&](int qb, float4 &t0, float4 &t1) {
+        const int qi = qb * 16 + lq;
+        const float *qrow = qkv + (base + (qi < L ? qi : L - 1)) * ld + h * HD + 8 * gq;
+        t0 = *reinterpret_cast<const float4 *>(qrow);
+        t1 = *reinterpret_cast<const float4 *>(qrow + 4);
+    };
+    float4 qn0 = make_float4(0.f, 0.f, 0.f, 0.f), qn1 = qn0;
+    int qb_next = mine ? 31 - __builtin_clz(mine) : -1;
+    if (qb_next >= 0) load_q(qb_next, qn0, qn1);
     // K / V of this (sequence, head) -> LDS.  32 consecutive lanes take 32 consecutive keys of one 16-byte
     // column chunk: conflict-free ds_write_b128 (K) and ds_write_b32 (V^T).  ALL global loads are issued
     // before the first LDS store (one memory round trip per workgroup, not one per 32 keys).
@@ -1384,27 +1408,15 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
     const float scale = LOG2E / sqrtf((float)HD);
     const bool tgt_ok = irn && (seq[(int64_t)b * Lmax + Lmax - 1] != 0);
 
-    // longest-first assignment of the 16-query blocks (block qb costs qb + 1 key tiles) to the 4 waves
-    unsigned int mine = 0;
-    {
-        int load[4] = {0, 0, 0, 0};
-        for (int qb = NB16 - 1; qb >= 0; --qb) {
-            int w = 0;
-            if (load[1] < load[w]) w = 1;
-            if (load[2] < load[w]) w = 2;
-            if (load[3] < load[w]) w = 3;
-            load[w] += qb + 1;
-            if (w == wave) mine |= 1u << qb;
-        }
-    }
-    while (mine) {
-        const int qb = 31 - __builtin_clz(mine);
+    while (qb_next >= 0) {
+        const int qb = qb_next;
         mine &= ~(1u << qb);
         const int qi = qb * 16 + lq; // this lane's query
         float qf[8];
         {
-            const float *qrow = qkv + (base + (qi < L ? qi : L - 1)) * ld + h * HD + 8 * gq;
-            const float4 t0 = *reinterpret_cast<const float4 *>(qrow), t1 = *reinterpret_cast<const float4 *>(qrow + 4);
+            const float4 t0 = qn0, t1 = qn1;
+            qb_next = mine ? 31 - __builtin_clz(mine) : -1;
+            if (qb_next >= 0) load_q(qb_next, qn0, qn1);
             const float sc = qi < L ? scale : 0.f;
             qf[0] = t0.x * sc, qf[1] = t0.y * sc, qf[2] = t0.z * sc, qf[3] = t0.w * sc;
             qf[4] = t1.x * sc, qf[5] = t1.y * sc, qf[6] = t1.z * sc, qf[7] = t1.w * sc;
