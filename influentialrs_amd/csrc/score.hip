@@ -84,15 +84,19 @@ __device__ __forceinline__ bool sweep_map(const SweepArgs &a, int &strip, int &u
 }
 
 // ---- epilogues (lane = scored row `user`, regs = 16 items of tile `t`, half h)
-// Threshold hits are rare per element but frequent per tile, and a returning global atomic
-// inside a divergent branch costs a full memory round trip.  Hits therefore go to a small
-// wave-private LDS queue (LDS atomic) and are flushed 64 at a time, all global atomics of a
-// flush in flight together.
+// In-kernel timing (s_memtime) of the first version showed the emission epilogue at ~680 cycles per 32x32 tile
+// against ~260 cycles of MFMA: every hit paid a returning LDS atomic inside a divergent branch.  Now
+//   * a tile whose 16-register maximum is below the threshold in every lane is skipped after one v_max3 tree
+//     and one ballot (with ~300 emitted items per row that is ~3 tiles in 4),
+//   * otherwise one v_cmp per accumulator register yields the wave's hit mask in SGPRs and only non-empty
+//     masks enter the handler, which compacts the hits with mbcnt into a wave-private LDS queue whose fill
+//     count lives in a scalar register (nobody else touches the queue: no atomics),
+//   * a full queue is flushed with all its global atomics in flight together.
 #define EMIT_Q 128
 struct EmitQ {
     unsigned long long *keys; // [EMIT_Q]
     unsigned int *users;      // [EMIT_Q]
-    unsigned int *cnt;        // [1]
+    unsigned int n;           // entries queued (wave-uniform)
 };
 
 // candidate lists are bucketed by item tile (bucket = tile mod 64): 64 counters per row keep the
@@ -104,35 +108,30 @@ __device__ __forceinline__ void emit_append_global(const SweepArgs &a, unsigned 
     if (slot < IRS_CAND_SLOTS) a.cand[cell * IRS_CAND_SLOTS + slot] = key;
 }
 
-__device__ __forceinline__ void emit_flush(const SweepArgs &a, const EmitQ &q, int lane) {
-    unsigned int n = __hip_atomic_load(q.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (n > EMIT_Q) n = EMIT_Q;
-    for (unsigned int i = lane; i < n; i += 64) emit_append_global(a, q.users[i], q.keys[i]);
+__device__ __forceinline__ void emit_flush(const SweepArgs &a, EmitQ &q, int lane) {
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) __hip_atomic_store(q.cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (unsigned int i = lane; i < q.n; i += 64) emit_append_global(a, q.users[i], q.keys[i]);
     __builtin_amdgcn_wave_barrier();
+    q.n = 0;
 }
 
 __device__ __forceinline__ void emit_candidates(const SweepArgs &a, const f32x16 &acc, float thr, int user, int t, int h,
-                                                const EmitQ &q, int lane) {
-    float m = max16(acc);
-    if (!__any(m >= thr)) return;
-    if (__hip_atomic_load(q.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > EMIT_Q / 2) emit_flush(a, q, lane);
+                                                EmitQ &q, int lane) {
+    if (!__any(max16(acc) >= thr)) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const bool hit = acc[r] >= thr;
-        if (__any(hit)) {
+        const unsigned long long mask = __ballot(hit);
+        if (mask) { // wave-uniform
+            const unsigned int n = (unsigned int)__popcll(mask);
+            if (q.n + n > EMIT_Q) emit_flush(a, q, lane);
             if (hit) {
                 const unsigned int item = (unsigned int)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
-                const unsigned long long key = ((unsigned long long)irs_fkey(acc[r]) << 32) | item;
-                unsigned int pos = atomicAdd(q.cnt, 1u);
-                if (pos < EMIT_Q) {
-                    q.keys[pos] = key;
-                    q.users[pos] = (unsigned int)user;
-                } else {
-                    emit_append_global(a, (unsigned int)user, key); // queue full (dense hits): direct append
-                }
+                const unsigned int pos = q.n + __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+                q.keys[pos] = ((unsigned long long)irs_fkey(acc[r]) << 32) | item;
+                q.users[pos] = (unsigned int)user;
             }
+            q.n += n;
         }
     }
 }
@@ -143,7 +142,7 @@ __device__ __forceinline__ EmitQ emit_queue(char *base, int wave) {
     EmitQ q;
     q.keys = reinterpret_cast<unsigned long long *>(p);
     q.users = reinterpret_cast<unsigned int *>(p + EMIT_Q * 8);
-    q.cnt = reinterpret_cast<unsigned int *>(p + EMIT_Q * 12);
+    q.n = 0;
     return q;
 }
 #define EMIT_Q_BYTES (4 * (EMIT_Q * 12 + 16))
@@ -159,8 +158,7 @@ __global__ void __launch_bounds__(256, 2) k_sweep_bf16(SweepArgs a) {
     const int r = lane & 31, h = lane >> 5;
     const int ut0 = ublock * UB;
     const int ubc = min(UB, a.UT - ut0);
-    const EmitQ eq = emit_queue(smem + (size_t)UB * KS * 1024, wave);
-    if (MODE == MODE_EMIT && lane == 0) *eq.cnt = 0u;
+    EmitQ eq = emit_queue(smem + (size_t)UB * KS * 1024, wave);
     {
         const uint4 *src = a.xb + (size_t)ut0 * KS * 64;
         for (int i = tid; i < ubc * KS * 64; i += 256) xs[i] = src[i];
@@ -245,8 +243,7 @@ __global__ void __launch_bounds__(256, 2) k_sweep_f32(SweepArgs a) {
     const int r = lane & 31, h = lane >> 5;
     const int ut0 = ublock * UB;
     const int ubc = min(UB, a.UT - ut0);
-    const EmitQ eq = emit_queue(smem + (size_t)UB * KS * 2048, wave);
-    if (MODE == MODE_EMIT && lane == 0) *eq.cnt = 0u;
+    EmitQ eq = emit_queue(smem + (size_t)UB * KS * 2048, wave);
     for (int i = tid; i < ubc * QN * 64; i += 256) {
         int ln = i & 63, q = (i >> 6) % QN, u = (i >> 6) / QN;
         int row = (ut0 + u) * 32 + (ln & 31), hh = ln >> 5;
