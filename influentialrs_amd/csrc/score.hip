@@ -196,25 +196,42 @@ __global__ void __launch_bounds__(256, 2) k_sweep_bf16(SweepArgs a) {
                 for (int q = 0; q < 4; ++q)
                     bn[q] = *reinterpret_cast<const float4 *>(a.bias + (size_t)(t + ts) * 32 + 8 * q + 4 * h);
             }
+            // the bias vector is the C operand of each chain's first MFMA (no accumulator initialisation), and
+            // the B fragments of the next row tile are requested from LDS before the current chain is issued
+            f32x16 biasv;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                biasv[4 * q + 0] = bc[q].x;
+                biasv[4 * q + 1] = bc[q].y;
+                biasv[4 * q + 2] = bc[q].z;
+                biasv[4 * q + 3] = bc[q].w;
+            }
+            constexpr bool PF = KS <= 8; // register budget: no fragment prefetch at d_pad = 256
+            uint4 bcur[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bcur[ks] = xs[ks * 64 + lane];
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
                 if (u < ubc) {
+                    uint4 bnx[KS];
+                    if (PF && u + 1 < UB && u + 1 < ubc) {
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) bnx[ks] = xs[((u + 1) * KS + ks) * 64 + lane];
+                    }
                     f32x16 acc;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        acc[4 * q + 0] = bc[q].x;
-                        acc[4 * q + 1] = bc[q].y;
-                        acc[4 * q + 2] = bc[q].z;
-                        acc[4 * q + 3] = bc[q].w;
-                    }
-#pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
-                        uint4 bv = xs[(u * KS + ks) * 64 + lane];
+                        const uint4 bv = PF ? bcur[ks] : xs[(u * KS + ks) * 64 + lane];
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[ks]),
-                                                                      __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+                                                                      __builtin_bit_cast(bf16x8, bv), ks == 0 ? biasv : acc, 0, 0, 0);
                     }
                     if (MODE == MODE_PRE) aux[u] = fmaxf(aux[u], max16(acc));
                     else emit_candidates(a, acc, aux[u], (ut0 + u) * 32 + r, t, h, eq, lane);
+                    if (PF && u + 1 < UB && u + 1 < ubc) {
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) bcur[ks] = bnx[ks];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
