@@ -244,6 +244,151 @@ __global__ void __launch_bounds__(256, 2) k_sweep_bf16(SweepArgs a) {
     }
 }
 
+// =============================== bf16 sweep, row-stationary 2 x RT blocks (>= one full row block) ===============================
+// k_sweep_bf16 reads one B fragment from LDS per MFMA and runs one dependent MFMA chain per wave; measured
+// in-kernel (s_memtime) that is ~415 cycles for 256 cycles of matrix work per 32x32 tile.  Once the sweep is
+// compute bound (hundreds of rows) the roles are swapped: a wave keeps the bf16 fragments of ITS RT row tiles
+// in registers for the whole kernel, the four waves of a workgroup share the streamed W tiles through LDS
+// (staged ST tiles at a time by all 256 threads: registers -> LDS, double buffered, one barrier per stage), and
+// two item tiles are multiplied at once: per k-step 2 fragment reads feed 2 x RT MFMAs on independent
+// accumulators (half the LDS traffic per MFMA, no dependent-issue stalls).  Tiles, PRE groups and every
+// accumulated value are identical to k_sweep_bf16's: the workgroup walks the 4 x tiles_per_wave tiles its four
+// waves would have walked there; group id = (strip * 4 + quarter) * 2 + lane half.
+template <int KS, int RT, int MODE>
+__global__ void __launch_bounds__(256, 2) k_sweep_bf16_rs(SweepArgs a) {
+    constexpr int ST = KS >= 16 ? 2 : 4;       // W tiles per stage (even)
+    constexpr int STAGE_U4 = ST * KS * 64;     // uint4 per stage (fragments)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4 *ws = reinterpret_cast<uint4 *>(smem);                                  // [2][ST][KS][64]
+    float *bs = reinterpret_cast<float *>(smem + (size_t)2 * STAGE_U4 * 16);      // [2][ST][32] bias
+    int strip, ublock;
+    if (!sweep_map(a, strip, ublock)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int ut0 = ublock * 4 * RT + wave * RT; // this wave's first row tile
+    EmitQ eq = emit_queue(smem + (size_t)2 * STAGE_U4 * 16 + 2 * ST * 32 * 4, wave);
+    const int ts = a.tile_stride, tpw = a.tiles_per_wave;
+    const int tfirst = a.tile_begin + strip * 4 * tpw * ts;
+    int ntile = 4 * tpw; // tiles this workgroup walks: t(i) = tfirst + i * ts, while < tile_end
+    {
+        const int avail = (a.tile_end - tfirst + ts - 1) / ts;
+        if (avail < ntile) ntile = avail;
+    }
+    if (ntile <= 0) return;
+    // this wave's rows: fragments in registers for the whole kernel
+    uint4 xr[RT][KS];
+    float aux[RT];
+#pragma unroll
+    for (int u = 0; u < RT; ++u) {
+        const bool live = ut0 + u < a.UT;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            xr[u][ks] = live ? a.xb[((size_t)(ut0 + u) * KS + ks) * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
+        if (MODE == MODE_PRE) aux[u] = -INFINITY;
+        else aux[u] = live ? fmaxf(a.thr[(ut0 + u) * 32 + r], -3.0e38f) : INFINITY;
+    }
+    // staging: thread -> uint4 slots tid, tid + 256, ... of the stage image
+    constexpr int NLD = (STAGE_U4 + 255) / 256;
+    uint4 stg[NLD];
+    float stb = 0.f;
+    auto load_stage = [&](int i0) { // tiles i0 .. i0 + ST - 1 (clamped to the last tile: duplicates are never consumed)
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int idx = tid + j * 256;
+            if (idx < STAGE_U4) {
+                const int tl = idx / (KS * 64);
+                const int t = tfirst + min(i0 + tl, ntile - 1) * ts;
+                const unsigned int *p = reinterpret_cast<const unsigned int *>(a.wp + (size_t)t * KS * 64 + (idx - tl * KS * 64));
+                stg[j] = make_uint4(p[0], p[1], p[2], p[3]);
+            }
+        }
+        if (tid < ST * 32) {
+            const int t = tfirst + min(i0 + (tid >> 5), ntile - 1) * ts;
+            stb = a.bias[(size_t)t * 32 + (tid & 31)];
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int idx = tid + j * 256;
+            if (idx < STAGE_U4) ws[buf * STAGE_U4 + idx] = stg[j];
+        }
+        if (tid < ST * 32) bs[buf * ST * 32 + tid] = stb;
+    };
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    int cur = 0;
+    int gcount = 0, gw = strip * 4; // PRE: tiles seen in the current group, group (= wave id of k_sweep_bf16)
+    for (int i0 = 0; i0 < ntile; i0 += ST) {
+        const bool more = i0 + ST < ntile;
+        if (more) load_stage(i0 + ST);
+#pragma unroll
+        for (int tl = 0; tl < ST; tl += 2) {
+            const int i = i0 + tl;
+            if (i < ntile) { // workgroup-uniform; tile i + 1 may be a clamped duplicate (ignored below)
+                const uint4 *w0 = ws + cur * STAGE_U4 + tl * KS * 64 + lane;
+                const uint4 *w1 = w0 + KS * 64;
+                f32x16 acc[2][RT];
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti) {
+                    const float *bt = bs + (cur * ST + tl + ti) * 32 + 4 * h;
+                    const float4 b0 = *reinterpret_cast<const float4 *>(bt), b1 = *reinterpret_cast<const float4 *>(bt + 8);
+                    const float4 b2 = *reinterpret_cast<const float4 *>(bt + 16), b3 = *reinterpret_cast<const float4 *>(bt + 24);
+                    f32x16 bv;
+                    bv[0] = b0.x, bv[1] = b0.y, bv[2] = b0.z, bv[3] = b0.w, bv[4] = b1.x, bv[5] = b1.y, bv[6] = b1.z, bv[7] = b1.w;
+                    bv[8] = b2.x, bv[9] = b2.y, bv[10] = b2.z, bv[11] = b2.w, bv[12] = b3.x, bv[13] = b3.y, bv[14] = b3.z, bv[15] = b3.w;
+                    const uint4 av = ti == 0 ? w0[0] : w1[0];
+#pragma unroll
+                    for (int u = 0; u < RT; ++u) // the bias vector is the C operand of each chain's first MFMA
+                        acc[ti][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
+                                                                             __builtin_bit_cast(bf16x8, xr[u][0]), bv, 0, 0, 0);
+                }
+#pragma unroll
+                for (int ks = 1; ks < KS; ++ks) {
+                    const uint4 a0 = w0[ks * 64], a1 = w1[ks * 64];
+#pragma unroll
+                    for (int u = 0; u < RT; ++u) {
+                        acc[0][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0),
+                                                                            __builtin_bit_cast(bf16x8, xr[u][ks]), acc[0][u], 0, 0, 0);
+                        acc[1][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1),
+                                                                            __builtin_bit_cast(bf16x8, xr[u][ks]), acc[1][u], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti) {
+                    if (i + ti < ntile) {
+                        const int t = tfirst + (i + ti) * ts;
+#pragma unroll
+                        for (int u = 0; u < RT; ++u) {
+                            if (ut0 + u < a.UT) { // wave-uniform
+                                if (MODE == MODE_PRE) aux[u] = fmaxf(aux[u], max16(acc[ti][u]));
+                                else emit_candidates(a, acc[ti][u], aux[u], (ut0 + u) * 32 + r, t, h, eq, lane);
+                            }
+                        }
+                        if (MODE == MODE_PRE) {
+                            ++gcount;
+                            if (gcount == tpw || i + ti + 1 == ntile) { // end of a group: publish, restart
+#pragma unroll
+                                for (int u = 0; u < RT; ++u) {
+                                    if (ut0 + u < a.UT) a.gm[(size_t)(gw * 2 + h) * a.M_pad + (ut0 + u) * 32 + r] = aux[u];
+                                    aux[u] = -INFINITY;
+                                }
+                                gcount = 0;
+                                ++gw;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (more) store_stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (MODE == MODE_EMIT) emit_flush(a, eq, lane);
+}
+
 // =============================== fp32 sweep ===============================
 // v_mfma_f32_32x32x2_f32: lane (r, h) supplies A[r][k=h] and B[k=h][r]; one
 // instruction is fma(a_k1, b_k1, fma(a_k0, b_k0, C)), so issuing k pairs in
@@ -850,6 +995,23 @@ static int launch_sweep_bf16(irs_ctx *ctx, SweepArgs &a, hipStream_t s) {
     const int KS = ctx->KS, UB = ub_bf16(KS);
     a.n_ublocks = (a.UT + UB - 1) / UB;
     dim3 grid(((a.n_strips + 7) / 8) * 8 * a.n_ublocks);
+    // compute-bound regime (at least one full row block, d_pad <= 128): rows stay in registers, W tiles are shared
+    // through LDS.  At d_pad = 256 only one row tile per wave fits the register file and the streaming form wins.
+    if (a.UT >= UB && KS <= 8) {
+        const int ST = KS >= 16 ? 2 : 4; // as in the kernel
+        const size_t lds_rs = (size_t)2 * ST * KS * 1024 + 2 * ST * 32 * 4 + EMIT_Q_BYTES;
+#define R_(KS_, RT_) hipLaunchKernelGGL((k_sweep_bf16_rs<KS_, RT_, MODE>), grid, dim3(256), lds_rs, s, a)
+        switch (KS) { // UB = 4 * RT must equal ub_bf16(KS)
+        case 1: R_(1, 2); break;
+        case 2: R_(2, 2); break;
+        case 4: R_(4, 2); break;
+        case 8: R_(8, 2); break;
+        default: IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "unsupported d_pad %d", ctx->d_pad);
+        }
+#undef R_
+        IRS_CHECK_HIP(ctx, hipGetLastError());
+        return IRS_OK;
+    }
     size_t lds = (size_t)UB * KS * 1024 + EMIT_Q_BYTES;
 #define L_(KS_, UB_)                                                                                           \
     hipLaunchKernelGGL((k_sweep_bf16<KS_, UB_, MODE>), grid, dim3(256), lds, s, a)
