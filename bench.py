@@ -116,11 +116,15 @@ class Job:
         self.B = args.batch
         self.k = 100
         self.sweep = IRS_SWEEP_F32 if args.sweep == "f32" else IRS_SWEEP_BF16
-        rows = self.B * world
+        # Where the path shards: a large catalog is cut into item shards (one exchange step per search
+        # step); a catalog that fits every GPU many times over is replicated and the USERS are partitioned, with no
+        # data-path collective at all.
+        self.sharded = world > 1 and (args.shard == "items" or (args.shard == "auto" and cfg.n_item >= 262144))
+        rows = self.B * world if self.sharded else self.B
         self.eng = Engine(n_item=cfg.n_item, n_user=cfg.n_user, d=cfg.emb_dim, max_len=cfg.max_len,
                           n_heads=cfg.n_heads, ffn_dim=cfg.ffn_dim, n_layers=cfg.n_layers, u_dim=cfg.u_emb_dim,
                           mask_mode=IRS_MASK_IRN, device=device, max_rows=rows, max_seqs=self.B, max_k=self.k,
-                          rank=rank, world=world)
+                          rank=rank if self.sharded else 0, world=world if self.sharded else 1)
         if cfg.n_item <= 100_000:
             sd = {k: torch.from_numpy(v).to(device) for k, v in synth.irn_state_dict(cfg, 1234).items()}
         else:
@@ -131,7 +135,7 @@ class Job:
         self.hep = torch.full((self.B,), cfg.max_len - 2, dtype=torch.int32, device=device)
         self.paths = torch.zeros((self.B, 1), dtype=torch.float32, device=device)
         self.status = torch.zeros(self.B, dtype=torch.int32, device=device)
-        if world > 1:
+        if self.sharded:
             self.x_all = torch.empty((rows, cfg.emb_dim), dtype=torch.float32, device=device)
             # exchange of per-shard top-k lists: each rank only needs the lists of ITS rows -> all_to_all of
             # [world, B, k] (score f32 + id i32) instead of all-gathering every row's list on every rank
@@ -142,7 +146,7 @@ class Job:
     def step(self):
         eng = self.eng
         _, xr, _ = eng.decode(self.seqs, self.users, want_x=False, pos=self.hep)
-        if self.world == 1:
+        if not self.sharded:
             val, ids, _ = eng.score_topk(xr, self.k, self.sweep)
         else:
             import torch.distributed as dist
@@ -230,6 +234,10 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N > 1 code path with several ranks on ONE GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--shard", default="auto", choices=["auto", "items", "replicate"],
+                    help="N > 1: 'items' = every rank holds a slice of the catalog (rows all-gathered, per-shard top-k "
+                         "exchanged, merged); 'replicate' = every rank holds the whole catalog and scores its own users, no "
+                         "data-path collective; 'auto' = items from 262144 catalog entries up (a 3415-item catalog is 1.7 MB)")
     ap.add_argument("--exchange", default=None, choices=["all_to_all", "all_gather"],
                     help="how per-shard top-k lists travel (default: all_to_all on nccl, all_gather otherwise)")
     args = ap.parse_args()
@@ -341,7 +349,10 @@ def main():
                                   "(packed rows), results identical",
                        "packed_row_fraction": fam["linear"]["packed_fraction"],
                        "sweep": args.sweep + (" filter + exact f32 re-score" if args.sweep == "bf16" else ""),
-                       "parallelism": "single GPU" if world == 1 else f"rows data-parallel + item-sharded x{world}: RCCL all-gather of rows, {args.exchange} of per-shard top-100"},
+                       "parallelism": "single GPU" if world == 1 else (
+                           f"rows data-parallel + item-sharded x{world}: RCCL all-gather of rows, {args.exchange} of per-shard top-100"
+                           if job.sharded else
+                           f"users partitioned over {world} GPUs, catalog replicated ({cfg.n_item} items): no data-path collective")},
             "path_gen_p50_ms_b1": lat,
             "roofline": roof,
             "cpu_baseline": cpu,
