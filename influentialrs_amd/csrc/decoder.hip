@@ -714,12 +714,20 @@ struct FfnArgs {
     float *Y;  // row-major output [M][128] (may be null)
     int M;
     const int32_t *m_dev;
+    // QKV tail: the NEXT layer's in-projection qkv = x W_in^T + b_in, computed from the x tile still in registers
+    const float *Win, *bin; // [384][128], [384]
+    float *QKV;             // row-major [M][384]
 };
 
+// QKV = true appends the next layer's QKV projection: after LayerNorm the lane holds its token's 128 x values in
+// the 4 accumulator tiles -- again a valid B operand -- so qkv^T[n][token] = W_in[n][k] x^T[k][token] runs as
+// 2 passes of 6 output tiles (the hidden-activation registers are free by then) over 8 more k-slabs each, and
+// x never makes the trip through memory that a separate QKV GEMM would start with.
+template <bool QKV>
 __global__ void __launch_bounds__(256, 2) k_ffn_ln(FfnArgs a) {
     constexpr int D = 128, F = 256, BK = 16;
-    __shared__ __attribute__((aligned(16))) float sm[2 * F * BK + F + 3 * D];
-    float *vecs = sm + 2 * F * BK; // b1[256], b2[128], g[128], b[128]
+    __shared__ __attribute__((aligned(16))) float sm[2 * F * BK + F + 3 * D + (QKV ? 3 * D : 0)];
+    float *vecs = sm + 2 * F * BK; // b1[256], b2[128], g[128], b[128] (, b_in[384])
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lk = lane >> 5;
@@ -732,14 +740,27 @@ __global__ void __launch_bounds__(256, 2) k_ffn_ln(FfnArgs a) {
         vecs[F + D + tid] = a.g[tid];
         vecs[F + 2 * D + tid] = a.b[tid];
     }
+    if (QKV) {
+        vecs[F + 3 * D + tid] = a.bin[tid];
+        if (tid < D) vecs[F + 3 * D + 256 + tid] = a.bin[256 + tid];
+    }
     const int mtile = (m0 >> 5) + wave;
     const int mt = m0 + wave * 32 + li; // this lane's token
     const float4 *yfrag = reinterpret_cast<const float4 *>(a.Yf) + (size_t)mtile * 16 * 64 + lane; // + (tn*4+g)*64
 
-    // slab loaders: step t < 8 -> W1[:, 16t .. 16t+15] (256 rows), t >= 8 -> W2[:, 16(t-8) ..] (128 rows)
+    // slab loaders: step t < 8 -> W1[:, 16t .. 16t+15] (256 rows), 8 <= t < 24 -> W2[:, 16(t-8) ..] (128 rows),
+    // t >= 24 (QKV tail) -> W_in[192p .. 192p+191][16s ..] with p = (t-24)/8, s = (t-24)%8 (192 rows)
     float4 wv[4];
     auto load_slab = [&](int t) {
-        if (t < 8) {
+        if (QKV && t >= 24) {
+            const int pp = (t - 24) >> 3, ss = (t - 24) & 7;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int idx = tid + i * 256;
+                const float *p = a.Win + (size_t)(192 * pp + (idx >> 2)) * D + ss * BK + (idx & 3) * 4;
+                wv[i] = make_float4(p[0], p[1], p[2], p[3]);
+            }
+        } else if (t < 8) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int idx = tid + i * 256;
@@ -756,7 +777,7 @@ __global__ void __launch_bounds__(256, 2) k_ffn_ln(FfnArgs a) {
         }
     };
     auto store_slab = [&](int t, float *S) {
-        const int n = t < 8 ? 4 : 2;
+        const int n = t < 8 ? 4 : (t < 24 ? 2 : 3);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i < n) {
@@ -839,7 +860,7 @@ __global__ void __launch_bounds__(256, 2) k_ffn_ln(FfnArgs a) {
     // ---- GEMM 2: out^T = W2 h^T ; slab s covers f = 16s .. 16s+15 = tile ft = s/2, groups g = 2(s&1) + q
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) {
-        if (s2 + 1 < 16) load_slab(8 + s2 + 1);
+        if (s2 + 1 < 16 || QKV) load_slab(8 + s2 + 1);
         const float *wa = sm + cur * F * BK + li * BK;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -856,7 +877,7 @@ __global__ void __launch_bounds__(256, 2) k_ffn_ln(FfnArgs a) {
             FFN_STEP2(x, 0) FFN_STEP2(y, 1) FFN_STEP2(z, 2) FFN_STEP2(w, 3)
 #undef FFN_STEP2
         }
-        if (s2 + 1 < 16) store_slab(8 + s2 + 1, sm + (cur ^ 1) * F * BK);
+        if (s2 + 1 < 16 || QKV) store_slab(8 + s2 + 1, sm + (cur ^ 1) * F * BK);
         __syncthreads();
         cur ^= 1;
     }
@@ -895,7 +916,51 @@ __global__ void __launch_bounds__(256, 2) k_ffn_ln(FfnArgs a) {
                                          (acc[tn][4 * g + 2] - mu) * rstd * gg.z + be.z, (acc[tn][4 * g + 3] - mu) * rstd * gg.w + be.w);
             if (a.Xf) reinterpret_cast<float4 *>(a.Xf)[((size_t)(mtile * 4 + tn) * 4 + g) * 64 + lane] = o;
             if (a.Y && mt < M) *reinterpret_cast<float4 *>(a.Y + (int64_t)mt * D + n) = o;
+            if (QKV) acc[tn][4 * g + 0] = o.x, acc[tn][4 * g + 1] = o.y, acc[tn][4 * g + 2] = o.z, acc[tn][4 * g + 3] = o.w;
         }
+    if (!QKV) return;
+    // ---- QKV tail: qkv^T = W_in x^T, 2 passes x 6 output tiles, k-slab s <-> x tile tn = s/2, groups g = 2(s&1) + q
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        f32x16 qa[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qa[i][r] = 0.f;
+#pragma unroll
+        for (int ss = 0; ss < 8; ++ss) {
+            const int t = 24 + pp * 8 + ss;
+            if (t + 1 < 40) load_slab(t + 1);
+            const float *wa = sm + cur * F * BK + li * BK;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int off = ((2 * q + lk) ^ sw) << 2;
+                const int tn = ss >> 1, g = 2 * (ss & 1) + q;
+                float4 w[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) w[i] = *reinterpret_cast<const float4 *>(wa + i * 32 * BK + off);
+#define QKV_STEP(E, R)                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                           \
+        qa[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i].E, acc[tn][4 * g + R], qa[i], 0, 0, 0);
+                QKV_STEP(x, 0) QKV_STEP(y, 1) QKV_STEP(z, 2) QKV_STEP(w, 3)
+#undef QKV_STEP
+            }
+            if (t + 1 < 40) store_slab(t + 1, sm + (cur ^ 1) * F * BK);
+            __syncthreads();
+            cur ^= 1;
+        }
+        if (mt < M) {
+            float *qrow = a.QKV + (int64_t)mt * (3 * D) + pp * 192 + 4 * lk;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bb = *reinterpret_cast<const float4 *>(vecs + F + 3 * D + pp * 192 + i * 32 + 8 * g + 4 * lk);
+                    *reinterpret_cast<float4 *>(qrow + i * 32 + 8 * g) =
+                        make_float4(qa[i][4 * g + 0] + bb.x, qa[i][4 * g + 1] + bb.y, qa[i][4 * g + 2] + bb.z, qa[i][4 * g + 3] + bb.w);
+                }
+        }
+    }
 }
 
 // ------------------------------------------------------------------ small-M linear (latency path, few sequences)
@@ -1886,13 +1951,16 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         hipLaunchKernelGGL(k_embed, dim3((rows + 3) / 4), dim3(256), 0, s, seq, ctx->item_emb, ctx->pe, x, rows, L, d,
                            sqrtf((float)d), ctx->dims.n_item);
     IRS_CHECK_HIP(ctx, hipGetLastError());
+    bool qkv_done = false;
     for (int l = 0; l < ctx->dims.n_layers; ++l) {
         const irs_layer_w &w = ctx->layer[l];
         const bool last_rows = rows_only && (l + 1 == ctx->dims.n_layers);
-        // qkv = x W_in^T + b_in
-        if ((rc = launch_linear(ctx, x, w.sa_in_w, w.sa_in_b, nullptr, ctx->act_qkv, rows, 3 * d, d, false, s, nullptr, nullptr,
+        // qkv = x W_in^T + b_in (already produced by the previous layer's fused feed-forward kernel where that ran)
+        if (!qkv_done &&
+            (rc = launch_linear(ctx, x, w.sa_in_w, w.sa_in_b, nullptr, ctx->act_qkv, rows, 3 * d, d, false, s, nullptr, nullptr,
                                 nullptr, nullptr, nullptr, nullptr, nullptr, m_dev, frag ? xf : nullptr)))
             return rc;
+        qkv_done = false;
         const float *cl = ctx->c_l + (size_t)l * d;
         if (last_rows) {
             float *ao_r = ctx->act_ao;                 // [B, d] attention output rows
@@ -1923,10 +1991,16 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             // x <- LN3(y + relu(y W1^T + b1) W2^T + b2) back into xf (the last layer of a full decode writes the
             // row-major x the caller receives instead); d = 128, F = 256 runs as one kernel with h in registers
             if (d == 128 && F == 256) {
-                FfnArgs fa{yf, w.l1_w, w.l1_b, w.l2_w, w.l2_b, w.n3_w, w.n3_b, last ? nullptr : xf, last ? x : nullptr, rows, m_dev};
+                // ... and, except after the last layer, the NEXT layer's QKV projection from the x tile in registers
+                const bool tail = !last;
+                FfnArgs fa{yf, w.l1_w, w.l1_b, w.l2_w, w.l2_b, w.n3_w, w.n3_b, last ? nullptr : xf, last ? x : nullptr, rows, m_dev,
+                           tail ? ctx->layer[l + 1].sa_in_w : nullptr, tail ? ctx->layer[l + 1].sa_in_b : nullptr, ctx->act_qkv};
                 irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
-                hipLaunchKernelGGL(k_ffn_ln, dim3((rows + 127) / 128), dim3(256), 0, s, fa);
-                irs_prof_end(ctx, IRS_PROF_LINEAR, s, 4.0 * rows * (double)d * F, 8.0 * rows * (double)d);
+                if (tail) hipLaunchKernelGGL(k_ffn_ln<true>, dim3((rows + 127) / 128), dim3(256), 0, s, fa);
+                else hipLaunchKernelGGL(k_ffn_ln<false>, dim3((rows + 127) / 128), dim3(256), 0, s, fa);
+                irs_prof_end(ctx, IRS_PROF_LINEAR, s, 4.0 * rows * (double)d * F + (tail ? 6.0 * rows * (double)d * d : 0.0),
+                             8.0 * rows * (double)d + (tail ? 12.0 * rows * (double)d : 0.0));
+                qkv_done = tail;
             } else {
                 if ((rc = launch_linear(ctx, nullptr, w.l1_w, w.l1_b, nullptr, ctx->act_h, rows, F, d, true, s, nullptr, nullptr,
                                         nullptr, nullptr, nullptr, nullptr, nullptr, m_dev, yf)))

@@ -75,8 +75,12 @@ int main(int argc, char **argv) {
     }
     {   // fused FFN block (fragment-major in/out): compare with ffn1 + ffn2+ln above
         FfnArgs fa{R, W, B, W, B, G, G, Y, nullptr, M, nullptr};
-        float ms = time_it([&] { hipLaunchKernelGGL(k_ffn_ln, dim3((M + 127) / 128), dim3(256), 0, 0, fa); }, 20);
+        float ms = time_it([&] { hipLaunchKernelGGL(k_ffn_ln<false>, dim3((M + 127) / 128), dim3(256), 0, 0, fa); }, 20);
         printf("ffn fused     : %8.1f us  %6.1f TF\n", ms * 1e3, 4.0 * M * 128 * 256 / 1e9 / ms);
+        FfnArgs fq{R, W, B, W, B, G, G, Y, nullptr, M, nullptr, W, B, Y2 ? Y : Y};
+        fq.QKV = R; // any [M][384] buffer
+        ms = time_it([&] { hipLaunchKernelGGL(k_ffn_ln<true>, dim3((M + 127) / 128), dim3(256), 0, 0, fq); }, 20);
+        printf("ffn + next qkv: %8.1f us  %6.1f TF\n", ms * 1e3, (4.0 * M * 128 * 256 + 6.0 * M * 128 * 128) / 1e9 / ms);
     }
     CK(hipDeviceSynchronize());
     return 0;
