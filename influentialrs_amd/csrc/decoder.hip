@@ -697,62 +697,82 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(L
     }
 }
 
-// ------------------------------------------------------------------ fused feed-forward block (d = 128, F = 256)
-// xf <- LN3(y + relu(y W1^T + b1) W2^T + b2)        reference: nn.TransformerDecoderLayer._ff_block + norm3
-// The [tokens][F] hidden activation never leaves the registers: in the transposed orientation a wave owns 32
-// tokens; GEMM 1 leaves h^T[f][token] in 8 accumulator tiles (lane = token, 64+64 of the 256 f values in the
-// lane pair), bias + relu are applied in place, and because the MFMA C layout of a tile is a valid B-operand
-// layout (register 4g+e of tile ft <-> k-pair {32ft+8g+e, 32ft+8g+4+e}) those registers feed GEMM 2 directly,
-// whose A operand (W2) is read from LDS in the same chunk order every other GEMM here uses.  y is read from the
-// fragment-major layout as GEMM 1's B operand (contiguous KiB per wave) and again as the residual that seeds
-// GEMM 2's accumulators.  HBM traffic per token: 512 B in, 512 B out -- the unfused pair moved 3.5x that.
-// Workgroup = 4 waves = 128 tokens; W1 / W2 k-slabs of 16 stream through one double-buffered LDS image
-// (24 pipeline steps: 8 of [256][16] for W1, 16 of [128][16] for W2).
-struct FfnArgs {
-    const float *Yf, *W1, *b1, *W2, *b2, *g, *b;
+// ------------------------------------------------------------------ fused post-attention block (d = 128, F = 256)
+//   y  = LN2(LN1(x + ao W_o^T + b_o) + c_l)            (OUT: self-attention out-projection + norm1, constant
+//                                                        cross-attention + norm2)
+//   x' = LN3(y + relu(y W1^T + b1) W2^T + b2)           nn.TransformerDecoderLayer._ff_block + norm3
+//   qkv' = x' W_in'^T + b_in'                            (QKV: the NEXT layer's in-projection)
+// One kernel, activations chained through registers.  In the transposed MFMA orientation D[n][token] a wave owns
+// 32 tokens and a lane one token, and the C layout of an accumulator tile is a valid B-operand layout (register
+// 4g+e of tile tn <-> k-pair {32tn+8g+e, 32tn+8g+4+e}).  So: the out-projection accumulates onto the residual x
+// (fragment-major, contiguous KiB per wave) with the attention output as B operand straight from its
+// fragment-major image; LayerNorm is register-local; the y tile (4 accumulator tiles) is GEMM 1's B operand; the
+// hidden activation h^T (8 tiles) is GEMM 2's B operand and GEMM 2 accumulates onto y in place (the residual);
+// after LN3 the x' tile is the B operand of the next layer's QKV projection (2 passes of 6 output tiles in the
+// registers h occupied).  y, h and x' never travel through memory; HBM traffic per token is the attention output
+// and the residual in (1 KiB), x' and qkv' out (2 KiB).  Workgroup = 4 waves = 128 tokens; all weight k-slabs
+// of 16 stream through one double-buffered LDS image (8 + 8 + 16 + 16 pipeline steps).
+struct BlockArgs {
+    // OUT phase (null Wo: y is read from Yf instead)
+    const float *Af;  // attention output, fragment-major
+    const float *Rf;  // residual x, fragment-major
+    const float *Wo, *bo, *g1, *b1n, *c, *g2, *b2n;
+    const float *Yf;  // y, fragment-major (only when the OUT phase is not fused)
+    const float *W1, *b1, *W2, *b2, *g, *b;
     float *Xf; // fragment-major output (may be null)
     float *Y;  // row-major output [M][128] (may be null)
     int M;
     const int32_t *m_dev;
-    // QKV tail: the NEXT layer's in-projection qkv = x W_in^T + b_in, computed from the x tile still in registers
-    const float *Win, *bin; // [384][128], [384]
+    const float *Win, *bin; // QKV tail: [384][128], [384]
     float *QKV;             // row-major [M][384]
 };
 
-// QKV = true appends the next layer's QKV projection: after LayerNorm the lane holds its token's 128 x values in
-// the 4 accumulator tiles -- again a valid B operand -- so qkv^T[n][token] = W_in[n][k] x^T[k][token] runs as
-// 2 passes of 6 output tiles (the hidden-activation registers are free by then) over 8 more k-slabs each, and
-// x never makes the trip through memory that a separate QKV GEMM would start with.
-template <bool QKV>
-__global__ void __launch_bounds__(256, 2) k_ffn_ln(FfnArgs a) {
+template <bool OUT, bool QKV>
+__global__ void __launch_bounds__(256, 2) k_block(BlockArgs a) {
     constexpr int D = 128, F = 256, BK = 16;
-    __shared__ __attribute__((aligned(16))) float sm[2 * F * BK + F + 3 * D + (QKV ? 3 * D : 0)];
-    float *vecs = sm + 2 * F * BK; // b1[256], b2[128], g[128], b[128] (, b_in[384])
+    constexpr int V_B1 = 0, V_B2 = F, V_G = F + D, V_B = F + 2 * D, V_BIN = F + 3 * D, V_O = F + 3 * D + (QKV ? 3 * D : 0);
+    __shared__ __attribute__((aligned(16))) float sm[2 * F * BK + V_O + (OUT ? 6 * D : 0)];
+    float *vecs = sm + 2 * F * BK; // b1[256], b2, g, b [, b_in[384]] [, b_o, g1, b1n, c, g2, b2n]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lk = lane >> 5;
     const int m0 = blockIdx.x * 128;
     const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M;
     if (m0 >= M) return;
-    vecs[tid] = a.b1[tid];
+    vecs[V_B1 + tid] = a.b1[tid];
     if (tid < D) {
-        vecs[F + tid] = a.b2[tid];
-        vecs[F + D + tid] = a.g[tid];
-        vecs[F + 2 * D + tid] = a.b[tid];
+        vecs[V_B2 + tid] = a.b2[tid];
+        vecs[V_G + tid] = a.g[tid];
+        vecs[V_B + tid] = a.b[tid];
     }
     if (QKV) {
-        vecs[F + 3 * D + tid] = a.bin[tid];
-        if (tid < D) vecs[F + 3 * D + 256 + tid] = a.bin[256 + tid];
+        vecs[V_BIN + tid] = a.bin[tid];
+        if (tid < D) vecs[V_BIN + 256 + tid] = a.bin[256 + tid];
+    }
+    if (OUT && tid < D) {
+        vecs[V_O + 0 * D + tid] = a.bo ? a.bo[tid] : 0.f;
+        vecs[V_O + 1 * D + tid] = a.g1[tid];
+        vecs[V_O + 2 * D + tid] = a.b1n[tid];
+        vecs[V_O + 3 * D + tid] = a.c ? a.c[tid] : 0.f;
+        vecs[V_O + 4 * D + tid] = a.c ? a.g2[tid] : 0.f;
+        vecs[V_O + 5 * D + tid] = a.c ? a.b2n[tid] : 0.f;
     }
     const int mtile = (m0 >> 5) + wave;
     const int mt = m0 + wave * 32 + li; // this lane's token
-    const float4 *yfrag = reinterpret_cast<const float4 *>(a.Yf) + (size_t)mtile * 16 * 64 + lane; // + (tn*4+g)*64
+    const size_t fbase = (size_t)mtile * 16 * 64 + lane; // + (tn*4+g)*64: this lane's float4 of a fragment-major image
 
-    // slab loaders: step t < 8 -> W1[:, 16t .. 16t+15] (256 rows), 8 <= t < 24 -> W2[:, 16(t-8) ..] (128 rows),
-    // t >= 24 (QKV tail) -> W_in[192p .. 192p+191][16s ..] with p = (t-24)/8, s = (t-24)%8 (192 rows)
+    // slab loaders, step t: [-8, 0) W_o[:, 16(t+8) ..] (128 rows) | [0, 8) W1 (256 rows) | [8, 24) W2[:, 16(t-8) ..]
+    // (128 rows) | [24, 40) W_in[192p .. 192p+191][16s ..], p = (t-24)/8, s = (t-24)%8 (192 rows)
     float4 wv[4];
     auto load_slab = [&](int t) {
-        if (QKV && t >= 24) {
+        if (OUT && t < 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + i * 256;
+                const float *p = a.Wo + (size_t)(idx >> 2) * D + (t + 8) * BK + (idx & 3) * 4;
+                wv[i] = make_float4(p[0], p[1], p[2], p[3]);
+            }
+        } else if (QKV && t >= 24) {
             const int pp = (t - 24) >> 3, ss = (t - 24) & 7;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -777,7 +797,7 @@ __global__ void __launch_bounds__(256, 2) k_ffn_ln(FfnArgs a) {
         }
     };
     auto store_slab = [&](int t, float *S) {
-        const int n = t < 8 ? 4 : (t < 24 ? 2 : 3);
+        const int n = t < 0 ? 2 : (t < 8 ? 4 : (t < 24 ? 2 : 3));
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i < n) {
@@ -787,25 +807,116 @@ __global__ void __launch_bounds__(256, 2) k_ffn_ln(FfnArgs a) {
             }
     };
     const int sw = lin_swz<BK>(li);
+    const float invn = 1.0f / (float)D;
+    int cur = 0;
+    f32x16 acc[4]; // x + out-projection -> y -> y + FFN -> x' (this lane's token, 64 of its 128 columns)
+
+    float4 yv[2], yn[2]; // B fragments streamed from a fragment-major image (attention output / y)
+    if (OUT) {
+        // ---- accumulators start from the residual x; out-projection with the attention output as B operand
+        const float4 *rfrag = reinterpret_cast<const float4 *>(a.Rf) + fbase;
+        const float4 *afrag = reinterpret_cast<const float4 *>(a.Af) + fbase;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t4 = rfrag[(tn * 4 + g) * 64];
+                acc[tn][4 * g + 0] = t4.x, acc[tn][4 * g + 1] = t4.y, acc[tn][4 * g + 2] = t4.z, acc[tn][4 * g + 3] = t4.w;
+            }
+        load_slab(-8);
+        yv[0] = afrag[0];
+        yv[1] = afrag[64];
+        store_slab(-8, sm);
+        __syncthreads();
+#pragma unroll
+        for (int t = -8; t < 0; ++t) {
+            load_slab(t + 1); // t + 1 == 0 is W1's first slab
+            if (t + 1 < 0) {
+                yn[0] = afrag[(2 * (t + 9)) * 64];
+                yn[1] = afrag[(2 * (t + 9) + 1) * 64];
+            }
+            const float *wa = sm + cur * F * BK + li * BK;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int off = ((2 * q + lk) ^ sw) << 2;
+                const float4 x4 = yv[q];
+                float4 w[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = *reinterpret_cast<const float4 *>(wa + i * 32 * BK + off);
+#define OUT_STEP(E)                                                                    \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0].E, x4.E, acc[0], 0, 0, 0);      \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1].E, x4.E, acc[1], 0, 0, 0);      \
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2].E, x4.E, acc[2], 0, 0, 0);      \
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3].E, x4.E, acc[3], 0, 0, 0);
+                OUT_STEP(x) OUT_STEP(y) OUT_STEP(z) OUT_STEP(w)
+#undef OUT_STEP
+            }
+            store_slab(t + 1, sm + (cur ^ 1) * F * BK);
+            __syncthreads();
+            cur ^= 1;
+            yv[0] = yn[0];
+            yv[1] = yn[1];
+        }
+        // ---- + b_o, LN1 (+ c, LN2): register-local (64 of the 128 values here, 64 in lane^32)
+        auto layer_norm = [&](int vb, int vg, int vbeta, int vadd) {
+            float sum = 0.f;
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (vb >= 0) {
+                        const float4 bb = *reinterpret_cast<const float4 *>(vecs + vb + tn * 32 + 8 * g + 4 * lk);
+                        acc[tn][4 * g + 0] += bb.x, acc[tn][4 * g + 1] += bb.y, acc[tn][4 * g + 2] += bb.z, acc[tn][4 * g + 3] += bb.w;
+                    }
+                    sum += (acc[tn][4 * g + 0] + acc[tn][4 * g + 1]) + (acc[tn][4 * g + 2] + acc[tn][4 * g + 3]);
+                }
+            const float mu = (sum + __shfl_xor(sum, 32, 64)) * invn;
+            float qs = 0.f;
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float dlt = acc[tn][r] - mu;
+                    qs += dlt * dlt;
+                }
+            const float rstd = 1.0f / sqrtf((qs + __shfl_xor(qs, 32, 64)) * invn + 1e-5f);
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = tn * 32 + 8 * g + 4 * lk;
+                    const float4 gg = *reinterpret_cast<const float4 *>(vecs + vg + n);
+                    const float4 be = *reinterpret_cast<const float4 *>(vecs + vbeta + n);
+                    float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (vadd >= 0) ad = *reinterpret_cast<const float4 *>(vecs + vadd + n);
+                    acc[tn][4 * g + 0] = (acc[tn][4 * g + 0] - mu) * rstd * gg.x + be.x + ad.x;
+                    acc[tn][4 * g + 1] = (acc[tn][4 * g + 1] - mu) * rstd * gg.y + be.y + ad.y;
+                    acc[tn][4 * g + 2] = (acc[tn][4 * g + 2] - mu) * rstd * gg.z + be.z + ad.z;
+                    acc[tn][4 * g + 3] = (acc[tn][4 * g + 3] - mu) * rstd * gg.w + be.w + ad.w;
+                }
+        };
+        layer_norm(V_O + 0 * D, V_O + 1 * D, V_O + 2 * D, V_O + 3 * D);
+        if (a.c) layer_norm(-1, V_O + 4 * D, V_O + 5 * D, -1);
+    } else {
+        load_slab(0);
+        const float4 *yfrag = reinterpret_cast<const float4 *>(a.Yf) + fbase;
+        yv[0] = yfrag[0];
+        yv[1] = yfrag[64];
+        store_slab(0, sm);
+        __syncthreads();
+    }
 
     f32x16 h[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[i][r] = 0.f;
-
-    load_slab(0);
-    float4 yv[2], yn[2];
-    yv[0] = yfrag[0];
-    yv[1] = yfrag[64];
-    store_slab(0, sm);
-    __syncthreads();
-    int cur = 0;
-    // ---- GEMM 1: h^T = W1 y^T
+    // ---- GEMM 1: h^T = W1 y^T (B operand: the y tile in registers, or y fragments streamed from Yf)
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         load_slab(t + 1);
-        if (t + 1 < 8) {
+        if (!OUT && t + 1 < 8) {
+            const float4 *yfrag = reinterpret_cast<const float4 *>(a.Yf) + fbase;
             yn[0] = yfrag[(2 * (t + 1)) * 64];
             yn[1] = yfrag[(2 * (t + 1) + 1) * 64];
         }
@@ -813,7 +924,8 @@ __global__ void __launch_bounds__(256, 2) k_ffn_ln(FfnArgs a) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int off = ((2 * q + lk) ^ sw) << 2;
-            const float4 x4 = yv[q];
+            const int tn = t >> 1, g = 2 * (t & 1) + q;
+            const float4 x4 = OUT ? make_float4(acc[tn][4 * g + 0], acc[tn][4 * g + 1], acc[tn][4 * g + 2], acc[tn][4 * g + 3]) : yv[q];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 float4 w[4];
@@ -831,33 +943,34 @@ __global__ void __launch_bounds__(256, 2) k_ffn_ln(FfnArgs a) {
         store_slab(t + 1, sm + (cur ^ 1) * F * BK);
         __syncthreads();
         cur ^= 1;
-        yv[0] = yn[0];
-        yv[1] = yn[1];
+        if (!OUT) {
+            yv[0] = yn[0];
+            yv[1] = yn[1];
+        }
     }
     // ---- h = relu(h + b1) in place
 #pragma unroll
     for (int ft = 0; ft < 8; ++ft)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 bb = *reinterpret_cast<const float4 *>(vecs + ft * 32 + 8 * g + 4 * lk);
+            const float4 bb = *reinterpret_cast<const float4 *>(vecs + V_B1 + ft * 32 + 8 * g + 4 * lk);
             h[ft][4 * g + 0] = fmaxf(h[ft][4 * g + 0] + bb.x, 0.f);
             h[ft][4 * g + 1] = fmaxf(h[ft][4 * g + 1] + bb.y, 0.f);
             h[ft][4 * g + 2] = fmaxf(h[ft][4 * g + 2] + bb.z, 0.f);
             h[ft][4 * g + 3] = fmaxf(h[ft][4 * g + 3] + bb.w, 0.f);
         }
-    // ---- GEMM 2 accumulators start from the residual y of this lane's token
-    f32x16 acc[4];
+    // ---- GEMM 2 accumulates onto the residual y: already in the accumulators (OUT) or read from Yf
+    if (!OUT) {
+        const float4 *yfrag = reinterpret_cast<const float4 *>(a.Yf) + fbase;
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 t4 = yfrag[(tn * 4 + g) * 64];
-            acc[tn][4 * g + 0] = t4.x;
-            acc[tn][4 * g + 1] = t4.y;
-            acc[tn][4 * g + 2] = t4.z;
-            acc[tn][4 * g + 3] = t4.w;
-        }
-    // ---- GEMM 2: out^T = W2 h^T ; slab s covers f = 16s .. 16s+15 = tile ft = s/2, groups g = 2(s&1) + q
+            for (int g = 0; g < 4; ++g) {
+                const float4 t4 = yfrag[(tn * 4 + g) * 64];
+                acc[tn][4 * g + 0] = t4.x, acc[tn][4 * g + 1] = t4.y, acc[tn][4 * g + 2] = t4.z, acc[tn][4 * g + 3] = t4.w;
+            }
+    }
+    // ---- GEMM 2: out^T += W2 h^T ; slab s covers f = 16s .. 16s+15 = tile ft = s/2, groups g = 2(s&1) + q
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) {
         if (s2 + 1 < 16 || QKV) load_slab(8 + s2 + 1);
@@ -882,13 +995,12 @@ __global__ void __launch_bounds__(256, 2) k_ffn_ln(FfnArgs a) {
         cur ^= 1;
     }
     // ---- + b2, register-local LayerNorm (64 of the 128 values here, 64 in lane^32), stores
-    const float invn = 1.0f / (float)D;
     float sum = 0.f;
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 bb = *reinterpret_cast<const float4 *>(vecs + F + tn * 32 + 8 * g + 4 * lk);
+            const float4 bb = *reinterpret_cast<const float4 *>(vecs + V_B2 + tn * 32 + 8 * g + 4 * lk);
             acc[tn][4 * g + 0] += bb.x;
             acc[tn][4 * g + 1] += bb.y;
             acc[tn][4 * g + 2] += bb.z;
@@ -910,8 +1022,8 @@ __global__ void __launch_bounds__(256, 2) k_ffn_ln(FfnArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = tn * 32 + 8 * g + 4 * lk;
-            const float4 gg = *reinterpret_cast<const float4 *>(vecs + F + D + n);
-            const float4 be = *reinterpret_cast<const float4 *>(vecs + F + 2 * D + n);
+            const float4 gg = *reinterpret_cast<const float4 *>(vecs + V_G + n);
+            const float4 be = *reinterpret_cast<const float4 *>(vecs + V_B + n);
             const float4 o = make_float4((acc[tn][4 * g + 0] - mu) * rstd * gg.x + be.x, (acc[tn][4 * g + 1] - mu) * rstd * gg.y + be.y,
                                          (acc[tn][4 * g + 2] - mu) * rstd * gg.z + be.z, (acc[tn][4 * g + 3] - mu) * rstd * gg.w + be.w);
             if (a.Xf) reinterpret_cast<float4 *>(a.Xf)[((size_t)(mtile * 4 + tn) * 4 + g) * 64 + lane] = o;
@@ -955,7 +1067,7 @@ __global__ void __launch_bounds__(256, 2) k_ffn_ln(FfnArgs a) {
             for (int i = 0; i < 6; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 bb = *reinterpret_cast<const float4 *>(vecs + F + 3 * D + pp * 192 + i * 32 + 8 * g + 4 * lk);
+                    const float4 bb = *reinterpret_cast<const float4 *>(vecs + V_BIN + pp * 192 + i * 32 + 8 * g + 4 * lk);
                     *reinterpret_cast<float4 *>(qrow + i * 32 + 8 * g) =
                         make_float4(qa[i][4 * g + 0] + bb.x, qa[i][4 * g + 1] + bb.y, qa[i][4 * g + 2] + bb.z, qa[i][4 * g + 3] + bb.w);
                 }
@@ -1382,7 +1494,8 @@ template <int MAXT>
 __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
                                                 const float *__restrict__ r_u, float *__restrict__ out, int Lmax, int d,
                                                 int mask_mode, const int32_t *__restrict__ off,
-                                                const int32_t *__restrict__ cnt, const int32_t *__restrict__ padq) {
+                                                const int32_t *__restrict__ cnt, const int32_t *__restrict__ padq,
+                                                int out_frag) {
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     constexpr int HD = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1610,12 +1723,22 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
         lt += __shfl_xor(lt, 32, 64);
         const float inv = 1.0f / lt; // 0 (fully masked) -> inf, 0 * inf = NaN like torch
         if (qi < L) {
-            float *orow = out + (base + qi) * d + h * HD + 4 * gq;
+            if (out_frag) { // fragment-major image (d = 128: column block tn = head): the fused block kernel's B operand
+                const int64_t tk = base + qi;
+                float4 *of = reinterpret_cast<float4 *>(out) + ((size_t)(tk >> 5) * 4 + h) * 4 * 64 + (gq & 1) * 32 + (tk & 31);
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-                *reinterpret_cast<float4 *>(orow + 16 * ct) =
-                    make_float4((o[0][ct][0] + o[1][ct][0]) * inv, (o[0][ct][1] + o[1][ct][1]) * inv,
-                                (o[0][ct][2] + o[1][ct][2]) * inv, (o[0][ct][3] + o[1][ct][3]) * inv);
+                for (int ct = 0; ct < 2; ++ct)
+                    of[(2 * ct + (gq >> 1)) * 64] =
+                        make_float4((o[0][ct][0] + o[1][ct][0]) * inv, (o[0][ct][1] + o[1][ct][1]) * inv,
+                                    (o[0][ct][2] + o[1][ct][2]) * inv, (o[0][ct][3] + o[1][ct][3]) * inv);
+            } else {
+                float *orow = out + (base + qi) * d + h * HD + 4 * gq;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    *reinterpret_cast<float4 *>(orow + 16 * ct) =
+                        make_float4((o[0][ct][0] + o[1][ct][0]) * inv, (o[0][ct][1] + o[1][ct][1]) * inv,
+                                    (o[0][ct][2] + o[1][ct][2]) * inv, (o[0][ct][3] + o[1][ct][3]) * inv);
+            }
         }
     }
 }
@@ -1852,9 +1975,15 @@ static int launch_linear(irs_ctx *ctx, const float *X, const float *W, const flo
 
 static int g_attn16 = 1; // 16-query-block attention kernel for head dim 32 (0: k_attn_mfma everywhere)
 
+// attn16 is the only attention kernel that can write the fragment-major image the fused block kernel consumes
+static bool attn16_ok(const irs_ctx *ctx, const float *qkv, const float *out) {
+    const int L = ctx->dims.max_len, d = ctx->dims.d, H = ctx->dims.n_heads;
+    return g_attn16 && d % H == 0 && d / H == 32 && L <= 256 && d % 4 == 0 && ((((uintptr_t)qkv) | ((uintptr_t)out)) & 15) == 0;
+}
+
 static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const float *r_u, float *out, int B,
                        hipStream_t s, const int32_t *off = nullptr, const int32_t *cnt = nullptr,
-                       const int32_t *tok_row = nullptr) {
+                       const int32_t *tok_row = nullptr, bool frag_out = false) {
     const int L = ctx->dims.max_len, d = ctx->dims.d, H = ctx->dims.n_heads, hd = d / H;
     const int HDP = hd <= 8 ? 8 : hd <= 16 ? 16 : hd <= 32 ? 32 : 64;
     const int Lp = ((L + 31) / 32) * 32, VW = HDP < 32 ? 32 : HDP;
@@ -1863,12 +1992,13 @@ static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const
     dim3 grid(H, B);
     const int mm = ctx->dims.mask_mode;
     irs_prof_begin(ctx, IRS_PROF_ATTN, s);
+    if (frag_out && !attn16_ok(ctx, qkv, out)) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "fragment-major attention output needs the head-dim-32 kernel");
     if (hd == 32 && v4 && L <= 256 && g_attn16) {
         int S16 = (L + 7) & ~7; // attn16_vstride
         if ((S16 & 15) != 8) S16 += 8;
         const size_t lds16 = (size_t)32 * S16 * 4 + (size_t)((L + 15) & ~15) * 32 * 4 + 64;
         hipLaunchKernelGGL(k_attn16<16>, grid, dim3(256), lds16, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
-                           tok_row ? ctx->seq_padq : nullptr);
+                           tok_row ? ctx->seq_padq : nullptr, frag_out ? 1 : 0);
         irs_prof_end(ctx, IRS_PROF_ATTN, s, 2.0 * B * (double)H * L * L * hd, 4.0 * 4.0 * B * (double)L * d);
         IRS_CHECK_HIP(ctx, hipGetLastError());
         return IRS_OK;
@@ -1981,9 +2111,31 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             IRS_CHECK_HIP(ctx, hipGetLastError());
             return IRS_OK;
         }
-        if ((rc = launch_attn(ctx, ctx->act_qkv, seq, ctx->act_ru, ctx->act_ao, B, s, off, cnt, tok))) return rc;
+        // d = 128, F = 256, head dim 32: attention writes its output fragment-major and ONE kernel does the rest of
+        // the layer (out-projection + LN1/LN2, feed-forward + LN3, the next layer's QKV) with y, h, x' in registers
+        const bool fuse_block = frag && d == 128 && F == 256 && attn16_ok(ctx, ctx->act_qkv, yf);
+        if ((rc = launch_attn(ctx, ctx->act_qkv, seq, ctx->act_ru, fuse_block ? yf : ctx->act_ao, B, s, off, cnt, tok, fuse_block)))
+            return rc;
         if (frag) {
             const bool last = l + 1 == ctx->dims.n_layers;
+            const bool tail = !last && d == 128 && F == 256;
+            BlockArgs ba{};
+            ba.W1 = w.l1_w, ba.b1 = w.l1_b, ba.W2 = w.l2_w, ba.b2 = w.l2_b, ba.g = w.n3_w, ba.b = w.n3_b;
+            ba.Xf = last ? nullptr : xf, ba.Y = last ? x : nullptr, ba.M = rows, ba.m_dev = m_dev;
+            ba.Win = tail ? ctx->layer[l + 1].sa_in_w : nullptr, ba.bin = tail ? ctx->layer[l + 1].sa_in_b : nullptr;
+            ba.QKV = ctx->act_qkv;
+            const double ffn_flops = 4.0 * rows * (double)d * F + (tail ? 6.0 * rows * (double)d * d : 0.0);
+            if (fuse_block) {
+                ba.Af = yf, ba.Rf = xf, ba.Wo = w.sa_out_w, ba.bo = w.sa_out_b;
+                ba.g1 = w.n1_w, ba.b1n = w.n1_b, ba.c = cl, ba.g2 = w.n2_w, ba.b2n = w.n2_b;
+                irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
+                if (tail) hipLaunchKernelGGL((k_block<true, true>), dim3((rows + 127) / 128), dim3(256), 0, s, ba);
+                else hipLaunchKernelGGL((k_block<true, false>), dim3((rows + 127) / 128), dim3(256), 0, s, ba);
+                irs_prof_end(ctx, IRS_PROF_LINEAR, s, ffn_flops + 2.0 * rows * (double)d * d, (8.0 + 4.0 + (tail ? 12.0 : 0.0)) * rows * (double)d);
+                qkv_done = tail;
+                IRS_CHECK_HIP(ctx, hipGetLastError());
+                continue;
+            }
             // y <- LN2(LN1(x + ao W_o^T + b_o) + c_l): residual from xf, result to yf only
             if ((rc = launch_linear(ctx, ctx->act_ao, w.sa_out_w, w.sa_out_b, nullptr, nullptr, rows, d, d, false, s, w.n1_w,
                                     w.n1_b, cl, w.n2_w, w.n2_b, xf, yf, m_dev)))
@@ -1991,15 +2143,11 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             // x <- LN3(y + relu(y W1^T + b1) W2^T + b2) back into xf (the last layer of a full decode writes the
             // row-major x the caller receives instead); d = 128, F = 256 runs as one kernel with h in registers
             if (d == 128 && F == 256) {
-                // ... and, except after the last layer, the NEXT layer's QKV projection from the x tile in registers
-                const bool tail = !last;
-                FfnArgs fa{yf, w.l1_w, w.l1_b, w.l2_w, w.l2_b, w.n3_w, w.n3_b, last ? nullptr : xf, last ? x : nullptr, rows, m_dev,
-                           tail ? ctx->layer[l + 1].sa_in_w : nullptr, tail ? ctx->layer[l + 1].sa_in_b : nullptr, ctx->act_qkv};
+                ba.Yf = yf;
                 irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
-                if (tail) hipLaunchKernelGGL(k_ffn_ln<true>, dim3((rows + 127) / 128), dim3(256), 0, s, fa);
-                else hipLaunchKernelGGL(k_ffn_ln<false>, dim3((rows + 127) / 128), dim3(256), 0, s, fa);
-                irs_prof_end(ctx, IRS_PROF_LINEAR, s, 4.0 * rows * (double)d * F + (tail ? 6.0 * rows * (double)d * d : 0.0),
-                             8.0 * rows * (double)d + (tail ? 12.0 * rows * (double)d : 0.0));
+                if (tail) hipLaunchKernelGGL((k_block<false, true>), dim3((rows + 127) / 128), dim3(256), 0, s, ba);
+                else hipLaunchKernelGGL((k_block<false, false>), dim3((rows + 127) / 128), dim3(256), 0, s, ba);
+                irs_prof_end(ctx, IRS_PROF_LINEAR, s, ffn_flops, (8.0 + (tail ? 12.0 : 0.0)) * rows * (double)d);
                 qkv_done = tail;
             } else {
                 if ((rc = launch_linear(ctx, nullptr, w.l1_w, w.l1_b, nullptr, ctx->act_h, rows, F, d, true, s, nullptr, nullptr,

@@ -73,14 +73,17 @@ int main(int argc, char **argv) {
             printf("%s BK=%2d : %8.1f us  %6.1f TF\n", sh.name, bk, ms * 1e3, gf / ms);
         }
     }
-    {   // fused FFN block (fragment-major in/out): compare with ffn1 + ffn2+ln above
-        FfnArgs fa{R, W, B, W, B, G, G, Y, nullptr, M, nullptr};
-        float ms = time_it([&] { hipLaunchKernelGGL(k_ffn_ln<false>, dim3((M + 127) / 128), dim3(256), 0, 0, fa); }, 20);
-        printf("ffn fused     : %8.1f us  %6.1f TF\n", ms * 1e3, 4.0 * M * 128 * 256 / 1e9 / ms);
-        FfnArgs fq{R, W, B, W, B, G, G, Y, nullptr, M, nullptr, W, B, Y2 ? Y : Y};
-        fq.QKV = R; // any [M][384] buffer
-        ms = time_it([&] { hipLaunchKernelGGL(k_ffn_ln<true>, dim3((M + 127) / 128), dim3(256), 0, 0, fq); }, 20);
-        printf("ffn + next qkv: %8.1f us  %6.1f TF\n", ms * 1e3, (4.0 * M * 128 * 256 + 6.0 * M * 128 * 128) / 1e9 / ms);
+    {   // fused block kernel (fragment-major in/out): compare with out+ln, ffn1, ffn2+ln and the next qkv above
+        BlockArgs ba{};
+        ba.Yf = R, ba.W1 = W, ba.b1 = B, ba.W2 = W, ba.b2 = B, ba.g = G, ba.b = G, ba.Xf = Y, ba.M = M;
+        float ms = time_it([&] { hipLaunchKernelGGL((k_block<false, false>), dim3((M + 127) / 128), dim3(256), 0, 0, ba); }, 20);
+        printf("ffn fused           : %8.1f us  %6.1f TF\n", ms * 1e3, 4.0 * M * 128 * 256 / 1e9 / ms);
+        ba.Win = W, ba.bin = B, ba.QKV = R;
+        ms = time_it([&] { hipLaunchKernelGGL((k_block<false, true>), dim3((M + 127) / 128), dim3(256), 0, 0, ba); }, 20);
+        printf("ffn + next qkv      : %8.1f us  %6.1f TF\n", ms * 1e3, (4.0 * M * 128 * 256 + 6.0 * M * 128 * 128) / 1e9 / ms);
+        ba.Af = X, ba.Rf = Y2, ba.Wo = W, ba.bo = B, ba.g1 = G, ba.b1n = G, ba.c = G, ba.g2 = G, ba.b2n = G;
+        ms = time_it([&] { hipLaunchKernelGGL((k_block<true, true>), dim3((M + 127) / 128), dim3(256), 0, 0, ba); }, 20);
+        printf("out + ffn + next qkv: %8.1f us  %6.1f TF\n", ms * 1e3, (4.0 * M * 128 * 256 + 8.0 * M * 128 * 128) / 1e9 / ms);
     }
     CK(hipDeviceSynchronize());
     return 0;
