@@ -1535,12 +1535,15 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
     float4 qn0 = make_float4(0.f, 0.f, 0.f, 0.f), qn1 = qn0;
     int qb_next = mine ? 31 - __builtin_clz(mine) : -1;
     if (qb_next >= 0) load_q(qb_next, qn0, qn1);
-    // K / V of this (sequence, head) -> LDS.  32 consecutive lanes take 32 consecutive keys of one 16-byte
-    // column chunk: conflict-free ds_write_b128 (K) and ds_write_b32 (V^T).  ALL global loads are issued
-    // before the first LDS store (one memory round trip per workgroup, not one per 32 keys).
+    // K / V of this (sequence, head) -> LDS.  8 consecutive lanes take the 8 16-byte chunks of one key row, so a
+    // load instruction covers 8 whole 128-byte K_h (V_h) slices -- in-kernel timing showed the ISSUE of these
+    // loads, not their latency, dominating the fill when every lane touched a different row.  K's ds_write_b128
+    // stays conflict-free; the transposed V^T ds_write_b32 are 8-way conflicted (a row stride S = 8 mod 16 puts
+    // all 8 chunks of a key on one bank), ~1K cycles per wave once, cheaper than the slow loads were.  ALL global
+    // loads are issued before the first LDS store (one memory round trip per workgroup).
     {
         float4 kv[MAXT / 2], vv[MAXT / 2];
-        const int jl = tid & 31, c4 = (tid >> 5) & 7;
+        const int jl = tid >> 3, c4 = tid & 7; // 8 lanes per key row: 128-byte contiguous K_h / V_h slices
 #pragma unroll
         for (int it = 0; it < MAXT / 2; ++it) {
             const int j = jl + 32 * it;

@@ -15,7 +15,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _worker(rank, world, port, ret):
+    import faulthandler
     import sys
+    faulthandler.dump_traceback_later(150, exit=True)  # a stuck rank reports where, and dies
     sys.path.insert(0, REPO)
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -61,7 +63,13 @@ def test_sharded_handlers_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
+    try:
+        for p in procs:
+            p.join(200)
+            assert p.exitcode == 0, f"rank process exit code {p.exitcode} (None = still running after 200 s)"
+    finally:
+        for p in procs:  # never leave a rank behind: a live child keeps the whole test run from ending
+            if p.is_alive():
+                p.kill()
+                p.join(10)
     assert sorted(ret.keys()) == [0, 1]
