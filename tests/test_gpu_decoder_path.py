@@ -223,3 +223,32 @@ def test_throughput_shape_decode_matches_small_batches_and_oracle(oracle, cfgnam
         ok = np.isfinite(ref) & np.isfinite(got)
         assert np.array_equal(np.isnan(ref), np.isnan(got))
         assert np.abs(ref - got)[ok].max() < X_TOL
+
+
+def test_bench_scale_batch_duplicates_are_bit_identical_and_match_small_batches():
+    """Size-independent property at the bench's scale (thousands of sequences, hundreds of thousands of packed
+    rows: full rounds of workgroups, the split last round, every XCD): a batch made of shuffled copies of 16
+    distinct windows must give bit-identical rows for identical windows wherever they sit in the batch, and those
+    rows must equal the small-batch (golden-pinned) kernels' to float32 noise; the top-100 ids of all copies agree."""
+    cfg = synth.make_config("c2")
+    L, B, K = cfg.max_len, 2048, 16
+    sd = synth.irn_state_dict(cfg, 99)
+    eng = make_engine(cfg, sd, max_rows=B, max_seqs=B)
+    hists = synth.user_histories(K, cfg.n_item, seed=31)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=33)
+    _, base_seqs, base_users, _, _ = synth.collate_eval_irs(rows, L, gap_len=0)
+    base_seqs[3, : L // 2] = base_seqs[3, L - L // 2:]          # one window without padding
+    base_seqs[3, base_seqs[3] == 0] = 7
+    g = np.random.default_rng(5)
+    src = g.integers(0, K, size=B)
+    src[:K] = np.arange(K)
+    seq = torch.from_numpy(base_seqs[src]).cuda()
+    usr = torch.from_numpy(base_users[src]).cuda()
+    pos = torch.full((B,), L - 2, dtype=torch.int32, device="cuda")
+    _, xr, _ = eng.decode(seq, usr, want_x=False, pos=pos)
+    small = torch.cat([eng.decode(seq[i:i + 8], usr[i:i + 8], want_x=False, pos=pos[i:i + 8])[1] for i in range(0, K, 8)])
+    assert (xr[:K] - small).abs().max().item() < X_TOL
+    srct = torch.from_numpy(src).cuda()
+    assert torch.equal(xr, xr[:K][srct]), "identical windows must decode to identical bits anywhere in the batch"
+    val, ids, st = eng.score_topk(xr, 100, IRS_SWEEP_BF16)
+    assert torch.equal(ids, ids[:K][srct]) and torch.equal(val, val[:K][srct]) and not (st & 1).any()
