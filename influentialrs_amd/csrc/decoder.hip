@@ -1511,6 +1511,28 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
     const int ld = 3 * d;
     const bool irn = (mask_mode == IRS_MASK_IRN);
     const int L16 = (L + 15) & ~15, NB16 = L16 >> 4;
+    // K / V of this (sequence, head) -> LDS.  8 consecutive lanes take the 8 16-byte chunks of one key row, so a
+    // load instruction covers 8 whole 128-byte K_h (V_h) slices -- in-kernel timing showed the ISSUE of these
+    // loads, not their latency, dominating the fill when every lane touched a different row.  K's ds_write_b128
+    // stays conflict-free; the transposed V^T ds_write_b32 are 8-way conflicted (a row stride S = 8 mod 16 puts
+    // all 8 chunks of a key on one bank), ~1K cycles per wave once, cheaper than the slow loads were.  ALL global
+    // loads are issued before the first LDS store (one memory round trip per workgroup).
+    float4 kv[MAXT / 2], vv[MAXT / 2];
+    {
+        const int jl = tid >> 3, c4 = tid & 7; // 8 lanes per key row: 128-byte contiguous K_h / V_h slices
+#pragma unroll
+        for (int it = 0; it < MAXT / 2; ++it) {
+            const int j = jl + 32 * it;
+            kv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vv[it] = kv[it];
+            if (j < L) {
+                const float *row = qkv + (base + j) * ld + h * HD + 4 * c4;
+                kv[it] = *reinterpret_cast<const float4 *>(row + d);
+                vv[it] = *reinterpret_cast<const float4 *>(row + 2 * d);
+            }
+        }
+    }
+    // (the assignment below and the first Q request run while the K / V rows are in flight)
     // longest-first assignment of the 16-query blocks (block qb costs qb + 1 key tiles) to the 4 waves
     unsigned int mine = 0;
     {
@@ -1535,26 +1557,19 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
     float4 qn0 = make_float4(0.f, 0.f, 0.f, 0.f), qn1 = qn0;
     int qb_next = mine ? 31 - __builtin_clz(mine) : -1;
     if (qb_next >= 0) load_q(qb_next, qn0, qn1);
-    // K / V of this (sequence, head) -> LDS.  8 consecutive lanes take the 8 16-byte chunks of one key row, so a
-    // load instruction covers 8 whole 128-byte K_h (V_h) slices -- in-kernel timing showed the ISSUE of these
-    // loads, not their latency, dominating the fill when every lane touched a different row.  K's ds_write_b128
-    // stays conflict-free; the transposed V^T ds_write_b32 are 8-way conflicted (a row stride S = 8 mod 16 puts
-    // all 8 chunks of a key on one bank), ~1K cycles per wave once, cheaper than the slow loads were.  ALL global
-    // loads are issued before the first LDS store (one memory round trip per workgroup).
+    // masked-key bitmask of each 32-key block.  A packed sequence holds no pads except possibly its pos token
+    // (index padq[b], recorded by the plan): no global loads on that path.
+    const int pq = padq ? padq[b] : -1;
+    for (int kb = wave; kb < (L + 31) / 32; kb += 4) {
+        const int j = kb * 32 + (lane & 31);
+        bool masked = (j >= L) || (irn && j == L - 1);
+        if (padq) masked = masked || (j == pq);
+        else masked = masked || (seq[base + (j < L ? j : L - 1)] == 0);
+        const unsigned long long bal = __ballot(masked);
+        if (lane == 0) padbits[kb] = (unsigned int)bal;
+    }
     {
-        float4 kv[MAXT / 2], vv[MAXT / 2];
-        const int jl = tid >> 3, c4 = tid & 7; // 8 lanes per key row: 128-byte contiguous K_h / V_h slices
-#pragma unroll
-        for (int it = 0; it < MAXT / 2; ++it) {
-            const int j = jl + 32 * it;
-            kv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            vv[it] = kv[it];
-            if (j < L) {
-                const float *row = qkv + (base + j) * ld + h * HD + 4 * c4;
-                kv[it] = *reinterpret_cast<const float4 *>(row + d);
-                vv[it] = *reinterpret_cast<const float4 *>(row + 2 * d);
-            }
-        }
+        const int jl = tid >> 3, c4 = tid & 7;
 #pragma unroll
         for (int it = 0; it < MAXT / 2; ++it) {
             const int j = jl + 32 * it;
@@ -1568,17 +1583,6 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
                 }
             }
         }
-    }
-    // masked-key bitmask of each 32-key block.  A packed sequence holds no pads except possibly its pos token
-    // (index padq[b], recorded by the plan): no global loads on that path.
-    const int pq = padq ? padq[b] : -1;
-    for (int kb = wave; kb < (L + 31) / 32; kb += 4) {
-        const int j = kb * 32 + (lane & 31);
-        bool masked = (j >= L) || (irn && j == L - 1);
-        if (padq) masked = masked || (j == pq);
-        else masked = masked || (seq[base + (j < L ? j : L - 1)] == 0);
-        const unsigned long long bal = __ballot(masked);
-        if (lane == 0) padbits[kb] = (unsigned int)bal;
     }
     __syncthreads();
     // Scores are kept in the log2 domain (Q is pre-scaled by log2(e)/sqrt(hd), p = exp2(s - m)), and the IRN
