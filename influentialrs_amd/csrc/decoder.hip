@@ -1266,6 +1266,187 @@ __global__ void __launch_bounds__(256) k_linear_small(LinArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ small-batch fused layer tail (latency path, d = 128, F = 256)
+// With a few hundred rows a decoder layer is launch bound: out-proj+LN, FFN1, FFN2+LN and the next QKV are four
+// k_linear_small launches of ~10-15 us each for ~6 us of dependent work.  Here one workgroup (4 waves) owns 32 tokens
+// and runs the whole chain, the waves splitting the OUTPUT columns of every GEMM (out-proj 4 x 32, FFN1 4 x 64,
+// FFN2 4 x 32, QKV 4 x 96) in the transposed orientation (lane = token); the activation tiles pass from GEMM to GEMM
+// through LDS ([32 tokens][K + 4] floats: the +4 stride keeps the B-fragment ds_read_b128 conflict free), the
+// weights come straight from L2 into A-fragment registers, and the LayerNorm row statistics are combined across
+// the 4 waves through a small LDS scratch.  Same MFMA k order as the separate kernels.
+struct SmallBlockArgs {
+    const float *AO, *X;      // attention output, residual x: row-major [M][128]
+    const float *Wo, *bo, *g1, *b1n, *c, *g2, *b2n;
+    const float *W1, *b1, *W2, *b2, *g3, *b3n;
+    float *Xo;                // x' row-major [M][128]
+    const float *Win, *bin;   // next layer's in-projection (may be null)
+    float *QKV;               // [M][384]
+    int M;
+    const int32_t *m_dev;
+};
+
+__global__ void __launch_bounds__(256) k_block_small(SmallBlockArgs a) {
+    constexpr int D = 128, F = 256, LDA = D + 4, LDH = F + 4;
+    __shared__ __attribute__((aligned(16))) float bufA[32 * LDA]; // ao -> y -> x'
+    __shared__ __attribute__((aligned(16))) float bufH[32 * LDH]; // h
+    __shared__ float part[2][4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M;
+    const int m0 = blockIdx.x * 32;
+    if (m0 >= M) return;
+    const int mt = m0 + li;            // this lane's token
+    const bool live = mt < M;
+    // stage the attention-output tile (rows beyond M as zeros)
+    for (int i = tid; i < 32 * (D / 4); i += 256) {
+        const int rr = i / (D / 4), c4 = i % (D / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m0 + rr < M) v = *reinterpret_cast<const float4 *>(a.AO + (int64_t)(m0 + rr) * D + 4 * c4);
+        *reinterpret_cast<float4 *>(bufA + rr * LDA + 4 * c4) = v;
+    }
+    __syncthreads();
+    // acc[t] (+)= W[n0 + 32t + li][0 .. K) . B[token][0 .. K), NT tiles sharing every B fragment
+    auto gemm = [&](f32x16 *acc, int NT, const float *W, int n0, int K, const float *B, int ldb) {
+        const float *brow = B + li * ldb + 4 * lk;
+        for (int q0 = 0; q0 < K / 8; q0 += 8) { // 8 k-octets per round: the A fragments of a round are all in flight together
+            float4 bf[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bf[j] = *reinterpret_cast<const float4 *>(brow + 8 * (q0 + j));
+            for (int t = 0; t < NT; ++t) {
+                const float *wrow = W + (int64_t)(n0 + 32 * t + li) * K + 4 * lk + 8 * q0;
+                float4 wf[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wf[j] = *reinterpret_cast<const float4 *>(wrow + 8 * j);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j].x, bf[j].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j].y, bf[j].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j].z, bf[j].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j].w, bf[j].w, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    };
+    auto row_total = [&](float v, int slot) { // sum over the 128 columns of each token (4 waves x 2 lane halves)
+        v += __shfl_xor(v, 32, 64);
+        if (lk == 0) part[slot][wave][li] = v;
+        __syncthreads();
+        const float t = part[slot][0][li] + part[slot][1][li] + part[slot][2][li] + part[slot][3][li];
+        __syncthreads();
+        return t;
+    };
+    const float invn = 1.0f / (float)D;
+    // z (16 registers: columns n0 + (r&3) + 8(r>>2) + 4lk of this wave's 32) <- LN(z; g, b) + add
+    auto layer_norm = [&](float (&z)[16], int n0, const float *g, const float *b, const float *add) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s1 += z[r];
+        const float mu = row_total(s1, 0) * invn;
+        float q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q += (z[r] - mu) * (z[r] - mu);
+        const float rstd = 1.0f / sqrtf(row_total(q, 1) * invn + 1e-5f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            z[r] = (z[r] - mu) * rstd * g[n] + b[n] + (add ? add[n] : 0.f);
+        }
+    };
+    auto to_lds = [&](const float (&z)[16], float *buf, int ld, int n0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4 *>(buf + li * ld + n0 + 8 * g + 4 * lk) = make_float4(z[4 * g], z[4 * g + 1], z[4 * g + 2], z[4 * g + 3]);
+    };
+
+    // ---- y = LN2(LN1(x + ao W_o^T + b_o) + c): this wave's 32 columns
+    const int n0 = wave * 32;
+    float z[16];
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        float resv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            resv[r] = live ? a.X[(int64_t)mt * D + n] : 0.f;
+        }
+        gemm(&acc, 1, a.Wo, n0, D, bufA, LDA);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            z[r] = acc[r] + (a.bo ? a.bo[n] : 0.f) + resv[r];
+        }
+    }
+    layer_norm(z, n0, a.g1, a.b1n, a.c);
+    if (a.c) layer_norm(z, n0, a.g2, a.b2n, nullptr);
+    // every wave is past its last read of the ao tile (row_total's barriers): y replaces it
+    to_lds(z, bufA, LDA, n0);
+    __syncthreads();
+    // ---- h = relu(y W1^T + b1): this wave's 64 columns -> LDS
+    {
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        gemm(acc, 2, a.W1, wave * 64, D, bufA, LDA);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float hz[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = wave * 64 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                hz[r] = fmaxf(acc[t][r] + a.b1[n], 0.f);
+            }
+            to_lds(hz, bufH, LDH, wave * 64 + 32 * t);
+        }
+    }
+    __syncthreads();
+    // ---- x' = LN3(y + h W2^T + b2): this wave's 32 columns (y of these columns is still in z)
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        gemm(&acc, 1, a.W2, n0, F, bufH, LDH);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            z[r] = acc[r] + a.b2[n] + z[r];
+        }
+    }
+    layer_norm(z, n0, a.g3, a.b3n, nullptr);
+    if (live) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4 *>(a.Xo + (int64_t)mt * D + n0 + 8 * g + 4 * lk) = make_float4(z[4 * g], z[4 * g + 1], z[4 * g + 2], z[4 * g + 3]);
+    }
+    if (!a.Win) return;
+    // ---- qkv' = x' W_in^T + b_in: x' replaces y in LDS (all waves are past GEMM 1 and the FFN2 epilogue read y
+    //      from registers), this wave's 96 columns
+    to_lds(z, bufA, LDA, n0);
+    __syncthreads();
+    {
+        f32x16 acc[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        gemm(acc, 3, a.Win, wave * 96, D, bufA, LDA);
+        if (live) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = wave * 96 + 32 * t + 8 * g + 4 * lk;
+                    *reinterpret_cast<float4 *>(a.QKV + (int64_t)mt * (3 * D) + n) =
+                        make_float4(acc[t][4 * g] + a.bin[n], acc[t][4 * g + 1] + a.bin[n + 1], acc[t][4 * g + 2] + a.bin[n + 2],
+                                    acc[t][4 * g + 3] + a.bin[n + 3]);
+                }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ attention on fp32 MFMA
 // One workgroup per (head, sequence), 4 waves; K_h / V_h of the sequence in LDS.
 // A wave owns 32-query blocks.  Per (query block, key block):
@@ -2110,11 +2291,19 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             irs_prof_end(ctx, IRS_PROF_ATTN, s, 4.0 * B * (double)L * d, 4.0 * 3.0 * B * (double)L * d);
             if (frag) hipLaunchKernelGGL(k_gather_rows_frag, dim3(B), dim3(64), 0, s, xf, qrow, x_r, d);
             else hipLaunchKernelGGL(k_gather_rows_idx, dim3(B), dim3(64), 0, s, x, qrow, x_r, d);
-            if ((rc = launch_linear(ctx, ao_r, w.sa_out_w, w.sa_out_b, x_r, y_r, B, d, d, false, s, w.n1_w, w.n1_b, cl, w.n2_w,
-                                    w.n2_b)))
-                return rc;
-            if ((rc = launch_linear(ctx, y_r, w.l1_w, w.l1_b, nullptr, h_r, B, F, d, true, s))) return rc;
-            if ((rc = launch_linear(ctx, h_r, w.l2_w, w.l2_b, y_r, xrows, B, d, F, false, s, w.n3_w, w.n3_b))) return rc;
+            if (d == 128 && F == 256) { // one launch for the rest of the layer on the B consumed rows
+                SmallBlockArgs sb{ao_r, x_r, w.sa_out_w, w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, w.l1_w, w.l1_b, w.l2_w, w.l2_b,
+                                  w.n3_w, w.n3_b, xrows, nullptr, nullptr, nullptr, B, nullptr};
+                irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
+                hipLaunchKernelGGL(k_block_small, dim3((B + 31) / 32), dim3(256), 0, s, sb);
+                irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * B * ((double)d * d + 2.0 * d * F), 4.0 * 3.0 * B * (double)d);
+            } else {
+                if ((rc = launch_linear(ctx, ao_r, w.sa_out_w, w.sa_out_b, x_r, y_r, B, d, d, false, s, w.n1_w, w.n1_b, cl, w.n2_w,
+                                        w.n2_b)))
+                    return rc;
+                if ((rc = launch_linear(ctx, y_r, w.l1_w, w.l1_b, nullptr, h_r, B, F, d, true, s))) return rc;
+                if ((rc = launch_linear(ctx, h_r, w.l2_w, w.l2_b, y_r, xrows, B, d, F, false, s, w.n3_w, w.n3_b))) return rc;
+            }
             IRS_CHECK_HIP(ctx, hipGetLastError());
             return IRS_OK;
         }
@@ -2164,6 +2353,20 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                                         w.n3_b, nullptr, nullptr, nullptr, yf, last ? nullptr : xf, m_dev)))
                     return rc;
             }
+        } else if (d == 128 && F == 256 && rows <= 2048) {
+            // latency path: the rest of the layer (and the next layer's QKV) in one launch per 32 tokens; x -> y buffer
+            const bool last = l + 1 == ctx->dims.n_layers;
+            SmallBlockArgs sb{ctx->act_ao, x, w.sa_out_w, w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, w.l1_w, w.l1_b, w.l2_w, w.l2_b,
+                              w.n3_w, w.n3_b, y, last ? nullptr : ctx->layer[l + 1].sa_in_w, last ? nullptr : ctx->layer[l + 1].sa_in_b,
+                              ctx->act_qkv, rows, m_dev};
+            irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
+            hipLaunchKernelGGL(k_block_small, dim3((rows + 31) / 32), dim3(256), 0, s, sb);
+            irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * rows * ((double)d * d + 2.0 * d * F + (last ? 0.0 : 3.0 * d * d)),
+                         4.0 * (3.0 + (last ? 0.0 : 3.0)) * rows * (double)d);
+            qkv_done = !last;
+            float *tswap = x; // the new x lives in the other buffer
+            x = y;
+            y = tswap;
         } else if (d <= LIN_BN) {
             // x <- LN2(LN1(x + ao W_o^T + b_o) + c_l), fused into the GEMM epilogue (y, not in place)
             if ((rc = launch_linear(ctx, ctx->act_ao, w.sa_out_w, w.sa_out_b, x, y, rows, d, d, false, s, w.n1_w, w.n1_b,

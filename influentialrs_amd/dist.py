@@ -31,14 +31,31 @@ class ShardGroup:
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        # gloo (the CPU rehearsal backend) is only dependable on host tensors: with device tensors and several
+        # ranks sharing one GPU its collectives were seen to hang now and then.  Its payloads go through the host.
+        self._via_host = self.world > 1 and dist.get_backend(group) == "gloo"
 
     # -- plumbing ---------------------------------------------------------
     def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
         """[...] -> [world, ...] (same shape on every rank)."""
         t = t.contiguous()
+        if self._via_host and t.is_cuda:
+            h = t.cpu()
+            out = torch.empty((self.world,) + tuple(h.shape), dtype=h.dtype)
+            dist.all_gather_into_tensor(out.view(-1), h.view(-1), group=self.group)
+            return out.to(t.device)
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out.view(-1), t.view(-1), group=self.group)
         return out
+
+    def _all_reduce(self, t: torch.Tensor, op) -> torch.Tensor:
+        if self._via_host and t.is_cuda:
+            h = t.cpu()
+            dist.all_reduce(h, op=op, group=self.group)
+            t.copy_(h)
+            return t
+        dist.all_reduce(t, op=op, group=self.group)
+        return t
 
     def gather_rows(self, local_rows: torch.Tensor) -> torch.Tensor:
         """Rows decoded data-parallel -> all rows on every rank, rank-major."""
@@ -68,13 +85,12 @@ class ShardGroup:
         s = self.scorer.score_gather(xrows, ids0)
         if self.world == 1:
             return s
-        dist.all_reduce(s, op=dist.ReduceOp.MAX, group=self.group)
-        return s
+        return self._all_reduce(s, dist.ReduceOp.MAX)
 
     def count_before(self, xrows, ref_score, ref_id0, excl_ids0) -> torch.Tensor:
         c = self.scorer.score_count_before(xrows, ref_score, ref_id0, excl_ids0)
         if self.world > 1:
-            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(c, dist.ReduceOp.SUM)
         return c
 
     def lse(self, xrows: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -83,8 +99,8 @@ class ShardGroup:
         if self.world == 1:
             return m, s
         gm = m.clone()
-        dist.all_reduce(gm, op=dist.ReduceOp.MAX, group=self.group)
+        self._all_reduce(gm, dist.ReduceOp.MAX)
         s = s * torch.exp(m - gm)
         s = torch.where(torch.isfinite(m), s, torch.zeros_like(s))
-        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
+        self._all_reduce(s, dist.ReduceOp.SUM)
         return gm, s
