@@ -441,16 +441,24 @@ extern "C" int irs_path_step(irs_ctx *ctx, int64_t *seq, int32_t *hep, int32_t B
 }
 
 // one search step on one device: decode -> rows at hep -> top-k -> choose/update
+static bool step_merged(const irs_ctx *ctx, int B) { // see irs_launch_decode: the single-workgroup plan kernel runs
+    return B <= 64 && ctx->dims.d <= 128 && ctx->dims.max_len >= 4;
+}
+
 static int enqueue_step(irs_ctx *ctx, int64_t *seq, const int64_t *user, int32_t *hep, int B, int k, int sweep,
                         int sample, int sample_k, uint64_t seed, float *paths, int path_ld, int32_t *status,
                         hipStream_t s) {
     int rc;
-    if ((rc = irs_launch_decode(ctx, seq, user, B, nullptr, hep, ctx->xrows, nullptr, s))) return rc;
+    const bool merged = step_merged(ctx, B);
+    ctx->step_pair = merged ? ctx->step_ctr : nullptr;
+    rc = irs_launch_decode(ctx, seq, user, B, nullptr, hep, ctx->xrows, nullptr, s);
+    ctx->step_pair = nullptr;
+    if (rc) return rc;
     if ((rc = irs_launch_topk(ctx, ctx->xrows, B, k, sweep, ctx->top_val, ctx->top_ids, ctx->row_status, s))) return rc;
     if ((rc = irs_launch_path_step(ctx, seq, hep, B, ctx->top_val, ctx->top_ids, k, 0, ctx->step_ctr, paths, path_ld,
-                                   sample, sample_k, seed, status, s)))
+                                   sample, sample_k, seed, status, s, merged ? ctx->step_ctr + 1 : nullptr)))
         return rc;
-    return irs_launch_inc(ctx, ctx->step_ctr, s);
+    return merged ? IRS_OK : irs_launch_inc(ctx, ctx->step_ctr, s);
 }
 
 extern "C" int irs_generate_paths(irs_ctx *ctx, int64_t *seq, const int64_t *user, int32_t *hep, int32_t B,
@@ -464,7 +472,7 @@ extern "C" int irs_generate_paths(irs_ctx *ctx, int64_t *seq, const int64_t *use
     if (k < 1 || k > ctx->dims.max_k) IRS_FAIL(ctx, IRS_E_INVALID, "irs_generate_paths: bad k");
     if (sweep != IRS_SWEEP_BF16 && sweep != IRS_SWEEP_F32) IRS_FAIL(ctx, IRS_E_INVALID, "irs_generate_paths: bad sweep");
     hipStream_t s = (hipStream_t)stream;
-    IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->step_ctr, 0, sizeof(int32_t), s));
+    IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->step_ctr, 0, 2 * sizeof(int32_t), s));
     IRS_CHECK_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t) * B, s));
     if (!use_graph) {
         for (int i = 0; i < max_path_len; ++i)
@@ -567,7 +575,7 @@ extern "C" int irs_beam_search(irs_ctx *ctx, const int64_t *seq0, const int64_t 
     if (sweep != IRS_SWEEP_BF16 && sweep != IRS_SWEEP_F32) IRS_FAIL(ctx, IRS_E_INVALID, "irs_beam_search: bad sweep");
     if (ctx->dims.mask_mode == IRS_MASK_IRN && !user) IRS_FAIL(ctx, IRS_E_INVALID, "irs_beam_search: user is null");
     hipStream_t s = (hipStream_t)stream;
-    IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->step_ctr, 0, sizeof(int32_t), s));
+    IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->step_ctr, 0, 2 * sizeof(int32_t), s));
     IRS_CHECK_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t) * B, s));
     if ((rc = irs_launch_beam_init(ctx, seq0, user, hep0, B, W, P, ctx->bm_seq[0], ctx->bm_user, ctx->bm_hep[0],
                                    ctx->bm_cum[0], ctx->bm_paths[0], s)))

@@ -139,6 +139,77 @@ __global__ void __launch_bounds__(256) k_plan_fill(const int64_t *__restrict__ s
     }
 }
 
+// Few sequences (the latency path): count, scan and fill in ONE workgroup of 16 waves, together with the
+// personalised impressionability factor r_u (k_pif) and, inside a hipGraph path loop, the hand-over of the step
+// counter -- five launches of ~4.5 us each become one.
+__global__ void __launch_bounds__(1024) k_plan_small(const int64_t *__restrict__ seq, const int32_t *__restrict__ pos, int B, int L,
+                                                     int32_t *__restrict__ cnt, int32_t *__restrict__ off,
+                                                     int32_t *__restrict__ qrow, int32_t *__restrict__ tok_row,
+                                                     int32_t *__restrict__ padq, int32_t *__restrict__ m_dev,
+                                                     const int64_t *__restrict__ user, const float *__restrict__ U,
+                                                     const float *__restrict__ uw, const float *__restrict__ ub,
+                                                     float *__restrict__ r_u, int ud, int64_t n_user,
+                                                     int32_t *__restrict__ step_pair) {
+    __shared__ int s_cnt[64], s_off[64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int b = wave; b < B; b += 16) {
+        int p = pos[b];
+        p = p < 0 ? 0 : (p >= L ? L - 1 : p);
+        const int64_t *sq = seq + (int64_t)b * L;
+        int n = 0;
+        for (int t0 = 0; t0 < L; t0 += 64) n += __popcll(__ballot(plan_valid(sq, t0 + lane, L, p)));
+        if (lane == 0) s_cnt[b] = n;
+    }
+    if (tid < B) { // r_u = user_mask_layer(user_embedder(user)) (influentialRS.py:180), 0 without the user factor
+        float acc = 0.f;
+        if (U) {
+            int64_t u = user[tid];
+            if (u < 0) u = 0;
+            if (u >= n_user) u = n_user - 1;
+            const float *e = U + u * (int64_t)ud;
+            for (int c = 0; c < ud; ++c) acc = __fmaf_rn(e[c], uw[c], acc);
+            acc += ub[0];
+        }
+        r_u[tid] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int b = 0; b < B; ++b) {
+            s_off[b] = run;
+            run += s_cnt[b];
+        }
+        m_dev[0] = run;
+        if (step_pair) step_pair[0] = step_pair[1];
+    }
+    __syncthreads();
+    for (int b = wave; b < B; b += 16) {
+        int p = pos[b];
+        p = p < 0 ? 0 : (p >= L ? L - 1 : p);
+        const int64_t *sq = seq + (int64_t)b * L;
+        int o = s_off[b];
+        if (lane == 0) {
+            cnt[b] = s_cnt[b];
+            off[b] = o;
+        }
+        const int o0 = o;
+        for (int t0 = 0; t0 < L; t0 += 64) {
+            const int t = t0 + lane;
+            const bool v = plan_valid(sq, t, L, p);
+            const unsigned long long m = __ballot(v);
+            if (v) {
+                const int idx = o + __popcll(m & ((1ull << lane) - 1ull));
+                tok_row[idx] = b * L + t;
+                if (t == p) {
+                    qrow[b] = idx;
+                    padq[b] = (sq[t] == 0) ? idx - o0 : -1;
+                }
+            }
+            o += __popcll(m);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_embed_packed(const int64_t *__restrict__ seq, const float *__restrict__ E,
                                                       const float *__restrict__ pe, float *__restrict__ x,
                                                       const int32_t *__restrict__ tok_row, const int32_t *__restrict__ m_dev,
@@ -2235,8 +2306,10 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     const int L = ctx->dims.max_len, d = ctx->dims.d, F = ctx->dims.ffn_dim;
     const int rows = B * L;
     int rc;
-    if ((rc = irs_launch_pif(ctx, user, B, ctx->act_ru, s)) != IRS_OK) return rc;
-    if (r_u_out) IRS_CHECK_HIP(ctx, hipMemcpyAsync(r_u_out, ctx->act_ru, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
+    // rows-only decode of a few sequences: the plan kernel also computes r_u (and hands the step counter over)
+    const bool small_plan = (x_out == nullptr) && pos && xrows && d <= LIN_BN && L >= 4 && B <= 64;
+    if (ctx->step_pair && !small_plan) IRS_FAIL(ctx, IRS_E_STATE, "merged path step needs the single-workgroup plan kernel");
+    if (!small_plan && (rc = irs_launch_pif(ctx, user, B, ctx->act_ru, s)) != IRS_OK) return rc;
     float *x = ctx->act_x, *y = ctx->act_y;
     // rows-only decode: the caller wants x[b, pos[b], :] only.  Then (1) the decoder runs on the PACKED
     // non-pad tokens (k_plan), every kernel clamping its row count to the device-side total, and (2) the
@@ -2249,10 +2322,17 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     const bool frag = d <= LIN_BN && d % 32 == 0 && rows > 2048;
     float *xf = ctx->act_xf, *yf = ctx->act_yf;
     if (rows_only) {
-        hipLaunchKernelGGL(k_plan_count, dim3((B + 3) / 4), dim3(256), 0, s, seq, pos, B, L, ctx->seq_cnt);
-        hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, s, ctx->seq_cnt, B, ctx->seq_off, ctx->m_dev);
-        hipLaunchKernelGGL(k_plan_fill, dim3((B + 3) / 4), dim3(256), 0, s, seq, pos, B, L, ctx->seq_off, ctx->seq_qrow,
-                           ctx->tok_row, ctx->seq_padq);
+        if (small_plan) {
+            const bool pif = ctx->dims.mask_mode == IRS_MASK_IRN && ctx->user_emb;
+            hipLaunchKernelGGL(k_plan_small, dim3(1), dim3(1024), 0, s, seq, pos, B, L, ctx->seq_cnt, ctx->seq_off, ctx->seq_qrow,
+                               ctx->tok_row, ctx->seq_padq, ctx->m_dev, user, pif ? ctx->user_emb : nullptr, ctx->um_w, ctx->um_b,
+                               ctx->act_ru, ctx->dims.u_dim, ctx->dims.n_user, ctx->step_pair);
+        } else {
+            hipLaunchKernelGGL(k_plan_count, dim3((B + 3) / 4), dim3(256), 0, s, seq, pos, B, L, ctx->seq_cnt);
+            hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, s, ctx->seq_cnt, B, ctx->seq_off, ctx->m_dev);
+            hipLaunchKernelGGL(k_plan_fill, dim3((B + 3) / 4), dim3(256), 0, s, seq, pos, B, L, ctx->seq_off, ctx->seq_qrow,
+                               ctx->tok_row, ctx->seq_padq);
+        }
         off = ctx->seq_off;
         cnt = ctx->seq_cnt;
         tok = ctx->tok_row;
@@ -2269,6 +2349,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         hipLaunchKernelGGL(k_embed, dim3((rows + 3) / 4), dim3(256), 0, s, seq, ctx->item_emb, ctx->pe, x, rows, L, d,
                            sqrtf((float)d), ctx->dims.n_item);
     IRS_CHECK_HIP(ctx, hipGetLastError());
+    if (r_u_out) IRS_CHECK_HIP(ctx, hipMemcpyAsync(r_u_out, ctx->act_ru, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
     bool qkv_done = false;
     for (int l = 0; l < ctx->dims.n_layers; ++l) {
         const irs_layer_w &w = ctx->layer[l];

@@ -76,7 +76,9 @@ struct irs_ctx {
     float *top_val;     // [max_rows][max_k]
     int64_t *top_ids;   // [max_rows][max_k]
     int32_t *row_status;// [max_rows]
-    int32_t *step_ctr;  // [1]
+    int32_t *step_ctr;  // [2] current step, next step (hipGraph loops)
+    int32_t *step_pair; // set around a decode launched by the merged small-batch path loop: the plan kernel copies
+                        // step_pair[1] over step_pair[0]
     int32_t *pos_tmp;   // [max_seqs]
     // beam-search state, ping-pong [2]
     int64_t *bm_seq[2];  // [max_seqs][L]
@@ -144,7 +146,7 @@ int irs_launch_merge(irs_ctx *ctx, const float *val_in, const int64_t *ids_in, i
                      int64_t *ids0, hipStream_t s);
 int irs_launch_path_step(irs_ctx *ctx, int64_t *seq, int32_t *hep, int B, const float *val, const int64_t *ids0, int k,
                          int step, const int32_t *step_ptr, float *paths, int path_ld, int sample, int sample_k,
-                         uint64_t seed, int32_t *status, hipStream_t s);
+                         uint64_t seed, int32_t *status, hipStream_t s, int32_t *step_next = nullptr);
 int irs_launch_inc(irs_ctx *ctx, int32_t *ctr, hipStream_t s);
 int irs_launch_beam_init(irs_ctx *ctx, const int64_t *seq0, const int64_t *user0, const int32_t *hep0, int B, int W,
                          int P, int64_t *seq, int64_t *user, int32_t *hep, double *cum, float *paths, hipStream_t s);

@@ -12,11 +12,15 @@ __global__ void __launch_bounds__(256) k_path_step(int64_t *__restrict__ seq, in
                                                    const float *__restrict__ val, const int64_t *__restrict__ ids0,
                                                    int k, int step_arg, const int32_t *__restrict__ step_ptr,
                                                    float *__restrict__ paths, int path_ld, int sample, int sample_k,
-                                                   unsigned long long seed, int32_t *__restrict__ status) {
+                                                   unsigned long long seed, int32_t *__restrict__ status,
+                                                   int32_t *__restrict__ step_next) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= B) return;
     const int step = step_ptr ? step_ptr[0] : step_arg;
+    // merged small-batch loop: publish the next step index in a second word (nobody reads it during this kernel;
+    // the next step's first kernel copies it over step_ptr[0]) instead of a k_inc launch
+    if (step_next && row == 0 && lane == 0) step_next[0] = step + 1;
     int64_t *w = seq + (size_t)row * L;
     const int he = hep[row];
     const int wl = he + 1; // window = seq[row, 0 .. he]
@@ -325,9 +329,9 @@ int irs_launch_merge(irs_ctx *ctx, const float *val_in, const int64_t *ids_in, i
 
 int irs_launch_path_step(irs_ctx *ctx, int64_t *seq, int32_t *hep, int B, const float *val, const int64_t *ids0, int k,
                          int step, const int32_t *step_ptr, float *paths, int path_ld, int sample, int sample_k,
-                         uint64_t seed, int32_t *status, hipStream_t s) {
+                         uint64_t seed, int32_t *status, hipStream_t s, int32_t *step_next) {
     hipLaunchKernelGGL(k_path_step, dim3((B + 3) / 4), dim3(256), 0, s, seq, hep, B, ctx->dims.max_len, val, ids0, k,
-                       step, step_ptr, paths, path_ld, sample, sample_k, (unsigned long long)seed, status);
+                       step, step_ptr, paths, path_ld, sample, sample_k, (unsigned long long)seed, status, step_next);
     IRS_CHECK_HIP(ctx, hipGetLastError());
     return IRS_OK;
 }

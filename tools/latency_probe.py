@@ -4,11 +4,12 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from influentialrs_amd import synth
-from influentialrs_amd._lib import IRS_MASK_IRN, IRS_SWEEP_BF16
+from influentialrs_amd._lib import IRS_MASK_IRN, IRS_SWEEP_BF16, IRS_SWEEP_EXHAUSTIVE, IRS_SWEEP_F32
 from influentialrs_amd.engine import Engine
 cfgname = sys.argv[1] if len(sys.argv) > 1 else "c2"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+SWEEP = {"bf16": IRS_SWEEP_BF16, "f32": IRS_SWEEP_F32, "exh": IRS_SWEEP_EXHAUSTIVE}[sys.argv[4] if len(sys.argv) > 4 else "bf16"]
 cfg = synth.make_config(cfgname)
 dev = torch.device("cuda:0")
 eng = Engine(n_item=cfg.n_item, n_user=cfg.n_user, d=cfg.emb_dim, max_len=cfg.max_len, n_heads=cfg.n_heads, ffn_dim=cfg.ffn_dim,
@@ -26,7 +27,7 @@ for graph in (False, True):
         work.copy_(seqs); hep.fill_(cfg.max_len - 2)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        eng.generate_paths(work, users, hep, 20, k=100, sweep=IRS_SWEEP_BF16, use_graph=graph, paths=p, status=st)
+        eng.generate_paths(work, users, hep, 20, k=100, sweep=SWEEP, use_graph=graph, paths=p, status=st)
         torch.cuda.synchronize()
         if it >= 5:
             ts.append((time.perf_counter() - t0) * 1e3)
