@@ -302,6 +302,20 @@ def main():
                 ach = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f["ms"] > 0 else 0.0
                 roof = {"kernel": f"k_{dom}", "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": ach / PEAK_HBM_GBS, "traffic": None}
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the number is the
+        # per-launch mean of the committed rocprofv3 passes of this same command (FETCH_SIZE doubled per the gfx950
+        # note + WRITE_SIZE, separate --pmc passes), valid for the default workload only
+        pmc_file = os.path.join(REPO, "profiles", "r01", "c2_b4096_pmc_v7.json")
+        if dom == "linear" and world == 1 and args.workload == "c2" and args.batch == 4096 and not args.n_item and os.path.exists(pmc_file):
+            try:
+                with open(pmc_file) as fh:
+                    der = json.load(fh)["_derived"]
+                roof["traffic"] = float(next(v for k, v in der.items() if "HBM bytes per launch" in k))
+                roof["traffic_source"] = ("profiles/r01/c2_b4096_pmc_v7.json: k_block<true,true> (5 of the family's 6 launches per "
+                                          "step), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2 x FETCH_SIZE + WRITE_SIZE")
+                roof["algorithmic_bytes_per_launch"] = 4.0 * 128 * (2 + 1 + 3) * fam[dom]["packed_fraction"] * job.B * cfg.max_len
+            except Exception:
+                pass
         roof["flops_counted"] = "executed (dense-shape flops x packed non-pad row fraction %.3f)" % fam[dom].get("packed_fraction", 1.0)
         roof["avg_launch_ms"] = per_launch_ms
         roof["launches_per_step"] = f["launches"] / args.steps
