@@ -289,7 +289,7 @@ def main():
         per_launch_ms = f["ms"] / max(f["launches"], 1)
         if dom in ("linear", "attn"):
             ach = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
-            roof = {"kernel": {"linear": "k_linear (decoder fp32 MFMA GEMM)", "attn": "k_attn (decoder attention, fp32 VALU)"}[dom],
+            roof = {"kernel": {"linear": "k_block + k_linear (decoder fp32 MFMA GEMM family: fused layer kernel, layer-0 QKV)", "attn": "k_attn (decoder attention, fp32 VALU)"}[dom],
                     "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_F32_MATRIX_TFLOPS, "traffic": None}
         else:
