@@ -255,3 +255,31 @@ def test_bench_scale_batch_duplicates_are_bit_identical_and_match_small_batches(
     assert torch.equal(xr, xr[:K][srct]), "identical windows must decode to identical bits anywhere in the batch"
     val, ids, st = eng.score_topk(xr, 100, IRS_SWEEP_BF16)
     assert torch.equal(ids, ids[:K][srct]) and torch.equal(val, val[:K][srct]) and not (st & 1).any()
+
+
+def test_throughput_shape_evaluator_mask(oracle):
+    """The evaluator's decoder (SampleNet: causal mask, no user factor, POST-padded windows, uRS.py:47-64) on the
+    throughput kernels (d = 128: fused layer kernel, 16-query attention with pad keys inside the causal range)."""
+    cfg = synth.make_config("c2", n_user=0)
+    L, B = cfg.max_len, 16
+    sd = synth.irn_state_dict(cfg, 17, evaluator=True)
+    eng = make_engine(cfg, sd, evaluator=True, max_rows=B, max_seqs=B)
+    g = np.random.default_rng(3)
+    seqs = np.zeros((B, L), dtype=np.int64)
+    for b in range(B):
+        n = int(g.integers(1, L + 1))
+        seqs[b, :n] = g.integers(1, cfg.n_item + 1, size=n)  # post-padded: zeros at the tail
+    seqs[1, :] = 0
+    seqs[1, 0] = 5
+    seq = torch.from_numpy(seqs).cuda()
+    x_big = eng.decode(seq, None, want_x=True)[0]
+    x_small = torch.cat([eng.decode(seq[i:i + 8], None, want_x=True)[0] for i in range(0, B, 8)])
+    assert torch.equal(torch.isnan(x_big), torch.isnan(x_small))
+    ok = torch.isfinite(x_big) & torch.isfinite(x_small)
+    assert (x_big - x_small)[ok].abs().max().item() < X_TOL
+    for b in (0, 1, 7):
+        ref = oracle.decode(sd, cfg, seqs[b], None, evaluator=True)[0]
+        got = x_big[b].cpu().numpy()
+        assert np.array_equal(np.isnan(ref), np.isnan(got))
+        fin = np.isfinite(ref) & np.isfinite(got)
+        assert np.abs(ref - got)[fin].max() < X_TOL
