@@ -1518,6 +1518,159 @@ __global__ void __launch_bounds__(256) k_block_small(SmallBlockArgs a) {
     }
 }
 
+// The same chain on v_mfma_f32_16x16x4_f32 with 16 tokens per workgroup: for the single-user latency case
+// (~130 packed rows) twice as many workgroups run side by side and every wave's dependent MFMA work halves
+// (512 MFMAs of 32 cycles; 2-6 independent 16-column tiles per wave and GEMM).  lane = (token lq, k-slot gq):
+// B value x[token][16j + 4gq + e], A value W[n0 + lq][16j + 4gq + e], C register r <-> column n0 + 4gq + r.
+__global__ void __launch_bounds__(256) k_block_small16(SmallBlockArgs a) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    constexpr int D = 128, F = 256, LDA = D + 4, LDH = F + 4;
+    __shared__ __attribute__((aligned(16))) float bufA[16 * LDA]; // ao -> y -> x'
+    __shared__ __attribute__((aligned(16))) float bufH[16 * LDH]; // h
+    __shared__ float part[2][4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 15, gq = lane >> 4;
+    const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M;
+    const int m0 = blockIdx.x * 16;
+    if (m0 >= M) return;
+    const int mt = m0 + lq; // this lane's token
+    const bool live = mt < M;
+    for (int i = tid; i < 16 * (D / 4); i += 256) {
+        const int rr = i / (D / 4), c4 = i % (D / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m0 + rr < M) v = *reinterpret_cast<const float4 *>(a.AO + (int64_t)(m0 + rr) * D + 4 * c4);
+        *reinterpret_cast<float4 *>(bufA + rr * LDA + 4 * c4) = v;
+    }
+    __syncthreads();
+    // acc[t] += W[n0 + 16t + lq][0 .. K) . B[token][0 .. K): NT independent 16-column tiles share every B fragment
+    auto gemm = [&](f32x4 *acc, int NT, const float *W, int n0, int K, const float *B, int ldb) {
+        const float *brow = B + lq * ldb + 4 * gq;
+        for (int j0 = 0; j0 < K / 16; j0 += 4) { // 4 x 16 k per round
+            float4 bf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const float4 *>(brow + 16 * (j0 + j));
+            for (int t = 0; t < NT; ++t) {
+                const float *wrow = W + (int64_t)(n0 + 16 * t + lq) * K + 4 * gq + 16 * j0;
+                float4 wf[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const float4 *>(wrow + 16 * j);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j].x, bf[j].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j].y, bf[j].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j].z, bf[j].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j].w, bf[j].w, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    };
+    auto row_total = [&](float v, int slot) { // sum over the 128 columns of each token (4 waves x 4 k-slot lanes)
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (gq == 0) part[slot][wave][lq] = v;
+        __syncthreads();
+        const float t = part[slot][0][lq] + part[slot][1][lq] + part[slot][2][lq] + part[slot][3][lq];
+        __syncthreads();
+        return t;
+    };
+    const float invn = 1.0f / (float)D;
+    const int n0 = wave * 32; // this wave's 32 columns of a 128-wide output = tiles n0, n0 + 16
+    // z[t][r] = column n0 + 16t + 4gq + r of this lane's token
+    auto layer_norm = [&](float (&z)[2][4], const float *g, const float *b, const float *add) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s1 += z[t][r];
+        const float mu = row_total(s1, 0) * invn;
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q += (z[t][r] - mu) * (z[t][r] - mu);
+        const float rstd = 1.0f / sqrtf(row_total(q, 1) * invn + 1e-5f);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 16 * t + 4 * gq + r;
+                z[t][r] = (z[t][r] - mu) * rstd * g[n] + b[n] + (add ? add[n] : 0.f);
+            }
+    };
+    auto to_lds2 = [&](const float (&z)[2][4], float *buf, int ld) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            *reinterpret_cast<float4 *>(buf + lq * ld + n0 + 16 * t + 4 * gq) = make_float4(z[t][0], z[t][1], z[t][2], z[t][3]);
+    };
+    float z[2][4];
+    // ---- y = LN2(LN1(x + ao W_o^T + b_o) + c)
+    {
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        float4 res[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            res[t] = live ? *reinterpret_cast<const float4 *>(a.X + (int64_t)mt * D + n0 + 16 * t + 4 * gq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        gemm(acc, 2, a.Wo, n0, D, bufA, LDA);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int n = n0 + 16 * t + 4 * gq;
+            z[t][0] = acc[t][0] + (a.bo ? a.bo[n + 0] : 0.f) + res[t].x;
+            z[t][1] = acc[t][1] + (a.bo ? a.bo[n + 1] : 0.f) + res[t].y;
+            z[t][2] = acc[t][2] + (a.bo ? a.bo[n + 2] : 0.f) + res[t].z;
+            z[t][3] = acc[t][3] + (a.bo ? a.bo[n + 3] : 0.f) + res[t].w;
+        }
+    }
+    layer_norm(z, a.g1, a.b1n, a.c);
+    if (a.c) layer_norm(z, a.g2, a.b2n, nullptr);
+    to_lds2(z, bufA, LDA); // every wave is past its last read of the ao tile (row_total's barriers)
+    __syncthreads();
+    // ---- h = relu(y W1^T + b1): this wave's 64 columns (4 tiles) -> LDS
+    {
+        f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        gemm(acc, 4, a.W1, wave * 64, D, bufA, LDA);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = wave * 64 + 16 * t + 4 * gq;
+            *reinterpret_cast<float4 *>(bufH + lq * LDH + n) =
+                make_float4(fmaxf(acc[t][0] + a.b1[n + 0], 0.f), fmaxf(acc[t][1] + a.b1[n + 1], 0.f),
+                            fmaxf(acc[t][2] + a.b1[n + 2], 0.f), fmaxf(acc[t][3] + a.b1[n + 3], 0.f));
+        }
+    }
+    __syncthreads();
+    // ---- x' = LN3(y + h W2^T + b2)
+    {
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        gemm(acc, 2, a.W2, n0, F, bufH, LDH);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[t][r] = acc[t][r] + a.b2[n0 + 16 * t + 4 * gq + r] + z[t][r];
+    }
+    layer_norm(z, a.g3, a.b3n, nullptr);
+    if (live) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            *reinterpret_cast<float4 *>(a.Xo + (int64_t)mt * D + n0 + 16 * t + 4 * gq) = make_float4(z[t][0], z[t][1], z[t][2], z[t][3]);
+    }
+    if (!a.Win) return;
+    // ---- qkv' = x' W_in^T + b_in: this wave's 96 columns (6 tiles)
+    to_lds2(z, bufA, LDA);
+    __syncthreads();
+    {
+        f32x4 acc[6] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f},
+                        {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        gemm(acc, 6, a.Win, wave * 96, D, bufA, LDA);
+        if (live) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const int n = wave * 96 + 16 * t + 4 * gq;
+                *reinterpret_cast<float4 *>(a.QKV + (int64_t)mt * (3 * D) + n) =
+                    make_float4(acc[t][0] + a.bin[n], acc[t][1] + a.bin[n + 1], acc[t][2] + a.bin[n + 2], acc[t][3] + a.bin[n + 3]);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ attention on fp32 MFMA
 // One workgroup per (head, sequence), 4 waves; K_h / V_h of the sequence in LDS.
 // A wave owns 32-query blocks.  Per (query block, key block):
@@ -2376,7 +2529,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                 SmallBlockArgs sb{ao_r, x_r, w.sa_out_w, w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, w.l1_w, w.l1_b, w.l2_w, w.l2_b,
                                   w.n3_w, w.n3_b, xrows, nullptr, nullptr, nullptr, B, nullptr};
                 irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
-                hipLaunchKernelGGL(k_block_small, dim3((B + 31) / 32), dim3(256), 0, s, sb);
+                if (B <= 512) hipLaunchKernelGGL(k_block_small16, dim3((B + 15) / 16), dim3(256), 0, s, sb);
+                else hipLaunchKernelGGL(k_block_small, dim3((B + 31) / 32), dim3(256), 0, s, sb);
                 irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * B * ((double)d * d + 2.0 * d * F), 4.0 * 3.0 * B * (double)d);
             } else {
                 if ((rc = launch_linear(ctx, ao_r, w.sa_out_w, w.sa_out_b, x_r, y_r, B, d, d, false, s, w.n1_w, w.n1_b, cl, w.n2_w,
@@ -2441,7 +2595,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                               w.n3_w, w.n3_b, y, last ? nullptr : ctx->layer[l + 1].sa_in_w, last ? nullptr : ctx->layer[l + 1].sa_in_b,
                               ctx->act_qkv, rows, m_dev};
             irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
-            hipLaunchKernelGGL(k_block_small, dim3((rows + 31) / 32), dim3(256), 0, s, sb);
+            if (rows <= 512) hipLaunchKernelGGL(k_block_small16, dim3((rows + 15) / 16), dim3(256), 0, s, sb);
+            else hipLaunchKernelGGL(k_block_small, dim3((rows + 31) / 32), dim3(256), 0, s, sb);
             irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * rows * ((double)d * d + 2.0 * d * F + (last ? 0.0 : 3.0 * d * d)),
                          4.0 * (3.0 + (last ? 0.0 : 3.0)) * rows * (double)d);
             qkv_done = !last;
