@@ -305,7 +305,8 @@ extern "C" int irs_bind_workspace(irs_ctx *ctx, void *ws, size_t bytes) {
     ctx->top_val = (float *)(b + p.tval);
     ctx->top_ids = (int64_t *)(b + p.tids);
     ctx->row_status = (int32_t *)(b + p.status);
-    ctx->step_ctr = (int32_t *)(b + p.step);
+    ctx->step_ctr = (int32_t *)(b + p.step); // [0..1] step pair of the path loops, [8..40) arrival counters of k_topk_direct
+    IRS_CHECK_HIP(ctx, hipMemset(ctx->step_ctr, 0, 256));
     ctx->pos_tmp = (int32_t *)(b + p.pos);
     for (int i = 0; i < 2; ++i) {
         ctx->bm_seq[i] = (int64_t *)(b + p.bseq[i]);

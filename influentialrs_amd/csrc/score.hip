@@ -870,6 +870,94 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
 // Exhaustive exact top-k of one row over the whole shard (fallback and GPU-side yard-stick).
 // Streams every item through the exact chain; keeps the best k by (score desc, id asc).
 #define EXH_BUF 2048
+// Small shard x few rows (the single-user latency path on an ml-1m-sized catalog): the five-kernel filter pipeline
+// costs ~50 us of launches for ~2 us of work.  Here the workgroups of a row each score 256 items with the exact
+// chain (one item per thread) into a global key array; the LAST workgroup of the row to finish (arrival counter)
+// radix-selects the k-th largest key and sorts the survivors: one launch, same total order, same bits.
+#define DIRECT_MAX_ITEMS 4096 // keys of a row live in the candidate array ([M_pad][IRS_CAND_CAP] u64)
+__global__ void __launch_bounds__(256) k_topk_direct(const float *__restrict__ x, int d, const float *__restrict__ W,
+                                                     const float *__restrict__ bias, int n_local, int64_t item_lo, int k,
+                                                     unsigned long long *__restrict__ gkeys, unsigned int *__restrict__ arrive,
+                                                     float *__restrict__ val, int64_t *__restrict__ ids,
+                                                     int32_t *__restrict__ status) {
+    __shared__ unsigned long long keys[DIRECT_MAX_ITEMS];
+    __shared__ unsigned long long rkeys[IRS_REFINE_CAP];
+    __shared__ unsigned int hist[256];
+    __shared__ float xs[256];
+    __shared__ unsigned int s_prefix, s_k, s_nr, s_last;
+    const int row = blockIdx.y, tid = threadIdx.x;
+    for (int i = tid; i < d; i += 256) xs[i] = x[(size_t)row * d + i];
+    __syncthreads();
+    unsigned long long *gk = gkeys + (size_t)row * IRS_CAND_CAP;
+    {
+        const int j = blockIdx.x * 256 + tid;
+        if (j < n_local) {
+            const float e = irs_chain(xs, W + (size_t)j * d, bias[j], d);
+            gk[j] = ((unsigned long long)irs_fkey(e) << 32) | (0xFFFFFFFFu - (unsigned int)j);
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(&arrive[row], 1u) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (tid == 0) {
+        arrive[row] = 0u; // ready for the next call (graph replays included)
+        s_prefix = 0;
+        s_k = k;
+        s_nr = 0;
+        status[row] = 0;
+    }
+    for (int i = tid; i < n_local; i += 256) keys[i] = __builtin_nontemporal_load(gk + i);
+    __syncthreads();
+    unsigned long long thr = 0ull; // keep keys whose score key >= the k-th largest score key (ties included)
+    if (n_local > k) {
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            hist[tid] = 0;
+            __syncthreads();
+            const unsigned int prefix = s_prefix;
+            for (int i = tid; i < n_local; i += 256) {
+                const unsigned int key = (unsigned int)(keys[i] >> 32);
+                const bool match = (pass == 0) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+                if (match) atomicAdd(&hist[(key >> shift) & 255], 1u);
+            }
+            __syncthreads();
+            if (tid < 64) radix_find_bin(hist, s_k, tid, shift, &s_prefix, &s_k);
+            __syncthreads();
+        }
+        thr = (unsigned long long)s_prefix << 32;
+    }
+    for (int i = tid; i < n_local; i += 256) {
+        if (keys[i] >= thr) {
+            const unsigned int slot = atomicAdd(&s_nr, 1u);
+            if (slot < IRS_REFINE_CAP) rkeys[slot] = keys[i];
+        }
+    }
+    __syncthreads();
+    const unsigned int nr = s_nr;
+    if (nr > IRS_REFINE_CAP) { // more than 1024 - k exact ties at the boundary: the exhaustive kernel handles the row
+        if (tid == 0) status[row] |= IRS_ROW_FALLBACK;
+        return;
+    }
+    int n2 = 2;
+    while (n2 < (int)nr) n2 <<= 1;
+    for (int i = nr + tid; i < n2; i += 256) rkeys[i] = 0ull;
+    bitonic_desc(rkeys, n2);
+    for (int i = tid; i < k; i += 256) {
+        if (i < (int)nr) {
+            const unsigned long long kk = rkeys[i];
+            val[(size_t)row * k + i] = irs_unkey((unsigned int)(kk >> 32));
+            ids[(size_t)row * k + i] = item_lo + (int64_t)(0xFFFFFFFFu - (unsigned int)kk);
+        } else {
+            val[(size_t)row * k + i] = -INFINITY;
+            ids[(size_t)row * k + i] = -1;
+        }
+    }
+    if (tid == 0 && (int)nr < k) status[row] |= IRS_ROW_FEWER_THAN_K;
+}
+
 __global__ void __launch_bounds__(256) k_exhaustive(const float *__restrict__ x, int d, const float *__restrict__ W,
                                                     const float *__restrict__ bias, int64_t n_local, int64_t item_lo,
                                                     int k, int only_flagged, float *__restrict__ val,
@@ -1100,6 +1188,17 @@ int irs_launch_pack_w(irs_ctx *ctx, hipStream_t s) {
 
 int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, float *val, int64_t *ids0,
                     int32_t *status, hipStream_t s) {
+    if (M <= 32 && ctx->n_local <= DIRECT_MAX_ITEMS && k <= 512) { // latency path on a small shard: one kernel (+ the fallback)
+        irs_prof_begin(ctx, IRS_PROF_REFINE, s);
+        hipLaunchKernelGGL(k_topk_direct, dim3((unsigned)((ctx->n_local + 255) / 256), M), dim3(256), 0, s, xrows, ctx->dims.d,
+                           ctx->proj_w, ctx->proj_b, (int)ctx->n_local, ctx->shard.item_lo, k, ctx->cand,
+                           reinterpret_cast<unsigned int *>(ctx->step_ctr) + 8, val, ids0, status);
+        irs_prof_end(ctx, IRS_PROF_REFINE, s, 2.0 * ctx->dims.d * (double)M * (double)ctx->n_local, 0.0);
+        hipLaunchKernelGGL(k_exhaustive, dim3(M), dim3(256), 0, s, xrows, ctx->dims.d, ctx->proj_w, ctx->proj_b, ctx->n_local,
+                           ctx->shard.item_lo, k, 1, val, ids0, status);
+        IRS_CHECK_HIP(ctx, hipGetLastError());
+        return IRS_OK;
+    }
     SweepArgs a;
     sweep_common(ctx, a, xrows, M);
     const int M_pad = a.M_pad;
