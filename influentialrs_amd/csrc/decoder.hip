@@ -1354,6 +1354,7 @@ struct SmallBlockArgs {
     float *QKV;               // [M][384]
     int M;
     const int32_t *m_dev;
+    const int32_t *xidx;      // optional: residual row of token m is X[xidx[m]] (last layer: the consumed rows)
 };
 
 __global__ void __launch_bounds__(256) k_block_small(SmallBlockArgs a) {
@@ -1440,7 +1441,7 @@ __global__ void __launch_bounds__(256) k_block_small(SmallBlockArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            resv[r] = live ? a.X[(int64_t)mt * D + n] : 0.f;
+            resv[r] = live ? a.X[(int64_t)(a.xidx ? a.xidx[mt] : mt) * D + n] : 0.f;
         }
         gemm(&acc, 1, a.Wo, n0, D, bufA, LDA);
 #pragma unroll
@@ -1609,7 +1610,8 @@ __global__ void __launch_bounds__(256) k_block_small16(SmallBlockArgs a) {
         float4 res[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-            res[t] = live ? *reinterpret_cast<const float4 *>(a.X + (int64_t)mt * D + n0 + 16 * t + 4 * gq) : make_float4(0.f, 0.f, 0.f, 0.f);
+            res[t] = live ? *reinterpret_cast<const float4 *>(a.X + (int64_t)(a.xidx ? a.xidx[mt] : mt) * D + n0 + 16 * t + 4 * gq)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
         gemm(acc, 2, a.Wo, n0, D, bufA, LDA);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -2523,11 +2525,13 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             hipLaunchKernelGGL(k_attn_row, dim3(ctx->dims.n_heads, B), dim3(64), 0, s, ctx->act_qkv, seq, ctx->act_ru, pos,
                                ao_r, L, d, d / ctx->dims.n_heads, ctx->dims.mask_mode, off, cnt, tok, qrow);
             irs_prof_end(ctx, IRS_PROF_ATTN, s, 4.0 * B * (double)L * d, 4.0 * 3.0 * B * (double)L * d);
+            const bool fused_tail = d == 128 && F == 256;
+            const bool idx_res = fused_tail && !frag; // the layer kernel reads the residual rows x[qrow[b]] itself
             if (frag) hipLaunchKernelGGL(k_gather_rows_frag, dim3(B), dim3(64), 0, s, xf, qrow, x_r, d);
-            else hipLaunchKernelGGL(k_gather_rows_idx, dim3(B), dim3(64), 0, s, x, qrow, x_r, d);
-            if (d == 128 && F == 256) { // one launch for the rest of the layer on the B consumed rows
-                SmallBlockArgs sb{ao_r, x_r, w.sa_out_w, w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, w.l1_w, w.l1_b, w.l2_w, w.l2_b,
-                                  w.n3_w, w.n3_b, xrows, nullptr, nullptr, nullptr, B, nullptr};
+            else if (!idx_res) hipLaunchKernelGGL(k_gather_rows_idx, dim3(B), dim3(64), 0, s, x, qrow, x_r, d);
+            if (fused_tail) { // one launch for the rest of the layer on the B consumed rows
+                SmallBlockArgs sb{ao_r, idx_res ? x : x_r, w.sa_out_w, w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, w.l1_w, w.l1_b, w.l2_w, w.l2_b,
+                                  w.n3_w, w.n3_b, xrows, nullptr, nullptr, nullptr, B, nullptr, idx_res ? qrow : nullptr};
                 irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
                 if (B <= 512) hipLaunchKernelGGL(k_block_small16, dim3((B + 15) / 16), dim3(256), 0, s, sb);
                 else hipLaunchKernelGGL(k_block_small, dim3((B + 31) / 32), dim3(256), 0, s, sb);

@@ -936,18 +936,24 @@ __global__ void __launch_bounds__(256) k_topk_direct(const float *__restrict__ x
         }
     }
     __syncthreads();
-    const unsigned int nr = s_nr;
-    if (nr > IRS_REFINE_CAP) { // more than 1024 - k exact ties at the boundary: the exhaustive kernel handles the row
-        if (tid == 0) status[row] |= IRS_ROW_FALLBACK;
-        return;
+    unsigned int nr = s_nr;
+    const unsigned long long *sorted = rkeys;
+    if (nr > IRS_REFINE_CAP) { // > 1024 - k exact ties at the boundary: sort the whole key array (it is all in LDS)
+        int n2 = 2;
+        while (n2 < n_local) n2 <<= 1;
+        for (int i = n_local + tid; i < n2; i += 256) keys[i] = 0ull;
+        bitonic_desc(keys, n2);
+        sorted = keys;
+        nr = (unsigned int)n_local;
+    } else {
+        int n2 = 2;
+        while (n2 < (int)nr) n2 <<= 1;
+        for (int i = nr + tid; i < n2; i += 256) rkeys[i] = 0ull;
+        bitonic_desc(rkeys, n2);
     }
-    int n2 = 2;
-    while (n2 < (int)nr) n2 <<= 1;
-    for (int i = nr + tid; i < n2; i += 256) rkeys[i] = 0ull;
-    bitonic_desc(rkeys, n2);
     for (int i = tid; i < k; i += 256) {
         if (i < (int)nr) {
-            const unsigned long long kk = rkeys[i];
+            const unsigned long long kk = sorted[i];
             val[(size_t)row * k + i] = irs_unkey((unsigned int)(kk >> 32));
             ids[(size_t)row * k + i] = item_lo + (int64_t)(0xFFFFFFFFu - (unsigned int)kk);
         } else {
@@ -1188,14 +1194,12 @@ int irs_launch_pack_w(irs_ctx *ctx, hipStream_t s) {
 
 int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, float *val, int64_t *ids0,
                     int32_t *status, hipStream_t s) {
-    if (M <= 32 && ctx->n_local <= DIRECT_MAX_ITEMS && k <= 512) { // latency path on a small shard: one kernel (+ the fallback)
+    if (M <= 32 && ctx->n_local <= DIRECT_MAX_ITEMS && k <= 512) { // latency path on a small shard: one kernel, no fallback needed
         irs_prof_begin(ctx, IRS_PROF_REFINE, s);
         hipLaunchKernelGGL(k_topk_direct, dim3((unsigned)((ctx->n_local + 255) / 256), M), dim3(256), 0, s, xrows, ctx->dims.d,
                            ctx->proj_w, ctx->proj_b, (int)ctx->n_local, ctx->shard.item_lo, k, ctx->cand,
                            reinterpret_cast<unsigned int *>(ctx->step_ctr) + 8, val, ids0, status);
         irs_prof_end(ctx, IRS_PROF_REFINE, s, 2.0 * ctx->dims.d * (double)M * (double)ctx->n_local, 0.0);
-        hipLaunchKernelGGL(k_exhaustive, dim3(M), dim3(256), 0, s, xrows, ctx->dims.d, ctx->proj_w, ctx->proj_b, ctx->n_local,
-                           ctx->shard.item_lo, k, 1, val, ids0, status);
         IRS_CHECK_HIP(ctx, hipGetLastError());
         return IRS_OK;
     }
