@@ -796,6 +796,8 @@ struct BlockArgs {
     const int32_t *m_dev;
     const float *Win, *bin; // QKV tail: [384][128], [384]
     float *QKV;             // row-major [M][384]
+    int qkv_n0, qkv_nt1;    // QKV tail: first output column and tiles of the second pass: (0, 6) = all of q | k | v;
+                            // (128, 2) = k | v only (the last layer's queries are needed for one row per sequence)
 };
 
 template <bool OUT, bool QKV>
@@ -848,7 +850,8 @@ __global__ void __launch_bounds__(256, 2) k_block(BlockArgs a) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int idx = tid + i * 256;
-                const float *p = a.Win + (size_t)(192 * pp + (idx >> 2)) * D + ss * BK + (idx & 3) * 4;
+                const int wrow = min(a.qkv_n0 + 192 * pp + (idx >> 2), 3 * D - 1); // rows past the end: unused tiles
+                const float *p = a.Win + (size_t)wrow * D + ss * BK + (idx & 3) * 4;
                 wv[i] = make_float4(p[0], p[1], p[2], p[3]);
             }
         } else if (t < 8) {
@@ -1102,9 +1105,11 @@ __global__ void __launch_bounds__(256, 2) k_block(BlockArgs a) {
             if (QKV) acc[tn][4 * g + 0] = o.x, acc[tn][4 * g + 1] = o.y, acc[tn][4 * g + 2] = o.z, acc[tn][4 * g + 3] = o.w;
         }
     if (!QKV) return;
-    // ---- QKV tail: qkv^T = W_in x^T, 2 passes x 6 output tiles, k-slab s <-> x tile tn = s/2, groups g = 2(s&1) + q
+    // ---- QKV tail: qkv^T = W_in x^T, 2 passes x (6, qkv_nt1) output tiles from column qkv_n0, k-slab s <-> x tile
+    //      tn = s/2, groups g = 2(s&1) + q
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
+        const int nt = pp == 0 ? 6 : a.qkv_nt1; // workgroup-uniform
         f32x16 qa[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i)
@@ -1122,8 +1127,8 @@ __global__ void __launch_bounds__(256, 2) k_block(BlockArgs a) {
                 float4 w[6];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) w[i] = *reinterpret_cast<const float4 *>(wa + i * 32 * BK + off);
-#define QKV_STEP(E, R)                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                           \
+#define QKV_STEP(E, R)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 6; ++i) if (i < 2 || i < nt)                                          \
         qa[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i].E, acc[tn][4 * g + R], qa[i], 0, 0, 0);
                 QKV_STEP(x, 0) QKV_STEP(y, 1) QKV_STEP(z, 2) QKV_STEP(w, 3)
 #undef QKV_STEP
@@ -1133,14 +1138,17 @@ __global__ void __launch_bounds__(256, 2) k_block(BlockArgs a) {
             cur ^= 1;
         }
         if (mt < M) {
-            float *qrow = a.QKV + (int64_t)mt * (3 * D) + pp * 192 + 4 * lk;
+            const int c0 = a.qkv_n0 + pp * 192;
+            float *qrow = a.QKV + (int64_t)mt * (3 * D) + c0 + 4 * lk;
 #pragma unroll
             for (int i = 0; i < 6; ++i)
+                if (i < nt) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 bb = *reinterpret_cast<const float4 *>(vecs + V_BIN + pp * 192 + i * 32 + 8 * g + 4 * lk);
-                    *reinterpret_cast<float4 *>(qrow + i * 32 + 8 * g) =
-                        make_float4(qa[i][4 * g + 0] + bb.x, qa[i][4 * g + 1] + bb.y, qa[i][4 * g + 2] + bb.z, qa[i][4 * g + 3] + bb.w);
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 bb = *reinterpret_cast<const float4 *>(vecs + V_BIN + c0 + i * 32 + 8 * g + 4 * lk);
+                        *reinterpret_cast<float4 *>(qrow + i * 32 + 8 * g) =
+                            make_float4(qa[i][4 * g + 0] + bb.x, qa[i][4 * g + 1] + bb.y, qa[i][4 * g + 2] + bb.z, qa[i][4 * g + 3] + bb.w);
+                    }
                 }
         }
     }
@@ -2166,7 +2174,8 @@ __global__ void __launch_bounds__(64) k_attn_row(const float *__restrict__ qkv, 
                                                  const float *__restrict__ r_u, const int32_t *__restrict__ pos,
                                                  float *__restrict__ out_rows, int Lmax, int d, int hd, int mask_mode,
                                                  const int32_t *__restrict__ off, const int32_t *__restrict__ cnt,
-                                                 const int32_t *__restrict__ tok_row, const int32_t *__restrict__ qrow) {
+                                                 const int32_t *__restrict__ tok_row, const int32_t *__restrict__ qrow,
+                                                 const float *__restrict__ qrows) {
     __shared__ float p_s[256];
     __shared__ float q_s[64];
     const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
@@ -2180,7 +2189,8 @@ __global__ void __launch_bounds__(64) k_attn_row(const float *__restrict__ qkv, 
     const bool irn = (mask_mode == IRS_MASK_IRN);
     const float add_allowed = irn ? r_u[b] : 0.f;
     const float scale = 1.0f / sqrtf((float)hd);
-    if (lane < hd) q_s[lane] = qkv[(base + i) * ld + h * hd + lane] * scale;
+    // qrows: the queries of the consumed rows computed separately (the producer wrote k | v only)
+    if (lane < hd) q_s[lane] = (qrows ? qrows[(int64_t)b * d + h * hd + lane] : qkv[(base + i) * ld + h * hd + lane]) * scale;
     __syncthreads();
     float sc[4];
     float mx = -INFINITY;
@@ -2505,7 +2515,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                            sqrtf((float)d), ctx->dims.n_item);
     IRS_CHECK_HIP(ctx, hipGetLastError());
     if (r_u_out) IRS_CHECK_HIP(ctx, hipMemcpyAsync(r_u_out, ctx->act_ru, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
-    bool qkv_done = false;
+    bool qkv_done = false, q_split = false;
     for (int l = 0; l < ctx->dims.n_layers; ++l) {
         const irs_layer_w &w = ctx->layer[l];
         const bool last_rows = rows_only && (l + 1 == ctx->dims.n_layers);
@@ -2521,14 +2531,20 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             float *x_r = ctx->act_ao + (size_t)B * d;  // [B, d] residual rows x[b, pos[b]]
             float *y_r = ctx->act_ao + (size_t)2 * B * d;
             float *h_r = ctx->act_h;                   // [B, F]
+            const float *q_r = nullptr;
+            if (q_split) { // the previous layer's kernel wrote k | v only: queries for the B consumed rows here
+                hipLaunchKernelGGL(k_gather_rows_frag, dim3(B), dim3(64), 0, s, xf, qrow, x_r, d);
+                if ((rc = launch_linear(ctx, x_r, w.sa_in_w, w.sa_in_b, nullptr, h_r, B, d, d, false, s))) return rc;
+                q_r = h_r;
+            }
             irs_prof_begin(ctx, IRS_PROF_ATTN, s);
             hipLaunchKernelGGL(k_attn_row, dim3(ctx->dims.n_heads, B), dim3(64), 0, s, ctx->act_qkv, seq, ctx->act_ru, pos,
-                               ao_r, L, d, d / ctx->dims.n_heads, ctx->dims.mask_mode, off, cnt, tok, qrow);
+                               ao_r, L, d, d / ctx->dims.n_heads, ctx->dims.mask_mode, off, cnt, tok, qrow, q_r);
             irs_prof_end(ctx, IRS_PROF_ATTN, s, 4.0 * B * (double)L * d, 4.0 * 3.0 * B * (double)L * d);
             const bool fused_tail = d == 128 && F == 256;
             const bool idx_res = fused_tail && !frag; // the layer kernel reads the residual rows x[qrow[b]] itself
-            if (frag) hipLaunchKernelGGL(k_gather_rows_frag, dim3(B), dim3(64), 0, s, xf, qrow, x_r, d);
-            else if (!idx_res) hipLaunchKernelGGL(k_gather_rows_idx, dim3(B), dim3(64), 0, s, x, qrow, x_r, d);
+            if (frag && !q_split) hipLaunchKernelGGL(k_gather_rows_frag, dim3(B), dim3(64), 0, s, xf, qrow, x_r, d);
+            else if (!frag && !idx_res) hipLaunchKernelGGL(k_gather_rows_idx, dim3(B), dim3(64), 0, s, x, qrow, x_r, d);
             if (fused_tail) { // one launch for the rest of the layer on the B consumed rows
                 SmallBlockArgs sb{ao_r, idx_res ? x : x_r, w.sa_out_w, w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, w.l1_w, w.l1_b, w.l2_w, w.l2_b,
                                   w.n3_w, w.n3_b, xrows, nullptr, nullptr, nullptr, B, nullptr, idx_res ? qrow : nullptr};
@@ -2559,7 +2575,11 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             ba.Xf = last ? nullptr : xf, ba.Y = last ? x : nullptr, ba.M = rows, ba.m_dev = m_dev;
             ba.Win = tail ? ctx->layer[l + 1].sa_in_w : nullptr, ba.bin = tail ? ctx->layer[l + 1].sa_in_b : nullptr;
             ba.QKV = ctx->act_qkv;
-            const double ffn_flops = 4.0 * rows * (double)d * F + (tail ? 6.0 * rows * (double)d * d : 0.0);
+            // feeding the rows-only last layer: its queries are needed for B rows only -> write k | v, 8 of 12 tiles
+            const bool kv_only = tail && rows_only && l + 2 == ctx->dims.n_layers;
+            ba.qkv_n0 = kv_only ? 128 : 0, ba.qkv_nt1 = kv_only ? 2 : 6;
+            q_split = kv_only;
+            const double ffn_flops = 4.0 * rows * (double)d * F + (tail ? (kv_only ? 4.0 : 6.0) * rows * (double)d * d : 0.0);
             if (fuse_block) {
                 ba.Af = yf, ba.Rf = xf, ba.Wo = w.sa_out_w, ba.bo = w.sa_out_b;
                 ba.g1 = w.n1_w, ba.b1n = w.n1_b, ba.c = cl, ba.g2 = w.n2_w, ba.b2n = w.n2_b;

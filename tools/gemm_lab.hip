@@ -78,7 +78,7 @@ int main(int argc, char **argv) {
         ba.Yf = R, ba.W1 = W, ba.b1 = B, ba.W2 = W, ba.b2 = B, ba.g = G, ba.b = G, ba.Xf = Y, ba.M = M;
         float ms = time_it([&] { hipLaunchKernelGGL((k_block<false, false>), dim3((M + 127) / 128), dim3(256), 0, 0, ba); }, 20);
         printf("ffn fused           : %8.1f us  %6.1f TF\n", ms * 1e3, 4.0 * M * 128 * 256 / 1e9 / ms);
-        ba.Win = W, ba.bin = B, ba.QKV = R;
+        ba.Win = W, ba.bin = B, ba.QKV = R, ba.qkv_nt1 = 6;
         ms = time_it([&] { hipLaunchKernelGGL((k_block<false, true>), dim3((M + 127) / 128), dim3(256), 0, 0, ba); }, 20);
         printf("ffn + next qkv      : %8.1f us  %6.1f TF\n", ms * 1e3, (4.0 * M * 128 * 256 + 6.0 * M * 128 * 128) / 1e9 / ms);
         ba.Af = X, ba.Rf = Y2, ba.Wo = W, ba.bo = B, ba.g1 = G, ba.b1n = G, ba.c = G, ba.g2 = G, ba.b2n = G;
