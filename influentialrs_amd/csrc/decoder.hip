@@ -1154,6 +1154,127 @@ __global__ void __launch_bounds__(256, 2) k_block(BlockArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ embed + layer 0's QKV (d = 128, throughput shapes)
+// x = item_emb[seq] * sqrt(d) + pe[pos] is computed straight into the transposed accumulator layout (lane = token),
+// written once to the fragment-major image (layer 0's residual) and used as the B operand of the QKV projection,
+// exactly like k_block's tail: the first layer needs no separate embed kernel and no QKV GEMM reading x back.
+struct EmbedQkvArgs {
+    const int64_t *seq;
+    const float *E, *pe;
+    const int32_t *tok_row, *m_dev;
+    int rows, L;
+    float sqrtd;
+    int64_t n_item;
+    float *Xf;
+    const float *Win, *bin;
+    float *QKV;
+};
+
+__global__ void __launch_bounds__(256, 2) k_embed_qkv(EmbedQkvArgs a) {
+    constexpr int D = 128, BK = 16, NR = 192; // 192 W_in rows (6 output tiles) per pass
+    __shared__ __attribute__((aligned(16))) float sm[2 * NR * BK + 3 * D];
+    float *vb = sm + 2 * NR * BK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int m0 = blockIdx.x * 128;
+    const int M = a.m_dev ? min(a.rows, a.m_dev[0]) : a.rows;
+    if (m0 >= M) return;
+    vb[tid] = a.bin[tid];
+    if (tid < D) vb[256 + tid] = a.bin[256 + tid];
+    const int mtile = (m0 >> 5) + wave;
+    const int mt = m0 + wave * 32 + li;
+    const bool live = mt < M;
+    float4 wv[3];
+    auto load_slab = [&](int t) { // t = 8 pp + ss: W_in[192 pp .. 192 pp + 191][16 ss ..]
+        const int pp = t >> 3, ss = t & 7;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int idx = tid + i * 256;
+            const float *p = a.Win + (size_t)(NR * pp + (idx >> 2)) * D + ss * BK + (idx & 3) * 4;
+            wv[i] = make_float4(p[0], p[1], p[2], p[3]);
+        }
+    };
+    auto store_slab = [&](float *S) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int idx = tid + i * 256;
+            const int r = idx >> 2, c = idx & 3;
+            *reinterpret_cast<float4 *>(S + r * BK + ((c ^ lin_swz<BK>(r)) << 2)) = wv[i];
+        }
+    };
+    load_slab(0);
+    // ---- embed: this lane's token, columns 32tn + 8g + 4lk + e (same arithmetic as k_embed_frag)
+    f32x16 acc[4];
+    {
+        const int orig = live ? (a.tok_row ? a.tok_row[mt] : mt) : 0;
+        int64_t id = live ? a.seq[orig] : 0;
+        if (id < 0) id = 0;
+        if (id > a.n_item) id = a.n_item;
+        const float *e = a.E + id * (int64_t)D;
+        const float *p = a.pe + (int64_t)(orig % a.L) * D;
+        float4 *xo = reinterpret_cast<float4 *>(a.Xf) + (size_t)mtile * 16 * 64 + lane;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = tn * 32 + 8 * g + 4 * lk;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live) {
+                    const float4 ev = *reinterpret_cast<const float4 *>(e + n), pv = *reinterpret_cast<const float4 *>(p + n);
+                    v = make_float4(__fadd_rn(__fmul_rn(ev.x, a.sqrtd), pv.x), __fadd_rn(__fmul_rn(ev.y, a.sqrtd), pv.y),
+                                    __fadd_rn(__fmul_rn(ev.z, a.sqrtd), pv.z), __fadd_rn(__fmul_rn(ev.w, a.sqrtd), pv.w));
+                }
+                xo[(tn * 4 + g) * 64] = v;
+                acc[tn][4 * g + 0] = v.x, acc[tn][4 * g + 1] = v.y, acc[tn][4 * g + 2] = v.z, acc[tn][4 * g + 3] = v.w;
+            }
+    }
+    store_slab(sm);
+    __syncthreads();
+    const int sw = lin_swz<BK>(li);
+    int cur = 0;
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        f32x16 qa[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qa[i][r] = 0.f;
+#pragma unroll
+        for (int ss = 0; ss < 8; ++ss) {
+            const int t = pp * 8 + ss;
+            if (t + 1 < 16) load_slab(t + 1);
+            const float *wa = sm + cur * NR * BK + li * BK;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int off = ((2 * q + lk) ^ sw) << 2;
+                const int tn = ss >> 1, g = 2 * (ss & 1) + q;
+                float4 w[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) w[i] = *reinterpret_cast<const float4 *>(wa + i * 32 * BK + off);
+#define EQ_STEP(E_, R)                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                             \
+        qa[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i].E_, acc[tn][4 * g + R], qa[i], 0, 0, 0);
+                EQ_STEP(x, 0) EQ_STEP(y, 1) EQ_STEP(z, 2) EQ_STEP(w, 3)
+#undef EQ_STEP
+            }
+            if (t + 1 < 16) store_slab(sm + (cur ^ 1) * NR * BK);
+            __syncthreads();
+            cur ^= 1;
+        }
+        if (live) {
+            float *qrow = a.QKV + (int64_t)mt * (3 * D) + pp * NR + 4 * lk;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bb = *reinterpret_cast<const float4 *>(vb + pp * NR + i * 32 + 8 * g + 4 * lk);
+                    *reinterpret_cast<float4 *>(qrow + i * 32 + 8 * g) =
+                        make_float4(qa[i][4 * g + 0] + bb.x, qa[i][4 * g + 1] + bb.y, qa[i][4 * g + 2] + bb.z, qa[i][4 * g + 3] + bb.w);
+                }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ small-M linear (latency path, few sequences)
 // With a few hundred rows the 128x128 tiling uses 2-6 workgroups of the 256 CUs.  Here one WAVE
 // owns one 32x32 output tile and loads its operands straight from L2 into MFMA-fragment registers
@@ -2504,7 +2625,15 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         qrow = ctx->seq_qrow;
         m_dev = ctx->m_dev;
     }
-    if (frag)
+    bool qkv0_done = false;
+    if (frag && d == 128 && ctx->dims.n_layers > 1) { // embed + layer 0's QKV in one kernel
+        EmbedQkvArgs ea{seq, ctx->item_emb, ctx->pe, tok, m_dev, rows, L, sqrtf((float)d), ctx->dims.n_item, xf,
+                        ctx->layer[0].sa_in_w, ctx->layer[0].sa_in_b, ctx->act_qkv};
+        irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
+        hipLaunchKernelGGL(k_embed_qkv, dim3((rows + 127) / 128), dim3(256), 0, s, ea);
+        irs_prof_end(ctx, IRS_PROF_LINEAR, s, 6.0 * rows * (double)d * d, 4.0 * 4.0 * rows * (double)d);
+        qkv0_done = true;
+    } else if (frag)
         hipLaunchKernelGGL(k_embed_frag, dim3((rows + 127) / 128), dim3(256), 0, s, seq, ctx->item_emb, ctx->pe, xf, tok, m_dev,
                            rows, L, d, sqrtf((float)d), ctx->dims.n_item);
     else if (rows_only)
@@ -2515,7 +2644,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                            sqrtf((float)d), ctx->dims.n_item);
     IRS_CHECK_HIP(ctx, hipGetLastError());
     if (r_u_out) IRS_CHECK_HIP(ctx, hipMemcpyAsync(r_u_out, ctx->act_ru, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
-    bool qkv_done = false, q_split = false;
+    bool qkv_done = qkv0_done, q_split = false;
     for (int l = 0; l < ctx->dims.n_layers; ++l) {
         const irs_layer_w &w = ctx->layer[l];
         const bool last_rows = rows_only && (l + 1 == ctx->dims.n_layers);
