@@ -324,9 +324,13 @@ def main():
         lat = None
         if not args.no_latency and world == 1:
             # path-gen p50: one user, 20 greedy steps, hipGraph-replayed step
-            s1 = job.seqs[:1].clone()
-            u1 = job.users[:1].clone()
-            h1 = job.hep[:1].clone()
+            # the user whose window holds the median number of items of this workload (a window's length sets the
+            # decoder's row count, i.e. the latency)
+            nvalid = (job.seqs != 0).sum(dim=1)
+            iu = int(torch.argsort(nvalid)[nvalid.numel() // 2].item())
+            s1 = job.seqs[iu:iu + 1].clone()
+            u1 = job.users[iu:iu + 1].clone()
+            h1 = job.hep[iu:iu + 1].clone()
             p1 = torch.zeros((1, 20), dtype=torch.float32, device=device)
             st1 = torch.zeros(1, dtype=torch.int32, device=device)
             ts = []
