@@ -478,8 +478,8 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : 2) k_linear(LinArgs a) {
             // 64 output addresses are formed here, not hoisted out of the pipeline loop into live registers.
             int mrow = m0 + wr * 64 + 4 * lk;
             asm volatile("" : "+v"(mrow));
-            const bool interior = (m0 + LIN_BM <= M) && (n0 + LIN_BN <= N) && a.R == nullptr;
-            if (interior) { // workgroup-uniform: no per-element masks, no loads -> 64 back-to-back stores
+            const bool interior = (m0 + LIN_BM <= M) && (n0 + LIN_BN <= N);
+            if (interior && a.R == nullptr) { // workgroup-uniform: no per-element masks, no loads -> 64 back-to-back stores
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) {
                     const int n = n0 + wc * 64 + tn * 32 + li;
@@ -494,6 +494,28 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : 2) k_linear(LinArgs a) {
                             v = a.relu ? fmaxf(v, 0.f) : v;
                             yp[(int64_t)dm * N] = v;
                             acc[tm][tn][r] = 0.f;
+                        }
+                }
+            } else if (interior) { // residual: 8 loads in flight, then 8 stores (not a load-wait-store chain per element)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    const int n = n0 + wc * 64 + tn * 32 + li;
+                    const float bv = a.bias ? a.bias[n] : 0.f;
+                    const int64_t col = (int64_t)mrow * N + n;
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int r0 = 0; r0 < 16; r0 += 8) {
+                            float rv[8];
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) rv[r] = a.R[col + (int64_t)(tm * 32 + ((r0 + r) & 3) + 8 * ((r0 + r) >> 2)) * N];
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) {
+                                float v = acc[tm][tn][r0 + r] + bv;
+                                v = a.relu ? fmaxf(v, 0.f) : v;
+                                a.Y[col + (int64_t)(tm * 32 + ((r0 + r) & 3) + 8 * ((r0 + r) >> 2)) * N] = v + rv[r];
+                                acc[tm][tn][r0 + r] = 0.f;
+                            }
                         }
                 }
             } else {
