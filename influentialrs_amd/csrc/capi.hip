@@ -443,7 +443,7 @@ extern "C" int irs_path_step(irs_ctx *ctx, int64_t *seq, int32_t *hep, int32_t B
 
 // one search step on one device: decode -> rows at hep -> top-k -> choose/update
 static bool step_merged(const irs_ctx *ctx, int B) { // see irs_launch_decode: the single-workgroup plan kernel runs
-    return B <= 64 && ctx->dims.d <= 128 && ctx->dims.max_len >= 4;
+    return B <= 64 && ctx->dims.max_len >= 4;
 }
 
 static int enqueue_step(irs_ctx *ctx, int64_t *seq, const int64_t *user, int32_t *hep, int B, int k, int sweep,

@@ -2399,10 +2399,10 @@ __global__ void __launch_bounds__(64) k_attn_row(const float *__restrict__ qkv, 
 __global__ void __launch_bounds__(256) k_ln(const float *__restrict__ z, const float *__restrict__ g1,
                                             const float *__restrict__ b1, const float *__restrict__ c,
                                             const float *__restrict__ g2, const float *__restrict__ b2,
-                                            float *__restrict__ y, int rows, int d) {
+                                            float *__restrict__ y, int rows, int d, const int32_t *__restrict__ m_dev) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
-    if (row >= rows) return;
+    if (row >= rows || (m_dev && row >= m_dev[0])) return;
     const float *zr = z + (int64_t)row * d;
     float v[8];
     float s = 0.f;
@@ -2615,7 +2615,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     const int rows = B * L;
     int rc;
     // rows-only decode of a few sequences: the plan kernel also computes r_u (and hands the step counter over)
-    const bool small_plan = (x_out == nullptr) && pos && xrows && d <= LIN_BN && L >= 4 && B <= 64;
+    const bool small_plan = (x_out == nullptr) && pos && xrows && L >= 4 && B <= 64;
     if (ctx->step_pair && !small_plan) IRS_FAIL(ctx, IRS_E_STATE, "merged path step needs the single-workgroup plan kernel");
     if (!small_plan && (rc = irs_launch_pif(ctx, user, B, ctx->act_ru, s)) != IRS_OK) return rc;
     float *x = ctx->act_x, *y = ctx->act_y;
@@ -2623,7 +2623,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     // non-pad tokens (k_plan), every kernel clamping its row count to the device-side total, and (2) the
     // LAST layer is evaluated for the one consumed row per sequence (all earlier layers need every valid
     // row: they feed the next layer's keys and values).
-    const bool rows_only = (x_out == nullptr) && pos && xrows && d <= LIN_BN && L >= 4;
+    const bool rows_only = (x_out == nullptr) && pos && xrows && L >= 4;
     const int32_t *off = nullptr, *cnt = nullptr, *tok = nullptr, *qrow = nullptr, *m_dev = nullptr;
     // throughput shapes keep x / y ONLY in the fragment-major layout between the layers (see frag_index): the
     // LN-fused GEMMs write it, read their residual from it, and the QKV / FFN1 GEMMs load it as their X operand
@@ -2703,12 +2703,21 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                 if (B <= 512) hipLaunchKernelGGL(k_block_small16, dim3((B + 15) / 16), dim3(256), 0, s, sb);
                 else hipLaunchKernelGGL(k_block_small, dim3((B + 31) / 32), dim3(256), 0, s, sb);
                 irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * B * ((double)d * d + 2.0 * d * F), 4.0 * 3.0 * B * (double)d);
-            } else {
+            } else if (d <= LIN_BN) {
                 if ((rc = launch_linear(ctx, ao_r, w.sa_out_w, w.sa_out_b, x_r, y_r, B, d, d, false, s, w.n1_w, w.n1_b, cl, w.n2_w,
                                         w.n2_b)))
                     return rc;
                 if ((rc = launch_linear(ctx, y_r, w.l1_w, w.l1_b, nullptr, h_r, B, F, d, true, s))) return rc;
                 if ((rc = launch_linear(ctx, h_r, w.l2_w, w.l2_b, y_r, xrows, B, d, F, false, s, w.n3_w, w.n3_b))) return rc;
+            } else { // wider than the LN-fused GEMMs: residual GEMM, then LayerNorm, on the B rows
+                float *z_r = ctx->act_ao + (size_t)3 * B * d;
+                if ((rc = launch_linear(ctx, ao_r, w.sa_out_w, w.sa_out_b, x_r, z_r, B, d, d, false, s))) return rc;
+                hipLaunchKernelGGL(k_ln, dim3((B + 3) / 4), dim3(256), 0, s, z_r, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, y_r, B, d,
+                                   (const int32_t *)nullptr);
+                if ((rc = launch_linear(ctx, y_r, w.l1_w, w.l1_b, nullptr, h_r, B, F, d, true, s))) return rc;
+                if ((rc = launch_linear(ctx, h_r, w.l2_w, w.l2_b, y_r, z_r, B, d, F, false, s))) return rc;
+                hipLaunchKernelGGL(k_ln, dim3((B + 3) / 4), dim3(256), 0, s, z_r, w.n3_w, w.n3_b, (const float *)nullptr,
+                                   (const float *)nullptr, (const float *)nullptr, xrows, B, d, (const int32_t *)nullptr);
             }
             IRS_CHECK_HIP(ctx, hipGetLastError());
             return IRS_OK;
@@ -2791,15 +2800,21 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                                     nullptr, nullptr, nullptr, nullptr, m_dev)))
                 return rc;
         } else {
-            // y = x + ao W_o^T + b_o ; x = LN2(LN1(y) + c_l)
-            if ((rc = launch_linear(ctx, ctx->act_ao, w.sa_out_w, w.sa_out_b, x, y, rows, d, d, false, s))) return rc;
+            // y = x + ao W_o^T + b_o ; x = LN2(LN1(y) + c_l)          (packed rows: every kernel clamps to m_dev)
+            if ((rc = launch_linear(ctx, ctx->act_ao, w.sa_out_w, w.sa_out_b, x, y, rows, d, d, false, s, nullptr, nullptr, nullptr,
+                                    nullptr, nullptr, nullptr, nullptr, m_dev)))
+                return rc;
             hipLaunchKernelGGL(k_ln, dim3((rows + 3) / 4), dim3(256), 0, s, y, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, x,
-                               rows, d);
+                               rows, d, m_dev);
             // h = relu(x W1^T + b1); y = x + h W2^T + b2; x = LN3(y)
-            if ((rc = launch_linear(ctx, x, w.l1_w, w.l1_b, nullptr, ctx->act_h, rows, F, d, true, s))) return rc;
-            if ((rc = launch_linear(ctx, ctx->act_h, w.l2_w, w.l2_b, x, y, rows, d, F, false, s))) return rc;
+            if ((rc = launch_linear(ctx, x, w.l1_w, w.l1_b, nullptr, ctx->act_h, rows, F, d, true, s, nullptr, nullptr, nullptr,
+                                    nullptr, nullptr, nullptr, nullptr, m_dev)))
+                return rc;
+            if ((rc = launch_linear(ctx, ctx->act_h, w.l2_w, w.l2_b, x, y, rows, d, F, false, s, nullptr, nullptr, nullptr, nullptr,
+                                    nullptr, nullptr, nullptr, m_dev)))
+                return rc;
             hipLaunchKernelGGL(k_ln, dim3((rows + 3) / 4), dim3(256), 0, s, y, w.n3_w, w.n3_b, (const float *)nullptr,
-                               (const float *)nullptr, (const float *)nullptr, x, rows, d);
+                               (const float *)nullptr, (const float *)nullptr, x, rows, d, m_dev);
         }
         IRS_CHECK_HIP(ctx, hipGetLastError());
     }

@@ -185,14 +185,15 @@ def test_sampled_paths_distribution():
 
 
 @pytest.mark.parametrize("cfgname,B,over", [("c2", 24, {}), ("default", 80, {}), ("c1", 72, {}),
-                                             ("c2", 16, {"max_len": 256}), ("c2", 24, {"ffn_dim": 128})])
+                                             ("c2", 16, {"max_len": 256}), ("c2", 24, {"ffn_dim": 128}),
+                                             ("c2", 16, {"emb_dim": 256, "n_heads": 8})])
 def test_throughput_shape_decode_matches_small_batches_and_oracle(oracle, cfgname, B, over):
     """More than 2048 token rows per call switches the decoder to its throughput kernels (128-row MFMA tiles,
     activations kept fragment-major between the layers, packed rows when only x[b, pos[b]] is wanted).  The
     same sequences decoded eight at a time go through the small-batch kernels the goldens pin; both, and the
     numpy oracle on a few sequences, must agree to float32 accumulation noise.  The cases walk the kernel
     selection: c2 = fused layer kernel + 16-query attention; default (d = 30) = row-major GEMMs; c1 (d = 64, head
-    dim 16) fragment-major GEMMs with the 32-query attention; L = 256 = the 16-tile limit of the 16-query attention; ffn 128 = fragment-major, unfused FFN."""
+    dim 16) fragment-major GEMMs with the 32-query attention; L = 256 = the 16-tile limit of the 16-query attention; ffn 128 = fragment-major, unfused FFN; d = 256 (C4's decoder) = separate LayerNorm kernels on packed rows."""
     cfg = synth.make_config(cfgname, **over)
     L = cfg.max_len
     assert B * L > 2048
@@ -225,7 +226,9 @@ def test_throughput_shape_decode_matches_small_batches_and_oracle(oracle, cfgnam
         got = x_big[b].cpu().numpy()
         ok = np.isfinite(ref) & np.isfinite(got)
         assert np.array_equal(np.isnan(ref), np.isnan(got))
-        assert np.abs(ref - got)[ok].max() < X_TOL
+        # vs the numpy oracle the accumulation-order noise grows with the contraction length: 2e-5 up to d = 128,
+        # 4e-5 at d = 256 (the north star's bar is 1e-3 relative)
+        assert np.abs(ref - got)[ok].max() < X_TOL * (2.0 if cfg.emb_dim > 128 else 1.0)
 
 
 def test_bench_scale_batch_duplicates_are_bit_identical_and_match_small_batches():
