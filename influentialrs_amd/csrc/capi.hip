@@ -166,7 +166,7 @@ static int check_bound(irs_ctx *ctx) {
     return IRS_OK;
 }
 
-static size_t derived_plan(const irs_ctx *ctx, size_t *o_wp, size_t *o_bias, size_t *o_cl, size_t *o_wn) {
+static size_t derived_plan(const irs_ctx *ctx, size_t *o_wp, size_t *o_bias, size_t *o_cl, size_t *o_wn, size_t *o_wf) {
     size_t off = 0;
     *o_wp = off;
     off = align_up(off + (size_t)ctx->n_tiles * ctx->KS * 1024, 256);
@@ -176,20 +176,22 @@ static size_t derived_plan(const irs_ctx *ctx, size_t *o_wp, size_t *o_bias, siz
     off = align_up(off + (size_t)ctx->dims.n_layers * ctx->dims.d * sizeof(float), 256);
     *o_wn = off;
     off = align_up(off + 256, 256);
+    *o_wf = off;
+    off = align_up(off + irs_small_frag_floats(ctx) * sizeof(float), 256);
     return off;
 }
 
 extern "C" size_t irs_derived_bytes(const irs_ctx *ctx) {
-    size_t a, b, c, d;
-    return ctx ? derived_plan(ctx, &a, &b, &c, &d) : 0;
+    size_t a, b, c, d, e;
+    return ctx ? derived_plan(ctx, &a, &b, &c, &d, &e) : 0;
 }
 
 extern "C" int irs_finalize_weights(irs_ctx *ctx, void *arena, size_t bytes, void *stream) {
     if (!ctx || !arena) return IRS_E_INVALID;
     int rc = check_bound(ctx);
     if (rc) return rc;
-    size_t o_wp, o_bias, o_cl, o_wn;
-    size_t need = derived_plan(ctx, &o_wp, &o_bias, &o_cl, &o_wn);
+    size_t o_wp, o_bias, o_cl, o_wn, o_wf;
+    size_t need = derived_plan(ctx, &o_wp, &o_bias, &o_cl, &o_wn, &o_wf);
     if (bytes < need) IRS_FAIL(ctx, IRS_E_INVALID, "derived arena too small: %zu < %zu", bytes, need);
     if (((uintptr_t)arena) & 255) IRS_FAIL(ctx, IRS_E_INVALID, "derived arena must be 256-byte aligned");
     char *base = (char *)arena;
@@ -197,9 +199,11 @@ extern "C" int irs_finalize_weights(irs_ctx *ctx, void *arena, size_t bytes, voi
     ctx->bias_pad = (float *)(base + o_bias);
     ctx->c_l = (float *)(base + o_cl);
     ctx->wnorm_max = (float *)(base + o_wn);
+    ctx->w_frag16 = irs_small_frag_floats(ctx) ? (float *)(base + o_wf) : nullptr;
     hipStream_t s = (hipStream_t)stream;
     if ((rc = irs_launch_pack_w(ctx, s))) return rc;
     if ((rc = irs_launch_cross_const(ctx, s))) return rc;
+    if ((rc = irs_launch_pack_small(ctx, s))) return rc;
     ctx->finalized = true;
     if (ctx->graph_exec) {
         hipGraphExecDestroy(ctx->graph_exec);

@@ -1506,7 +1506,26 @@ struct SmallBlockArgs {
     int M;
     const int32_t *m_dev;
     const int32_t *xidx;      // optional: residual row of token m is X[xidx[m]] (last layer: the consumed rows)
+    const float *Wf, *Wfin;   // fragment-packed copies (k_pack_frag16) of {Wo, W1, W2} of this layer and of Win
 };
+
+// Weights of the 16-token latency kernel, re-ordered so that every wave load instruction of an MFMA A fragment reads
+// 1 KB of consecutive addresses: out[(((nt * K/64 + r) * 4 + j) * 64 + lane) * 4 + e] = W[16 nt + lq][64 r + 16 j + 4 gq + e],
+// lane = 16 gq + lq.  A lone workgroup fetches row-major fragments (16 rows x 64 B per instruction) at ~30 GB/s and
+// packed ones at ~59 GB/s (tools/small_lab.hip), and that fetch is what bounds the kernel.
+#define SMALL_WF_WO 0
+#define SMALL_WF_W1 16384
+#define SMALL_WF_W2 49152
+#define SMALL_WF_LAYER 81920 // floats per layer of {Wo, W1, W2}
+#define SMALL_WF_WIN 49152   // floats per layer of Win
+__global__ void k_pack_frag16(const float *__restrict__ W, float *__restrict__ out, int N, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x; // one float4 of the packed image
+    if (i >= N * K / 4) return;
+    const int lane = i & 63, j = (i >> 6) & 3, rr = i >> 8;
+    const int r = rr % (K / 64), nt = rr / (K / 64);
+    const int lq = lane & 15, gq = lane >> 4;
+    reinterpret_cast<float4 *>(out)[i] = *reinterpret_cast<const float4 *>(W + (size_t)(16 * nt + lq) * K + 64 * r + 16 * j + 4 * gq);
+}
 
 __global__ void __launch_bounds__(256) k_block_small(SmallBlockArgs a) {
     constexpr int D = 128, F = 256, LDA = D + 4, LDH = F + 4;
@@ -1674,6 +1693,13 @@ __global__ void __launch_bounds__(256) k_block_small(SmallBlockArgs a) {
 // (~130 packed rows) twice as many workgroups run side by side and every wave's dependent MFMA work halves
 // (512 MFMAs of 32 cycles; 2-6 independent 16-column tiles per wave and GEMM).  lane = (token lq, k-slot gq):
 // B value x[token][16j + 4gq + e], A value W[n0 + lq][16j + 4gq + e], C register r <-> column n0 + 4gq + r.
+#ifdef IRS_SMALL_TIMING
+__device__ unsigned long long g_small_t[16];
+#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_small_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i)
+#endif
+template <bool QKV>
 __global__ void __launch_bounds__(256) k_block_small16(SmallBlockArgs a) {
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     constexpr int D = 128, F = 256, LDA = D + 4, LDH = F + 4;
@@ -1681,12 +1707,61 @@ __global__ void __launch_bounds__(256) k_block_small16(SmallBlockArgs a) {
     __shared__ __attribute__((aligned(16))) float bufH[16 * LDH]; // h
     __shared__ float part[2][4][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    STAMP(0);
     const int lq = lane & 15, gq = lane >> 4;
+    // One ROUND = 64 k of NT independent 16-column tiles: A values W[n0 + 16t + lq][64r + 16j + 4gq + e] come
+    // straight from L2 (fragment-packed copies, see k_pack_frag16), B values from the LDS tile.  At this size nothing but the kernel's own instruction stream
+    // can hide the L2 round trip, so the rounds of the four GEMMs form one software pipeline: round i+1's weight
+    // fragments (they do not depend on the activations) are requested before round i's MFMAs, across the LayerNorm
+    // epilogues and barriers as well.  ~11 workgroups are resident in this regime and every kernel starts with cold
+    // caches (a weight fragment takes ~1 us to arrive), so the look-ahead is as deep as the register file allows:
+    // up to 16 tile-rounds (256 registers) in flight, the first 12 requested before anything else happens.
+    float4 wo[2][2][4], w1[2][4][4], w2[4][2][4], wq[2][6][4];
+#define W_LOAD(wf, NT, W, n0_, K, r)                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                                  \
+        const float *wfr = (W) + ((((n0_) / 16 + t) * ((K) / 64) + (r)) * 4) * 256 + lane * 4;                        \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) wf[t][j] = *reinterpret_cast<const float4 *>(wfr + 256 * j);    \
+    }                                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+#define MMA_ROUND(acc, wf, NT, B, ldb, r)                                                                             \
+    {                                                                                                                 \
+        float4 bf[4];                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
+            bf[j] = *reinterpret_cast<const float4 *>((B) + lq * (ldb) + 4 * gq + 64 * (r) + 16 * j);                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int t = 0; t < NT; ++t) {                \
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][j].x, bf[j].x, acc[t], 0, 0, 0);                      \
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][j].y, bf[j].y, acc[t], 0, 0, 0);                      \
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][j].z, bf[j].z, acc[t], 0, 0, 0);                      \
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][j].w, bf[j].w, acc[t], 0, 0, 0);                      \
+        }                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    }
+    // the per-column vectors ride the same pipeline: requested a phase ahead, never on the critical path
+#define V_LOAD(v, NT, p, n0_)                                                                                         \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                    \
+    {                                                                                                                 \
+        const float4 ld_ = *reinterpret_cast<const float4 *>(((p) ? (p) : a.g3) + (n0_) + 16 * t + 4 * gq);          \
+        v[t] = (p) ? ld_ : make_float4(0.f, 0.f, 0.f, 0.f);                                                           \
+    }
+    const float4 zero2[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    float4 vbo[2], vg1[2], vb1n[2], vc[2], vg2[2], vb2n[2], vb1[4], vb2[2], vg3[2], vb3n[2], vbin[6];
+    W_LOAD(wo[0], 2, a.Wf + SMALL_WF_WO, wave * 32, D, 0);
+    W_LOAD(wo[1], 2, a.Wf + SMALL_WF_WO, wave * 32, D, 1);
     const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M;
     const int m0 = blockIdx.x * 16;
-    if (m0 >= M) return;
     const int mt = m0 + lq; // this lane's token
     const bool live = mt < M;
+    const int xrow = (live && a.xidx) ? a.xidx[mt] : mt;
+    W_LOAD(w1[0], 4, a.Wf + SMALL_WF_W1, wave * 64, D, 0);
+    W_LOAD(w1[1], 4, a.Wf + SMALL_WF_W1, wave * 64, D, 1);
+    V_LOAD(vbo, 2, a.bo, wave * 32);
+    V_LOAD(vg1, 2, a.g1, wave * 32);
+    V_LOAD(vb1n, 2, a.b1n, wave * 32);
+    V_LOAD(vc, 2, a.c, wave * 32);
+    V_LOAD(vg2, 2, a.g2, wave * 32);
+    V_LOAD(vb2n, 2, a.b2n, wave * 32);
+    __builtin_amdgcn_sched_barrier(0);
+    if (m0 >= M) return;
     for (int i = tid; i < 16 * (D / 4); i += 256) {
         const int rr = i / (D / 4), c4 = i % (D / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1694,28 +1769,6 @@ __global__ void __launch_bounds__(256) k_block_small16(SmallBlockArgs a) {
         *reinterpret_cast<float4 *>(bufA + rr * LDA + 4 * c4) = v;
     }
     __syncthreads();
-    // acc[t] += W[n0 + 16t + lq][0 .. K) . B[token][0 .. K): NT independent 16-column tiles share every B fragment
-    auto gemm = [&](f32x4 *acc, int NT, const float *W, int n0, int K, const float *B, int ldb) {
-        const float *brow = B + lq * ldb + 4 * gq;
-        for (int j0 = 0; j0 < K / 16; j0 += 4) { // 4 x 16 k per round
-            float4 bf[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const float4 *>(brow + 16 * (j0 + j));
-            for (int t = 0; t < NT; ++t) {
-                const float *wrow = W + (int64_t)(n0 + 16 * t + lq) * K + 4 * gq + 16 * j0;
-                float4 wf[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const float4 *>(wrow + 16 * j);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j].x, bf[j].x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j].y, bf[j].y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j].z, bf[j].z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j].w, bf[j].w, acc[t], 0, 0, 0);
-                }
-            }
-        }
-    };
     auto row_total = [&](float v, int slot) { // sum over the 128 columns of each token (4 waves x 4 k-slot lanes)
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
@@ -1728,7 +1781,7 @@ __global__ void __launch_bounds__(256) k_block_small16(SmallBlockArgs a) {
     const float invn = 1.0f / (float)D;
     const int n0 = wave * 32; // this wave's 32 columns of a 128-wide output = tiles n0, n0 + 16
     // z[t][r] = column n0 + 16t + 4gq + r of this lane's token
-    auto layer_norm = [&](float (&z)[2][4], const float *g, const float *b, const float *add) {
+    auto layer_norm = [&](float (&z)[2][4], const float4 (&g)[2], const float4 (&b)[2], const float4 (&add)[2]) {
         float s1 = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -1744,16 +1797,15 @@ __global__ void __launch_bounds__(256) k_block_small16(SmallBlockArgs a) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + 16 * t + 4 * gq + r;
-                z[t][r] = (z[t][r] - mu) * rstd * g[n] + b[n] + (add ? add[n] : 0.f);
-            }
+            for (int r = 0; r < 4; ++r)
+                z[t][r] = (z[t][r] - mu) * rstd * (&g[t].x)[r] + (&b[t].x)[r] + (&add[t].x)[r];
     };
     auto to_lds2 = [&](const float (&z)[2][4], float *buf, int ld) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
             *reinterpret_cast<float4 *>(buf + lq * ld + n0 + 16 * t + 4 * gq) = make_float4(z[t][0], z[t][1], z[t][2], z[t][3]);
     };
+    STAMP(1);
     float z[2][4];
     // ---- y = LN2(LN1(x + ao W_o^T + b_o) + c)
     {
@@ -1761,67 +1813,100 @@ __global__ void __launch_bounds__(256) k_block_small16(SmallBlockArgs a) {
         float4 res[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-            res[t] = live ? *reinterpret_cast<const float4 *>(a.X + (int64_t)(a.xidx ? a.xidx[mt] : mt) * D + n0 + 16 * t + 4 * gq)
+            res[t] = live ? *reinterpret_cast<const float4 *>(a.X + (int64_t)xrow * D + n0 + 16 * t + 4 * gq)
                           : make_float4(0.f, 0.f, 0.f, 0.f);
-        gemm(acc, 2, a.Wo, n0, D, bufA, LDA);
+        V_LOAD(vb1, 4, a.b1, wave * 64);
+        MMA_ROUND(acc, wo[0], 2, bufA, LDA, 0);
+        W_LOAD(w2[0], 2, a.Wf + SMALL_WF_W2, n0, F, 0);
+        MMA_ROUND(acc, wo[1], 2, bufA, LDA, 1);
+        W_LOAD(w2[1], 2, a.Wf + SMALL_WF_W2, n0, F, 1);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int n = n0 + 16 * t + 4 * gq;
-            z[t][0] = acc[t][0] + (a.bo ? a.bo[n + 0] : 0.f) + res[t].x;
-            z[t][1] = acc[t][1] + (a.bo ? a.bo[n + 1] : 0.f) + res[t].y;
-            z[t][2] = acc[t][2] + (a.bo ? a.bo[n + 2] : 0.f) + res[t].z;
-            z[t][3] = acc[t][3] + (a.bo ? a.bo[n + 3] : 0.f) + res[t].w;
+            z[t][0] = acc[t][0] + vbo[t].x + res[t].x;
+            z[t][1] = acc[t][1] + vbo[t].y + res[t].y;
+            z[t][2] = acc[t][2] + vbo[t].z + res[t].z;
+            z[t][3] = acc[t][3] + vbo[t].w + res[t].w;
         }
     }
-    layer_norm(z, a.g1, a.b1n, a.c);
-    if (a.c) layer_norm(z, a.g2, a.b2n, nullptr);
+    STAMP(2);
+    layer_norm(z, vg1, vb1n, vc);
+    if (a.c) layer_norm(z, vg2, vb2n, zero2);
+    STAMP(3);
     to_lds2(z, bufA, LDA); // every wave is past its last read of the ao tile (row_total's barriers)
     __syncthreads();
+    STAMP(4);
     // ---- h = relu(y W1^T + b1): this wave's 64 columns (4 tiles) -> LDS
     {
         f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        gemm(acc, 4, a.W1, wave * 64, D, bufA, LDA);
+        V_LOAD(vb2, 2, a.b2, n0);
+        V_LOAD(vg3, 2, a.g3, n0);
+        V_LOAD(vb3n, 2, a.b3n, n0);
+        MMA_ROUND(acc, w1[0], 4, bufA, LDA, 0);
+        W_LOAD(w2[2], 2, a.Wf + SMALL_WF_W2, n0, F, 2);
+        W_LOAD(w2[3], 2, a.Wf + SMALL_WF_W2, n0, F, 3);
+        MMA_ROUND(acc, w1[1], 4, bufA, LDA, 1);
+        if constexpr (QKV) { // unconditional in the instantiation: a branch here would force vmcnt(0) at the merge
+            V_LOAD(vbin, 6, a.bin, wave * 96);
+            W_LOAD(wq[0], 6, a.Wfin, wave * 96, D, 0);
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n = wave * 64 + 16 * t + 4 * gq;
             *reinterpret_cast<float4 *>(bufH + lq * LDH + n) =
-                make_float4(fmaxf(acc[t][0] + a.b1[n + 0], 0.f), fmaxf(acc[t][1] + a.b1[n + 1], 0.f),
-                            fmaxf(acc[t][2] + a.b1[n + 2], 0.f), fmaxf(acc[t][3] + a.b1[n + 3], 0.f));
+                make_float4(fmaxf(acc[t][0] + vb1[t].x, 0.f), fmaxf(acc[t][1] + vb1[t].y, 0.f),
+                            fmaxf(acc[t][2] + vb1[t].z, 0.f), fmaxf(acc[t][3] + vb1[t].w, 0.f));
         }
     }
     __syncthreads();
+    STAMP(5);
     // ---- x' = LN3(y + h W2^T + b2)
     {
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        gemm(acc, 2, a.W2, n0, F, bufH, LDH);
+        STAMP(9);
+        MMA_ROUND(acc, w2[0], 2, bufH, LDH, 0);
+        STAMP(10);
+        MMA_ROUND(acc, w2[1], 2, bufH, LDH, 1);
+        STAMP(11);
+        if constexpr (QKV) { W_LOAD(wq[1], 6, a.Wfin, wave * 96, D, 1); }
+        STAMP(12);
+        MMA_ROUND(acc, w2[2], 2, bufH, LDH, 2);
+        STAMP(13);
+        MMA_ROUND(acc, w2[3], 2, bufH, LDH, 3);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z[t][r] = acc[t][r] + a.b2[n0 + 16 * t + 4 * gq + r] + z[t][r];
+            for (int r = 0; r < 4; ++r) z[t][r] = acc[t][r] + (&vb2[t].x)[r] + z[t][r];
     }
-    layer_norm(z, a.g3, a.b3n, nullptr);
+    STAMP(6);
+    layer_norm(z, vg3, vb3n, zero2);
+    STAMP(7);
     if (live) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
             *reinterpret_cast<float4 *>(a.Xo + (int64_t)mt * D + n0 + 16 * t + 4 * gq) = make_float4(z[t][0], z[t][1], z[t][2], z[t][3]);
     }
-    if (!a.Win) return;
+    if constexpr (!QKV) return;
     // ---- qkv' = x' W_in^T + b_in: this wave's 96 columns (6 tiles)
     to_lds2(z, bufA, LDA);
     __syncthreads();
     {
         f32x4 acc[6] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f},
                         {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        gemm(acc, 6, a.Win, wave * 96, D, bufA, LDA);
+        MMA_ROUND(acc, wq[0], 6, bufA, LDA, 0);
+        MMA_ROUND(acc, wq[1], 6, bufA, LDA, 1);
         if (live) {
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
                 const int n = wave * 96 + 16 * t + 4 * gq;
                 *reinterpret_cast<float4 *>(a.QKV + (int64_t)mt * (3 * D) + n) =
-                    make_float4(acc[t][0] + a.bin[n], acc[t][1] + a.bin[n + 1], acc[t][2] + a.bin[n + 2], acc[t][3] + a.bin[n + 3]);
+                    make_float4(acc[t][0] + vbin[t].x, acc[t][1] + vbin[t].y, acc[t][2] + vbin[t].z, acc[t][3] + vbin[t].w);
             }
         }
     }
+    STAMP(8);
+#undef W_LOAD
+#undef V_LOAD
+#undef MMA_ROUND
 }
 
 // ------------------------------------------------------------------ attention on fp32 MFMA
@@ -2609,6 +2694,27 @@ int irs_launch_cross_const(irs_ctx *ctx, hipStream_t s) {
     return IRS_OK;
 }
 
+// fragment-packed weight copies for k_block_small16: [n_layers][Wo | W1 | W2] then [n_layers][Win]
+size_t irs_small_frag_floats(const irs_ctx *ctx) {
+    if (ctx->dims.d != 128 || ctx->dims.ffn_dim != 256) return 0;
+    return (size_t)ctx->dims.n_layers * (SMALL_WF_LAYER + SMALL_WF_WIN);
+}
+
+int irs_launch_pack_small(irs_ctx *ctx, hipStream_t s) {
+    if (!ctx->w_frag16) return IRS_OK;
+    const int nl = ctx->dims.n_layers;
+    for (int l = 0; l < nl; ++l) {
+        const irs_layer_w &w = ctx->layer[l];
+        float *o = ctx->w_frag16 + (size_t)l * SMALL_WF_LAYER;
+        hipLaunchKernelGGL(k_pack_frag16, dim3(16), dim3(256), 0, s, w.sa_out_w, o + SMALL_WF_WO, 128, 128);
+        hipLaunchKernelGGL(k_pack_frag16, dim3(32), dim3(256), 0, s, w.l1_w, o + SMALL_WF_W1, 256, 128);
+        hipLaunchKernelGGL(k_pack_frag16, dim3(32), dim3(256), 0, s, w.l2_w, o + SMALL_WF_W2, 128, 256);
+        hipLaunchKernelGGL(k_pack_frag16, dim3(48), dim3(256), 0, s, w.sa_in_w, ctx->w_frag16 + (size_t)nl * SMALL_WF_LAYER + (size_t)l * SMALL_WF_WIN, 384, 128);
+    }
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}
+
 int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int B, float *x_out, const int32_t *pos,
                       float *xrows, float *r_u_out, hipStream_t s) {
     const int L = ctx->dims.max_len, d = ctx->dims.d, F = ctx->dims.ffn_dim;
@@ -2698,9 +2804,13 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             else if (!frag && !idx_res) hipLaunchKernelGGL(k_gather_rows_idx, dim3(B), dim3(64), 0, s, x, qrow, x_r, d);
             if (fused_tail) { // one launch for the rest of the layer on the B consumed rows
                 SmallBlockArgs sb{ao_r, idx_res ? x : x_r, w.sa_out_w, w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, w.l1_w, w.l1_b, w.l2_w, w.l2_b,
-                                  w.n3_w, w.n3_b, xrows, nullptr, nullptr, nullptr, B, nullptr, idx_res ? qrow : nullptr};
+                                  w.n3_w, w.n3_b, xrows, nullptr, nullptr, nullptr, B, nullptr, idx_res ? qrow : nullptr,
+                                  ctx->w_frag16 + (size_t)l * SMALL_WF_LAYER, nullptr};
                 irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
-                if (B <= 512) hipLaunchKernelGGL(k_block_small16, dim3((B + 15) / 16), dim3(256), 0, s, sb);
+                if (B <= 512) {
+                    if (sb.Win) hipLaunchKernelGGL((k_block_small16<true>), dim3((B + 15) / 16), dim3(256), 0, s, sb);
+                    else hipLaunchKernelGGL((k_block_small16<false>), dim3((B + 15) / 16), dim3(256), 0, s, sb);
+                }
                 else hipLaunchKernelGGL(k_block_small, dim3((B + 31) / 32), dim3(256), 0, s, sb);
                 irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * B * ((double)d * d + 2.0 * d * F), 4.0 * 3.0 * B * (double)d);
             } else if (d <= LIN_BN) {
@@ -2777,9 +2887,14 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             const bool last = l + 1 == ctx->dims.n_layers;
             SmallBlockArgs sb{ctx->act_ao, x, w.sa_out_w, w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, w.l1_w, w.l1_b, w.l2_w, w.l2_b,
                               w.n3_w, w.n3_b, y, last ? nullptr : ctx->layer[l + 1].sa_in_w, last ? nullptr : ctx->layer[l + 1].sa_in_b,
-                              ctx->act_qkv, rows, m_dev};
+                              ctx->act_qkv, rows, m_dev, nullptr, ctx->w_frag16 ? ctx->w_frag16 + (size_t)l * SMALL_WF_LAYER : nullptr,
+                              (last || !ctx->w_frag16) ? nullptr
+                                                       : ctx->w_frag16 + (size_t)ctx->dims.n_layers * SMALL_WF_LAYER + (size_t)(l + 1) * SMALL_WF_WIN};
             irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
-            if (rows <= 512) hipLaunchKernelGGL(k_block_small16, dim3((rows + 15) / 16), dim3(256), 0, s, sb);
+            if (rows <= 512) {
+                if (sb.Win) hipLaunchKernelGGL((k_block_small16<true>), dim3((rows + 15) / 16), dim3(256), 0, s, sb);
+                else hipLaunchKernelGGL((k_block_small16<false>), dim3((rows + 15) / 16), dim3(256), 0, s, sb);
+            }
             else hipLaunchKernelGGL(k_block_small, dim3((rows + 31) / 32), dim3(256), 0, s, sb);
             irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * rows * ((double)d * d + 2.0 * d * F + (last ? 0.0 : 3.0 * d * d)),
                          4.0 * (3.0 + (last ? 0.0 : 3.0)) * rows * (double)d);

@@ -48,6 +48,7 @@ struct irs_ctx {
     float *bias_pad;  // [n_tiles*32], -inf beyond n_local
     float *c_l;       // [n_layers][d] cross-attention constants
     float *wnorm_max; // [1] max_j ||W_j||_2
+    float *w_frag16;  // fragment-packed layer weights of the 16-token latency kernel (d = 128, F = 256), or null
     bool finalized;
 
     // workspace (device, caller-owned)
@@ -130,6 +131,8 @@ int irs_launch_pif(irs_ctx *ctx, const int64_t *user, int B, float *r_u, hipStre
 int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int B, float *x_out, const int32_t *pos,
                       float *xrows, float *r_u_out, hipStream_t s);
 int irs_launch_cross_const(irs_ctx *ctx, hipStream_t s);
+size_t irs_small_frag_floats(const irs_ctx *ctx);
+int irs_launch_pack_small(irs_ctx *ctx, hipStream_t s);
 
 // ---- score.hip ----
 int irs_launch_pack_w(irs_ctx *ctx, hipStream_t s);
