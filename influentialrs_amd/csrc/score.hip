@@ -871,97 +871,190 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
 // Streams every item through the exact chain; keeps the best k by (score desc, id asc).
 #define EXH_BUF 2048
 // Small shard x few rows (the single-user latency path on an ml-1m-sized catalog): the five-kernel filter pipeline
-// costs ~50 us of launches for ~2 us of work.  Here the workgroups of a row each score 256 items with the exact
-// chain (one item per thread) into a global key array; the LAST workgroup of the row to finish (arrival counter)
-// radix-selects the k-th largest key and sorts the survivors: one launch, same total order, same bits.
+// costs ~50 us of launches for ~2 us of work.  Here a workgroup scores 64 items of a row with the exact chain into a
+// global key array; the LAST workgroup of the row to finish (arrival counter) selects the k-th largest key and sorts
+// the survivors: one launch, same total order, same bits.  Every launch starts with cold caches and a lone CU fetches
+// ~30-60 GB/s, so the work is spread thin (64 items = 32 KB of W per CU, staged into LDS with fully coalesced loads by
+// all four waves; wave 0 then runs one item per lane) and the selection avoids LDS atomics on a handful of hot radix
+// bins: the keys of the row sit in registers (16 per thread) and the threshold is found bit by bit with ballots.
 #define DIRECT_MAX_ITEMS 4096 // keys of a row live in the candidate array ([M_pad][IRS_CAND_CAP] u64)
+#define DIRECT_TILE 64
+#define DIRECT_MAX_D 256
+#ifdef IRS_DIRECT_TIMING
+__device__ unsigned long long g_direct_t[16];
+#define DSTAMP(i) do { if (threadIdx.x == 0) tstamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DSTAMP(i)
+#endif
 __global__ void __launch_bounds__(256) k_topk_direct(const float *__restrict__ x, int d, const float *__restrict__ W,
                                                      const float *__restrict__ bias, int n_local, int64_t item_lo, int k,
                                                      unsigned long long *__restrict__ gkeys, unsigned int *__restrict__ arrive,
                                                      float *__restrict__ val, int64_t *__restrict__ ids,
                                                      int32_t *__restrict__ status) {
-    __shared__ unsigned long long keys[DIRECT_MAX_ITEMS];
-    __shared__ unsigned long long rkeys[IRS_REFINE_CAP];
-    __shared__ unsigned int hist[256];
-    __shared__ float xs[256];
-    __shared__ unsigned int s_prefix, s_k, s_nr, s_last;
-    const int row = blockIdx.y, tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float tile[DIRECT_TILE * (DIRECT_MAX_D + 4)]; // W tile, later the key array
+    __shared__ __attribute__((aligned(16))) unsigned long long rkeys[IRS_REFINE_CAP + 2];
+    __shared__ __attribute__((aligned(16))) float xs[DIRECT_MAX_D];
+    __shared__ __attribute__((aligned(16))) unsigned long long tmax[256];
+    __shared__ unsigned int wsum[4];
+    __shared__ unsigned int s_last, s_thr;
+    const int row = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef IRS_DIRECT_TIMING
+    unsigned long long tstamp[10];
+#endif
+    DSTAMP(0);
+    const int S = (d & 7) ? d : d + 4; // row stride = 4 mod 8 floats: conflict-free ds_read_b128 of one row per lane
+    const int j0 = blockIdx.x * DIRECT_TILE;
+    const int nj = min(DIRECT_TILE, n_local - j0);
+    const int d4 = d >> 2;
+    for (int i = tid; i < nj * d4; i += 256) { // the tile is nj * d consecutive floats of W
+        const int jj = i / d4, c4 = i - jj * d4;
+        *reinterpret_cast<float4 *>(tile + jj * S + 4 * c4) = reinterpret_cast<const float4 *>(W + (size_t)j0 * d)[i];
+    }
     for (int i = tid; i < d; i += 256) xs[i] = x[(size_t)row * d + i];
     __syncthreads();
-    unsigned long long *gk = gkeys + (size_t)row * IRS_CAND_CAP;
-    {
-        const int j = blockIdx.x * 256 + tid;
-        if (j < n_local) {
-            const float e = irs_chain(xs, W + (size_t)j * d, bias[j], d);
-            gk[j] = ((unsigned long long)irs_fkey(e) << 32) | (0xFFFFFFFFu - (unsigned int)j);
+    DSTAMP(1);
+    // the row's score keys (32 bits per item, the item id is the position): 16 KB for the last workgroup to fetch
+    unsigned int *gk = reinterpret_cast<unsigned int *>(gkeys + (size_t)row * IRS_CAND_CAP);
+    if (wave == 0 && lane < nj) {
+        float acc = bias[j0 + lane];
+        const float4 *w4 = reinterpret_cast<const float4 *>(tile + lane * S);
+        const float4 *x4 = reinterpret_cast<const float4 *>(xs);
+        for (int c = 0; c < d4; ++c) { // the k-ascending fma chain of irs_chain
+            const float4 wv = w4[c], xv = x4[c];
+            acc = __fmaf_rn(xv.x, wv.x, acc);
+            acc = __fmaf_rn(xv.y, wv.y, acc);
+            acc = __fmaf_rn(xv.z, wv.z, acc);
+            acc = __fmaf_rn(xv.w, wv.w, acc);
         }
+        gk[j0 + lane] = irs_fkey(acc);
     }
-    __threadfence();
+    DSTAMP(2);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the keys reach memory before the arrival is counted
     __syncthreads();
+    DSTAMP(3);
     if (tid == 0) s_last = (atomicAdd(&arrive[row], 1u) == gridDim.x - 1) ? 1u : 0u;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // and are read from memory, not from a stale L2 line
+    DSTAMP(4);
     if (tid == 0) {
         arrive[row] = 0u; // ready for the next call (graph replays included)
-        s_prefix = 0;
-        s_k = k;
-        s_nr = 0;
         status[row] = 0;
     }
-    for (int i = tid; i < n_local; i += 256) keys[i] = __builtin_nontemporal_load(gk + i);
+    constexpr int KPT = DIRECT_MAX_ITEMS / 256;
+    unsigned long long key[KPT]; // this thread's items: 1024 q + 4 tid + e, key = (score key, ~id); 0 where there is none
+#pragma unroll
+    for (int q = 0; q < KPT / 4; ++q) {
+        const int j = q * 1024 + 4 * tid;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (j < n_local) v = *reinterpret_cast<const uint4 *>(gk + j);
+        key[4 * q + 0] = (j + 0 < n_local) ? ((unsigned long long)v.x << 32) | (0xFFFFFFFFu - (unsigned int)(j + 0)) : 0ull;
+        key[4 * q + 1] = (j + 1 < n_local) ? ((unsigned long long)v.y << 32) | (0xFFFFFFFFu - (unsigned int)(j + 1)) : 0ull;
+        key[4 * q + 2] = (j + 2 < n_local) ? ((unsigned long long)v.z << 32) | (0xFFFFFFFFu - (unsigned int)(j + 2)) : 0ull;
+        key[4 * q + 3] = (j + 3 < n_local) ? ((unsigned long long)v.w << 32) | (0xFFFFFFFFu - (unsigned int)(j + 3)) : 0ull;
+    }
+    // A lower bound T <= (k-th largest score key) that keeps barely more than k keys, without a search: take each
+    // thread's largest key; the k-th largest of those 256 maxima has at least k keys at or above it, and since a
+    // thread's keys are an arbitrary 1/256 sample only ~1.1 k of the row's keys pass it.  The k-th largest maximum is
+    // found by rank counting (keys are unique: the item id is part of them).
+    unsigned int thr = 0u;
+    DSTAMP(5);
+    if (n_local >= 4 * k) { // thread t holds items 4t .. 4t+3 (+1024 q): then at least k threads hold a key (k <= 256);
+                            // smaller rows (< 4k <= 1024 keys) keep every key and sort them all
+        unsigned long long mx = 0ull;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) mx = key[i] > mx ? key[i] : mx;
+        tmax[tid] = mx;
+        __syncthreads();
+        int above = 0;
+        const ulonglong2 *t2 = reinterpret_cast<const ulonglong2 *>(tmax);
+#pragma unroll 8
+        for (int i = 0; i < 128; ++i) {
+            const ulonglong2 v = t2[i];
+            above += (v.x > mx) + (v.y > mx);
+        }
+        if (above == k - 1) s_thr = (unsigned int)(mx >> 32);
+        __syncthreads();
+        thr = s_thr;
+    } else
+        __syncthreads();
+    DSTAMP(6);
+    // survivors (ties at the threshold included) -> rkeys at slots from an exclusive scan of the per-thread counts
+    int mine = 0;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) mine += (key[i] != 0ull && (unsigned int)(key[i] >> 32) >= thr) ? 1 : 0;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    unsigned long long thr = 0ull; // keep keys whose score key >= the k-th largest score key (ties included)
-    if (n_local > k) {
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            hist[tid] = 0;
-            __syncthreads();
-            const unsigned int prefix = s_prefix;
-            for (int i = tid; i < n_local; i += 256) {
-                const unsigned int key = (unsigned int)(keys[i] >> 32);
-                const bool match = (pass == 0) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
-                if (match) atomicAdd(&hist[(key >> shift) & 255], 1u);
+    unsigned int slot = incl - mine;
+    for (int w = 0; w < wave; ++w) slot += wsum[w];
+    unsigned int nr = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    DSTAMP(7);
+    if (nr <= IRS_REFINE_CAP) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i)
+            if (key[i] != 0ull && (unsigned int)(key[i] >> 32) >= thr) rkeys[slot++] = key[i];
+        if ((nr & 1) && tid == 0) rkeys[nr] = 0ull; // the rank loop below reads pairs
+        __syncthreads();
+    }
+    if (nr <= 256) {
+        // the usual case (~1.1 k survivors): rank by counting, write the winners straight out -- no sort stages
+        DSTAMP(8);
+        if (tid < (int)nr) {
+            const unsigned long long me = rkeys[tid];
+            int above = 0;
+            const ulonglong2 *r2 = reinterpret_cast<const ulonglong2 *>(rkeys);
+            for (int i = 0; i < (int)(nr + 1) / 2; ++i) {
+                const ulonglong2 v = r2[i];
+                above += (v.x > me) + (v.y > me);
             }
-            __syncthreads();
-            if (tid < 64) radix_find_bin(hist, s_k, tid, shift, &s_prefix, &s_k);
-            __syncthreads();
+            if (above < k) {
+                val[(size_t)row * k + above] = irs_unkey((unsigned int)(me >> 32));
+                ids[(size_t)row * k + above] = item_lo + (int64_t)(0xFFFFFFFFu - (unsigned int)me);
+            }
         }
-        thr = (unsigned long long)s_prefix << 32;
-    }
-    for (int i = tid; i < n_local; i += 256) {
-        if (keys[i] >= thr) {
-            const unsigned int slot = atomicAdd(&s_nr, 1u);
-            if (slot < IRS_REFINE_CAP) rkeys[slot] = keys[i];
-        }
-    }
-    __syncthreads();
-    unsigned int nr = s_nr;
-    const unsigned long long *sorted = rkeys;
-    if (nr > IRS_REFINE_CAP) { // > 1024 - k exact ties at the boundary: sort the whole key array (it is all in LDS)
-        int n2 = 2;
-        while (n2 < n_local) n2 <<= 1;
-        for (int i = n_local + tid; i < n2; i += 256) keys[i] = 0ull;
-        bitonic_desc(keys, n2);
-        sorted = keys;
-        nr = (unsigned int)n_local;
-    } else {
-        int n2 = 2;
-        while (n2 < (int)nr) n2 <<= 1;
-        for (int i = nr + tid; i < n2; i += 256) rkeys[i] = 0ull;
-        bitonic_desc(rkeys, n2);
-    }
-    for (int i = tid; i < k; i += 256) {
-        if (i < (int)nr) {
-            const unsigned long long kk = sorted[i];
-            val[(size_t)row * k + i] = irs_unkey((unsigned int)(kk >> 32));
-            ids[(size_t)row * k + i] = item_lo + (int64_t)(0xFFFFFFFFu - (unsigned int)kk);
-        } else {
+        for (int i = (int)nr + tid; i < k; i += 256) {
             val[(size_t)row * k + i] = -INFINITY;
             ids[(size_t)row * k + i] = -1;
         }
+    } else {
+        const unsigned long long *sorted = rkeys;
+        if (nr > IRS_REFINE_CAP) { // > 1024 - k exact ties at the boundary: sort the whole key array in LDS (the W tile is dead)
+            unsigned long long *keys = reinterpret_cast<unsigned long long *>(tile);
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) keys[i * 256 + tid] = key[i]; // all DIRECT_MAX_ITEMS slots, empty ones = 0
+            bitonic_desc(keys, DIRECT_MAX_ITEMS);
+            sorted = keys;
+            nr = (unsigned int)n_local;
+        } else {
+            int n2 = 2;
+            while (n2 < (int)nr) n2 <<= 1;
+            for (int i = nr + tid; i < n2; i += 256) rkeys[i] = 0ull;
+            bitonic_desc(rkeys, n2);
+        }
+        DSTAMP(8);
+        for (int i = tid; i < k; i += 256) {
+            if (i < (int)nr) {
+                const unsigned long long kk = sorted[i];
+                val[(size_t)row * k + i] = irs_unkey((unsigned int)(kk >> 32));
+                ids[(size_t)row * k + i] = item_lo + (int64_t)(0xFFFFFFFFu - (unsigned int)kk);
+            } else {
+                val[(size_t)row * k + i] = -INFINITY;
+                ids[(size_t)row * k + i] = -1;
+            }
+        }
     }
     if (tid == 0 && (int)nr < k) status[row] |= IRS_ROW_FEWER_THAN_K;
+#ifdef IRS_DIRECT_TIMING
+    DSTAMP(9);
+    if (tid == 0)
+        for (int i = 0; i < 10; ++i) g_direct_t[i] = tstamp[i];
+#endif
 }
 
 __global__ void __launch_bounds__(256) k_exhaustive(const float *__restrict__ x, int d, const float *__restrict__ W,
@@ -1194,9 +1287,10 @@ int irs_launch_pack_w(irs_ctx *ctx, hipStream_t s) {
 
 int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, float *val, int64_t *ids0,
                     int32_t *status, hipStream_t s) {
-    if (M <= 32 && ctx->n_local <= DIRECT_MAX_ITEMS && k <= 512) { // latency path on a small shard: one kernel, no fallback needed
+    if (M <= 32 && ctx->n_local <= DIRECT_MAX_ITEMS && k <= 256 && (ctx->dims.d & 3) == 0 && ctx->dims.d <= DIRECT_MAX_D) {
+        // latency path on a small shard: one kernel, no fallback needed
         irs_prof_begin(ctx, IRS_PROF_REFINE, s);
-        hipLaunchKernelGGL(k_topk_direct, dim3((unsigned)((ctx->n_local + 255) / 256), M), dim3(256), 0, s, xrows, ctx->dims.d,
+        hipLaunchKernelGGL(k_topk_direct, dim3((unsigned)((ctx->n_local + DIRECT_TILE - 1) / DIRECT_TILE), M), dim3(256), 0, s, xrows, ctx->dims.d,
                            ctx->proj_w, ctx->proj_b, (int)ctx->n_local, ctx->shard.item_lo, k, ctx->cand,
                            reinterpret_cast<unsigned int *>(ctx->step_ctr) + 8, val, ids0, status);
         irs_prof_end(ctx, IRS_PROF_REFINE, s, 2.0 * ctx->dims.d * (double)M * (double)ctx->n_local, 0.0);

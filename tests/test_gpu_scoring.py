@@ -79,6 +79,51 @@ def test_topk_ties_and_fallback(oracle):
             assert np.array_equal(val[m].cpu().numpy().view(np.uint32), ov.view(np.uint32))
 
 
+DIRECT_CASES = [  # the one-launch small-shard path (M <= 32, n_item <= 4096, k <= 256, d % 4 == 0)
+    (3415, 128, 1, 100),    # the single-user step
+    (3415, 128, 8, 100),
+    (4096, 64, 32, 256),    # every limit at once
+    (1000, 32, 4, 100),     # sampled threshold with few keys per thread
+    (400, 16, 3, 100),      # exactly 4k: the smallest row that takes the sampled threshold
+    (399, 16, 3, 100),      # below it: every key kept, bitonic sort of 399
+    (130, 8, 2, 1),         # k = 1
+]
+
+
+@pytest.mark.parametrize("n_item,d,M,k", DIRECT_CASES)
+def test_topk_direct_path(oracle, n_item, d, M, k):
+    W, b = _weights(n_item, d, 11)
+    x = _rows(M, d, 12)
+    eng = scoring_only_engine(n_item, d, W, b, max_rows=M, max_k=k)
+    for rep in range(2):  # twice: the arrival counters must be left ready for the next call
+        val, ids, st = eng.score_topk(torch.from_numpy(x).cuda(), k, IRS_SWEEP_BF16)
+        torch.cuda.synchronize()
+        val, ids, st = val.cpu().numpy(), ids.cpu().numpy(), st.cpu().numpy()
+        assert (st == 0).all()
+        for m in range(M):
+            ov, oi = oracle.topk(oracle.score_chain(x[m], W, b), k)
+            assert np.array_equal(ids[m], oi), f"row {m}: ids differ"
+            assert np.array_equal(val[m].view(np.uint32), ov.view(np.uint32)), f"row {m}: values differ"
+
+
+@pytest.mark.parametrize("n_distinct", [7, 40])
+def test_topk_direct_path_ties(oracle, n_distinct):
+    """Duplicate item rows on the small-shard path: with 7 distinct rows the ties at the threshold overflow the
+    survivor buffer (full sort of the row's keys), with 40 they do not; the order stays (score desc, id asc)."""
+    n_item, d, M, k = 3000, 32, 4, 100
+    W, b = _weights(n_item, d, 3)
+    W[:] = W[:n_distinct][np.arange(n_item) % n_distinct]
+    b[:] = 0.25
+    x = _rows(M, d, 4)
+    eng = scoring_only_engine(n_item, d, W, b, max_rows=M)
+    val, ids, st = eng.score_topk(torch.from_numpy(x).cuda(), k, IRS_SWEEP_BF16)
+    torch.cuda.synchronize()
+    for m in range(M):
+        ov, oi = oracle.topk(oracle.score_chain(x[m], W, b), k)
+        assert np.array_equal(ids[m].cpu().numpy(), oi)
+        assert np.array_equal(val[m].cpu().numpy().view(np.uint32), ov.view(np.uint32))
+
+
 @pytest.mark.parametrize("n_item,d,M", [(257, 16, 5), (3415, 30, 7), (3415, 128, 40), (40_000, 256, 3)])
 def test_dense_and_gather_bitwise(oracle, n_item, d, M):
     """fp32 MFMA sweep == VALU chain == oracle chain, bit for bit."""
