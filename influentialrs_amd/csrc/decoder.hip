@@ -2154,6 +2154,12 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
     const int ld = 3 * d;
     const bool irn = (mask_mode == IRS_MASK_IRN);
     const int L16 = (L + 15) & ~15, NB16 = L16 >> 4;
+    // gridDim.z > 1 (few sequences, the latency path): the query blocks of a (sequence, head) are dealt one per wave
+    // over 4 gridDim.z waves, largest first -- a wave's dependent chain is then one block instead of three, on
+    // three times as many CUs.  Workgroup z owns blocks NB16-1-4z .. NB16-4-4z; each stages the whole K / V of the
+    // (sequence, head) -- the loads of a fill are all in flight together, and the IRN target column needs key L-1.
+    const int zsplit = blockIdx.z;
+    if (gridDim.z > 1 && 4 * zsplit >= NB16) return;
     // K / V of this (sequence, head) -> LDS.  8 consecutive lanes take the 8 16-byte chunks of one key row, so a
     // load instruction covers 8 whole 128-byte K_h (V_h) slices -- in-kernel timing showed the ISSUE of these
     // loads, not their latency, dominating the fill when every lane touched a different row.  K's ds_write_b128
@@ -2178,7 +2184,10 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
     // (the assignment below and the first Q request run while the K / V rows are in flight)
     // longest-first assignment of the 16-query blocks (block qb costs qb + 1 key tiles) to the 4 waves
     unsigned int mine = 0;
-    {
+    if (gridDim.z > 1) {
+        const int v = 4 * zsplit + wave;
+        if (v < NB16) mine = 1u << (NB16 - 1 - v);
+    } else {
         int load[4] = {0, 0, 0, 0};
         for (int qb = NB16 - 1; qb >= 0; --qb) {
             int w = 0;
@@ -2649,6 +2658,7 @@ static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const
         int S16 = (L + 7) & ~7; // attn16_vstride
         if ((S16 & 15) != 8) S16 += 8;
         const size_t lds16 = (size_t)32 * S16 * 4 + (size_t)((L + 15) & ~15) * 32 * 4 + 64;
+        if (H * B <= 64) grid.z = (((L + 15) / 16) + 3) / 4; // latency path: one query block per wave
         hipLaunchKernelGGL(k_attn16<16>, grid, dim3(256), lds16, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
                            tok_row ? ctx->seq_padq : nullptr, frag_out ? 1 : 0);
         irs_prof_end(ctx, IRS_PROF_ATTN, s, 2.0 * B * (double)H * L * L * hd, 4.0 * 4.0 * B * (double)L * d);
