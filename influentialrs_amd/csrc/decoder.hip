@@ -1904,10 +1904,78 @@ __global__ void __launch_bounds__(256) k_block_small16(SmallBlockArgs a) {
         }
     }
     STAMP(8);
+}
+
+// Embedding + layer 0's in-projection of the latency path, 16 packed tokens per workgroup: x = E[seq] sqrt(d) + pe
+// goes to global memory (the residual of layer 0) and to LDS (the B operand); the in-projection runs on the
+// fragment-packed W_in of layer 0, all 12 tile-rounds of a wave requested before the embedding rows are.
+struct SmallEmbedArgs {
+    const int64_t *seq;
+    const float *E, *pe;
+    const int32_t *tok_row, *m_dev;
+    int rows, L;
+    float sqrtd;
+    int64_t n_item;
+    float *X;               // [rows][128]
+    const float *Wfin, *bin; // fragment-packed W_in of layer 0, its bias
+    float *QKV;             // [rows][384]
+};
+
+__global__ void __launch_bounds__(256) k_embed_qkv_small16(SmallEmbedArgs a) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    constexpr int D = 128, LDA = D + 4;
+    __shared__ __attribute__((aligned(16))) float bufA[16 * LDA];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 15, gq = lane >> 4;
+    float4 wq[2][6][4], vbin[6];
+    W_LOAD(wq[0], 6, a.Wfin, wave * 96, D, 0);
+    W_LOAD(wq[1], 6, a.Wfin, wave * 96, D, 1);
+#pragma unroll
+    for (int t = 0; t < 6; ++t) vbin[t] = *reinterpret_cast<const float4 *>(a.bin + wave * 96 + 16 * t + 4 * gq);
+    __builtin_amdgcn_sched_barrier(0);
+    const int M = a.m_dev ? min(a.rows, a.m_dev[0]) : a.rows;
+    const int m0 = blockIdx.x * 16;
+    if (m0 >= M) return;
+    {
+        const int rr = tid >> 4, c8 = tid & 15, row = m0 + rr;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (row < M) {
+            const int orig = a.tok_row ? a.tok_row[row] : row;
+            int64_t id = a.seq[orig];
+            if (id < 0) id = 0;
+            if (id > a.n_item) id = a.n_item;
+            const float *e = a.E + id * (int64_t)D + 8 * c8;
+            const float *pp = a.pe + (int64_t)(orig % a.L) * D + 8 * c8;
+            const float4 e0 = *reinterpret_cast<const float4 *>(e), e1 = *reinterpret_cast<const float4 *>(e + 4);
+            const float4 p0 = *reinterpret_cast<const float4 *>(pp), p1 = *reinterpret_cast<const float4 *>(pp + 4);
+            v0 = make_float4(__fadd_rn(__fmul_rn(e0.x, a.sqrtd), p0.x), __fadd_rn(__fmul_rn(e0.y, a.sqrtd), p0.y),
+                             __fadd_rn(__fmul_rn(e0.z, a.sqrtd), p0.z), __fadd_rn(__fmul_rn(e0.w, a.sqrtd), p0.w));
+            v1 = make_float4(__fadd_rn(__fmul_rn(e1.x, a.sqrtd), p1.x), __fadd_rn(__fmul_rn(e1.y, a.sqrtd), p1.y),
+                             __fadd_rn(__fmul_rn(e1.z, a.sqrtd), p1.z), __fadd_rn(__fmul_rn(e1.w, a.sqrtd), p1.w));
+            *reinterpret_cast<float4 *>(a.X + (int64_t)row * D + 8 * c8) = v0;
+            *reinterpret_cast<float4 *>(a.X + (int64_t)row * D + 8 * c8 + 4) = v1;
+        }
+        *reinterpret_cast<float4 *>(bufA + rr * LDA + 8 * c8) = v0;
+        *reinterpret_cast<float4 *>(bufA + rr * LDA + 8 * c8 + 4) = v1;
+    }
+    __syncthreads();
+    f32x4 acc[6] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f},
+                    {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    MMA_ROUND(acc, wq[0], 6, bufA, LDA, 0);
+    MMA_ROUND(acc, wq[1], 6, bufA, LDA, 1);
+    const int mt = m0 + lq;
+    if (mt < M) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int n = wave * 96 + 16 * t + 4 * gq;
+            *reinterpret_cast<float4 *>(a.QKV + (int64_t)mt * (3 * D) + n) =
+                make_float4(acc[t][0] + vbin[t].x, acc[t][1] + vbin[t].y, acc[t][2] + vbin[t].z, acc[t][3] + vbin[t].w);
+        }
+    }
+}
 #undef W_LOAD
 #undef V_LOAD
 #undef MMA_ROUND
-}
 
 // ------------------------------------------------------------------ attention on fp32 MFMA
 // One workgroup per (head, sequence), 4 waves; K_h / V_h of the sequence in LDS.
@@ -2878,7 +2946,15 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     } else if (frag)
         hipLaunchKernelGGL(k_embed_frag, dim3((rows + 127) / 128), dim3(256), 0, s, seq, ctx->item_emb, ctx->pe, xf, tok, m_dev,
                            rows, L, d, sqrtf((float)d), ctx->dims.n_item);
-    else if (rows_only)
+    else if (rows_only && d == 128 && F == 256 && rows <= 512 && ctx->w_frag16 && ctx->dims.n_layers > 1) {
+        // latency path (the k_block_small16 regime): embed + layer 0's QKV in one 16-token kernel
+        SmallEmbedArgs ea{seq, ctx->item_emb, ctx->pe, tok, m_dev, rows, L, sqrtf((float)d), ctx->dims.n_item, x,
+                          ctx->w_frag16 + (size_t)ctx->dims.n_layers * SMALL_WF_LAYER, ctx->layer[0].sa_in_b, ctx->act_qkv};
+        irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
+        hipLaunchKernelGGL(k_embed_qkv_small16, dim3((rows + 15) / 16), dim3(256), 0, s, ea);
+        irs_prof_end(ctx, IRS_PROF_LINEAR, s, 6.0 * rows * (double)d * d, 4.0 * 4.0 * rows * (double)d);
+        qkv0_done = true;
+    } else if (rows_only)
         hipLaunchKernelGGL(k_embed_packed, dim3((rows + 3) / 4), dim3(256), 0, s, seq, ctx->item_emb, ctx->pe, x, tok, m_dev,
                            L, d, sqrtf((float)d), ctx->dims.n_item);
     else
