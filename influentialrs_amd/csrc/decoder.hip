@@ -1699,13 +1699,15 @@ __device__ unsigned long long g_small_t[16];
 #else
 #define STAMP(i)
 #endif
+#define SB_NW 8 // waves per workgroup: two per SIMD, so that one wave's barrier / LDS / load waits hide behind the other's MFMAs
 template <bool QKV>
-__global__ void __launch_bounds__(256) k_block_small16(SmallBlockArgs a) {
+__global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) {
+    constexpr int T1 = 8 / SB_NW, T2 = 16 / SB_NW, T3 = 24 / SB_NW; // 16-column tiles per wave of a 128 / 256 / 384 wide output
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     constexpr int D = 128, F = 256, LDA = D + 4, LDH = F + 4;
     __shared__ __attribute__((aligned(16))) float bufA[16 * LDA]; // ao -> y -> x'
     __shared__ __attribute__((aligned(16))) float bufH[16 * LDH]; // h
-    __shared__ float part[2][4][16];
+    __shared__ float part[2][SB_NW][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     STAMP(0);
     const int lq = lane & 15, gq = lane >> 4;
@@ -1716,7 +1718,7 @@ __global__ void __launch_bounds__(256) k_block_small16(SmallBlockArgs a) {
     // epilogues and barriers as well.  ~11 workgroups are resident in this regime and every kernel starts with cold
     // caches (a weight fragment takes ~1 us to arrive), so the look-ahead is as deep as the register file allows:
     // up to 16 tile-rounds (256 registers) in flight, the first 12 requested before anything else happens.
-    float4 wo[2][2][4], w1[2][4][4], w2[4][2][4], wq[2][6][4];
+    float4 wo[2][T1][4], w1[2][T2][4], w2[4][T1][4], wq[2][T3][4];
 #define W_LOAD(wf, NT, W, n0_, K, r)                                                                                  \
     _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                                  \
         const float *wfr = (W) + ((((n0_) / 16 + t) * ((K) / 64) + (r)) * 4) * 256 + lane * 4;                        \
@@ -1743,85 +1745,100 @@ __global__ void __launch_bounds__(256) k_block_small16(SmallBlockArgs a) {
         const float4 ld_ = *reinterpret_cast<const float4 *>(((p) ? (p) : a.g3) + (n0_) + 16 * t + 4 * gq);          \
         v[t] = (p) ? ld_ : make_float4(0.f, 0.f, 0.f, 0.f);                                                           \
     }
-    const float4 zero2[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-    float4 vbo[2], vg1[2], vb1n[2], vc[2], vg2[2], vb2n[2], vb1[4], vb2[2], vg3[2], vb3n[2], vbin[6];
-    W_LOAD(wo[0], 2, a.Wf + SMALL_WF_WO, wave * 32, D, 0);
-    W_LOAD(wo[1], 2, a.Wf + SMALL_WF_WO, wave * 32, D, 1);
-    const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M;
+    float4 zero2[T1];
+#pragma unroll
+    for (int t = 0; t < T1; ++t) zero2[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 vbo[T1], vg1[T1], vb1n[T1], vc[T1], vg2[T1], vb2n[T1], vb1[T2], vb2[T1], vg3[T1], vb3n[T1], vbin[T3];
+    // A wave's loads return in order: the activation tile (and the residual row index) go first, clamped to the
+    // static row bound and masked once the device-side count is known, then the 6-12 tile-rounds of weights.
     const int m0 = blockIdx.x * 16;
     const int mt = m0 + lq; // this lane's token
+    constexpr int NAO = 16 * (D / 4) / (64 * SB_NW);
+    float4 aov[NAO];
+#pragma unroll
+    for (int u = 0; u < NAO; ++u) {
+        const int i = tid + u * 64 * SB_NW, rr = i / (D / 4), c4 = i % (D / 4);
+        aov[u] = *reinterpret_cast<const float4 *>(a.AO + (int64_t)min(m0 + rr, a.M - 1) * D + 4 * c4);
+    }
+    const int xrow = a.xidx ? a.xidx[min(mt, a.M - 1)] : mt;
+    __builtin_amdgcn_sched_barrier(0);
+    W_LOAD(wo[0], T1, a.Wf + SMALL_WF_WO, wave * 16 * T1, D, 0);
+    W_LOAD(wo[1], T1, a.Wf + SMALL_WF_WO, wave * 16 * T1, D, 1);
+    const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M;
     const bool live = mt < M;
-    const int xrow = (live && a.xidx) ? a.xidx[mt] : mt;
-    W_LOAD(w1[0], 4, a.Wf + SMALL_WF_W1, wave * 64, D, 0);
-    W_LOAD(w1[1], 4, a.Wf + SMALL_WF_W1, wave * 64, D, 1);
-    V_LOAD(vbo, 2, a.bo, wave * 32);
-    V_LOAD(vg1, 2, a.g1, wave * 32);
-    V_LOAD(vb1n, 2, a.b1n, wave * 32);
-    V_LOAD(vc, 2, a.c, wave * 32);
-    V_LOAD(vg2, 2, a.g2, wave * 32);
-    V_LOAD(vb2n, 2, a.b2n, wave * 32);
+    W_LOAD(w1[0], T2, a.Wf + SMALL_WF_W1, wave * 16 * T2, D, 0);
+    W_LOAD(w1[1], T2, a.Wf + SMALL_WF_W1, wave * 16 * T2, D, 1);
+    V_LOAD(vbo, T1, a.bo, wave * 16 * T1);
+    V_LOAD(vg1, T1, a.g1, wave * 16 * T1);
+    V_LOAD(vb1n, T1, a.b1n, wave * 16 * T1);
+    V_LOAD(vc, T1, a.c, wave * 16 * T1);
+    V_LOAD(vg2, T1, a.g2, wave * 16 * T1);
+    V_LOAD(vb2n, T1, a.b2n, wave * 16 * T1);
     __builtin_amdgcn_sched_barrier(0);
     if (m0 >= M) return;
-    for (int i = tid; i < 16 * (D / 4); i += 256) {
-        const int rr = i / (D / 4), c4 = i % (D / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m0 + rr < M) v = *reinterpret_cast<const float4 *>(a.AO + (int64_t)(m0 + rr) * D + 4 * c4);
-        *reinterpret_cast<float4 *>(bufA + rr * LDA + 4 * c4) = v;
+#pragma unroll
+    for (int u = 0; u < NAO; ++u) {
+        const int i = tid + u * 64 * SB_NW, rr = i / (D / 4), c4 = i % (D / 4);
+        *reinterpret_cast<float4 *>(bufA + rr * LDA + 4 * c4) = (m0 + rr < M) ? aov[u] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    auto row_total = [&](float v, int slot) { // sum over the 128 columns of each token (4 waves x 4 k-slot lanes)
+    auto row_total = [&](float v, int slot) { // sum over the 128 columns of each token (SB_NW waves x 4 k-slot lanes)
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
         if (gq == 0) part[slot][wave][lq] = v;
         __syncthreads();
-        const float t = part[slot][0][lq] + part[slot][1][lq] + part[slot][2][lq] + part[slot][3][lq];
-        __syncthreads();
-        return t;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < SB_NW; ++w) t += part[slot][w][lq];
+        return t; // no second barrier: the slots strictly alternate (mean 0, variance 1), so slot s is rewritten only
+                  // by waves that have passed the barrier of slot 1-s, which every wave reaches after this read
     };
     const float invn = 1.0f / (float)D;
-    const int n0 = wave * 32; // this wave's 32 columns of a 128-wide output = tiles n0, n0 + 16
+    const int n0 = wave * 16 * T1; // this wave's T1 tiles of a 128-wide output
     // z[t][r] = column n0 + 16t + 4gq + r of this lane's token
-    auto layer_norm = [&](float (&z)[2][4], const float4 (&g)[2], const float4 (&b)[2], const float4 (&add)[2]) {
+    auto layer_norm = [&](float (&z)[T1][4], const float4 (&g)[T1], const float4 (&b)[T1], const float4 (&add)[T1]) {
         float s1 = 0.f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < T1; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) s1 += z[t][r];
         const float mu = row_total(s1, 0) * invn;
         float q = 0.f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < T1; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) q += (z[t][r] - mu) * (z[t][r] - mu);
         const float rstd = 1.0f / sqrtf(row_total(q, 1) * invn + 1e-5f);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < T1; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 z[t][r] = (z[t][r] - mu) * rstd * (&g[t].x)[r] + (&b[t].x)[r] + (&add[t].x)[r];
     };
-    auto to_lds2 = [&](const float (&z)[2][4], float *buf, int ld) {
+    auto to_lds2 = [&](const float (&z)[T1][4], float *buf, int ld) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < T1; ++t)
             *reinterpret_cast<float4 *>(buf + lq * ld + n0 + 16 * t + 4 * gq) = make_float4(z[t][0], z[t][1], z[t][2], z[t][3]);
     };
     STAMP(1);
-    float z[2][4];
+    float z[T1][4];
     // ---- y = LN2(LN1(x + ao W_o^T + b_o) + c)
     {
-        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        float4 res[2];
+        f32x4 acc[T1];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < T1; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+        float4 res[T1];
+#pragma unroll
+        for (int t = 0; t < T1; ++t)
             res[t] = live ? *reinterpret_cast<const float4 *>(a.X + (int64_t)xrow * D + n0 + 16 * t + 4 * gq)
                           : make_float4(0.f, 0.f, 0.f, 0.f);
-        V_LOAD(vb1, 4, a.b1, wave * 64);
-        MMA_ROUND(acc, wo[0], 2, bufA, LDA, 0);
-        W_LOAD(w2[0], 2, a.Wf + SMALL_WF_W2, n0, F, 0);
-        MMA_ROUND(acc, wo[1], 2, bufA, LDA, 1);
-        W_LOAD(w2[1], 2, a.Wf + SMALL_WF_W2, n0, F, 1);
+        V_LOAD(vb1, T2, a.b1, wave * 16 * T2);
+        MMA_ROUND(acc, wo[0], T1, bufA, LDA, 0);
+        W_LOAD(w2[0], T1, a.Wf + SMALL_WF_W2, n0, F, 0);
+        MMA_ROUND(acc, wo[1], T1, bufA, LDA, 1);
+        W_LOAD(w2[1], T1, a.Wf + SMALL_WF_W2, n0, F, 1);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < T1; ++t) {
             z[t][0] = acc[t][0] + vbo[t].x + res[t].x;
             z[t][1] = acc[t][1] + vbo[t].y + res[t].y;
             z[t][2] = acc[t][2] + vbo[t].z + res[t].z;
@@ -1837,21 +1854,23 @@ __global__ void __launch_bounds__(256) k_block_small16(SmallBlockArgs a) {
     STAMP(4);
     // ---- h = relu(y W1^T + b1): this wave's 64 columns (4 tiles) -> LDS
     {
-        f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        V_LOAD(vb2, 2, a.b2, n0);
-        V_LOAD(vg3, 2, a.g3, n0);
-        V_LOAD(vb3n, 2, a.b3n, n0);
-        MMA_ROUND(acc, w1[0], 4, bufA, LDA, 0);
-        W_LOAD(w2[2], 2, a.Wf + SMALL_WF_W2, n0, F, 2);
-        W_LOAD(w2[3], 2, a.Wf + SMALL_WF_W2, n0, F, 3);
-        MMA_ROUND(acc, w1[1], 4, bufA, LDA, 1);
+        f32x4 acc[T2];
+#pragma unroll
+        for (int t = 0; t < T2; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+        V_LOAD(vb2, T1, a.b2, n0);
+        V_LOAD(vg3, T1, a.g3, n0);
+        V_LOAD(vb3n, T1, a.b3n, n0);
+        MMA_ROUND(acc, w1[0], T2, bufA, LDA, 0);
+        W_LOAD(w2[2], T1, a.Wf + SMALL_WF_W2, n0, F, 2);
+        W_LOAD(w2[3], T1, a.Wf + SMALL_WF_W2, n0, F, 3);
+        MMA_ROUND(acc, w1[1], T2, bufA, LDA, 1);
         if constexpr (QKV) { // unconditional in the instantiation: a branch here would force vmcnt(0) at the merge
-            V_LOAD(vbin, 6, a.bin, wave * 96);
-            W_LOAD(wq[0], 6, a.Wfin, wave * 96, D, 0);
+            V_LOAD(vbin, T3, a.bin, wave * 16 * T3);
+            W_LOAD(wq[0], T3, a.Wfin, wave * 16 * T3, D, 0);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int n = wave * 64 + 16 * t + 4 * gq;
+        for (int t = 0; t < T2; ++t) {
+            const int n = wave * 16 * T2 + 16 * t + 4 * gq;
             *reinterpret_cast<float4 *>(bufH + lq * LDH + n) =
                 make_float4(fmaxf(acc[t][0] + vb1[t].x, 0.f), fmaxf(acc[t][1] + vb1[t].y, 0.f),
                             fmaxf(acc[t][2] + vb1[t].z, 0.f), fmaxf(acc[t][3] + vb1[t].w, 0.f));
@@ -1861,19 +1880,21 @@ __global__ void __launch_bounds__(256) k_block_small16(SmallBlockArgs a) {
     STAMP(5);
     // ---- x' = LN3(y + h W2^T + b2)
     {
-        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        STAMP(9);
-        MMA_ROUND(acc, w2[0], 2, bufH, LDH, 0);
-        STAMP(10);
-        MMA_ROUND(acc, w2[1], 2, bufH, LDH, 1);
-        STAMP(11);
-        if constexpr (QKV) { W_LOAD(wq[1], 6, a.Wfin, wave * 96, D, 1); }
-        STAMP(12);
-        MMA_ROUND(acc, w2[2], 2, bufH, LDH, 2);
-        STAMP(13);
-        MMA_ROUND(acc, w2[3], 2, bufH, LDH, 3);
+        f32x4 acc[T1];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < T1; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+        STAMP(9);
+        MMA_ROUND(acc, w2[0], T1, bufH, LDH, 0);
+        STAMP(10);
+        MMA_ROUND(acc, w2[1], T1, bufH, LDH, 1);
+        STAMP(11);
+        if constexpr (QKV) { W_LOAD(wq[1], T3, a.Wfin, wave * 16 * T3, D, 1); }
+        STAMP(12);
+        MMA_ROUND(acc, w2[2], T1, bufH, LDH, 2);
+        STAMP(13);
+        MMA_ROUND(acc, w2[3], T1, bufH, LDH, 3);
+#pragma unroll
+        for (int t = 0; t < T1; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) z[t][r] = acc[t][r] + (&vb2[t].x)[r] + z[t][r];
     }
@@ -1882,7 +1903,7 @@ __global__ void __launch_bounds__(256) k_block_small16(SmallBlockArgs a) {
     STAMP(7);
     if (live) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < T1; ++t)
             *reinterpret_cast<float4 *>(a.Xo + (int64_t)mt * D + n0 + 16 * t + 4 * gq) = make_float4(z[t][0], z[t][1], z[t][2], z[t][3]);
     }
     if constexpr (!QKV) return;
@@ -1890,14 +1911,15 @@ __global__ void __launch_bounds__(256) k_block_small16(SmallBlockArgs a) {
     to_lds2(z, bufA, LDA);
     __syncthreads();
     {
-        f32x4 acc[6] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f},
-                        {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        MMA_ROUND(acc, wq[0], 6, bufA, LDA, 0);
-        MMA_ROUND(acc, wq[1], 6, bufA, LDA, 1);
+        f32x4 acc[T3];
+#pragma unroll
+        for (int t = 0; t < T3; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+        MMA_ROUND(acc, wq[0], T3, bufA, LDA, 0);
+        MMA_ROUND(acc, wq[1], T3, bufA, LDA, 1);
         if (live) {
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                const int n = wave * 96 + 16 * t + 4 * gq;
+            for (int t = 0; t < T3; ++t) {
+                const int n = wave * 16 * T3 + 16 * t + 4 * gq;
                 *reinterpret_cast<float4 *>(a.QKV + (int64_t)mt * (3 * D) + n) =
                     make_float4(acc[t][0] + vbin[t].x, acc[t][1] + vbin[t].y, acc[t][2] + vbin[t].z, acc[t][3] + vbin[t].w);
             }
@@ -3002,8 +3024,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                                   ctx->w_frag16 + (size_t)l * SMALL_WF_LAYER, nullptr};
                 irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
                 if (B <= 512) {
-                    if (sb.Win) hipLaunchKernelGGL((k_block_small16<true>), dim3((B + 15) / 16), dim3(256), 0, s, sb);
-                    else hipLaunchKernelGGL((k_block_small16<false>), dim3((B + 15) / 16), dim3(256), 0, s, sb);
+                    if (sb.Win) hipLaunchKernelGGL((k_block_small16<true>), dim3((B + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
+                    else hipLaunchKernelGGL((k_block_small16<false>), dim3((B + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
                 }
                 else hipLaunchKernelGGL(k_block_small, dim3((B + 31) / 32), dim3(256), 0, s, sb);
                 irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * B * ((double)d * d + 2.0 * d * F), 4.0 * 3.0 * B * (double)d);
@@ -3086,8 +3108,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                                                        : ctx->w_frag16 + (size_t)ctx->dims.n_layers * SMALL_WF_LAYER + (size_t)(l + 1) * SMALL_WF_WIN};
             irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
             if (rows <= 512) {
-                if (sb.Win) hipLaunchKernelGGL((k_block_small16<true>), dim3((rows + 15) / 16), dim3(256), 0, s, sb);
-                else hipLaunchKernelGGL((k_block_small16<false>), dim3((rows + 15) / 16), dim3(256), 0, s, sb);
+                if (sb.Win) hipLaunchKernelGGL((k_block_small16<true>), dim3((rows + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
+                else hipLaunchKernelGGL((k_block_small16<false>), dim3((rows + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
             }
             else hipLaunchKernelGGL(k_block_small, dim3((rows + 31) / 32), dim3(256), 0, s, sb);
             irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * rows * ((double)d * d + 2.0 * d * F + (last ? 0.0 : 3.0 * d * d)),

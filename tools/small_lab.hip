@@ -28,6 +28,25 @@ __global__ void __launch_bounds__(1024) k_wload(const float *W, float *out, int 
     }
     if (acc.x + acc.y + acc.z + acc.w == 12345.f) out[0] = acc.x;
 }
+
+// Is a launch's first touch of the weights slower than a second pass inside the same kernel (cold caches per launch)?
+__device__ unsigned long long g_pass_t[4];
+__global__ void __launch_bounds__(256) k_wload2(const float *W, float *out, int n_inst) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *base = W + (size_t)wave * n_inst * 256;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int pass = 0; pass < 3; ++pass) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_pass_t[pass] = __builtin_amdgcn_s_memtime();
+#pragma unroll 16
+        for (int i = 0; i < n_inst; ++i) {
+            const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)i * 256 + lane * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_pass_t[3] = __builtin_amdgcn_s_memtime();
+    if (acc.x + acc.y + acc.z + acc.w == 12345.f) out[0] = acc.x;
+}
 int main(int argc, char **argv) {
     int M = argc > 1 ? atoi(argv[1]) : 165;
     float *buf; CK(hipMalloc(&buf, (size_t)(M * 1024 + 400000) * 4));
@@ -49,7 +68,7 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0, 0));
-        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_block_small16<true>), dim3((M + 15) / 16), dim3(256), 0, 0, a);
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_block_small16<true>), dim3((M + 15) / 16), dim3(64 * SB_NW), 0, 0, a);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         unsigned long long t[16]; CK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_small_t), sizeof t));
@@ -91,6 +110,16 @@ int main(int argc, char **argv) {
                 best = ms < best ? ms : best;
             }
             printf("wload contiguous, 11 wgs x %d threads: %.2f us for 512 KB per workgroup\n", threads, best * 1e3);
+        }
+    }
+    {
+        float *big; CK(hipMalloc(&big, (size_t)64 << 20));
+        CK(hipMemset(big, 0, (size_t)64 << 20));
+        for (int rep = 0; rep < 3; ++rep) {
+            hipLaunchKernelGGL(k_wload2, dim3(11), dim3(256), 0, 0, big, buf, 128);
+            CK(hipDeviceSynchronize());
+            unsigned long long t[4]; CK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_pass_t), sizeof t));
+            printf("512 KB per workgroup, three passes inside one launch: %llu %llu %llu ticks\n", t[1] - t[0], t[2] - t[1], t[3] - t[2]);
         }
     }
     return 0;
