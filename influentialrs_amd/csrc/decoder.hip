@@ -1489,13 +1489,14 @@ __global__ void __launch_bounds__(256) k_linear_small(LinArgs a) {
 }
 
 // ------------------------------------------------------------------ small-batch fused layer tail (latency path, d = 128, F = 256)
-// With a few hundred rows a decoder layer is launch bound: out-proj+LN, FFN1, FFN2+LN and the next QKV are four
-// k_linear_small launches of ~10-15 us each for ~6 us of dependent work.  Here one workgroup (4 waves) owns 32 tokens
-// and runs the whole chain, the waves splitting the OUTPUT columns of every GEMM (out-proj 4 x 32, FFN1 4 x 64,
-// FFN2 4 x 32, QKV 4 x 96) in the transposed orientation (lane = token); the activation tiles pass from GEMM to GEMM
-// through LDS ([32 tokens][K + 4] floats: the +4 stride keeps the B-fragment ds_read_b128 conflict free), the
-// weights come straight from L2 into A-fragment registers, and the LayerNorm row statistics are combined across
-// the 4 waves through a small LDS scratch.  Same MFMA k order as the separate kernels.
+// With up to a few thousand rows a decoder layer is launch and latency bound: out-proj+LN, FFN1, FFN2+LN and the next
+// QKV as separate launches cost ~10-15 us each for ~6 us of dependent work, and the 128-token kernels of the
+// throughput path have a ~100 us floor per layer.  Here one workgroup owns 16 tokens and runs the whole chain on
+// v_mfma_f32_16x16x4_f32, the waves splitting the OUTPUT columns of every GEMM in the transposed orientation
+// (lane = (token lq, k-slot gq): B value x[token][16j + 4gq + e], A value W[n0 + lq][16j + 4gq + e], C register r <->
+// column n0 + 4gq + r); the activation tiles pass from GEMM to GEMM through LDS ([16 tokens][K + 4] floats: the +4
+// stride keeps the B-fragment ds_read_b128 conflict free), the weights come straight from L2 into A-fragment
+// registers, and the LayerNorm row statistics are combined across the waves through a small LDS scratch.
 struct SmallBlockArgs {
     const float *AO, *X;      // attention output, residual x: row-major [M][128]
     const float *Wo, *bo, *g1, *b1n, *c, *g2, *b2n;
@@ -1527,178 +1528,15 @@ __global__ void k_pack_frag16(const float *__restrict__ W, float *__restrict__ o
     reinterpret_cast<float4 *>(out)[i] = *reinterpret_cast<const float4 *>(W + (size_t)(16 * nt + lq) * K + 64 * r + 16 * j + 4 * gq);
 }
 
-__global__ void __launch_bounds__(256) k_block_small(SmallBlockArgs a) {
-    constexpr int D = 128, F = 256, LDA = D + 4, LDH = F + 4;
-    __shared__ __attribute__((aligned(16))) float bufA[32 * LDA]; // ao -> y -> x'
-    __shared__ __attribute__((aligned(16))) float bufH[32 * LDH]; // h
-    __shared__ float part[2][4][32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lk = lane >> 5;
-    const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M;
-    const int m0 = blockIdx.x * 32;
-    if (m0 >= M) return;
-    const int mt = m0 + li;            // this lane's token
-    const bool live = mt < M;
-    // stage the attention-output tile (rows beyond M as zeros)
-    for (int i = tid; i < 32 * (D / 4); i += 256) {
-        const int rr = i / (D / 4), c4 = i % (D / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m0 + rr < M) v = *reinterpret_cast<const float4 *>(a.AO + (int64_t)(m0 + rr) * D + 4 * c4);
-        *reinterpret_cast<float4 *>(bufA + rr * LDA + 4 * c4) = v;
-    }
-    __syncthreads();
-    // acc[t] (+)= W[n0 + 32t + li][0 .. K) . B[token][0 .. K), NT tiles sharing every B fragment
-    auto gemm = [&](f32x16 *acc, int NT, const float *W, int n0, int K, const float *B, int ldb) {
-        const float *brow = B + li * ldb + 4 * lk;
-        for (int q0 = 0; q0 < K / 8; q0 += 8) { // 8 k-octets per round: the A fragments of a round are all in flight together
-            float4 bf[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) bf[j] = *reinterpret_cast<const float4 *>(brow + 8 * (q0 + j));
-            for (int t = 0; t < NT; ++t) {
-                const float *wrow = W + (int64_t)(n0 + 32 * t + li) * K + 4 * lk + 8 * q0;
-                float4 wf[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) wf[j] = *reinterpret_cast<const float4 *>(wrow + 8 * j);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j].x, bf[j].x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j].y, bf[j].y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j].z, bf[j].z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j].w, bf[j].w, acc[t], 0, 0, 0);
-                }
-            }
-        }
-    };
-    auto row_total = [&](float v, int slot) { // sum over the 128 columns of each token (4 waves x 2 lane halves)
-        v += __shfl_xor(v, 32, 64);
-        if (lk == 0) part[slot][wave][li] = v;
-        __syncthreads();
-        const float t = part[slot][0][li] + part[slot][1][li] + part[slot][2][li] + part[slot][3][li];
-        __syncthreads();
-        return t;
-    };
-    const float invn = 1.0f / (float)D;
-    // z (16 registers: columns n0 + (r&3) + 8(r>>2) + 4lk of this wave's 32) <- LN(z; g, b) + add
-    auto layer_norm = [&](float (&z)[16], int n0, const float *g, const float *b, const float *add) {
-        float s1 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s1 += z[r];
-        const float mu = row_total(s1, 0) * invn;
-        float q = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) q += (z[r] - mu) * (z[r] - mu);
-        const float rstd = 1.0f / sqrtf(row_total(q, 1) * invn + 1e-5f);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            z[r] = (z[r] - mu) * rstd * g[n] + b[n] + (add ? add[n] : 0.f);
-        }
-    };
-    auto to_lds = [&](const float (&z)[16], float *buf, int ld, int n0) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4 *>(buf + li * ld + n0 + 8 * g + 4 * lk) = make_float4(z[4 * g], z[4 * g + 1], z[4 * g + 2], z[4 * g + 3]);
-    };
-
-    // ---- y = LN2(LN1(x + ao W_o^T + b_o) + c): this wave's 32 columns
-    const int n0 = wave * 32;
-    float z[16];
-    {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        float resv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            resv[r] = live ? a.X[(int64_t)(a.xidx ? a.xidx[mt] : mt) * D + n] : 0.f;
-        }
-        gemm(&acc, 1, a.Wo, n0, D, bufA, LDA);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            z[r] = acc[r] + (a.bo ? a.bo[n] : 0.f) + resv[r];
-        }
-    }
-    layer_norm(z, n0, a.g1, a.b1n, a.c);
-    if (a.c) layer_norm(z, n0, a.g2, a.b2n, nullptr);
-    // every wave is past its last read of the ao tile (row_total's barriers): y replaces it
-    to_lds(z, bufA, LDA, n0);
-    __syncthreads();
-    // ---- h = relu(y W1^T + b1): this wave's 64 columns -> LDS
-    {
-        f32x16 acc[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        gemm(acc, 2, a.W1, wave * 64, D, bufA, LDA);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float hz[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = wave * 64 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                hz[r] = fmaxf(acc[t][r] + a.b1[n], 0.f);
-            }
-            to_lds(hz, bufH, LDH, wave * 64 + 32 * t);
-        }
-    }
-    __syncthreads();
-    // ---- x' = LN3(y + h W2^T + b2): this wave's 32 columns (y of these columns is still in z)
-    {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        gemm(&acc, 1, a.W2, n0, F, bufH, LDH);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            z[r] = acc[r] + a.b2[n] + z[r];
-        }
-    }
-    layer_norm(z, n0, a.g3, a.b3n, nullptr);
-    if (live) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4 *>(a.Xo + (int64_t)mt * D + n0 + 8 * g + 4 * lk) = make_float4(z[4 * g], z[4 * g + 1], z[4 * g + 2], z[4 * g + 3]);
-    }
-    if (!a.Win) return;
-    // ---- qkv' = x' W_in^T + b_in: x' replaces y in LDS (all waves are past GEMM 1 and the FFN2 epilogue read y
-    //      from registers), this wave's 96 columns
-    to_lds(z, bufA, LDA, n0);
-    __syncthreads();
-    {
-        f32x16 acc[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        gemm(acc, 3, a.Win, wave * 96, D, bufA, LDA);
-        if (live) {
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = wave * 96 + 32 * t + 8 * g + 4 * lk;
-                    *reinterpret_cast<float4 *>(a.QKV + (int64_t)mt * (3 * D) + n) =
-                        make_float4(acc[t][4 * g] + a.bin[n], acc[t][4 * g + 1] + a.bin[n + 1], acc[t][4 * g + 2] + a.bin[n + 2],
-                                    acc[t][4 * g + 3] + a.bin[n + 3]);
-                }
-        }
-    }
-}
-
-// The same chain on v_mfma_f32_16x16x4_f32 with 16 tokens per workgroup: for the single-user latency case
-// (~130 packed rows) twice as many workgroups run side by side and every wave's dependent MFMA work halves
-// (512 MFMAs of 32 cycles; 2-6 independent 16-column tiles per wave and GEMM).  lane = (token lq, k-slot gq):
-// B value x[token][16j + 4gq + e], A value W[n0 + lq][16j + 4gq + e], C register r <-> column n0 + 4gq + r.
+// What bounds it (tools/small_lab.hip): a workgroup fetches its 512 KB of weights at ~38 B/clk per CU (~14K cycles),
+// its 2048 MFMAs keep each SIMD busy 16.4K cycles, and ~10K cycles go to the prologue and the LayerNorm exchanges.
 #ifdef IRS_SMALL_TIMING
 __device__ unsigned long long g_small_t[16];
 #define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_small_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(i)
 #endif
+#define SMALL_ROWS_MAX 32768 // packed rows up to which the 16-token kernel beats the 128-token path (see irs_launch_decode)
 #define SB_NW 8 // waves per workgroup: two per SIMD, so that one wave's barrier / LDS / load waits hide behind the other's MFMAs
 template <bool QKV>
 __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) {
@@ -2937,7 +2775,11 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     const int32_t *off = nullptr, *cnt = nullptr, *tok = nullptr, *qrow = nullptr, *m_dev = nullptr;
     // throughput shapes keep x / y ONLY in the fragment-major layout between the layers (see frag_index): the
     // LN-fused GEMMs write it, read their residual from it, and the QKV / FFN1 GEMMs load it as their X operand
-    const bool frag = d <= LIN_BN && d % 32 == 0 && rows > 2048;
+    // The 16-token layer kernel's regime.  Measured crossover with the 128-token fragment-major path on C2 (L = 200):
+    // 564 vs 720 us per path step at 128 users, 921 vs 797 at 256 (the big path has a ~700 us floor per step: one round
+    // of 128-token tiles streams the weights serially through LDS whatever the number of tiles).
+    const bool small_cfg = d == 128 && F == 256 && ctx->w_frag16 && rows <= SMALL_ROWS_MAX;
+    const bool frag = d <= LIN_BN && d % 32 == 0 && rows > 2048 && !small_cfg;
     float *xf = ctx->act_xf, *yf = ctx->act_yf;
     if (rows_only) {
         if (small_plan) {
@@ -2968,7 +2810,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     } else if (frag)
         hipLaunchKernelGGL(k_embed_frag, dim3((rows + 127) / 128), dim3(256), 0, s, seq, ctx->item_emb, ctx->pe, xf, tok, m_dev,
                            rows, L, d, sqrtf((float)d), ctx->dims.n_item);
-    else if (rows_only && d == 128 && F == 256 && rows <= 512 && ctx->w_frag16 && ctx->dims.n_layers > 1) {
+    else if (rows_only && small_cfg && ctx->dims.n_layers > 1) {
         // latency path (the k_block_small16 regime): embed + layer 0's QKV in one 16-token kernel
         SmallEmbedArgs ea{seq, ctx->item_emb, ctx->pe, tok, m_dev, rows, L, sqrtf((float)d), ctx->dims.n_item, x,
                           ctx->w_frag16 + (size_t)ctx->dims.n_layers * SMALL_WF_LAYER, ctx->layer[0].sa_in_b, ctx->act_qkv};
@@ -3023,11 +2865,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                                   w.n3_w, w.n3_b, xrows, nullptr, nullptr, nullptr, B, nullptr, idx_res ? qrow : nullptr,
                                   ctx->w_frag16 + (size_t)l * SMALL_WF_LAYER, nullptr};
                 irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
-                if (B <= 512) {
-                    if (sb.Win) hipLaunchKernelGGL((k_block_small16<true>), dim3((B + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
-                    else hipLaunchKernelGGL((k_block_small16<false>), dim3((B + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
-                }
-                else hipLaunchKernelGGL(k_block_small, dim3((B + 31) / 32), dim3(256), 0, s, sb);
+                hipLaunchKernelGGL((k_block_small16<false>), dim3((B + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
                 irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * B * ((double)d * d + 2.0 * d * F), 4.0 * 3.0 * B * (double)d);
             } else if (d <= LIN_BN) {
                 if ((rc = launch_linear(ctx, ao_r, w.sa_out_w, w.sa_out_b, x_r, y_r, B, d, d, false, s, w.n1_w, w.n1_b, cl, w.n2_w,
@@ -3098,7 +2936,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                                         w.n3_b, nullptr, nullptr, nullptr, yf, last ? nullptr : xf, m_dev)))
                     return rc;
             }
-        } else if (d == 128 && F == 256 && rows <= 2048) {
+        } else if (small_cfg) {
             // latency path: the rest of the layer (and the next layer's QKV) in one launch per 32 tokens; x -> y buffer
             const bool last = l + 1 == ctx->dims.n_layers;
             SmallBlockArgs sb{ctx->act_ao, x, w.sa_out_w, w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, w.l1_w, w.l1_b, w.l2_w, w.l2_b,
@@ -3107,11 +2945,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                               (last || !ctx->w_frag16) ? nullptr
                                                        : ctx->w_frag16 + (size_t)ctx->dims.n_layers * SMALL_WF_LAYER + (size_t)(l + 1) * SMALL_WF_WIN};
             irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
-            if (rows <= 512) {
-                if (sb.Win) hipLaunchKernelGGL((k_block_small16<true>), dim3((rows + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
-                else hipLaunchKernelGGL((k_block_small16<false>), dim3((rows + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
-            }
-            else hipLaunchKernelGGL(k_block_small, dim3((rows + 31) / 32), dim3(256), 0, s, sb);
+            if (sb.Win) hipLaunchKernelGGL((k_block_small16<true>), dim3((rows + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
+            else hipLaunchKernelGGL((k_block_small16<false>), dim3((rows + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
             irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * rows * ((double)d * d + 2.0 * d * F + (last ? 0.0 : 3.0 * d * d)),
                          4.0 * (3.0 + (last ? 0.0 : 3.0)) * rows * (double)d);
             qkv_done = !last;
