@@ -184,15 +184,18 @@ def test_sampled_paths_distribution():
     assert np.abs(freq - p).max() < 0.08, (freq, p)
 
 
-@pytest.mark.parametrize("cfgname,B,over", [("c2", 24, {}), ("default", 80, {}), ("c1", 72, {}),
-                                             ("c2", 16, {"max_len": 256}), ("c2", 24, {"ffn_dim": 128}),
-                                             ("c2", 16, {"emb_dim": 256, "n_heads": 8}), ("c2", 24, {"n_heads": 8})])
+@pytest.mark.parametrize("cfgname,B,over", [("c2", 176, {}), ("c2", 24, {}), ("c2", 72, {}), ("default", 80, {}), ("c1", 72, {}),
+                                             ("c2", 136, {"max_len": 256}), ("c2", 24, {"ffn_dim": 128}),
+                                             ("c2", 16, {"emb_dim": 256, "n_heads": 8}), ("c2", 176, {"n_heads": 8}),
+                                             ("c2", 24, {"n_heads": 8})])
 def test_throughput_shape_decode_matches_small_batches_and_oracle(oracle, cfgname, B, over):
-    """More than 2048 token rows per call switches the decoder to its throughput kernels (128-row MFMA tiles,
+    """More than 2048 token rows per call (more than 32768 at d = 128, ffn 256, where the 16-token layer kernel
+    covers the range in between) switches the decoder to its throughput kernels (128-row MFMA tiles,
     activations kept fragment-major between the layers, packed rows when only x[b, pos[b]] is wanted).  The
     same sequences decoded eight at a time go through the small-batch kernels the goldens pin; both, and the
     numpy oracle on a few sequences, must agree to float32 accumulation noise.  The cases walk the kernel
-    selection: c2 = fused layer kernel + 16-query attention; default (d = 30) = row-major GEMMs; c1 (d = 64, head
+    selection: c2 x 176 = fused 128-token layer kernel + 16-query attention; c2 x 24 / x 72 = the 16-token layer
+    kernel beyond the single-workgroup plan (24) and beyond the one-launch plan (72); default (d = 30) = row-major GEMMs; c1 (d = 64, head
     dim 16) fragment-major GEMMs with the 32-query attention; L = 256 = the 16-tile limit of the 16-query attention; ffn 128 = fragment-major, unfused FFN; d = 256 (C4's decoder) = separate LayerNorm kernels on packed rows; 8 heads at d = 128 (head dim 16) = 32-query
     attention + LN-fused out-projection + the layer kernel without its out-projection phase."""
     cfg = synth.make_config(cfgname, **over)
