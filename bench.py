@@ -321,7 +321,7 @@ def main():
         roof["launches_per_step"] = f["launches"] / args.steps
         roof["family_ms_per_step"] = {k: v["ms"] / args.steps for k, v in fam.items()}
 
-        lat = None
+        lat = lat128 = None
         if not args.no_latency and world == 1:
             # path-gen p50: one user, 20 greedy steps, hipGraph-replayed step
             # the user whose window holds the median number of items of this workload (a window's length sets the
@@ -333,15 +333,22 @@ def main():
             h1 = job.hep[iu:iu + 1].clone()
             p1 = torch.zeros((1, 20), dtype=torch.float32, device=device)
             st1 = torch.zeros(1, dtype=torch.int32, device=device)
-            ts = []
-            for it in range(35):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                job.eng.generate_paths(s1, u1, h1, 20, k=100, sweep=job.sweep, use_graph=True, paths=p1, status=st1)
-                torch.cuda.synchronize()
-                if it >= 5:
-                    ts.append((time.perf_counter() - t0) * 1e3)
-            lat = float(np.median(ts))
+            def p50(ss, uu, hh, pp, stt, warm, reps):
+                ts = []
+                for it in range(warm + reps):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    job.eng.generate_paths(ss, uu, hh, 20, k=100, sweep=job.sweep, use_graph=True, paths=pp, status=stt)
+                    torch.cuda.synchronize()
+                    if it >= warm:
+                        ts.append((time.perf_counter() - t0) * 1e3)
+                return float(np.median(ts))
+
+            lat = p50(s1, u1, h1, p1, st1, 20, 200)  # >= 200 repetitions after 20 warm-ups
+            nb = min(128, job.B)
+            lat128 = p50(job.seqs[:nb].clone(), job.users[:nb].clone(), job.hep[:nb].clone(),
+                         torch.zeros((nb, 20), dtype=torch.float32, device=device),
+                         torch.zeros(nb, dtype=torch.int32, device=device), 5, 30) / nb
 
         cpu = None
         if not args.no_cpu_baseline and world == 1:
@@ -372,6 +379,7 @@ def main():
                            if job.sharded else
                            f"users partitioned over {world} GPUs, catalog replicated ({cfg.n_item} items): no data-path collective")},
             "path_gen_p50_ms_b1": lat,
+            "path_gen_ms_per_user_b128": lat128,
             "roofline": roof,
             "cpu_baseline": cpu,
         }
