@@ -1537,15 +1537,18 @@ __device__ unsigned long long g_small_t[16];
 #define STAMP(i)
 #endif
 #define SMALL_ROWS_MAX 32768 // packed rows up to which the 16-token kernel beats the 128-token path (see irs_launch_decode)
+#define SMALL_MT2_ROWS 8192
 #define SB_NW 8 // waves per workgroup: two per SIMD, so that one wave's barrier / LDS / load waits hide behind the other's MFMAs
-template <bool QKV>
+// MT = 16-token tiles per workgroup: 1 on the latency path; 2 above SMALL_MT2_ROWS rows, where every weight fragment
+// is then fetched once per 32 tokens and feeds two MFMAs.
+template <bool QKV, int MT>
 __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) {
     constexpr int T1 = 8 / SB_NW, T2 = 16 / SB_NW, T3 = 24 / SB_NW; // 16-column tiles per wave of a 128 / 256 / 384 wide output
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     constexpr int D = 128, F = 256, LDA = D + 4, LDH = F + 4;
-    __shared__ __attribute__((aligned(16))) float bufA[16 * LDA]; // ao -> y -> x'
-    __shared__ __attribute__((aligned(16))) float bufH[16 * LDH]; // h
-    __shared__ float part[2][SB_NW][16];
+    __shared__ __attribute__((aligned(16))) float bufA[16 * MT * LDA]; // ao -> y -> x'
+    __shared__ __attribute__((aligned(16))) float bufH[16 * MT * LDH]; // h
+    __shared__ float part[2][SB_NW][16 * MT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     STAMP(0);
     const int lq = lane & 15, gq = lane >> 4;
@@ -1565,14 +1568,16 @@ __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) 
     __builtin_amdgcn_sched_barrier(0);
 #define MMA_ROUND(acc, wf, NT, B, ldb, r)                                                                             \
     {                                                                                                                 \
-        float4 bf[4];                                                                                                 \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
-            bf[j] = *reinterpret_cast<const float4 *>((B) + lq * (ldb) + 4 * gq + 64 * (r) + 16 * j);                 \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int t = 0; t < NT; ++t) {                \
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][j].x, bf[j].x, acc[t], 0, 0, 0);                      \
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][j].y, bf[j].y, acc[t], 0, 0, 0);                      \
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][j].z, bf[j].z, acc[t], 0, 0, 0);                      \
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][j].w, bf[j].w, acc[t], 0, 0, 0);                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                               \
+            float4 bf[MT];                                                                                            \
+            _Pragma("unroll") for (int u = 0; u < MT; ++u)                                                            \
+                bf[u] = *reinterpret_cast<const float4 *>((B) + (16 * u + lq) * (ldb) + 4 * gq + 64 * (r) + 16 * j);  \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int u = 0; u < MT; ++u) {           \
+                acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][j].x, bf[u].x, acc[u][t], 0, 0, 0);            \
+                acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][j].y, bf[u].y, acc[u][t], 0, 0, 0);            \
+                acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][j].z, bf[u].z, acc[u][t], 0, 0, 0);            \
+                acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][j].w, bf[u].w, acc[u][t], 0, 0, 0);            \
+            }                                                                                                         \
         }                                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
     }
@@ -1589,21 +1594,25 @@ __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) 
     float4 vbo[T1], vg1[T1], vb1n[T1], vc[T1], vg2[T1], vb2n[T1], vb1[T2], vb2[T1], vg3[T1], vb3n[T1], vbin[T3];
     // A wave's loads return in order: the activation tile (and the residual row index) go first, clamped to the
     // static row bound and masked once the device-side count is known, then the 6-12 tile-rounds of weights.
-    const int m0 = blockIdx.x * 16;
-    const int mt = m0 + lq; // this lane's token
-    constexpr int NAO = 16 * (D / 4) / (64 * SB_NW);
+    const int m0 = blockIdx.x * 16 * MT;
+    const int mt = m0 + lq; // this lane's tokens: mt + 16 u
+    constexpr int NAO = 16 * MT * (D / 4) / (64 * SB_NW);
     float4 aov[NAO];
 #pragma unroll
     for (int u = 0; u < NAO; ++u) {
         const int i = tid + u * 64 * SB_NW, rr = i / (D / 4), c4 = i % (D / 4);
         aov[u] = *reinterpret_cast<const float4 *>(a.AO + (int64_t)min(m0 + rr, a.M - 1) * D + 4 * c4);
     }
-    const int xrow = a.xidx ? a.xidx[min(mt, a.M - 1)] : mt;
+    int xrow[MT];
+#pragma unroll
+    for (int u = 0; u < MT; ++u) xrow[u] = a.xidx ? a.xidx[min(mt + 16 * u, a.M - 1)] : mt + 16 * u;
     __builtin_amdgcn_sched_barrier(0);
     W_LOAD(wo[0], T1, a.Wf + SMALL_WF_WO, wave * 16 * T1, D, 0);
     W_LOAD(wo[1], T1, a.Wf + SMALL_WF_WO, wave * 16 * T1, D, 1);
     const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M;
-    const bool live = mt < M;
+    bool live[MT];
+#pragma unroll
+    for (int u = 0; u < MT; ++u) live[u] = mt + 16 * u < M;
     W_LOAD(w1[0], T2, a.Wf + SMALL_WF_W1, wave * 16 * T2, D, 0);
     W_LOAD(w1[1], T2, a.Wf + SMALL_WF_W1, wave * 16 * T2, D, 1);
     V_LOAD(vbo, T1, a.bo, wave * 16 * T1);
@@ -1620,68 +1629,94 @@ __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) 
         *reinterpret_cast<float4 *>(bufA + rr * LDA + 4 * c4) = (m0 + rr < M) ? aov[u] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    auto row_total = [&](float v, int slot) { // sum over the 128 columns of each token (SB_NW waves x 4 k-slot lanes)
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (gq == 0) part[slot][wave][lq] = v;
-        __syncthreads();
-        float t = 0.f;
+    auto row_total = [&](float (&v)[MT], int slot) { // sums over the 128 columns of each token (SB_NW waves x 4 k-slot lanes)
 #pragma unroll
-        for (int w = 0; w < SB_NW; ++w) t += part[slot][w][lq];
-        return t; // no second barrier: the slots strictly alternate (mean 0, variance 1), so slot s is rewritten only
-                  // by waves that have passed the barrier of slot 1-s, which every wave reaches after this read
+        for (int u = 0; u < MT; ++u) {
+            v[u] += __shfl_xor(v[u], 16, 64);
+            v[u] += __shfl_xor(v[u], 32, 64);
+            if (gq == 0) part[slot][wave][16 * u + lq] = v[u];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < SB_NW; ++w) t += part[slot][w][16 * u + lq];
+            v[u] = t;
+        }
+        // no second barrier: the slots strictly alternate (mean 0, variance 1), so slot s is rewritten only
+        // by waves that have passed the barrier of slot 1-s, which every wave reaches after this read
     };
     const float invn = 1.0f / (float)D;
     const int n0 = wave * 16 * T1; // this wave's T1 tiles of a 128-wide output
-    // z[t][r] = column n0 + 16t + 4gq + r of this lane's token
-    auto layer_norm = [&](float (&z)[T1][4], const float4 (&g)[T1], const float4 (&b)[T1], const float4 (&add)[T1]) {
-        float s1 = 0.f;
+    // z[u][t][r] = column n0 + 16t + 4gq + r of this lane's token mt + 16u
+    auto layer_norm = [&](float (&z)[MT][T1][4], const float4 (&g)[T1], const float4 (&b)[T1], const float4 (&add)[T1]) {
+        float mu[MT], q[MT];
 #pragma unroll
-        for (int t = 0; t < T1; ++t)
+        for (int u = 0; u < MT; ++u) {
+            mu[u] = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s1 += z[t][r];
-        const float mu = row_total(s1, 0) * invn;
-        float q = 0.f;
+            for (int t = 0; t < T1; ++t)
 #pragma unroll
-        for (int t = 0; t < T1; ++t)
+                for (int r = 0; r < 4; ++r) mu[u] += z[u][t][r];
+        }
+        row_total(mu, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) q += (z[t][r] - mu) * (z[t][r] - mu);
-        const float rstd = 1.0f / sqrtf(row_total(q, 1) * invn + 1e-5f);
+        for (int u = 0; u < MT; ++u) {
+            mu[u] *= invn;
+            q[u] = 0.f;
 #pragma unroll
-        for (int t = 0; t < T1; ++t)
+            for (int t = 0; t < T1; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                z[t][r] = (z[t][r] - mu) * rstd * (&g[t].x)[r] + (&b[t].x)[r] + (&add[t].x)[r];
+                for (int r = 0; r < 4; ++r) q[u] += (z[u][t][r] - mu[u]) * (z[u][t][r] - mu[u]);
+        }
+        row_total(q, 1);
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {
+            const float rstd = 1.0f / sqrtf(q[u] * invn + 1e-5f);
+#pragma unroll
+            for (int t = 0; t < T1; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    z[u][t][r] = (z[u][t][r] - mu[u]) * rstd * (&g[t].x)[r] + (&b[t].x)[r] + (&add[t].x)[r];
+        }
     };
-    auto to_lds2 = [&](const float (&z)[T1][4], float *buf, int ld) {
+    auto to_lds2 = [&](const float (&z)[MT][T1][4], float *buf, int ld) {
 #pragma unroll
-        for (int t = 0; t < T1; ++t)
-            *reinterpret_cast<float4 *>(buf + lq * ld + n0 + 16 * t + 4 * gq) = make_float4(z[t][0], z[t][1], z[t][2], z[t][3]);
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+            for (int t = 0; t < T1; ++t)
+                *reinterpret_cast<float4 *>(buf + (16 * u + lq) * ld + n0 + 16 * t + 4 * gq) =
+                    make_float4(z[u][t][0], z[u][t][1], z[u][t][2], z[u][t][3]);
     };
     STAMP(1);
-    float z[T1][4];
+    float z[MT][T1][4];
     // ---- y = LN2(LN1(x + ao W_o^T + b_o) + c)
     {
-        f32x4 acc[T1];
+        f32x4 acc[MT][T1];
+        float4 res[MT][T1];
 #pragma unroll
-        for (int t = 0; t < T1; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
-        float4 res[T1];
+        for (int u = 0; u < MT; ++u)
 #pragma unroll
-        for (int t = 0; t < T1; ++t)
-            res[t] = live ? *reinterpret_cast<const float4 *>(a.X + (int64_t)xrow * D + n0 + 16 * t + 4 * gq)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = 0; t < T1; ++t) {
+                acc[u][t] = {0.f, 0.f, 0.f, 0.f};
+                res[u][t] = live[u] ? *reinterpret_cast<const float4 *>(a.X + (int64_t)xrow[u] * D + n0 + 16 * t + 4 * gq)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         V_LOAD(vb1, T2, a.b1, wave * 16 * T2);
         MMA_ROUND(acc, wo[0], T1, bufA, LDA, 0);
         W_LOAD(w2[0], T1, a.Wf + SMALL_WF_W2, n0, F, 0);
         MMA_ROUND(acc, wo[1], T1, bufA, LDA, 1);
         W_LOAD(w2[1], T1, a.Wf + SMALL_WF_W2, n0, F, 1);
 #pragma unroll
-        for (int t = 0; t < T1; ++t) {
-            z[t][0] = acc[t][0] + vbo[t].x + res[t].x;
-            z[t][1] = acc[t][1] + vbo[t].y + res[t].y;
-            z[t][2] = acc[t][2] + vbo[t].z + res[t].z;
-            z[t][3] = acc[t][3] + vbo[t].w + res[t].w;
-        }
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+            for (int t = 0; t < T1; ++t) {
+                z[u][t][0] = acc[u][t][0] + vbo[t].x + res[u][t].x;
+                z[u][t][1] = acc[u][t][1] + vbo[t].y + res[u][t].y;
+                z[u][t][2] = acc[u][t][2] + vbo[t].z + res[u][t].z;
+                z[u][t][3] = acc[u][t][3] + vbo[t].w + res[u][t].w;
+            }
     }
     STAMP(2);
     layer_norm(z, vg1, vb1n, vc);
@@ -1692,9 +1727,11 @@ __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) 
     STAMP(4);
     // ---- h = relu(y W1^T + b1): this wave's 64 columns (4 tiles) -> LDS
     {
-        f32x4 acc[T2];
+        f32x4 acc[MT][T2];
 #pragma unroll
-        for (int t = 0; t < T2; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+            for (int t = 0; t < T2; ++t) acc[u][t] = {0.f, 0.f, 0.f, 0.f};
         V_LOAD(vb2, T1, a.b2, n0);
         V_LOAD(vg3, T1, a.g3, n0);
         V_LOAD(vb3n, T1, a.b3n, n0);
@@ -1707,20 +1744,24 @@ __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) 
             W_LOAD(wq[0], T3, a.Wfin, wave * 16 * T3, D, 0);
         }
 #pragma unroll
-        for (int t = 0; t < T2; ++t) {
-            const int n = wave * 16 * T2 + 16 * t + 4 * gq;
-            *reinterpret_cast<float4 *>(bufH + lq * LDH + n) =
-                make_float4(fmaxf(acc[t][0] + vb1[t].x, 0.f), fmaxf(acc[t][1] + vb1[t].y, 0.f),
-                            fmaxf(acc[t][2] + vb1[t].z, 0.f), fmaxf(acc[t][3] + vb1[t].w, 0.f));
-        }
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+            for (int t = 0; t < T2; ++t) {
+                const int n = wave * 16 * T2 + 16 * t + 4 * gq;
+                *reinterpret_cast<float4 *>(bufH + (16 * u + lq) * LDH + n) =
+                    make_float4(fmaxf(acc[u][t][0] + vb1[t].x, 0.f), fmaxf(acc[u][t][1] + vb1[t].y, 0.f),
+                                fmaxf(acc[u][t][2] + vb1[t].z, 0.f), fmaxf(acc[u][t][3] + vb1[t].w, 0.f));
+            }
     }
     __syncthreads();
     STAMP(5);
     // ---- x' = LN3(y + h W2^T + b2)
     {
-        f32x4 acc[T1];
+        f32x4 acc[MT][T1];
 #pragma unroll
-        for (int t = 0; t < T1; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+            for (int t = 0; t < T1; ++t) acc[u][t] = {0.f, 0.f, 0.f, 0.f};
         STAMP(9);
         MMA_ROUND(acc, w2[0], T1, bufH, LDH, 0);
         STAMP(10);
@@ -1732,36 +1773,46 @@ __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) 
         STAMP(13);
         MMA_ROUND(acc, w2[3], T1, bufH, LDH, 3);
 #pragma unroll
-        for (int t = 0; t < T1; ++t)
+        for (int u = 0; u < MT; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z[t][r] = acc[t][r] + (&vb2[t].x)[r] + z[t][r];
+            for (int t = 0; t < T1; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[u][t][r] = acc[u][t][r] + (&vb2[t].x)[r] + z[u][t][r];
     }
     STAMP(6);
     layer_norm(z, vg3, vb3n, zero2);
     STAMP(7);
-    if (live) {
 #pragma unroll
-        for (int t = 0; t < T1; ++t)
-            *reinterpret_cast<float4 *>(a.Xo + (int64_t)mt * D + n0 + 16 * t + 4 * gq) = make_float4(z[t][0], z[t][1], z[t][2], z[t][3]);
-    }
+    for (int u = 0; u < MT; ++u)
+        if (live[u]) {
+#pragma unroll
+            for (int t = 0; t < T1; ++t)
+                *reinterpret_cast<float4 *>(a.Xo + (int64_t)(mt + 16 * u) * D + n0 + 16 * t + 4 * gq) =
+                    make_float4(z[u][t][0], z[u][t][1], z[u][t][2], z[u][t][3]);
+        }
     if constexpr (!QKV) return;
     // ---- qkv' = x' W_in^T + b_in: this wave's 96 columns (6 tiles)
     to_lds2(z, bufA, LDA);
     __syncthreads();
     {
-        f32x4 acc[T3];
+        f32x4 acc[MT][T3];
 #pragma unroll
-        for (int t = 0; t < T3; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+            for (int t = 0; t < T3; ++t) acc[u][t] = {0.f, 0.f, 0.f, 0.f};
         MMA_ROUND(acc, wq[0], T3, bufA, LDA, 0);
         MMA_ROUND(acc, wq[1], T3, bufA, LDA, 1);
-        if (live) {
 #pragma unroll
-            for (int t = 0; t < T3; ++t) {
-                const int n = wave * 16 * T3 + 16 * t + 4 * gq;
-                *reinterpret_cast<float4 *>(a.QKV + (int64_t)mt * (3 * D) + n) =
-                    make_float4(acc[t][0] + vbin[t].x, acc[t][1] + vbin[t].y, acc[t][2] + vbin[t].z, acc[t][3] + vbin[t].w);
+        for (int u = 0; u < MT; ++u)
+            if (live[u]) {
+#pragma unroll
+                for (int t = 0; t < T3; ++t) {
+                    const int n = wave * 16 * T3 + 16 * t + 4 * gq;
+                    *reinterpret_cast<float4 *>(a.QKV + (int64_t)(mt + 16 * u) * (3 * D) + n) =
+                        make_float4(acc[u][t][0] + vbin[t].x, acc[u][t][1] + vbin[t].y, acc[u][t][2] + vbin[t].z,
+                                    acc[u][t][3] + vbin[t].w);
+                }
             }
-        }
     }
     STAMP(8);
 }
@@ -1783,7 +1834,7 @@ struct SmallEmbedArgs {
 
 __global__ void __launch_bounds__(256) k_embed_qkv_small16(SmallEmbedArgs a) {
     typedef __attribute__((ext_vector_type(4))) float f32x4;
-    constexpr int D = 128, LDA = D + 4;
+    constexpr int D = 128, LDA = D + 4, MT = 1;
     __shared__ __attribute__((aligned(16))) float bufA[16 * LDA];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 15, gq = lane >> 4;
@@ -1819,8 +1870,8 @@ __global__ void __launch_bounds__(256) k_embed_qkv_small16(SmallEmbedArgs a) {
         *reinterpret_cast<float4 *>(bufA + rr * LDA + 8 * c8 + 4) = v1;
     }
     __syncthreads();
-    f32x4 acc[6] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f},
-                    {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[1][6] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f},
+                        {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
     MMA_ROUND(acc, wq[0], 6, bufA, LDA, 0);
     MMA_ROUND(acc, wq[1], 6, bufA, LDA, 1);
     const int mt = m0 + lq;
@@ -1829,7 +1880,7 @@ __global__ void __launch_bounds__(256) k_embed_qkv_small16(SmallEmbedArgs a) {
         for (int t = 0; t < 6; ++t) {
             const int n = wave * 96 + 16 * t + 4 * gq;
             *reinterpret_cast<float4 *>(a.QKV + (int64_t)mt * (3 * D) + n) =
-                make_float4(acc[t][0] + vbin[t].x, acc[t][1] + vbin[t].y, acc[t][2] + vbin[t].z, acc[t][3] + vbin[t].w);
+                make_float4(acc[0][t][0] + vbin[t].x, acc[0][t][1] + vbin[t].y, acc[0][t][2] + vbin[t].z, acc[0][t][3] + vbin[t].w);
         }
     }
 }
@@ -2865,7 +2916,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                                   w.n3_w, w.n3_b, xrows, nullptr, nullptr, nullptr, B, nullptr, idx_res ? qrow : nullptr,
                                   ctx->w_frag16 + (size_t)l * SMALL_WF_LAYER, nullptr};
                 irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
-                hipLaunchKernelGGL((k_block_small16<false>), dim3((B + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
+                if (B > 2048) hipLaunchKernelGGL((k_block_small16<false, 2>), dim3((B + 31) / 32), dim3(64 * SB_NW), 0, s, sb);
+                else hipLaunchKernelGGL((k_block_small16<false, 1>), dim3((B + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
                 irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * B * ((double)d * d + 2.0 * d * F), 4.0 * 3.0 * B * (double)d);
             } else if (d <= LIN_BN) {
                 if ((rc = launch_linear(ctx, ao_r, w.sa_out_w, w.sa_out_b, x_r, y_r, B, d, d, false, s, w.n1_w, w.n1_b, cl, w.n2_w,
@@ -2945,8 +2997,15 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                               (last || !ctx->w_frag16) ? nullptr
                                                        : ctx->w_frag16 + (size_t)ctx->dims.n_layers * SMALL_WF_LAYER + (size_t)(l + 1) * SMALL_WF_WIN};
             irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
-            if (sb.Win) hipLaunchKernelGGL((k_block_small16<true>), dim3((rows + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
-            else hipLaunchKernelGGL((k_block_small16<false>), dim3((rows + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
+            // 32 tokens per workgroup once the 16-token tiles outnumber the resident workgroups (2 per CU): per path
+            // step 518 vs 563 us at 128 users, but 267 vs 222 at 16 users; 64 tokens measured no better than 32
+            if (rows > SMALL_MT2_ROWS) {
+                if (sb.Win) hipLaunchKernelGGL((k_block_small16<true, 2>), dim3((rows + 31) / 32), dim3(64 * SB_NW), 0, s, sb);
+                else hipLaunchKernelGGL((k_block_small16<false, 2>), dim3((rows + 31) / 32), dim3(64 * SB_NW), 0, s, sb);
+            } else {
+                if (sb.Win) hipLaunchKernelGGL((k_block_small16<true, 1>), dim3((rows + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
+                else hipLaunchKernelGGL((k_block_small16<false, 1>), dim3((rows + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
+            }
             irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * rows * ((double)d * d + 2.0 * d * F + (last ? 0.0 : 3.0 * d * d)),
                          4.0 * (3.0 + (last ? 0.0 : 3.0)) * rows * (double)d);
             qkv_done = !last;

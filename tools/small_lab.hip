@@ -68,7 +68,7 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0, 0));
-        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_block_small16<true>), dim3((M + 15) / 16), dim3(64 * SB_NW), 0, 0, a);
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_block_small16<true, 1>), dim3((M + 15) / 16), dim3(64 * SB_NW), 0, 0, a);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         unsigned long long t[16]; CK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_small_t), sizeof t));
