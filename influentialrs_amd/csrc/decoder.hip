@@ -2470,51 +2470,39 @@ __global__ void __launch_bounds__(64) k_attn_row(const float *__restrict__ qkv, 
 // The same row for head dim 32 and L <= 256 on four waves: 8 lanes per key (one 16-byte chunk of K_h and of V_h
 // each), every load of the workgroup requested before the first use -- one memory round trip instead of the ~10
 // dependent ones of the one-wave loop above (14 -> 5 us on the single-user path, where every launch starts cold).
-// padq (packed sequences): the plan's record of the one pad a packed sequence may hold, instead of seq lookups.
+// Packed sequences only: padq is the plan's record of the one pad a packed sequence may hold (no seq lookups).
 __global__ void __launch_bounds__(256) k_attn_row32(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
-                                                    const float *__restrict__ r_u, const int32_t *__restrict__ pos,
-                                                    float *__restrict__ out_rows, int Lmax, int d, int mask_mode,
+                                                    const float *__restrict__ r_u, float *__restrict__ out_rows, int Lmax, int d, int mask_mode,
                                                     const int32_t *__restrict__ off, const int32_t *__restrict__ cnt,
-                                                    const int32_t *__restrict__ tok_row, const int32_t *__restrict__ qrow,
-                                                    const float *__restrict__ qrows, const int32_t *__restrict__ padq) {
+                                                    const int32_t *__restrict__ qrow, const float *__restrict__ qrows,
+                                                    const int32_t *__restrict__ padq) {
     constexpr int HD = 32, NIT = 8;
     __shared__ float red[4][36]; // per wave: 32 output columns, [32] max, [33] sum
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int L = cnt ? cnt[b] : Lmax;
-    const int64_t base = off ? (int64_t)off[b] : (int64_t)b * Lmax;
+    const int L = cnt[b];
+    const int64_t base = off[b];
     const int ld = 3 * d;
     const int jl = tid >> 3, c4 = tid & 7;
     float4 kv[NIT], vv[NIT];
-    int tokv[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int j = jl + 32 * it;
         kv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         vv[it] = kv[it];
-        tokv[it] = 1;
         if (j < L) {
             const float *row = qkv + (base + j) * ld + h * HD + 4 * c4;
             kv[it] = *reinterpret_cast<const float4 *>(row + d);
             vv[it] = *reinterpret_cast<const float4 *>(row + 2 * d);
-            if (!padq && !tok_row) tokv[it] = (int)seq[base + j];
         }
     }
-    if (!padq && tok_row) { // dependent lookups (token of a packed row): still all in flight together
-        int tr[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) tr[it] = (jl + 32 * it < L) ? tok_row[base + jl + 32 * it] : 0;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it)
-            if (jl + 32 * it < L) tokv[it] = (int)seq[tr[it]];
-    }
-    int i = qrow ? qrow[b] - (int)base : pos[b]; // query row within the sequence
+    int i = qrow[b] - (int)base; // query row within the packed sequence
     if (i < 0) i = 0;
     if (i >= L) i = L - 1;
     const bool has_tgt = (seq[(int64_t)b * Lmax + Lmax - 1] != 0);
     const bool irn = (mask_mode == IRS_MASK_IRN);
     const float add_allowed = irn ? r_u[b] : 0.f;
     const float scale = 1.0f / sqrtf((float)HD);
-    const int pq = padq ? padq[b] : -1;
+    const int pq = padq[b];
     float4 q4 = *reinterpret_cast<const float4 *>(qrows ? qrows + (int64_t)b * d + h * HD + 4 * c4
                                                          : qkv + (base + i) * ld + h * HD + 4 * c4);
     q4.x *= scale, q4.y *= scale, q4.z *= scale, q4.w *= scale;
@@ -2531,7 +2519,7 @@ __global__ void __launch_bounds__(256) k_attn_row32(const float *__restrict__ qk
         part += __shfl_xor(part, 2, 64);
         part += __shfl_xor(part, 4, 64);
         const bool is_tgt = irn && has_tgt && (j == L - 1);
-        const bool ok = (j < L) && (padq ? (j != pq) : (tokv[it] != 0)) && (is_tgt || j <= i);
+        const bool ok = (j < L) && (j != pq) && (is_tgt || j <= i);
         sc[it] = ok ? part + (is_tgt ? 1.0f : add_allowed) : -INFINITY;
         mx = fmaxf(mx, sc[it]);
     }
@@ -2901,8 +2889,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             }
             irs_prof_begin(ctx, IRS_PROF_ATTN, s);
             if (d / ctx->dims.n_heads == 32 && L <= 256 && d % 4 == 0 && (((uintptr_t)ctx->act_qkv | (uintptr_t)q_r) & 15) == 0)
-                hipLaunchKernelGGL(k_attn_row32, dim3(ctx->dims.n_heads, B), dim3(256), 0, s, ctx->act_qkv, seq, ctx->act_ru, pos,
-                                   ao_r, L, d, ctx->dims.mask_mode, off, cnt, tok, qrow, q_r, tok ? ctx->seq_padq : nullptr);
+                hipLaunchKernelGGL(k_attn_row32, dim3(ctx->dims.n_heads, B), dim3(256), 0, s, ctx->act_qkv, seq, ctx->act_ru,
+                                   ao_r, L, d, ctx->dims.mask_mode, off, cnt, qrow, q_r, ctx->seq_padq);
             else
                 hipLaunchKernelGGL(k_attn_row, dim3(ctx->dims.n_heads, B), dim3(64), 0, s, ctx->act_qkv, seq, ctx->act_ru, pos,
                                    ao_r, L, d, d / ctx->dims.n_heads, ctx->dims.mask_mode, off, cnt, tok, qrow, q_r);
