@@ -1817,6 +1817,199 @@ __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) 
     STAMP(8);
 }
 
+// Zero-padded fragment-packed copy of W[N][K] for k_block_small_any: [Np/16 tiles][Kp/16 k groups][64 lanes] float4.
+__global__ void k_pack_frag16_any(const float *__restrict__ W, float *__restrict__ out, int N, int K, int Np, int Kp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x; // one float4 of the packed image
+    if (i >= Np * Kp / 4) return;
+    const int lane = i & 63, rest = i >> 6, KG = Kp >> 4;
+    const int kg = rest % KG, nt = rest / KG;
+    const int n = 16 * nt + (lane & 15), k = 16 * kg + 4 * (lane >> 4);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (n < N && k + e < K) ? W[(size_t)n * K + k + e] : 0.f;
+    reinterpret_cast<float4 *>(out)[i] = make_float4(v[0], v[1], v[2], v[3]);
+}
+// per-layer image: [Wo dp x dp | W1 Fp x dp | W2 dp x Fp | Win Qp x dp]
+static inline bool small_any_shape(int d, int F) {
+    const int Fp = (F + 15) & ~15, ksh = Fp > 128 ? 2 : Fp > 64 ? 1 : 0; // the k groups of W2 must split evenly into its chunks
+    return !(d == 128 && F == 256) && d <= 96 && F <= 256 && ((Fp >> 4) & ((1 << ksh) - 1)) == 0;
+}
+static inline size_t small_any_win_off(int d, int F) {
+    const size_t dp = (d + 15) & ~15, Fp = (F + 15) & ~15;
+    return dp * dp + 2 * Fp * dp;
+}
+static inline size_t small_any_layer_floats(int d, int F) {
+    const size_t dp = (d + 15) & ~15, Qp = (3 * d + 15) & ~15;
+    return small_any_win_off(d, F) + Qp * dp;
+}
+
+// The same layer tail for ANY small shape (d <= 96, F <= 256: the reference's CLI default d = 30, config 1's d = 64,
+// the evaluator's d = 30 / F = 120), where a step is launch bound (four GEMM launches per layer for ~1 MFLOP of
+// work).  16 tokens per workgroup, 4 waves, v_mfma_f32_16x16x4_f32 with zero-padded tiles: the weights come from
+// zero-padded fragment-packed copies (row-major dword fragments measured 2.5x slower: 16 cache lines per wave load),
+// activations sit in LDS padded to 16 columns; work items = (16-column output tile, k chunk) dealt round-robin to the waves -- the FFN's second GEMM
+// (K = F) is split into up to 4 k chunks whose partial tiles are summed in a fixed order -- and the LayerNorms run on
+// the LDS tile with 16 lanes per token.
+template <bool QKV>
+__global__ void __launch_bounds__(256) k_block_small_any(SmallBlockArgs a, int d, int F) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    extern __shared__ __attribute__((aligned(16))) float sm_any[];
+    const int dp = (d + 15) & ~15, Fp = (F + 15) & ~15, lda = dp + 4, ldh = Fp + 4;
+    float *bufA = sm_any;            // [16][lda] GEMM input: ao -> y -> x'
+    float *bufZ = bufA + 16 * lda;   // [16][lda] x + b_o (+ GEMM) -> y ; y + b2 (+ GEMM) -> x'
+    float *bufH = bufZ + 16 * lda;   // [16][ldh] h
+    float *bufP = bufH + 16 * ldh;   // [4][16][lda] partial tiles of the k-split GEMM
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 15, gq = lane >> 4;
+    const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M;
+    const int m0 = blockIdx.x * 16;
+    if (m0 >= M) return;
+    const int KSF = Fp > 128 ? 2 : Fp > 64 ? 1 : 0, KCF = 1 << KSF; // k chunks of the FFN's second GEMM: 4 / 2 / 1
+    for (int i = tid; i < 16 * dp; i += 256) {
+        const int rr = i / dp, c = i - rr * dp, row = m0 + rr;
+        const bool ok = row < M && c < d;
+        const int xr = (row < M && a.xidx) ? a.xidx[row] : row;
+        bufA[rr * lda + c] = ok ? a.AO[(int64_t)row * d + c] : 0.f;
+        bufZ[rr * lda + c] = ok ? a.X[(int64_t)xr * d + c] + (a.bo ? a.bo[c] : 0.f) : 0.f;
+    }
+    // acc(item) = W[16 nt .. +15][k range of chunk kc] . B[token][same k] on zero-padded, fragment-packed weights
+    // (k_pack_frag16_any: float4 ((nt * Kp/16 + kg) * 64 + lane) = W[16nt + lq][16kg + 4gq .. +3], so a wave load is
+    // 1 KB contiguous and needs no guards); B = buf[lq][same k] as one ds_read_b128; C register r <-> column
+    // 16nt + 4gq + r of token lq.  A wave owns items wave, wave + 4, ... (item = nt * KC + kc, KC a power of two).
+    // ALL the weight fragments of a wave's share of a GEMM (<= 6 items x 6 k groups) are requested at once, before
+    // the barrier / LayerNorm in front of the GEMM: weights do not depend on the activations.
+    constexpr int MAXI = 6, MAXG = 6;
+    struct Gemm {
+        const float4 *W;
+        int KG, ksh, gpi, nit; // k groups of 16 in a row, log2(k chunks), groups per item, this wave's items
+    };
+    auto plan = [&](const float *Wp, int Np, int Kp, int ksh) {
+        Gemm g;
+        g.W = reinterpret_cast<const float4 *>(Wp), g.KG = Kp >> 4, g.ksh = ksh;
+        g.gpi = g.KG >> ksh; // Kp / 16 is a multiple of the chunk count for every shape the launcher admits
+        const int items = (Np >> 4) << ksh;
+        g.nit = items > wave ? (items - wave + 3) >> 2 : 0;
+        return g;
+    };
+    auto load_a = [&](const Gemm &g, float4 (&av)[MAXI][MAXG]) {
+#pragma unroll
+        for (int ii = 0; ii < MAXI; ++ii) {
+            const int item = wave + 4 * ii, nt = item >> g.ksh, kc = item & ((1 << g.ksh) - 1);
+            const float4 *wp = g.W + ((size_t)nt * g.KG + kc * g.gpi) * 64 + lane;
+#pragma unroll
+            for (int kg = 0; kg < MAXG; ++kg)
+                if (ii < g.nit && kg < g.gpi) av[ii][kg] = wp[kg * 64]; // wave-uniform
+        }
+    };
+    auto gemm = [&](const Gemm &g, const float4 (&av)[MAXI][MAXG], const float *B, int ldb, auto emit) {
+        const float *brow = B + lq * ldb + 4 * gq;
+#pragma unroll
+        for (int ii = 0; ii < MAXI; ++ii) {
+            if (ii < g.nit) {
+                const int item = wave + 4 * ii, nt = item >> g.ksh, kc = item & ((1 << g.ksh) - 1);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kg = 0; kg < MAXG; ++kg) {
+                    if (kg < g.gpi) {
+                        const float4 bv = *reinterpret_cast<const float4 *>(brow + 16 * (kc * g.gpi + kg));
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ii][kg].x, bv.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ii][kg].y, bv.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ii][kg].z, bv.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ii][kg].w, bv.w, acc, 0, 0, 0);
+                    }
+                }
+                emit(nt, kc, acc);
+            }
+        }
+    };
+    // LayerNorm of the 16 rows of bufZ in place (16 lanes per token: columns sub, sub + 16, ...)
+    const int tk = tid >> 4, sub = tid & 15;
+    auto group_sum = [&](float v) {
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        return v;
+    };
+    auto layer_norm = [&](const float *g, const float *b, const float *add) {
+        float *zr = bufZ + tk * lda;
+        float s1 = 0.f;
+        for (int c = sub; c < d; c += 16) s1 += zr[c];
+        const float mu = group_sum(s1) / (float)d;
+        float q = 0.f;
+        for (int c = sub; c < d; c += 16) q += (zr[c] - mu) * (zr[c] - mu);
+        const float rstd = 1.0f / sqrtf(group_sum(q) / (float)d + 1e-5f);
+        for (int c = sub; c < d; c += 16) zr[c] = (zr[c] - mu) * rstd * g[c] + b[c] + (add ? add[c] : 0.f);
+    };
+    // ---- y = LN2(LN1(x + ao W_o^T + b_o) + c)
+    float4 av[MAXI][MAXG];
+    const Gemm go = plan(a.Wf, dp, dp, 0), g1 = plan(a.Wf + dp * dp, Fp, dp, 0), g2 = plan(a.Wf + dp * dp + Fp * dp, dp, Fp, KSF);
+    load_a(go, av);
+    __syncthreads(); // the tile fill above
+    gemm(go, av, bufA, lda, [&](int nt, int, const f32x4 &acc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bufZ[lq * lda + nt * 16 + 4 * gq + r] += acc[r]; // padded columns: += 0
+    });
+    load_a(g1, av);
+    __syncthreads();
+    layer_norm(a.g1, a.b1n, a.c);
+    if (a.c) layer_norm(a.g2, a.b2n, nullptr);
+    for (int c = sub; c < d; c += 16) bufA[tk * lda + c] = bufZ[tk * lda + c]; // columns d .. dp stay zero
+    __syncthreads();
+    // ---- h = relu(y W1^T + b1)
+    gemm(g1, av, bufA, lda, [&](int nt, int, const f32x4 &acc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nt * 16 + 4 * gq + r;
+            bufH[lq * ldh + n] = n < F ? fmaxf(acc[r] + a.b1[n], 0.f) : 0.f;
+        }
+    });
+    load_a(g2, av);
+    __syncthreads();
+    // ---- x' = LN3(y + h W2^T + b2): k-split partial tiles, then a fixed-order sum
+    gemm(g2, av, bufH, ldh, [&](int nt, int kc, const f32x4 &acc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bufP[(kc * 16 + lq) * lda + nt * 16 + 4 * gq + r] = acc[r];
+    });
+    Gemm gq3 = go;
+    if constexpr (QKV) {
+        gq3 = plan(a.Wfin, (3 * d + 15) & ~15, dp, 0);
+        load_a(gq3, av);
+    }
+    __syncthreads();
+    for (int c = sub; c < d; c += 16) {
+        float v = bufZ[tk * lda + c] + a.b2[c];
+        for (int kc = 0; kc < KCF; ++kc) v += bufP[(kc * 16 + tk) * lda + c];
+        bufZ[tk * lda + c] = v;
+    }
+    layer_norm(a.g3, a.b3n, nullptr);
+    {
+        const int row = m0 + tk;
+        for (int c = sub; c < d; c += 16) {
+            const float v = bufZ[tk * lda + c];
+            bufA[tk * lda + c] = v;
+            if (row < M) a.Xo[(int64_t)row * d + c] = v;
+        }
+    }
+    if constexpr (!QKV) return;
+    __syncthreads();
+    // ---- qkv' = x' W_in^T + b_in
+    gemm(gq3, av, bufA, lda, [&](int nt, int, const f32x4 &acc) {
+        const int row = m0 + lq;
+        if (row < M) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = nt * 16 + 4 * gq + r;
+                if (n < 3 * d) a.QKV[(int64_t)row * (3 * d) + n] = acc[r] + a.bin[n];
+            }
+        }
+    });
+}
+static inline size_t small_any_lds(int d, int F) {
+    const int dp = (d + 15) & ~15, Fp = (F + 15) & ~15;
+    return (size_t)(6 * 16 * (dp + 4) + 16 * (Fp + 4)) * sizeof(float);
+}
+
 // Embedding + layer 0's in-projection of the latency path, 16 packed tokens per workgroup: x = E[seq] sqrt(d) + pe
 // goes to global memory (the residual of layer 0) and to LDS (the B operand); the in-projection runs on the
 // fragment-packed W_in of layer 0, all 12 tile-rounds of a wave requested before the embedding rows are.
@@ -2777,13 +2970,31 @@ int irs_launch_cross_const(irs_ctx *ctx, hipStream_t s) {
 
 // fragment-packed weight copies for k_block_small16: [n_layers][Wo | W1 | W2] then [n_layers][Win]
 size_t irs_small_frag_floats(const irs_ctx *ctx) {
-    if (ctx->dims.d != 128 || ctx->dims.ffn_dim != 256) return 0;
+    const int d = ctx->dims.d, F = ctx->dims.ffn_dim;
+    if (small_any_shape(d, F)) return (size_t)ctx->dims.n_layers * small_any_layer_floats(d, F);
+    if (d != 128 || F != 256) return 0;
     return (size_t)ctx->dims.n_layers * (SMALL_WF_LAYER + SMALL_WF_WIN);
 }
 
 int irs_launch_pack_small(irs_ctx *ctx, hipStream_t s) {
     if (!ctx->w_frag16) return IRS_OK;
     const int nl = ctx->dims.n_layers;
+    if (small_any_shape(ctx->dims.d, ctx->dims.ffn_dim)) {
+        const int d = ctx->dims.d, F = ctx->dims.ffn_dim, dp = (d + 15) & ~15, Fp = (F + 15) & ~15, Qp = (3 * d + 15) & ~15;
+        for (int l = 0; l < nl; ++l) {
+            const irs_layer_w &w = ctx->layer[l];
+            float *o = ctx->w_frag16 + (size_t)l * small_any_layer_floats(d, F);
+            auto pk = [&](const float *W, float *out, int N, int K, int Np, int Kp) {
+                hipLaunchKernelGGL(k_pack_frag16_any, dim3((Np * Kp / 4 + 255) / 256), dim3(256), 0, s, W, out, N, K, Np, Kp);
+            };
+            pk(w.sa_out_w, o, d, d, dp, dp);
+            pk(w.l1_w, o + (size_t)dp * dp, F, d, Fp, dp);
+            pk(w.l2_w, o + (size_t)dp * dp + (size_t)Fp * dp, d, F, dp, Fp);
+            pk(w.sa_in_w, o + small_any_win_off(d, F), 3 * d, d, Qp, dp);
+        }
+        IRS_CHECK_HIP(ctx, hipGetLastError());
+        return IRS_OK;
+    }
     for (int l = 0; l < nl; ++l) {
         const irs_layer_w &w = ctx->layer[l];
         float *o = ctx->w_frag16 + (size_t)l * SMALL_WF_LAYER;
@@ -2819,6 +3030,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     // of 128-token tiles streams the weights serially through LDS whatever the number of tiles).
     const bool small_cfg = d == 128 && F == 256 && ctx->w_frag16 && rows <= SMALL_ROWS_MAX;
     const bool frag = d <= LIN_BN && d % 32 == 0 && rows > 2048 && !small_cfg;
+    // any other small shape at a launch-bound row count: the generic fused layer tail
+    const bool any_cfg = small_any_shape(d, F) && ctx->w_frag16 && rows <= 2048;
     float *xf = ctx->act_xf, *yf = ctx->act_yf;
     if (rows_only) {
         if (small_plan) {
@@ -2896,7 +3109,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                                    ao_r, L, d, d / ctx->dims.n_heads, ctx->dims.mask_mode, off, cnt, tok, qrow, q_r);
             irs_prof_end(ctx, IRS_PROF_ATTN, s, 4.0 * B * (double)L * d, 4.0 * 3.0 * B * (double)L * d);
             const bool fused_tail = d == 128 && F == 256;
-            const bool idx_res = fused_tail && !frag; // the layer kernel reads the residual rows x[qrow[b]] itself
+            const bool any_tail = small_any_shape(d, F) && ctx->w_frag16 && !frag && B <= 2048;
+            const bool idx_res = (fused_tail || any_tail) && !frag; // the layer kernel reads the residual rows x[qrow[b]] itself
             if (frag && !q_split) hipLaunchKernelGGL(k_gather_rows_frag, dim3(B), dim3(64), 0, s, xf, qrow, x_r, d);
             else if (!frag && !idx_res) hipLaunchKernelGGL(k_gather_rows_idx, dim3(B), dim3(64), 0, s, x, qrow, x_r, d);
             if (fused_tail) { // one launch for the rest of the layer on the B consumed rows
@@ -2906,6 +3120,13 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                 irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
                 if (B > 2048) hipLaunchKernelGGL((k_block_small16<false, 2>), dim3((B + 31) / 32), dim3(64 * SB_NW), 0, s, sb);
                 else hipLaunchKernelGGL((k_block_small16<false, 1>), dim3((B + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
+                irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * B * ((double)d * d + 2.0 * d * F), 4.0 * 3.0 * B * (double)d);
+            } else if (any_tail) {
+                SmallBlockArgs sb{ao_r, x, w.sa_out_w, w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, w.l1_w, w.l1_b, w.l2_w, w.l2_b,
+                                  w.n3_w, w.n3_b, xrows, nullptr, nullptr, nullptr, B, nullptr, qrow,
+                                  ctx->w_frag16 + (size_t)l * small_any_layer_floats(d, F), nullptr};
+                irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
+                hipLaunchKernelGGL((k_block_small_any<false>), dim3((B + 15) / 16), dim3(256), small_any_lds(d, F), s, sb, d, F);
                 irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * B * ((double)d * d + 2.0 * d * F), 4.0 * 3.0 * B * (double)d);
             } else if (d <= LIN_BN) {
                 if ((rc = launch_linear(ctx, ao_r, w.sa_out_w, w.sa_out_b, x_r, y_r, B, d, d, false, s, w.n1_w, w.n1_b, cl, w.n2_w,
@@ -2994,6 +3215,22 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                 if (sb.Win) hipLaunchKernelGGL((k_block_small16<true, 1>), dim3((rows + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
                 else hipLaunchKernelGGL((k_block_small16<false, 1>), dim3((rows + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
             }
+            irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * rows * ((double)d * d + 2.0 * d * F + (last ? 0.0 : 3.0 * d * d)),
+                         4.0 * (3.0 + (last ? 0.0 : 3.0)) * rows * (double)d);
+            qkv_done = !last;
+            float *tswap = x; // the new x lives in the other buffer
+            x = y;
+            y = tswap;
+        } else if (any_cfg) {
+            // launch-bound small shapes: the rest of the layer (and the next layer's QKV) in one launch per 16 tokens
+            const bool last = l + 1 == ctx->dims.n_layers;
+            SmallBlockArgs sb{ctx->act_ao, x, w.sa_out_w, w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, w.l1_w, w.l1_b, w.l2_w, w.l2_b,
+                              w.n3_w, w.n3_b, y, last ? nullptr : ctx->layer[l + 1].sa_in_w, last ? nullptr : ctx->layer[l + 1].sa_in_b,
+                              ctx->act_qkv, rows, m_dev, nullptr, ctx->w_frag16 + (size_t)l * small_any_layer_floats(d, F),
+                              last ? nullptr : ctx->w_frag16 + (size_t)(l + 1) * small_any_layer_floats(d, F) + small_any_win_off(d, F)};
+            irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
+            if (last) hipLaunchKernelGGL((k_block_small_any<false>), dim3((rows + 15) / 16), dim3(256), small_any_lds(d, F), s, sb, d, F);
+            else hipLaunchKernelGGL((k_block_small_any<true>), dim3((rows + 15) / 16), dim3(256), small_any_lds(d, F), s, sb, d, F);
             irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * rows * ((double)d * d + 2.0 * d * F + (last ? 0.0 : 3.0 * d * d)),
                          4.0 * (3.0 + (last ? 0.0 : 3.0)) * rows * (double)d);
             qkv_done = !last;
