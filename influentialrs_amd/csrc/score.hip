@@ -902,13 +902,23 @@ __global__ void __launch_bounds__(256) k_topk_direct(const float *__restrict__ x
     unsigned long long tstamp[10];
 #endif
     DSTAMP(0);
-    const int S = (d & 7) ? d : d + 4; // row stride = 4 mod 8 floats: conflict-free ds_read_b128 of one row per lane
+    const bool vec = (d & 3) == 0;
+    // row stride: 4 mod 8 floats (conflict-free ds_read_b128 of one row per lane), or odd when d is not a multiple
+    // of 4 (the reference's default d = 30: scalar staging and ds_read_b32)
+    const int S = vec ? ((d & 7) ? d : d + 4) : (d | 1);
     const int j0 = blockIdx.x * DIRECT_TILE;
     const int nj = min(DIRECT_TILE, n_local - j0);
     const int d4 = d >> 2;
-    for (int i = tid; i < nj * d4; i += 256) { // the tile is nj * d consecutive floats of W
-        const int jj = i / d4, c4 = i - jj * d4;
-        *reinterpret_cast<float4 *>(tile + jj * S + 4 * c4) = reinterpret_cast<const float4 *>(W + (size_t)j0 * d)[i];
+    if (vec) {
+        for (int i = tid; i < nj * d4; i += 256) { // the tile is nj * d consecutive floats of W
+            const int jj = i / d4, c4 = i - jj * d4;
+            *reinterpret_cast<float4 *>(tile + jj * S + 4 * c4) = reinterpret_cast<const float4 *>(W + (size_t)j0 * d)[i];
+        }
+    } else {
+        for (int i = tid; i < nj * d; i += 256) {
+            const int jj = i / d, c = i - jj * d;
+            tile[jj * S + c] = W[(size_t)j0 * d + i];
+        }
     }
     for (int i = tid; i < d; i += 256) xs[i] = x[(size_t)row * d + i];
     __syncthreads();
@@ -917,14 +927,19 @@ __global__ void __launch_bounds__(256) k_topk_direct(const float *__restrict__ x
     unsigned int *gk = reinterpret_cast<unsigned int *>(gkeys + (size_t)row * IRS_CAND_CAP);
     if (wave == 0 && lane < nj) {
         float acc = bias[j0 + lane];
-        const float4 *w4 = reinterpret_cast<const float4 *>(tile + lane * S);
-        const float4 *x4 = reinterpret_cast<const float4 *>(xs);
-        for (int c = 0; c < d4; ++c) { // the k-ascending fma chain of irs_chain
-            const float4 wv = w4[c], xv = x4[c];
-            acc = __fmaf_rn(xv.x, wv.x, acc);
-            acc = __fmaf_rn(xv.y, wv.y, acc);
-            acc = __fmaf_rn(xv.z, wv.z, acc);
-            acc = __fmaf_rn(xv.w, wv.w, acc);
+        if (vec) {
+            const float4 *w4 = reinterpret_cast<const float4 *>(tile + lane * S);
+            const float4 *x4 = reinterpret_cast<const float4 *>(xs);
+            for (int c = 0; c < d4; ++c) { // the k-ascending fma chain of irs_chain
+                const float4 wv = w4[c], xv = x4[c];
+                acc = __fmaf_rn(xv.x, wv.x, acc);
+                acc = __fmaf_rn(xv.y, wv.y, acc);
+                acc = __fmaf_rn(xv.z, wv.z, acc);
+                acc = __fmaf_rn(xv.w, wv.w, acc);
+            }
+        } else {
+            const float *wr = tile + lane * S;
+            for (int c = 0; c < d; ++c) acc = __fmaf_rn(xs[c], wr[c], acc);
         }
         gk[j0 + lane] = irs_fkey(acc);
     }
@@ -1287,7 +1302,7 @@ int irs_launch_pack_w(irs_ctx *ctx, hipStream_t s) {
 
 int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, float *val, int64_t *ids0,
                     int32_t *status, hipStream_t s) {
-    if (M <= 32 && ctx->n_local <= DIRECT_MAX_ITEMS && k <= 256 && (ctx->dims.d & 3) == 0 && ctx->dims.d <= DIRECT_MAX_D) {
+    if (M <= 32 && ctx->n_local <= DIRECT_MAX_ITEMS && k <= 256 && ctx->dims.d <= DIRECT_MAX_D) {
         // latency path on a small shard: one kernel, no fallback needed
         irs_prof_begin(ctx, IRS_PROF_REFINE, s);
         hipLaunchKernelGGL(k_topk_direct, dim3((unsigned)((ctx->n_local + DIRECT_TILE - 1) / DIRECT_TILE), M), dim3(256), 0, s, xrows, ctx->dims.d,

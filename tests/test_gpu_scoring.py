@@ -79,7 +79,7 @@ def test_topk_ties_and_fallback(oracle):
             assert np.array_equal(val[m].cpu().numpy().view(np.uint32), ov.view(np.uint32))
 
 
-DIRECT_CASES = [  # the one-launch small-shard path (M <= 32, n_item <= 4096, k <= 256, d % 4 == 0)
+DIRECT_CASES = [  # the one-launch small-shard path (M <= 32, n_item <= 4096, k <= 256)
     (3415, 128, 1, 100),    # the single-user step
     (3415, 128, 8, 100),
     (4096, 64, 32, 256),    # every limit at once
@@ -87,6 +87,8 @@ DIRECT_CASES = [  # the one-launch small-shard path (M <= 32, n_item <= 4096, k 
     (400, 16, 3, 100),      # exactly 4k: the smallest row that takes the sampled threshold
     (399, 16, 3, 100),      # below it: every key kept, bitonic sort of 399
     (130, 8, 2, 1),         # k = 1
+    (3415, 30, 5, 100),     # the reference's default d (not a multiple of 4: scalar staging)
+    (700, 6, 3, 20),        # d = 2 mod 4
 ]
 
 
