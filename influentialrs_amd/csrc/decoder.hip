@@ -3029,9 +3029,11 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     // 564 vs 720 us per path step at 128 users, 921 vs 797 at 256 (the big path has a ~700 us floor per step: one round
     // of 128-token tiles streams the weights serially through LDS whatever the number of tiles).
     const bool small_cfg = d == 128 && F == 256 && ctx->w_frag16 && rows <= SMALL_ROWS_MAX;
-    const bool frag = d <= LIN_BN && d % 32 == 0 && rows > 2048 && !small_cfg;
-    // any other small shape at a launch-bound row count: the generic fused layer tail
-    const bool any_cfg = small_any_shape(d, F) && ctx->w_frag16 && rows <= 2048;
+    // any other small shape: the generic fused layer tail.  Measured against the per-GEMM kernels (per path step):
+    // default (d = 30, L = 60) 235 vs 582 us at 64 users, 859 vs 1055 at 1024; config 1 (d = 64, L = 50) 259 vs 653
+    // at 64 users, 888 vs 1040 at 1024 -- ahead over the whole tested range
+    const bool any_cfg = small_any_shape(d, F) && ctx->w_frag16 && rows <= 65536;
+    const bool frag = d <= LIN_BN && d % 32 == 0 && rows > 2048 && !small_cfg && !any_cfg;
     float *xf = ctx->act_xf, *yf = ctx->act_yf;
     if (rows_only) {
         if (small_plan) {

@@ -185,6 +185,7 @@ def test_sampled_paths_distribution():
 
 
 @pytest.mark.parametrize("cfgname,B,over", [("c2", 176, {}), ("c2", 24, {}), ("c2", 72, {}), ("default", 80, {}), ("c1", 72, {}),
+                                             ("default", 1100, {}), ("c1", 1320, {}),
                                              ("c2", 136, {"max_len": 256}), ("c2", 24, {"ffn_dim": 128}),
                                              ("c2", 16, {"emb_dim": 256, "n_heads": 8}), ("c2", 176, {"n_heads": 8}),
                                              ("c2", 24, {"n_heads": 8})])
@@ -195,7 +196,9 @@ def test_throughput_shape_decode_matches_small_batches_and_oracle(oracle, cfgnam
     same sequences decoded eight at a time go through the small-batch kernels the goldens pin; both, and the
     numpy oracle on a few sequences, must agree to float32 accumulation noise.  The cases walk the kernel
     selection: c2 x 176 = fused 128-token layer kernel + 16-query attention; c2 x 24 / x 72 = the 16-token layer
-    kernel beyond the single-workgroup plan (24) and beyond the one-launch plan (72); default (d = 30) = row-major GEMMs; c1 (d = 64, head
+    kernel beyond the single-workgroup plan (24) and beyond the one-launch plan (72); default x 80 / c1 x 72 = the
+    generic fused layer kernel (any d <= 96) at a few thousand rows; default x 1100 / c1 x 1320 (> 65536 rows) = the
+    per-GEMM throughput kernels: default (d = 30) = row-major GEMMs; c1 (d = 64, head
     dim 16) fragment-major GEMMs with the 32-query attention; L = 256 = the 16-tile limit of the 16-query attention; ffn 128 = fragment-major, unfused FFN; d = 256 (C4's decoder) = separate LayerNorm kernels on packed rows; 8 heads at d = 128 (head dim 16) = 32-query
     attention + LN-fused out-projection + the layer kernel without its out-projection phase."""
     cfg = synth.make_config(cfgname, **over)
