@@ -1834,12 +1834,13 @@ static inline bool small_any_shape(int d, int F) {
     const int Fp = (F + 15) & ~15, ksh = Fp > 128 ? 2 : Fp > 64 ? 1 : 0; // the k groups of W2 must split evenly into its chunks
     return !(d == 128 && F == 256) && d <= 96 && F <= 256 && ((Fp >> 4) & ((1 << ksh) - 1)) == 0;
 }
+static inline int small_any_dp(int d) { return d <= 32 ? 32 : d <= 64 ? 64 : 96; } // padded width: one of three instantiations
 static inline size_t small_any_win_off(int d, int F) {
-    const size_t dp = (d + 15) & ~15, Fp = (F + 15) & ~15;
+    const size_t dp = small_any_dp(d), Fp = (F + 15) & ~15;
     return dp * dp + 2 * Fp * dp;
 }
 static inline size_t small_any_layer_floats(int d, int F) {
-    const size_t dp = (d + 15) & ~15, Qp = (3 * d + 15) & ~15;
+    const size_t dp = small_any_dp(d), Qp = (3 * d + 15) & ~15;
     return small_any_win_off(d, F) + Qp * dp;
 }
 
@@ -1850,78 +1851,106 @@ static inline size_t small_any_layer_floats(int d, int F) {
 // activations sit in LDS padded to 16 columns; work items = (16-column output tile, k chunk) dealt round-robin to the waves -- the FFN's second GEMM
 // (K = F) is split into up to 4 k chunks whose partial tiles are summed in a fixed order -- and the LayerNorms run on
 // the LDS tile with 16 lanes per token.
-template <bool QKV>
+#ifdef IRS_SMALL_TIMING
+#define ASTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_small_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ASTAMP(i)
+#endif
+// DPT = padded width / 16 (2, 4 or 6) is a template parameter so that the fragment arrays have static shapes and the
+// k loops of the three K = d GEMMs carry no run-time guards (the fully run-time version spent ~600 scalar branches).
+template <int MAXI, int MAXG>
+__device__ __forceinline__ void any_load(const float4 *W, int KG, int ksh, int gpi, int nit, int wave, int lane,
+                                         float4 (&av)[MAXI][MAXG]) {
+#pragma unroll
+    for (int ii = 0; ii < MAXI; ++ii) {
+        const int item = wave + 4 * ii, nt = item >> ksh, kc = item & ((1 << ksh) - 1);
+        const float4 *wp = W + ((size_t)nt * KG + kc * gpi) * 64 + lane;
+        if (ii < nit) { // wave-uniform
+#pragma unroll
+            for (int kg = 0; kg < MAXG; ++kg)
+                if (kg < gpi) av[ii][kg] = wp[kg * 64];
+        }
+    }
+}
+template <int MAXI, int MAXG, class Emit>
+__device__ __forceinline__ void any_gemm(int ksh, int gpi, int nit, int wave, const float4 (&av)[MAXI][MAXG], const float *brow,
+                                         Emit emit) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+#pragma unroll
+    for (int ii = 0; ii < MAXI; ++ii) {
+        if (ii < nit) {
+            const int item = wave + 4 * ii, nt = item >> ksh, kc = item & ((1 << ksh) - 1);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kg = 0; kg < MAXG; ++kg) {
+                if (kg < gpi) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(brow + 16 * (kc * gpi + kg));
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ii][kg].x, bv.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ii][kg].y, bv.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ii][kg].z, bv.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ii][kg].w, bv.w, acc, 0, 0, 0);
+                }
+            }
+            emit(nt, kc, acc);
+        }
+    }
+}
+
+template <bool QKV, int DPT>
 __global__ void __launch_bounds__(256) k_block_small_any(SmallBlockArgs a, int d, int F) {
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     extern __shared__ __attribute__((aligned(16))) float sm_any[];
-    const int dp = (d + 15) & ~15, Fp = (F + 15) & ~15, lda = dp + 4, ldh = Fp + 4;
+    constexpr int dp = 16 * DPT;
+    const int Fp = (F + 15) & ~15, lda = dp + 4, ldh = Fp + 4;
     float *bufA = sm_any;            // [16][lda] GEMM input: ao -> y -> x'
     float *bufZ = bufA + 16 * lda;   // [16][lda] x + b_o (+ GEMM) -> y ; y + b2 (+ GEMM) -> x'
     float *bufH = bufZ + 16 * lda;   // [16][ldh] h
     float *bufP = bufH + 16 * ldh;   // [4][16][lda] partial tiles of the k-split GEMM
+    // every per-column vector, staged once with the activation tile (in-kernel timing: read from global memory where
+    // they are used, each LayerNorm / epilogue paid its own ~1 us round trip): 9 x [d] | b1 [F] | b_in [3d]
+    float *vecs = bufP + 4 * 16 * lda;
+    const float *vbo = vecs, *vg1 = vecs + d, *vb1n = vecs + 2 * d, *vc = vecs + 3 * d, *vg2 = vecs + 4 * d, *vb2n = vecs + 5 * d;
+    const float *vb2 = vecs + 6 * d, *vg3 = vecs + 7 * d, *vb3n = vecs + 8 * d, *vb1 = vecs + 9 * d, *vbin = vecs + 9 * d + F;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 15, gq = lane >> 4;
+    ASTAMP(0);
     const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M;
     const int m0 = blockIdx.x * 16;
     if (m0 >= M) return;
     const int KSF = Fp > 128 ? 2 : Fp > 64 ? 1 : 0, KCF = 1 << KSF; // k chunks of the FFN's second GEMM: 4 / 2 / 1
+    {
+        const float *src[9] = {a.bo, a.g1, a.b1n, a.c, a.g2, a.b2n, a.b2, a.g3, a.b3n};
+        for (int i = tid; i < 9 * d; i += 256) {
+            const int v = i / d;
+            const float *p = src[0];
+#pragma unroll
+            for (int u = 1; u < 9; ++u) p = (v == u) ? src[u] : p;
+            vecs[i] = p ? p[i - v * d] : 0.f;
+        }
+        for (int i = tid; i < F; i += 256) vecs[9 * d + i] = a.b1[i];
+        if constexpr (QKV)
+            for (int i = tid; i < 3 * d; i += 256) vecs[9 * d + F + i] = a.bin[i];
+    }
     for (int i = tid; i < 16 * dp; i += 256) {
         const int rr = i / dp, c = i - rr * dp, row = m0 + rr;
         const bool ok = row < M && c < d;
         const int xr = (row < M && a.xidx) ? a.xidx[row] : row;
         bufA[rr * lda + c] = ok ? a.AO[(int64_t)row * d + c] : 0.f;
-        bufZ[rr * lda + c] = ok ? a.X[(int64_t)xr * d + c] + (a.bo ? a.bo[c] : 0.f) : 0.f;
+        bufZ[rr * lda + c] = ok ? a.X[(int64_t)xr * d + c] : 0.f; // + b_o below, once the vectors are visible
     }
     // acc(item) = W[16 nt .. +15][k range of chunk kc] . B[token][same k] on zero-padded, fragment-packed weights
     // (k_pack_frag16_any: float4 ((nt * Kp/16 + kg) * 64 + lane) = W[16nt + lq][16kg + 4gq .. +3], so a wave load is
     // 1 KB contiguous and needs no guards); B = buf[lq][same k] as one ds_read_b128; C register r <-> column
     // 16nt + 4gq + r of token lq.  A wave owns items wave, wave + 4, ... (item = nt * KC + kc, KC a power of two).
-    // ALL the weight fragments of a wave's share of a GEMM (<= 6 items x 6 k groups) are requested at once, before
-    // the barrier / LayerNorm in front of the GEMM: weights do not depend on the activations.
-    constexpr int MAXI = 6, MAXG = 6;
-    struct Gemm {
-        const float4 *W;
-        int KG, ksh, gpi, nit; // k groups of 16 in a row, log2(k chunks), groups per item, this wave's items
-    };
-    auto plan = [&](const float *Wp, int Np, int Kp, int ksh) {
-        Gemm g;
-        g.W = reinterpret_cast<const float4 *>(Wp), g.KG = Kp >> 4, g.ksh = ksh;
-        g.gpi = g.KG >> ksh; // Kp / 16 is a multiple of the chunk count for every shape the launcher admits
-        const int items = (Np >> 4) << ksh;
-        g.nit = items > wave ? (items - wave + 3) >> 2 : 0;
-        return g;
-    };
-    auto load_a = [&](const Gemm &g, float4 (&av)[MAXI][MAXG]) {
-#pragma unroll
-        for (int ii = 0; ii < MAXI; ++ii) {
-            const int item = wave + 4 * ii, nt = item >> g.ksh, kc = item & ((1 << g.ksh) - 1);
-            const float4 *wp = g.W + ((size_t)nt * g.KG + kc * g.gpi) * 64 + lane;
-#pragma unroll
-            for (int kg = 0; kg < MAXG; ++kg)
-                if (ii < g.nit && kg < g.gpi) av[ii][kg] = wp[kg * 64]; // wave-uniform
-        }
-    };
-    auto gemm = [&](const Gemm &g, const float4 (&av)[MAXI][MAXG], const float *B, int ldb, auto emit) {
-        const float *brow = B + lq * ldb + 4 * gq;
-#pragma unroll
-        for (int ii = 0; ii < MAXI; ++ii) {
-            if (ii < g.nit) {
-                const int item = wave + 4 * ii, nt = item >> g.ksh, kc = item & ((1 << g.ksh) - 1);
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kg = 0; kg < MAXG; ++kg) {
-                    if (kg < g.gpi) {
-                        const float4 bv = *reinterpret_cast<const float4 *>(brow + 16 * (kc * g.gpi + kg));
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ii][kg].x, bv.x, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ii][kg].y, bv.y, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ii][kg].z, bv.z, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ii][kg].w, bv.w, acc, 0, 0, 0);
-                    }
-                }
-                emit(nt, kc, acc);
-            }
-        }
-    };
+    // ALL the weight fragments of a wave's share of a GEMM are requested at once, before the barrier / LayerNorm in
+    // front of the GEMM: weights do not depend on the activations.
+    const float4 *Wo4 = reinterpret_cast<const float4 *>(a.Wf), *W14 = Wo4 + dp * dp / 4, *W24 = W14 + Fp * dp / 4;
+    const float4 *Wq4 = reinterpret_cast<const float4 *>(a.Wfin);
+    auto items_of = [&](int items) { return items > wave ? (items - wave + 3) >> 2 : 0; };
+    constexpr int IO = (DPT + 3) / 4, I1 = 4, I2 = DPT, IQ = (3 * DPT + 3) / 4; // static bounds of a wave's items
+    const int nit_o = items_of(DPT), nit_1 = items_of(Fp >> 4), nit_2 = items_of(DPT << KSF), gpi_2 = (Fp >> 4) >> KSF;
+    const int nit_q = items_of((3 * d + 15) >> 4);
+    const float *browA = bufA + lq * lda + 4 * gq, *browH = bufH + lq * ldh + 4 * gq;
     // LayerNorm of the 16 rows of bufZ in place (16 lanes per token: columns sub, sub + 16, ...)
     const int tk = tid >> 4, sub = tid & 15;
     auto group_sum = [&](float v) {
@@ -1942,47 +1971,52 @@ __global__ void __launch_bounds__(256) k_block_small_any(SmallBlockArgs a, int d
         for (int c = sub; c < d; c += 16) zr[c] = (zr[c] - mu) * rstd * g[c] + b[c] + (add ? add[c] : 0.f);
     };
     // ---- y = LN2(LN1(x + ao W_o^T + b_o) + c)
-    float4 av[MAXI][MAXG];
-    const Gemm go = plan(a.Wf, dp, dp, 0), g1 = plan(a.Wf + dp * dp, Fp, dp, 0), g2 = plan(a.Wf + dp * dp + Fp * dp, dp, Fp, KSF);
-    load_a(go, av);
+    float4 avo[IO][DPT], av1[I1][DPT], av2[I2][4], avq[IQ][DPT];
+    any_load<IO, DPT>(Wo4, DPT, 0, DPT, nit_o, wave, lane, avo);
     __syncthreads(); // the tile fill above
-    gemm(go, av, bufA, lda, [&](int nt, int, const f32x4 &acc) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bufZ[lq * lda + nt * 16 + 4 * gq + r] += acc[r]; // padded columns: += 0
-    });
-    load_a(g1, av);
-    __syncthreads();
-    layer_norm(a.g1, a.b1n, a.c);
-    if (a.c) layer_norm(a.g2, a.b2n, nullptr);
-    for (int c = sub; c < d; c += 16) bufA[tk * lda + c] = bufZ[tk * lda + c]; // columns d .. dp stay zero
-    __syncthreads();
-    // ---- h = relu(y W1^T + b1)
-    gemm(g1, av, bufA, lda, [&](int nt, int, const f32x4 &acc) {
+    ASTAMP(1);
+    any_gemm<IO, DPT>(0, DPT, nit_o, wave, avo, browA, [&](int nt, int, const f32x4 &acc) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = nt * 16 + 4 * gq + r;
-            bufH[lq * ldh + n] = n < F ? fmaxf(acc[r] + a.b1[n], 0.f) : 0.f;
+            if (n < d) bufZ[lq * lda + n] += acc[r] + vbo[n];
         }
     });
-    load_a(g2, av);
+    ASTAMP(2);
+    any_load<I1, DPT>(W14, DPT, 0, DPT, nit_1, wave, lane, av1);
+    __syncthreads();
+    layer_norm(vg1, vb1n, vc);
+    if (a.c) layer_norm(vg2, vb2n, nullptr);
+    for (int c = sub; c < d; c += 16) bufA[tk * lda + c] = bufZ[tk * lda + c]; // columns d .. dp stay zero
+    __syncthreads();
+    ASTAMP(3);
+    // ---- h = relu(y W1^T + b1)
+    any_gemm<I1, DPT>(0, DPT, nit_1, wave, av1, browA, [&](int nt, int, const f32x4 &acc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nt * 16 + 4 * gq + r;
+            bufH[lq * ldh + n] = n < F ? fmaxf(acc[r] + vb1[n], 0.f) : 0.f;
+        }
+    });
+    ASTAMP(4);
+    any_load<I2, 4>(W24, Fp >> 4, KSF, gpi_2, nit_2, wave, lane, av2);
     __syncthreads();
     // ---- x' = LN3(y + h W2^T + b2): k-split partial tiles, then a fixed-order sum
-    gemm(g2, av, bufH, ldh, [&](int nt, int kc, const f32x4 &acc) {
+    any_gemm<I2, 4>(KSF, gpi_2, nit_2, wave, av2, browH, [&](int nt, int kc, const f32x4 &acc) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) bufP[(kc * 16 + lq) * lda + nt * 16 + 4 * gq + r] = acc[r];
     });
-    Gemm gq3 = go;
-    if constexpr (QKV) {
-        gq3 = plan(a.Wfin, (3 * d + 15) & ~15, dp, 0);
-        load_a(gq3, av);
-    }
+    ASTAMP(5);
+    if constexpr (QKV) any_load<IQ, DPT>(Wq4, DPT, 0, DPT, nit_q, wave, lane, avq);
     __syncthreads();
     for (int c = sub; c < d; c += 16) {
-        float v = bufZ[tk * lda + c] + a.b2[c];
+        float v = bufZ[tk * lda + c] + vb2[c];
         for (int kc = 0; kc < KCF; ++kc) v += bufP[(kc * 16 + tk) * lda + c];
         bufZ[tk * lda + c] = v;
     }
-    layer_norm(a.g3, a.b3n, nullptr);
+    ASTAMP(6);
+    layer_norm(vg3, vb3n, nullptr);
+    ASTAMP(7);
     {
         const int row = m0 + tk;
         for (int c = sub; c < d; c += 16) {
@@ -1993,21 +2027,35 @@ __global__ void __launch_bounds__(256) k_block_small_any(SmallBlockArgs a, int d
     }
     if constexpr (!QKV) return;
     __syncthreads();
+    ASTAMP(8);
     // ---- qkv' = x' W_in^T + b_in
-    gemm(gq3, av, bufA, lda, [&](int nt, int, const f32x4 &acc) {
+    any_gemm<IQ, DPT>(0, DPT, nit_q, wave, avq, browA, [&](int nt, int, const f32x4 &acc) {
         const int row = m0 + lq;
         if (row < M) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = nt * 16 + 4 * gq + r;
-                if (n < 3 * d) a.QKV[(int64_t)row * (3 * d) + n] = acc[r] + a.bin[n];
+                if (n < 3 * d) a.QKV[(int64_t)row * (3 * d) + n] = acc[r] + vbin[n];
             }
         }
     });
+    ASTAMP(9);
+}
+static inline size_t small_any_lds(int d, int F);
+static void launch_small_any(bool qkv, int rows, int d, int F, const SmallBlockArgs &sb, hipStream_t s) {
+    const dim3 grid((rows + 15) / 16);
+    const size_t lds = small_any_lds(d, F);
+#define A_(Q_, T_) hipLaunchKernelGGL((k_block_small_any<Q_, T_>), grid, dim3(256), lds, s, sb, d, F)
+    switch (small_any_dp(d)) {
+    case 32: if (qkv) A_(true, 2); else A_(false, 2); break;
+    case 64: if (qkv) A_(true, 4); else A_(false, 4); break;
+    default: if (qkv) A_(true, 6); else A_(false, 6); break;
+    }
+#undef A_
 }
 static inline size_t small_any_lds(int d, int F) {
-    const int dp = (d + 15) & ~15, Fp = (F + 15) & ~15;
-    return (size_t)(6 * 16 * (dp + 4) + 16 * (Fp + 4)) * sizeof(float);
+    const int dp = small_any_dp(d), Fp = (F + 15) & ~15;
+    return (size_t)(6 * 16 * (dp + 4) + 16 * (Fp + 4) + 12 * d + F) * sizeof(float);
 }
 
 // Embedding + layer 0's in-projection of the latency path, 16 packed tokens per workgroup: x = E[seq] sqrt(d) + pe
@@ -2980,7 +3028,7 @@ int irs_launch_pack_small(irs_ctx *ctx, hipStream_t s) {
     if (!ctx->w_frag16) return IRS_OK;
     const int nl = ctx->dims.n_layers;
     if (small_any_shape(ctx->dims.d, ctx->dims.ffn_dim)) {
-        const int d = ctx->dims.d, F = ctx->dims.ffn_dim, dp = (d + 15) & ~15, Fp = (F + 15) & ~15, Qp = (3 * d + 15) & ~15;
+        const int d = ctx->dims.d, F = ctx->dims.ffn_dim, dp = small_any_dp(d), Fp = (F + 15) & ~15, Qp = (3 * d + 15) & ~15;
         for (int l = 0; l < nl; ++l) {
             const irs_layer_w &w = ctx->layer[l];
             float *o = ctx->w_frag16 + (size_t)l * small_any_layer_floats(d, F);
@@ -3128,7 +3176,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                                   w.n3_w, w.n3_b, xrows, nullptr, nullptr, nullptr, B, nullptr, qrow,
                                   ctx->w_frag16 + (size_t)l * small_any_layer_floats(d, F), nullptr};
                 irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
-                hipLaunchKernelGGL((k_block_small_any<false>), dim3((B + 15) / 16), dim3(256), small_any_lds(d, F), s, sb, d, F);
+                launch_small_any(false, B, d, F, sb, s);
                 irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * B * ((double)d * d + 2.0 * d * F), 4.0 * 3.0 * B * (double)d);
             } else if (d <= LIN_BN) {
                 if ((rc = launch_linear(ctx, ao_r, w.sa_out_w, w.sa_out_b, x_r, y_r, B, d, d, false, s, w.n1_w, w.n1_b, cl, w.n2_w,
@@ -3231,8 +3279,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                               ctx->act_qkv, rows, m_dev, nullptr, ctx->w_frag16 + (size_t)l * small_any_layer_floats(d, F),
                               last ? nullptr : ctx->w_frag16 + (size_t)(l + 1) * small_any_layer_floats(d, F) + small_any_win_off(d, F)};
             irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
-            if (last) hipLaunchKernelGGL((k_block_small_any<false>), dim3((rows + 15) / 16), dim3(256), small_any_lds(d, F), s, sb, d, F);
-            else hipLaunchKernelGGL((k_block_small_any<true>), dim3((rows + 15) / 16), dim3(256), small_any_lds(d, F), s, sb, d, F);
+            launch_small_any(!last, rows, d, F, sb, s);
             irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * rows * ((double)d * d + 2.0 * d * F + (last ? 0.0 : 3.0 * d * d)),
                          4.0 * (3.0 + (last ? 0.0 : 3.0)) * rows * (double)d);
             qkv_done = !last;

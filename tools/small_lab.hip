@@ -76,6 +76,30 @@ int main(int argc, char **argv) {
         for (int i = 1; i <= 13; ++i) printf(" %llu", t[i] - t[0]);
         printf("\n");
     }
+    for (int dd : {30, 64}) { // the generic kernel: phase stamps at the reference's default d and at config 1's
+        const int F = 256, dp = small_any_dp(dd), Fp = 256, Qp = (3 * dd + 15) & ~15;
+        float *wfa; CK(hipMalloc(&wfa, (size_t)2 * small_any_layer_floats(dd, F) * 4));
+        auto pk = [&](const float *Wsrc, float *out, int N, int K, int Np, int Kp) {
+            hipLaunchKernelGGL(k_pack_frag16_any, dim3((Np * Kp / 4 + 255) / 256), dim3(256), 0, 0, Wsrc, out, N, K, Np, Kp);
+        };
+        pk(a.Wo, wfa, dd, dd, dp, dp);
+        pk(a.W1, wfa + dp * dp, F, dd, Fp, dp);
+        pk(a.W2, wfa + dp * dp + Fp * dp, dd, F, dp, Fp);
+        pk(a.Win, wfa + small_any_win_off(dd, F), 3 * dd, dd, Qp, dp);
+        SmallBlockArgs b = a;
+        b.Wf = wfa; b.Wfin = wfa + small_any_win_off(dd, F); b.M = 50;
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < 20; ++i)
+                launch_small_any(true, b.M, dd, F, b, 0);
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            unsigned long long t[16]; CK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_small_t), sizeof t));
+            printf("any d=%d M=%d: %.2f us per launch; stamps:", dd, b.M, ms * 1e3 / 20);
+            for (int i = 1; i <= 9; ++i) printf(" %llu", t[i] - t[0]);
+            printf("\n");
+        }
+    }
     {
         float *big; CK(hipMalloc(&big, (size_t)64 << 20));
         CK(hipMemset(big, 0, (size_t)64 << 20));
