@@ -1817,6 +1817,19 @@ __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) 
     STAMP(8);
 }
 
+// arguments of the embedding + layer-0 in-projection kernels of the latency paths
+struct SmallEmbedArgs {
+    const int64_t *seq;
+    const float *E, *pe;
+    const int32_t *tok_row, *m_dev;
+    int rows, L;
+    float sqrtd;
+    int64_t n_item;
+    float *X;               // [rows][128]
+    const float *Wfin, *bin; // fragment-packed W_in of layer 0, its bias
+    float *QKV;             // [rows][384]
+};
+
 // Zero-padded fragment-packed copy of W[N][K] for k_block_small_any: [Np/16 tiles][Kp/16 k groups][64 lanes] float4.
 __global__ void k_pack_frag16_any(const float *__restrict__ W, float *__restrict__ out, int N, int K, int Np, int Kp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x; // one float4 of the packed image
@@ -2041,6 +2054,49 @@ __global__ void __launch_bounds__(256) k_block_small_any(SmallBlockArgs a, int d
     });
     ASTAMP(9);
 }
+// Embedding + layer 0's in-projection for the same shapes: x = E[seq] sqrt(d) + pe to global memory and to the
+// LDS tile, then the QKV GEMM on the zero-padded packed W_in of layer 0 (one launch instead of two).
+template <int DPT>
+__global__ void __launch_bounds__(256) k_embed_qkv_small_any(SmallEmbedArgs a, int d) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    constexpr int dp = 16 * DPT, lda = dp + 4, IQ = (3 * DPT + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float bufA[16 * lda];
+    __shared__ float vbin[3 * dp];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 15, gq = lane >> 4;
+    const int Qt = (3 * d + 15) >> 4; // 16-column tiles of the QKV output
+    const int nit_q = Qt > wave ? (Qt - wave + 3) >> 2 : 0;
+    float4 avq[IQ][DPT];
+    any_load<IQ, DPT>(reinterpret_cast<const float4 *>(a.Wfin), DPT, 0, DPT, nit_q, wave, lane, avq);
+    const int M = a.m_dev ? min(a.rows, a.m_dev[0]) : a.rows;
+    const int m0 = blockIdx.x * 16;
+    if (m0 >= M) return;
+    for (int i = tid; i < 3 * d; i += 256) vbin[i] = a.bin[i];
+    for (int i = tid; i < 16 * dp; i += 256) {
+        const int rr = i / dp, c = i - rr * dp, row = m0 + rr;
+        float v = 0.f;
+        if (row < M && c < d) {
+            const int orig = a.tok_row ? a.tok_row[row] : row;
+            int64_t id = a.seq[orig];
+            if (id < 0) id = 0;
+            if (id > a.n_item) id = a.n_item;
+            v = __fadd_rn(__fmul_rn(a.E[id * (int64_t)d + c], a.sqrtd), a.pe[(int64_t)(orig % a.L) * d + c]);
+            a.X[(int64_t)row * d + c] = v;
+        }
+        bufA[rr * lda + c] = v;
+    }
+    __syncthreads();
+    any_gemm<IQ, DPT>(0, DPT, nit_q, wave, avq, bufA + lq * lda + 4 * gq, [&](int nt, int, const f32x4 &acc) {
+        const int row = m0 + lq;
+        if (row < M) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = nt * 16 + 4 * gq + r;
+                if (n < 3 * d) a.QKV[(int64_t)row * (3 * d) + n] = acc[r] + vbin[n];
+            }
+        }
+    });
+}
 static inline size_t small_any_lds(int d, int F);
 static void launch_small_any(bool qkv, int rows, int d, int F, const SmallBlockArgs &sb, hipStream_t s) {
     const dim3 grid((rows + 15) / 16);
@@ -2061,17 +2117,6 @@ static inline size_t small_any_lds(int d, int F) {
 // Embedding + layer 0's in-projection of the latency path, 16 packed tokens per workgroup: x = E[seq] sqrt(d) + pe
 // goes to global memory (the residual of layer 0) and to LDS (the B operand); the in-projection runs on the
 // fragment-packed W_in of layer 0, all 12 tile-rounds of a wave requested before the embedding rows are.
-struct SmallEmbedArgs {
-    const int64_t *seq;
-    const float *E, *pe;
-    const int32_t *tok_row, *m_dev;
-    int rows, L;
-    float sqrtd;
-    int64_t n_item;
-    float *X;               // [rows][128]
-    const float *Wfin, *bin; // fragment-packed W_in of layer 0, its bias
-    float *QKV;             // [rows][384]
-};
 
 __global__ void __launch_bounds__(256) k_embed_qkv_small16(SmallEmbedArgs a) {
     typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -3118,6 +3163,18 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                           ctx->w_frag16 + (size_t)ctx->dims.n_layers * SMALL_WF_LAYER, ctx->layer[0].sa_in_b, ctx->act_qkv};
         irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
         hipLaunchKernelGGL(k_embed_qkv_small16, dim3((rows + 15) / 16), dim3(256), 0, s, ea);
+        irs_prof_end(ctx, IRS_PROF_LINEAR, s, 6.0 * rows * (double)d * d, 4.0 * 4.0 * rows * (double)d);
+        qkv0_done = true;
+    } else if (rows_only && any_cfg && ctx->dims.n_layers > 1) {
+        SmallEmbedArgs ea{seq, ctx->item_emb, ctx->pe, tok, m_dev, rows, L, sqrtf((float)d), ctx->dims.n_item, x,
+                          ctx->w_frag16 + small_any_win_off(d, F), ctx->layer[0].sa_in_b, ctx->act_qkv};
+        irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
+        const dim3 grid((rows + 15) / 16);
+        switch (small_any_dp(d)) {
+        case 32: hipLaunchKernelGGL(k_embed_qkv_small_any<2>, grid, dim3(256), 0, s, ea, d); break;
+        case 64: hipLaunchKernelGGL(k_embed_qkv_small_any<4>, grid, dim3(256), 0, s, ea, d); break;
+        default: hipLaunchKernelGGL(k_embed_qkv_small_any<6>, grid, dim3(256), 0, s, ea, d); break;
+        }
         irs_prof_end(ctx, IRS_PROF_LINEAR, s, 6.0 * rows * (double)d * d, 4.0 * 4.0 * rows * (double)d);
         qkv0_done = true;
     } else if (rows_only)
