@@ -459,6 +459,12 @@ static int enqueue_step(irs_ctx *ctx, int64_t *seq, const int64_t *user, int32_t
     rc = irs_launch_decode(ctx, seq, user, B, nullptr, hep, ctx->xrows, nullptr, s);
     ctx->step_pair = nullptr;
     if (rc) return rc;
+    // small shard, few rows: the workgroup that ranks a row's candidates also takes the row's path step
+    if (merged && sweep != IRS_SWEEP_EXHAUSTIVE && irs_topk_is_direct(ctx, B, k)) {
+        const irs_path_args pa{seq, hep, ctx->dims.max_len, paths, path_ld, sample, sample_k, (unsigned long long)seed, status,
+                               ctx->step_ctr, 0, ctx->step_ctr + 1, 1};
+        return irs_launch_topk(ctx, ctx->xrows, B, k, sweep, ctx->top_val, ctx->top_ids, ctx->row_status, s, &pa);
+    }
     if ((rc = irs_launch_topk(ctx, ctx->xrows, B, k, sweep, ctx->top_val, ctx->top_ids, ctx->row_status, s))) return rc;
     if ((rc = irs_launch_path_step(ctx, seq, hep, B, ctx->top_val, ctx->top_ids, k, 0, ctx->step_ctr, paths, path_ld,
                                    sample, sample_k, seed, status, s, merged ? ctx->step_ctr + 1 : nullptr)))

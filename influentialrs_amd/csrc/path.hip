@@ -7,7 +7,7 @@
 // (no .item() host round trips; the reference pays B x 20 of them per batch).
 #include "irs_internal.h"
 
-// One wave per row.
+// One wave per row (the row body lives in irs_internal.h: the one-launch small-shard top-k runs it in its tail).
 __global__ void __launch_bounds__(256) k_path_step(int64_t *__restrict__ seq, int32_t *__restrict__ hep, int B, int L,
                                                    const float *__restrict__ val, const int64_t *__restrict__ ids0,
                                                    int k, int step_arg, const int32_t *__restrict__ step_ptr,
@@ -17,92 +17,8 @@ __global__ void __launch_bounds__(256) k_path_step(int64_t *__restrict__ seq, in
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= B) return;
-    const int step = step_ptr ? step_ptr[0] : step_arg;
-    // merged small-batch loop: publish the next step index in a second word (nobody reads it during this kernel;
-    // the next step's first kernel copies it over step_ptr[0]) instead of a k_inc launch
-    if (step_next && row == 0 && lane == 0) step_next[0] = step + 1;
-    int64_t *w = seq + (size_t)row * L;
-    const int he = hep[row];
-    const int wl = he + 1; // window = seq[row, 0 .. he]
-    // window into registers (L <= 256 -> 4 per lane)
-    int64_t wv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int p = lane + 64 * i;
-        wv[i] = (p < wl && p < L) ? w[p] : (int64_t)-1;
-    }
-    int64_t chosen = 0;
-    int found = 0;
-    float surv_val[8];
-    int64_t surv_id[8];
-    if (sample_k > 8) sample_k = 8;
-    const int want = sample ? sample_k : 1;
-    for (int c = 0; c < k && found < want; ++c) {
-        int64_t id0 = ids0[(size_t)row * k + c];
-        if (id0 < 0) break;
-        int64_t item = id0 + 1;
-        bool hit = false;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) hit |= (wv[i] == item);
-        if (!__any(hit)) {
-            surv_val[found] = val[(size_t)row * k + c];
-            surv_id[found] = item;
-            ++found;
-        }
-    }
-    if (found == 0) {
-        if (lane == 0) status[row] |= IRS_ROW_NO_CANDIDATE;
-        chosen = 0;
-    } else if (!sample) {
-        chosen = surv_id[0];
-    } else {
-        // multinomial over the first `found` survivors with weights exp(val) (softmax's
-        // normaliser cancels, influentialRS.py:431-434).  Counter RNG: splitmix64(seed, row, step).
-        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)row * 1315423911ull + (unsigned long long)step + 1ull);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        z = z ^ (z >> 31);
-        float u = (float)((z >> 40) & 0xFFFFFF) * (1.0f / 16777216.0f);
-        float mx = surv_val[0], tot = 0.f, p[8];
-        for (int i = 0; i < found; ++i) {
-            p[i] = __expf(surv_val[i] - mx);
-            tot += p[i];
-        }
-        float acc = 0.f;
-        chosen = surv_id[found - 1];
-        for (int i = 0; i < found; ++i) {
-            acc += p[i] / tot;
-            if (u < acc) {
-                chosen = surv_id[i];
-                break;
-            }
-        }
-    }
-    if (lane == 0 && step < path_ld) paths[(size_t)row * path_ld + step] = (float)chosen;
-    if (found == 0) return;
-    if (he < L - 2) { // room before the target: grow (influentialRS.py:438-441)
-        if (lane == 0) {
-            w[he + 1] = chosen;
-            hep[row] = he + 1;
-        }
-    } else { // shift left by one, keep the target last (influentialRS.py:442-450)
-        int64_t nv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int p = lane + 64 * i;
-            nv[i] = (p + 1 <= L - 2) ? w[p + 1] : 0;
-        }
-        // all loads of this wave are complete before the stores (single wave, in-order memory ops per lane;
-        // cross-lane overlap p <-> p+1 needs the explicit fence below)
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_s_waitcnt(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int p = lane + 64 * i;
-            if (p < L - 2) w[p] = nv[i];
-        }
-        if (lane == 0) w[L - 2] = chosen;
-    }
+    const irs_path_args pa{seq, hep, L, paths, path_ld, sample, sample_k, seed, status, step_ptr, step_arg, step_next, 1};
+    irs_path_step_row(pa, row, lane, val, ids0, k);
 }
 
 __global__ void k_inc(int32_t *ctr) {

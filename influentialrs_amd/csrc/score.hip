@@ -890,7 +890,7 @@ __global__ void __launch_bounds__(256) k_topk_direct(const float *__restrict__ x
                                                      const float *__restrict__ bias, int n_local, int64_t item_lo, int k,
                                                      unsigned long long *__restrict__ gkeys, unsigned int *__restrict__ arrive,
                                                      float *__restrict__ val, int64_t *__restrict__ ids,
-                                                     int32_t *__restrict__ status) {
+                                                     int32_t *__restrict__ status, irs_path_args pa) {
     __shared__ __attribute__((aligned(16))) float tile[DIRECT_TILE * (DIRECT_MAX_D + 4)]; // W tile, later the key array
     __shared__ __attribute__((aligned(16))) unsigned long long rkeys[IRS_REFINE_CAP + 2];
     __shared__ __attribute__((aligned(16))) float xs[DIRECT_MAX_D];
@@ -1065,6 +1065,12 @@ __global__ void __launch_bounds__(256) k_topk_direct(const float *__restrict__ x
         }
     }
     if (tid == 0 && (int)nr < k) status[row] |= IRS_ROW_FEWER_THAN_K;
+    // path search: the row's step (window filter of the ranked candidates, choice, window update) right here, by
+    // the workgroup that has just ranked them -- one launch fewer per step
+    if (pa.enabled) {
+        __syncthreads(); // val / ids of this row are written
+        if (wave == 0) irs_path_step_row(pa, row, lane, val, ids, k);
+    }
 #ifdef IRS_DIRECT_TIMING
     DSTAMP(9);
     if (tid == 0)
@@ -1300,14 +1306,19 @@ int irs_launch_pack_w(irs_ctx *ctx, hipStream_t s) {
     return IRS_OK;
 }
 
+bool irs_topk_is_direct(const irs_ctx *ctx, int M, int k) {
+    return M <= 32 && ctx->n_local <= DIRECT_MAX_ITEMS && k <= 256 && ctx->dims.d <= DIRECT_MAX_D;
+}
+
 int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, float *val, int64_t *ids0,
-                    int32_t *status, hipStream_t s) {
-    if (M <= 32 && ctx->n_local <= DIRECT_MAX_ITEMS && k <= 256 && ctx->dims.d <= DIRECT_MAX_D) {
+                    int32_t *status, hipStream_t s, const irs_path_args *path) {
+    if (path && !irs_topk_is_direct(ctx, M, k)) IRS_FAIL(ctx, IRS_E_STATE, "fused path step needs the one-launch top-k");
+    if (irs_topk_is_direct(ctx, M, k)) {
         // latency path on a small shard: one kernel, no fallback needed
         irs_prof_begin(ctx, IRS_PROF_REFINE, s);
         hipLaunchKernelGGL(k_topk_direct, dim3((unsigned)((ctx->n_local + DIRECT_TILE - 1) / DIRECT_TILE), M), dim3(256), 0, s, xrows, ctx->dims.d,
                            ctx->proj_w, ctx->proj_b, (int)ctx->n_local, ctx->shard.item_lo, k, ctx->cand,
-                           reinterpret_cast<unsigned int *>(ctx->step_ctr) + 8, val, ids0, status);
+                           reinterpret_cast<unsigned int *>(ctx->step_ctr) + 8, val, ids0, status, path ? *path : irs_path_args{});
         irs_prof_end(ctx, IRS_PROF_REFINE, s, 2.0 * ctx->dims.d * (double)M * (double)ctx->n_local, 0.0);
         IRS_CHECK_HIP(ctx, hipGetLastError());
         return IRS_OK;
