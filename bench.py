@@ -321,7 +321,7 @@ def main():
         roof["launches_per_step"] = f["launches"] / args.steps
         roof["family_ms_per_step"] = {k: v["ms"] / args.steps for k, v in fam.items()}
 
-        lat = lat128 = None
+        lat = lat128 = lat1024 = None
         if not args.no_latency and world == 1:
             # path-gen p50: one user, 20 greedy steps, hipGraph-replayed step
             # the user whose window holds the median number of items of this workload (a window's length sets the
@@ -345,10 +345,13 @@ def main():
                 return float(np.median(ts))
 
             lat = p50(s1, u1, h1, p1, st1, 20, 200)  # >= 200 repetitions after 20 warm-ups
-            nb = min(128, job.B)
-            lat128 = p50(job.seqs[:nb].clone(), job.users[:nb].clone(), job.hep[:nb].clone(),
-                         torch.zeros((nb, 20), dtype=torch.float32, device=device),
-                         torch.zeros(nb, dtype=torch.int32, device=device), 5, 30) / nb
+            def per_user(nb, warm, reps):
+                return p50(job.seqs[:nb].clone(), job.users[:nb].clone(), job.hep[:nb].clone(),
+                           torch.zeros((nb, 20), dtype=torch.float32, device=device),
+                           torch.zeros(nb, dtype=torch.int32, device=device), warm, reps) / nb
+
+            lat128 = per_user(min(128, job.B), 5, 30)
+            lat1024 = per_user(min(1024, job.B), 3, 10)
 
         cpu = None
         if not args.no_cpu_baseline and world == 1:
@@ -380,6 +383,7 @@ def main():
                            f"users partitioned over {world} GPUs, catalog replicated ({cfg.n_item} items): no data-path collective")},
             "path_gen_p50_ms_b1": lat,
             "path_gen_ms_per_user_b128": lat128,
+            "path_gen_ms_per_user_b1024": lat1024,
             "roofline": roof,
             "cpu_baseline": cpu,
         }
