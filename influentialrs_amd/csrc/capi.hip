@@ -218,7 +218,7 @@ extern "C" int irs_finalize_weights(irs_ctx *ctx, void *arena, size_t bytes, voi
 
 // ------------------------------------------------------------------ workspace
 struct ws_plan {
-    size_t x, y, xf, yf, qkv, ao, h, ru, xb, eps, thr, gm, cnt, cand, lse, ref, xrows, tval, tids, status, step, pos;
+    size_t x, y, xf, yf, qkv, qkv_b1, ao, h, ru, xb, eps, thr, gm, cnt, cand, lse, ref, xrows, tval, tids, status, step, pos;
     size_t bseq[2], bhep[2], bcum[2], bpaths[2], buser, lmax, lsum, tokrow, scnt, soff, sqrow, spadq, mdev, total;
 };
 
@@ -238,6 +238,7 @@ static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
     p->xf = take(RLf * 128 * 4);
     p->yf = take(RLf * 128 * 4);
     p->qkv = take(RL * 3 * D.d * 4);
+    p->qkv_b1 = take((RL < 256 ? RL : 256) * 3 * D.d * 4);
     p->ao = take(RL * D.d * 4);
     p->h = take(RL * D.ffn_dim * 4);
     p->ru = take((size_t)ctx->max_seqs * 4);
@@ -294,6 +295,7 @@ extern "C" int irs_bind_workspace(irs_ctx *ctx, void *ws, size_t bytes) {
     ctx->act_xf = (float *)(b + p.xf);
     ctx->act_yf = (float *)(b + p.yf);
     ctx->act_qkv = (float *)(b + p.qkv);
+    ctx->act_qkv_b1 = (float *)(b + p.qkv_b1);
     ctx->act_ao = (float *)(b + p.ao);
     ctx->act_h = (float *)(b + p.h);
     ctx->act_ru = (float *)(b + p.ru);

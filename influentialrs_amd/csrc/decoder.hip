@@ -1508,6 +1508,11 @@ struct SmallBlockArgs {
     const int32_t *m_dev;
     const int32_t *xidx;      // optional: residual row of token m is X[xidx[m]] (last layer: the consumed rows)
     const float *Wf, *Wfin;   // fragment-packed copies (k_pack_frag16) of {Wo, W1, W2} of this layer and of Win
+    // fused self-attention (single sequence, see k_block_small16<.., ATT = true>): this layer's q | k | v rows
+    const float *QKVin, *r_u;
+    const int64_t *seq_last;  // the window's last token (the IRN target: 0 = no target)
+    const int32_t *cnt, *padq;
+    int mask_mode;
 };
 
 // Weights of the 16-token latency kernel, re-ordered so that every wave load instruction of an MFMA A fragment reads
@@ -1541,8 +1546,15 @@ __device__ unsigned long long g_small_t[16];
 #define SB_NW 8 // waves per workgroup: two per SIMD, so that one wave's barrier / LDS / load waits hide behind the other's MFMAs
 // MT = 16-token tiles per workgroup: 1 on the latency path; 2 above SMALL_MT2_ROWS rows, where every weight fragment
 // is then fetched once per 32 tokens and feeds two MFMAs.
-template <bool QKV, int MT>
+// ATT = true (one sequence, head dim 32, 8 waves, MT = 1): the self-attention of the 16-token tile runs in front, in
+// the same launch -- wave w takes head w & 3 and the key tiles of parity w >> 2, K / Q / V fragments come straight
+// from global memory (no LDS staging, nothing to wait for but one round trip), the two halves of a head are combined
+// through LDS and the attention output lands in the LDS tile the out-projection reads.  The first weight rounds are
+// requested before the attention starts, so their latency hides behind it.  q | k | v ping-pong between two buffers
+// (other workgroups of this launch still read this layer's k | v while this one writes the next layer's).
+template <bool QKV, int MT, bool ATT = false>
 __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) {
+    static_assert(!ATT || (MT == 1 && SB_NW == 8), "fused attention: one token tile, eight waves");
     constexpr int T1 = 8 / SB_NW, T2 = 16 / SB_NW, T3 = 24 / SB_NW; // 16-column tiles per wave of a 128 / 256 / 384 wide output
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     constexpr int D = 128, F = 256, LDA = D + 4, LDH = F + 4;
@@ -1598,10 +1610,35 @@ __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) 
     const int mt = m0 + lq; // this lane's tokens: mt + 16 u
     constexpr int NAO = 16 * MT * (D / 4) / (64 * SB_NW);
     float4 aov[NAO];
+    if constexpr (!ATT) {
 #pragma unroll
-    for (int u = 0; u < NAO; ++u) {
-        const int i = tid + u * 64 * SB_NW, rr = i / (D / 4), c4 = i % (D / 4);
-        aov[u] = *reinterpret_cast<const float4 *>(a.AO + (int64_t)min(m0 + rr, a.M - 1) * D + 4 * c4);
+        for (int u = 0; u < NAO; ++u) {
+            const int i = tid + u * 64 * SB_NW, rr = i / (D / 4), c4 = i % (D / 4);
+            aov[u] = *reinterpret_cast<const float4 *>(a.AO + (int64_t)min(m0 + rr, a.M - 1) * D + 4 * c4);
+        }
+    }
+    // ---- fused attention, part 1: requests.  lane (lq, gq): query m0 + lq / key 16kt + lq, head columns 8gq .. 8gq+7
+    constexpr int ATN = 8; // key tiles per wave (L <= 256: 16 tiles over the two halves)
+    const int ah = wave & 3, ahalf = wave >> 2, aqb = blockIdx.x;
+    const int aL = ATT ? a.cnt[0] : 0;
+    const int ant = ATT ? (aqb >= ahalf ? (aqb - ahalf) / 2 + 1 : 0) : 0; // my key tiles: ahalf, ahalf + 2, ... <= aqb
+    float4 aq0, aq1, akf[ATN][2], aktg0, aktg1;
+    if constexpr (ATT) {
+        const int ld = 3 * D;
+        const float *qrow = a.QKVin + (int64_t)min(m0 + lq, aL - 1) * ld + ah * 32 + 8 * gq;
+        aq0 = *reinterpret_cast<const float4 *>(qrow);
+        aq1 = *reinterpret_cast<const float4 *>(qrow + 4);
+#pragma unroll
+        for (int i = 0; i < ATN; ++i) {
+            if (i < ant) { // wave-uniform
+                const float *kr = a.QKVin + (int64_t)min(16 * (ahalf + 2 * i) + lq, aL - 1) * ld + D + ah * 32 + 8 * gq;
+                akf[i][0] = *reinterpret_cast<const float4 *>(kr);
+                akf[i][1] = *reinterpret_cast<const float4 *>(kr + 4);
+            }
+        }
+        const float *ktr = a.QKVin + (int64_t)(aL - 1) * ld + D + ah * 32 + 8 * gq; // the IRN target column's key
+        aktg0 = *reinterpret_cast<const float4 *>(ktr);
+        aktg1 = *reinterpret_cast<const float4 *>(ktr + 4);
     }
     int xrow[MT];
 #pragma unroll
@@ -1613,8 +1650,10 @@ __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) 
     bool live[MT];
 #pragma unroll
     for (int u = 0; u < MT; ++u) live[u] = mt + 16 * u < M;
-    W_LOAD(w1[0], T2, a.Wf + SMALL_WF_W1, wave * 16 * T2, D, 0);
-    W_LOAD(w1[1], T2, a.Wf + SMALL_WF_W1, wave * 16 * T2, D, 1);
+    if constexpr (!ATT) { // (with the attention in front, FFN1's weights are requested after it: register budget)
+        W_LOAD(w1[0], T2, a.Wf + SMALL_WF_W1, wave * 16 * T2, D, 0);
+        W_LOAD(w1[1], T2, a.Wf + SMALL_WF_W1, wave * 16 * T2, D, 1);
+    }
     V_LOAD(vbo, T1, a.bo, wave * 16 * T1);
     V_LOAD(vg1, T1, a.g1, wave * 16 * T1);
     V_LOAD(vb1n, T1, a.b1n, wave * 16 * T1);
@@ -1623,10 +1662,137 @@ __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) 
     V_LOAD(vb2n, T1, a.b2n, wave * 16 * T1);
     __builtin_amdgcn_sched_barrier(0);
     if (m0 >= M) return;
+    if constexpr (!ATT) {
 #pragma unroll
-    for (int u = 0; u < NAO; ++u) {
-        const int i = tid + u * 64 * SB_NW, rr = i / (D / 4), c4 = i % (D / 4);
-        *reinterpret_cast<float4 *>(bufA + rr * LDA + 4 * c4) = (m0 + rr < M) ? aov[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < NAO; ++u) {
+            const int i = tid + u * 64 * SB_NW, rr = i / (D / 4), c4 = i % (D / 4);
+            *reinterpret_cast<float4 *>(bufA + rr * LDA + 4 * c4) = (m0 + rr < M) ? aov[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
+        // ---- fused attention, part 2 (same mathematics as k_attn16: log2-domain scores, two passes, the IRN target
+        //      column as a separate key with +1.0 where every other visible key carries +r_u)
+        const int ld = 3 * D;
+        const float LOG2E = 1.4426950408889634f;
+        const bool irn = a.mask_mode == IRS_MASK_IRN;
+        const bool tgt_ok = irn && a.seq_last[0] != 0;
+        const float tgt_add = irn ? (1.0f - a.r_u[0]) * LOG2E : 0.f;
+        const int qi = m0 + lq, pq = a.padq[0];
+        const float sc = qi < aL ? LOG2E / sqrtf(32.0f) : 0.f;
+        const float qf[8] = {aq0.x * sc, aq0.y * sc, aq0.z * sc, aq0.w * sc, aq1.x * sc, aq1.y * sc, aq1.z * sc, aq1.w * sc};
+        f32x4 sacc[ATN];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < ATN; ++i) {
+            if (i < ant) {
+                f32x4 sa = {0.f, 0.f, 0.f, 0.f};
+                sa = __builtin_amdgcn_mfma_f32_16x16x4f32(akf[i][0].x, qf[0], sa, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_16x16x4f32(akf[i][0].y, qf[1], sa, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_16x16x4f32(akf[i][0].z, qf[2], sa, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_16x16x4f32(akf[i][0].w, qf[3], sa, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_16x16x4f32(akf[i][1].x, qf[4], sa, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_16x16x4f32(akf[i][1].y, qf[5], sa, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_16x16x4f32(akf[i][1].z, qf[6], sa, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_16x16x4f32(akf[i][1].w, qf[7], sa, 0, 0, 0);
+                sacc[i] = sa;
+            }
+        }
+        // V fragments of my tiles (A operand of O^T += V^T P^T: lane (col lq, k-slot gq), MFMA r <-> key 16kt + 4gq + r)
+        float avf[ATN][2][4];
+        const float *vbase = a.QKVin + 2 * D + ah * 32 + lq;
+#pragma unroll
+        for (int i = 0; i < ATN; ++i) {
+            if (i < ant) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float *vr = vbase + (int64_t)min(16 * (ahalf + 2 * i) + 4 * gq + r, aL - 1) * ld;
+                    avf[i][0][r] = vr[0];
+                    avf[i][1][r] = vr[16];
+                }
+            }
+        }
+        const float *vtr = a.QKVin + (int64_t)(aL - 1) * ld + 2 * D + ah * 32 + 4 * gq; // V[L-1][16ct + 4gq ..]
+        const float4 avt0 = *reinterpret_cast<const float4 *>(vtr), avt1 = *reinterpret_cast<const float4 *>(vtr + 16);
+        // masks: key j visible to query qi iff j <= qi, j < L, j is not the pad the packed window may hold, and j is not
+        // the target column (that one is added below); C register r of tile kt <-> key 16kt + 4gq + r
+#pragma unroll
+        for (int i = 0; i < ATN; ++i) {
+            if (i < ant) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * (ahalf + 2 * i) + 4 * gq + r;
+                    const bool ok = j <= qi && j < aL && j != pq && !(irn && j == aL - 1);
+                    const float v = ok ? sacc[i][r] : -INFINITY;
+                    sacc[i][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        }
+        float st = -INFINITY;
+        if (tgt_ok && ahalf == 0) {
+            float partv = qf[0] * aktg0.x;
+            partv = __fmaf_rn(qf[1], aktg0.y, partv);
+            partv = __fmaf_rn(qf[2], aktg0.z, partv);
+            partv = __fmaf_rn(qf[3], aktg0.w, partv);
+            partv = __fmaf_rn(qf[4], aktg1.x, partv);
+            partv = __fmaf_rn(qf[5], aktg1.y, partv);
+            partv = __fmaf_rn(qf[6], aktg1.z, partv);
+            partv = __fmaf_rn(qf[7], aktg1.w, partv);
+            partv += __shfl_xor(partv, 16, 64);
+            partv += __shfl_xor(partv, 32, 64);
+            st = partv + tgt_add;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = fmaxf(mx, st);
+        float *amax = bufH;                 // [4 heads][2 halves][16 queries]
+        float *aobuf = bufH + 128;          // [4 heads][64 lanes][8]: the odd half's partial O^T
+        float *alsum = bufH + 128 + 4 * 64 * 8; // [4 heads][16]
+        if (gq == 0) amax[(ah * 2 + ahalf) * 16 + lq] = mx;
+        __syncthreads();
+        float m = fmaxf(amax[(ah * 2) * 16 + lq], amax[(ah * 2 + 1) * 16 + lq]);
+        if (m == -INFINITY) m = 0.f; // nothing visible: l = 0 -> NaN row like torch
+        float l = 0.f;
+        f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (tgt_ok && ahalf == 0) {
+            const float pt = __builtin_amdgcn_exp2f(st - m);
+            l = (gq == 0) ? pt : 0.f;
+            o[0] = {pt * avt0.x, pt * avt0.y, pt * avt0.z, pt * avt0.w};
+            o[1] = {pt * avt1.x, pt * avt1.y, pt * avt1.z, pt * avt1.w};
+        }
+#pragma unroll
+        for (int i = 0; i < ATN; ++i) {
+            if (i < ant) {
+                float pa[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pa[r] = __builtin_amdgcn_exp2f(sacc[i][r] - m);
+                    l += pa[r];
+                }
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(avf[i][ct][r], pa[r], o[ct], 0, 0, 0);
+            }
+        }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (ahalf == 1) {
+            float *ob = aobuf + (ah * 64 + lane) * 8;
+            *reinterpret_cast<float4 *>(ob) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
+            *reinterpret_cast<float4 *>(ob + 4) = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
+            if (gq == 0) alsum[ah * 16 + lq] = l;
+        }
+        __syncthreads();
+        if (ahalf == 0) {
+            const float *ob = aobuf + (ah * 64 + lane) * 8;
+            const float4 p0 = *reinterpret_cast<const float4 *>(ob), p1 = *reinterpret_cast<const float4 *>(ob + 4);
+            const float inv = 1.0f / (l + alsum[ah * 16 + lq]);
+            float *dst = bufA + lq * LDA + ah * 32 + 4 * gq; // O^T register r of column tile ct <-> column 16ct + 4gq + r
+            *reinterpret_cast<float4 *>(dst) = make_float4((o[0][0] + p0.x) * inv, (o[0][1] + p0.y) * inv, (o[0][2] + p0.z) * inv, (o[0][3] + p0.w) * inv);
+            *reinterpret_cast<float4 *>(dst + 16) = make_float4((o[1][0] + p1.x) * inv, (o[1][1] + p1.y) * inv, (o[1][2] + p1.z) * inv, (o[1][3] + p1.w) * inv);
+        }
+        W_LOAD(w1[0], T2, a.Wf + SMALL_WF_W1, wave * 16 * T2, D, 0);
+        W_LOAD(w1[1], T2, a.Wf + SMALL_WF_W1, wave * 16 * T2, D, 1);
     }
     __syncthreads();
     auto row_total = [&](float (&v)[MT], int slot) { // sums over the 128 columns of each token (SB_NW waves x 4 k-slot lanes)
@@ -3127,6 +3293,11 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     // at 64 users, 888 vs 1040 at 1024 -- ahead over the whole tested range
     const bool any_cfg = small_any_shape(d, F) && ctx->w_frag16 && rows <= 65536;
     const bool frag = d <= LIN_BN && d % 32 == 0 && rows > 2048 && !small_cfg && !any_cfg;
+    // one sequence (the reference IRN's own regime, and the latency metric's): self-attention runs inside the layer
+    // kernel; q | k | v alternate between two buffers so that the last (rows-only) layer reads ctx->act_qkv
+    const bool att_fused = small_cfg && rows_only && B == 1 && ctx->dims.n_heads == 4 && L <= 256 && ctx->act_qkv_b1 &&
+                           ctx->dims.n_layers > 1;
+    auto qkv_in = [&](int l) { return (!att_fused || ((ctx->dims.n_layers - 1 - l) & 1) == 0) ? ctx->act_qkv : ctx->act_qkv_b1; };
     float *xf = ctx->act_xf, *yf = ctx->act_yf;
     if (rows_only) {
         if (small_plan) {
@@ -3160,7 +3331,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     else if (rows_only && small_cfg && ctx->dims.n_layers > 1) {
         // latency path (the k_block_small16 regime): embed + layer 0's QKV in one 16-token kernel
         SmallEmbedArgs ea{seq, ctx->item_emb, ctx->pe, tok, m_dev, rows, L, sqrtf((float)d), ctx->dims.n_item, x,
-                          ctx->w_frag16 + (size_t)ctx->dims.n_layers * SMALL_WF_LAYER, ctx->layer[0].sa_in_b, ctx->act_qkv};
+                          ctx->w_frag16 + (size_t)ctx->dims.n_layers * SMALL_WF_LAYER, ctx->layer[0].sa_in_b, qkv_in(0)};
         irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
         hipLaunchKernelGGL(k_embed_qkv_small16, dim3((rows + 15) / 16), dim3(256), 0, s, ea);
         irs_prof_end(ctx, IRS_PROF_LINEAR, s, 6.0 * rows * (double)d * d, 4.0 * 4.0 * rows * (double)d);
@@ -3257,7 +3428,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         // d = 128, F = 256, head dim 32: attention writes its output fragment-major and ONE kernel does the rest of
         // the layer (out-projection + LN1/LN2, feed-forward + LN3, the next layer's QKV) with y, h, x' in registers
         const bool fuse_block = frag && d == 128 && F == 256 && attn16_ok(ctx, ctx->act_qkv, yf);
-        if ((rc = launch_attn(ctx, ctx->act_qkv, seq, ctx->act_ru, fuse_block ? yf : ctx->act_ao, B, s, off, cnt, tok, fuse_block)))
+        if (!att_fused &&
+            (rc = launch_attn(ctx, ctx->act_qkv, seq, ctx->act_ru, fuse_block ? yf : ctx->act_ao, B, s, off, cnt, tok, fuse_block)))
             return rc;
         if (frag) {
             const bool last = l + 1 == ctx->dims.n_layers;
@@ -3309,15 +3481,22 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             const bool last = l + 1 == ctx->dims.n_layers;
             SmallBlockArgs sb{ctx->act_ao, x, w.sa_out_w, w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, w.l1_w, w.l1_b, w.l2_w, w.l2_b,
                               w.n3_w, w.n3_b, y, last ? nullptr : ctx->layer[l + 1].sa_in_w, last ? nullptr : ctx->layer[l + 1].sa_in_b,
-                              ctx->act_qkv, rows, m_dev, nullptr, ctx->w_frag16 ? ctx->w_frag16 + (size_t)l * SMALL_WF_LAYER : nullptr,
+                              qkv_in(l + 1), rows, m_dev, nullptr, ctx->w_frag16 ? ctx->w_frag16 + (size_t)l * SMALL_WF_LAYER : nullptr,
                               (last || !ctx->w_frag16) ? nullptr
                                                        : ctx->w_frag16 + (size_t)ctx->dims.n_layers * SMALL_WF_LAYER + (size_t)(l + 1) * SMALL_WF_WIN};
+            if (att_fused) {
+                sb.QKVin = qkv_in(l), sb.r_u = ctx->act_ru, sb.seq_last = seq + (L - 1), sb.cnt = cnt, sb.padq = ctx->seq_padq;
+                sb.mask_mode = ctx->dims.mask_mode;
+            }
             irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
             // 32 tokens per workgroup once the 16-token tiles outnumber the resident workgroups (2 per CU): per path
             // step 518 vs 563 us at 128 users, but 267 vs 222 at 16 users; 64 tokens measured no better than 32
             if (rows > SMALL_MT2_ROWS) {
                 if (sb.Win) hipLaunchKernelGGL((k_block_small16<true, 2>), dim3((rows + 31) / 32), dim3(64 * SB_NW), 0, s, sb);
                 else hipLaunchKernelGGL((k_block_small16<false, 2>), dim3((rows + 31) / 32), dim3(64 * SB_NW), 0, s, sb);
+            } else if (att_fused) {
+                if (sb.Win) hipLaunchKernelGGL((k_block_small16<true, 1, true>), dim3((rows + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
+                else hipLaunchKernelGGL((k_block_small16<false, 1, true>), dim3((rows + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
             } else {
                 if (sb.Win) hipLaunchKernelGGL((k_block_small16<true, 1>), dim3((rows + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
                 else hipLaunchKernelGGL((k_block_small16<false, 1>), dim3((rows + 15) / 16), dim3(64 * SB_NW), 0, s, sb);

@@ -56,6 +56,7 @@ struct irs_ctx {
     size_t ws_bytes;
     // decoder activations
     float *act_x, *act_y, *act_qkv, *act_ao, *act_h, *act_ru;
+    float *act_qkv_b1; // second q | k | v buffer of the single-sequence fused-attention path (<= 256 rows)
     float *act_xf, *act_yf; // fragment-major copies of x / y (residual inputs of the LN-fused GEMMs)
     // packed (pad-free) decode plan
     int32_t *tok_row;  // [max_seqs * L] packed index -> b*L + t

@@ -101,6 +101,34 @@ def test_paths_vs_reference_goldens(golden, name, cfgname, use_graph):
     assert np.array_equal(w[:, L - 1 - P:L - 1] if P < L - 1 else w[:, :L - 1], paths[:, -(L - 1):].astype(np.int64) if P >= L - 1 else paths.astype(np.int64))
 
 
+@pytest.mark.parametrize("name,cfgname", [("irn_tiny", "tiny"), ("irn_default", "default"), ("irn_c1", "c1"), ("irn_c2", "c2")])
+def test_single_sequence_calls_match_goldens(golden, name, cfgname):
+    """One sequence per call -- the reference IRN's own regime and the latency metric's.  At d = 128 / 4 heads that
+    is a path of its own (self-attention inside the 16-token layer kernel, q | k | v ping-pong buffers): decoder
+    rows, top-100 ids and 20-step paths of every golden sequence, one at a time, against the reference's outputs."""
+    g = golden(name)
+    cfg = synth.make_config(cfgname)
+    sd = synth.irn_state_dict(cfg, 1234)
+    eng = make_engine(cfg, sd, max_rows=8)
+    raws, seqs, users, targets, labels = _irn_inputs(g)
+    B, L = seqs.shape
+    P = int(g["meta"][2])
+    for b in range(B):
+        seq1 = torch.from_numpy(seqs[b:b + 1].copy()).cuda()
+        u1 = torch.from_numpy(users[b:b + 1]).cuda()
+        pos = torch.full((1,), L - 2, dtype=torch.int32, device="cuda")
+        _, xr, ru = eng.decode(seq1, u1, want_x=False, pos=pos, want_r_u=True)
+        assert np.abs(ru.cpu().numpy() - g["r_u"][b]).max() < 1e-6
+        assert np.abs(xr.cpu().numpy()[0] - g["x_hep"][b]).max() < X_TOL
+        for use_graph in (False, True):
+            work = seq1.clone()
+            hep = torch.full((1,), L - 2, dtype=torch.int32, device="cuda")
+            paths, st = eng.generate_paths(work, u1, hep, P, k=100, sweep=IRS_SWEEP_BF16, use_graph=use_graph)
+            torch.cuda.synchronize()
+            assert (st.cpu().numpy() & 2).sum() == 0
+            assert np.array_equal(paths.cpu().numpy()[0], g["paths"][b]), (b, use_graph)
+
+
 @pytest.mark.parametrize("cfgname", ["tiny", "default", "c2"])
 def test_rows_only_decode_equals_full_decode(cfgname):
     """When only x[b, pos[b]] is requested the last layer is evaluated for that row alone
