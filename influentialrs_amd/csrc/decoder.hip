@@ -1622,7 +1622,8 @@ __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) 
     const int ah = wave & 3, ahalf = wave >> 2, aqb = blockIdx.x;
     const int aL = ATT ? a.cnt[0] : 0;
     const int ant = ATT ? (aqb >= ahalf ? (aqb - ahalf) / 2 + 1 : 0) : 0; // my key tiles: ahalf, ahalf + 2, ... <= aqb
-    float4 aq0, aq1, akf[ATN][2], aktg0, aktg1;
+    float4 aq0, aq1, akf[ATN][2], aktg0, aktg1, avt0, avt1;
+    float avf[ATN][2][4]; // V fragments (A operand of O^T += V^T P^T: lane (col lq, k-slot gq), MFMA r <-> key 16kt + 4gq + r)
     if constexpr (ATT) {
         const int ld = 3 * D;
         const float *qrow = a.QKVin + (int64_t)min(m0 + lq, aL - 1) * ld + ah * 32 + 8 * gq;
@@ -1639,6 +1640,21 @@ __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) 
         const float *ktr = a.QKVin + (int64_t)(aL - 1) * ld + D + ah * 32 + 8 * gq; // the IRN target column's key
         aktg0 = *reinterpret_cast<const float4 *>(ktr);
         aktg1 = *reinterpret_cast<const float4 *>(ktr + 4);
+        const float *vbase = a.QKVin + 2 * D + ah * 32 + lq;
+#pragma unroll
+        for (int i = 0; i < ATN; ++i) {
+            if (i < ant) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float *vr = vbase + (int64_t)min(16 * (ahalf + 2 * i) + 4 * gq + r, aL - 1) * ld;
+                    avf[i][0][r] = vr[0];
+                    avf[i][1][r] = vr[16];
+                }
+            }
+        }
+        const float *vtr = a.QKVin + (int64_t)(aL - 1) * ld + 2 * D + ah * 32 + 4 * gq; // V[L-1][16ct + 4gq ..]
+        avt0 = *reinterpret_cast<const float4 *>(vtr);
+        avt1 = *reinterpret_cast<const float4 *>(vtr + 16);
     }
     int xrow[MT];
 #pragma unroll
@@ -1696,22 +1712,6 @@ __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) 
                 sacc[i] = sa;
             }
         }
-        // V fragments of my tiles (A operand of O^T += V^T P^T: lane (col lq, k-slot gq), MFMA r <-> key 16kt + 4gq + r)
-        float avf[ATN][2][4];
-        const float *vbase = a.QKVin + 2 * D + ah * 32 + lq;
-#pragma unroll
-        for (int i = 0; i < ATN; ++i) {
-            if (i < ant) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float *vr = vbase + (int64_t)min(16 * (ahalf + 2 * i) + 4 * gq + r, aL - 1) * ld;
-                    avf[i][0][r] = vr[0];
-                    avf[i][1][r] = vr[16];
-                }
-            }
-        }
-        const float *vtr = a.QKVin + (int64_t)(aL - 1) * ld + 2 * D + ah * 32 + 4 * gq; // V[L-1][16ct + 4gq ..]
-        const float4 avt0 = *reinterpret_cast<const float4 *>(vtr), avt1 = *reinterpret_cast<const float4 *>(vtr + 16);
         // masks: key j visible to query qi iff j <= qi, j < L, j is not the pad the packed window may hold, and j is not
         // the target column (that one is added below); C register r of tile kt <-> key 16kt + 4gq + r
 #pragma unroll
