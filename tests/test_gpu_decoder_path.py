@@ -129,6 +129,36 @@ def test_single_sequence_calls_match_goldens(golden, name, cfgname):
             assert np.array_equal(paths.cpu().numpy()[0], g["paths"][b]), (b, use_graph)
 
 
+@pytest.mark.parametrize("n_layers", [2, 3])
+def test_single_sequence_fused_attention_matches_batched_kernels(oracle, n_layers):
+    """The one-sequence path (attention inside the layer kernel, q | k | v ping-pong whose parity depends on the
+    layer count) against the same windows decoded two at a time (separate attention kernel) and the numpy oracle:
+    short / full / all-pad windows, every consumed position class."""
+    cfg = synth.make_config("c2", n_layers=n_layers)
+    L = cfg.max_len
+    sd = synth.irn_state_dict(cfg, 77)
+    eng = make_engine(cfg, sd, max_rows=8)
+    hists = synth.user_histories(6, cfg.n_item, seed=41)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=43)
+    raws, seqs, users, targets, labels = synth.collate_eval_irs(rows, L, gap_len=1)
+    seqs[1, :] = 0
+    seqs[1, -1] = targets[1]                       # all-pad window
+    seqs[2, : L // 2] = seqs[2, L - L // 2:]
+    seqs[2, seqs[2] == 0] = 1                      # full window
+    pos = np.array([L - 2, L - 2, L - 2, 0, L - 1, L // 2], dtype=np.int32)
+    seq, u, p = torch.from_numpy(seqs).cuda(), torch.from_numpy(users).cuda(), torch.from_numpy(pos).cuda()
+    pair = torch.cat([eng.decode(seq[i:i + 2], u[i:i + 2], want_x=False, pos=p[i:i + 2])[1] for i in range(0, 6, 2)])
+    for b in range(6):
+        one = eng.decode(seq[b:b + 1], u[b:b + 1], want_x=False, pos=p[b:b + 1])[1][0]
+        a, c = one, pair[b]
+        assert torch.equal(torch.isnan(a), torch.isnan(c))
+        ok = torch.isfinite(a) & torch.isfinite(c)
+        assert (a - c)[ok].abs().max().item() < X_TOL, b
+        if b in (0, 2, 5):
+            ref = oracle.decode(sd, cfg, seqs[b], int(users[b]))[0][pos[b]]
+            assert np.abs(ref - one.cpu().numpy()).max() < X_TOL, b
+
+
 @pytest.mark.parametrize("cfgname", ["tiny", "default", "c2"])
 def test_rows_only_decode_equals_full_decode(cfgname):
     """When only x[b, pos[b]] is requested the last layer is evaluated for that row alone
