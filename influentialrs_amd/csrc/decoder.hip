@@ -1994,6 +1994,15 @@ struct SmallEmbedArgs {
     float *X;               // [rows][128]
     const float *Wfin, *bin; // fragment-packed W_in of layer 0, its bias
     float *QKV;             // [rows][384]
+    // packing plan of a single sequence computed in this kernel (k_embed_qkv_small16<true>; see k_plan_small)
+    const int32_t *pos;
+    int32_t *cnt, *off, *qrow, *tok_out, *padq, *mdev_out;
+    const int64_t *user;
+    const float *U, *uw, *ub;
+    float *r_u;
+    int ud;
+    int64_t n_user;
+    int32_t *step_pair;
 };
 
 // Zero-padded fragment-packed copy of W[N][K] for k_block_small_any: [Np/16 tiles][Kp/16 k groups][64 lanes] float4.
@@ -2284,10 +2293,15 @@ static inline size_t small_any_lds(int d, int F) {
 // goes to global memory (the residual of layer 0) and to LDS (the B operand); the in-projection runs on the
 // fragment-packed W_in of layer 0, all 12 tile-rounds of a wave requested before the embedding rows are.
 
+// PLAN = true (one sequence of L <= 256 tokens): every workgroup derives the packing plan itself -- thread t looks
+// at token t, ballots and a four-entry scan give the packed index -- instead of reading it from a k_plan_small launch
+// in front; workgroup 0 also writes the plan arrays, r_u and the step hand-over for the kernels that follow.
+template <bool PLAN>
 __global__ void __launch_bounds__(256) k_embed_qkv_small16(SmallEmbedArgs a) {
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     constexpr int D = 128, LDA = D + 4, MT = 1;
     __shared__ __attribute__((aligned(16))) float bufA[16 * LDA];
+    __shared__ int s_tok[256], s_id[256], s_wcnt[4], s_q[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 15, gq = lane >> 4;
     float4 wq[2][6][4], vbin[6];
@@ -2296,15 +2310,53 @@ __global__ void __launch_bounds__(256) k_embed_qkv_small16(SmallEmbedArgs a) {
 #pragma unroll
     for (int t = 0; t < 6; ++t) vbin[t] = *reinterpret_cast<const float4 *>(a.bin + wave * 96 + 16 * t + 4 * gq);
     __builtin_amdgcn_sched_barrier(0);
-    const int M = a.m_dev ? min(a.rows, a.m_dev[0]) : a.rows;
+    int M;
+    if constexpr (PLAN) {
+        int p = a.pos[0];
+        p = p < 0 ? 0 : (p >= a.L ? a.L - 1 : p);
+        const int64_t sv = tid < a.L ? a.seq[tid] : 0;
+        const bool v = tid < a.L && (sv != 0 || tid == p); // plan_valid
+        const unsigned long long bm = __ballot(v);
+        if (lane == 0) s_wcnt[wave] = __popcll(bm);
+        __syncthreads();
+        int basei = 0;
+        for (int w = 0; w < wave; ++w) basei += s_wcnt[w];
+        M = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        if (v) {
+            const int idx = basei + __popcll(bm & ((1ull << lane) - 1ull));
+            s_tok[idx] = tid;
+            s_id[idx] = (int)(sv < 0 ? 0 : (sv > a.n_item ? a.n_item : sv));
+            if (tid == p) {
+                s_q[0] = idx;
+                s_q[1] = (sv == 0) ? idx : -1; // the only pad a packed sequence can hold
+            }
+            if (blockIdx.x == 0) a.tok_out[idx] = tid;
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && tid == 0) {
+            a.cnt[0] = M, a.off[0] = 0, a.qrow[0] = s_q[0], a.padq[0] = s_q[1], a.mdev_out[0] = M;
+            float acc = 0.f; // r_u = user_mask_layer(user_embedder(user)) (influentialRS.py:180), 0 without the user factor
+            if (a.U) {
+                int64_t u = a.user[0];
+                if (u < 0) u = 0;
+                if (u >= a.n_user) u = a.n_user - 1;
+                const float *e = a.U + u * (int64_t)a.ud;
+                for (int c = 0; c < a.ud; ++c) acc = __fmaf_rn(e[c], a.uw[c], acc);
+                acc += a.ub[0];
+            }
+            a.r_u[0] = acc;
+            if (a.step_pair) a.step_pair[0] = a.step_pair[1];
+        }
+    } else
+        M = a.m_dev ? min(a.rows, a.m_dev[0]) : a.rows;
     const int m0 = blockIdx.x * 16;
     if (m0 >= M) return;
     {
         const int rr = tid >> 4, c8 = tid & 15, row = m0 + rr;
         float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
         if (row < M) {
-            const int orig = a.tok_row ? a.tok_row[row] : row;
-            int64_t id = a.seq[orig];
+            const int orig = PLAN ? s_tok[row] : (a.tok_row ? a.tok_row[row] : row);
+            int64_t id = PLAN ? (int64_t)s_id[row] : a.seq[orig];
             if (id < 0) id = 0;
             if (id > a.n_item) id = a.n_item;
             const float *e = a.E + id * (int64_t)D + 8 * c8;
@@ -3300,7 +3352,9 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     auto qkv_in = [&](int l) { return (!att_fused || ((ctx->dims.n_layers - 1 - l) & 1) == 0) ? ctx->act_qkv : ctx->act_qkv_b1; };
     float *xf = ctx->act_xf, *yf = ctx->act_yf;
     if (rows_only) {
-        if (small_plan) {
+        if (small_plan && att_fused) {
+            // one sequence: the embedding kernel below derives the plan itself
+        } else if (small_plan) {
             const bool pif = ctx->dims.mask_mode == IRS_MASK_IRN && ctx->user_emb;
             hipLaunchKernelGGL(k_plan_small, dim3(1), dim3(1024), 0, s, seq, pos, B, L, ctx->seq_cnt, ctx->seq_off, ctx->seq_qrow,
                                ctx->tok_row, ctx->seq_padq, ctx->m_dev, user, pif ? ctx->user_emb : nullptr, ctx->um_w, ctx->um_b,
@@ -3333,7 +3387,15 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         SmallEmbedArgs ea{seq, ctx->item_emb, ctx->pe, tok, m_dev, rows, L, sqrtf((float)d), ctx->dims.n_item, x,
                           ctx->w_frag16 + (size_t)ctx->dims.n_layers * SMALL_WF_LAYER, ctx->layer[0].sa_in_b, qkv_in(0)};
         irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
-        hipLaunchKernelGGL(k_embed_qkv_small16, dim3((rows + 15) / 16), dim3(256), 0, s, ea);
+        if (att_fused) {
+            const bool pif = ctx->dims.mask_mode == IRS_MASK_IRN && ctx->user_emb;
+            ea.pos = pos, ea.cnt = ctx->seq_cnt, ea.off = ctx->seq_off, ea.qrow = ctx->seq_qrow, ea.tok_out = ctx->tok_row;
+            ea.padq = ctx->seq_padq, ea.mdev_out = ctx->m_dev, ea.user = user, ea.U = pif ? ctx->user_emb : nullptr;
+            ea.uw = ctx->um_w, ea.ub = ctx->um_b, ea.r_u = ctx->act_ru, ea.ud = ctx->dims.u_dim, ea.n_user = ctx->dims.n_user;
+            ea.step_pair = ctx->step_pair;
+            hipLaunchKernelGGL(k_embed_qkv_small16<true>, dim3((rows + 15) / 16), dim3(256), 0, s, ea);
+        } else
+            hipLaunchKernelGGL(k_embed_qkv_small16<false>, dim3((rows + 15) / 16), dim3(256), 0, s, ea);
         irs_prof_end(ctx, IRS_PROF_LINEAR, s, 6.0 * rows * (double)d * d, 4.0 * 4.0 * rows * (double)d);
         qkv0_done = true;
     } else if (rows_only && any_cfg && ctx->dims.n_layers > 1) {
