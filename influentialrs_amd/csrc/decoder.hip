@@ -3539,7 +3539,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                     return rc;
             }
         } else if (small_cfg) {
-            // latency path: the rest of the layer (and the next layer's QKV) in one launch per 32 tokens; x -> y buffer
+            // latency path: the rest of the layer (and the next layer's QKV) in one launch per 16 (or 32) tokens; x -> y buffer
             const bool last = l + 1 == ctx->dims.n_layers;
             SmallBlockArgs sb{ctx->act_ao, x, w.sa_out_w, w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, w.l1_w, w.l1_b, w.l2_w, w.l2_b,
                               w.n3_w, w.n3_b, y, last ? nullptr : ctx->layer[l + 1].sa_in_w, last ? nullptr : ctx->layer[l + 1].sa_in_b,
