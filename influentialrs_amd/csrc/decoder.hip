@@ -2005,6 +2005,49 @@ struct SmallEmbedArgs {
     int32_t *step_pair;
 };
 
+// Packing plan of ONE sequence of L <= 256 tokens inside a 256-thread workgroup (see k_plan_small): thread t looks at
+// token t; s_tok[i] / s_id[i] = window position / clamped item id of packed row i; returns the packed row count.
+// Workgroup 0 also writes the plan arrays, r_u and the step hand-over for the kernels that follow.
+__device__ __forceinline__ int small_plan_single(const SmallEmbedArgs &a, int *s_tok, int *s_id, int *s_wcnt, int *s_q) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int p = a.pos[0];
+    p = p < 0 ? 0 : (p >= a.L ? a.L - 1 : p);
+    const int64_t sv = tid < a.L ? a.seq[tid] : 0;
+    const bool v = tid < a.L && (sv != 0 || tid == p); // plan_valid
+    const unsigned long long bm = __ballot(v);
+    if (lane == 0) s_wcnt[wave] = __popcll(bm);
+    __syncthreads();
+    int basei = 0;
+    for (int w = 0; w < wave; ++w) basei += s_wcnt[w];
+    const int M = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    if (v) {
+        const int idx = basei + __popcll(bm & ((1ull << lane) - 1ull));
+        s_tok[idx] = tid;
+        s_id[idx] = (int)(sv < 0 ? 0 : (sv > a.n_item ? a.n_item : sv));
+        if (tid == p) {
+            s_q[0] = idx;
+            s_q[1] = (sv == 0) ? idx : -1; // the only pad a packed sequence can hold
+        }
+        if (blockIdx.x == 0) a.tok_out[idx] = tid;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid == 0) {
+        a.cnt[0] = M, a.off[0] = 0, a.qrow[0] = s_q[0], a.padq[0] = s_q[1], a.mdev_out[0] = M;
+        float acc = 0.f; // r_u = user_mask_layer(user_embedder(user)) (influentialRS.py:180), 0 without the user factor
+        if (a.U) {
+            int64_t u = a.user[0];
+            if (u < 0) u = 0;
+            if (u >= a.n_user) u = a.n_user - 1;
+            const float *e = a.U + u * (int64_t)a.ud;
+            for (int c = 0; c < a.ud; ++c) acc = __fmaf_rn(e[c], a.uw[c], acc);
+            acc += a.ub[0];
+        }
+        a.r_u[0] = acc;
+        if (a.step_pair) a.step_pair[0] = a.step_pair[1];
+    }
+    return M;
+}
+
 // Zero-padded fragment-packed copy of W[N][K] for k_block_small_any: [Np/16 tiles][Kp/16 k groups][64 lanes] float4.
 __global__ void k_pack_frag16_any(const float *__restrict__ W, float *__restrict__ out, int N, int K, int Np, int Kp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x; // one float4 of the packed image
@@ -2231,19 +2274,22 @@ __global__ void __launch_bounds__(256) k_block_small_any(SmallBlockArgs a, int d
 }
 // Embedding + layer 0's in-projection for the same shapes: x = E[seq] sqrt(d) + pe to global memory and to the
 // LDS tile, then the QKV GEMM on the zero-padded packed W_in of layer 0 (one launch instead of two).
-template <int DPT>
+template <int DPT, bool PLAN>
 __global__ void __launch_bounds__(256) k_embed_qkv_small_any(SmallEmbedArgs a, int d) {
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     constexpr int dp = 16 * DPT, lda = dp + 4, IQ = (3 * DPT + 3) / 4;
     __shared__ __attribute__((aligned(16))) float bufA[16 * lda];
     __shared__ float vbin[3 * dp];
+    __shared__ int s_tok[256], s_id[256], s_wcnt[4], s_q[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 15, gq = lane >> 4;
     const int Qt = (3 * d + 15) >> 4; // 16-column tiles of the QKV output
     const int nit_q = Qt > wave ? (Qt - wave + 3) >> 2 : 0;
     float4 avq[IQ][DPT];
     any_load<IQ, DPT>(reinterpret_cast<const float4 *>(a.Wfin), DPT, 0, DPT, nit_q, wave, lane, avq);
-    const int M = a.m_dev ? min(a.rows, a.m_dev[0]) : a.rows;
+    int M;
+    if constexpr (PLAN) M = small_plan_single(a, s_tok, s_id, s_wcnt, s_q);
+    else M = a.m_dev ? min(a.rows, a.m_dev[0]) : a.rows;
     const int m0 = blockIdx.x * 16;
     if (m0 >= M) return;
     for (int i = tid; i < 3 * d; i += 256) vbin[i] = a.bin[i];
@@ -2251,8 +2297,8 @@ __global__ void __launch_bounds__(256) k_embed_qkv_small_any(SmallEmbedArgs a, i
         const int rr = i / dp, c = i - rr * dp, row = m0 + rr;
         float v = 0.f;
         if (row < M && c < d) {
-            const int orig = a.tok_row ? a.tok_row[row] : row;
-            int64_t id = a.seq[orig];
+            const int orig = PLAN ? s_tok[row] : (a.tok_row ? a.tok_row[row] : row);
+            int64_t id = PLAN ? (int64_t)s_id[row] : a.seq[orig];
             if (id < 0) id = 0;
             if (id > a.n_item) id = a.n_item;
             v = __fadd_rn(__fmul_rn(a.E[id * (int64_t)d + c], a.sqrtd), a.pe[(int64_t)(orig % a.L) * d + c]);
@@ -2312,41 +2358,7 @@ __global__ void __launch_bounds__(256) k_embed_qkv_small16(SmallEmbedArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     int M;
     if constexpr (PLAN) {
-        int p = a.pos[0];
-        p = p < 0 ? 0 : (p >= a.L ? a.L - 1 : p);
-        const int64_t sv = tid < a.L ? a.seq[tid] : 0;
-        const bool v = tid < a.L && (sv != 0 || tid == p); // plan_valid
-        const unsigned long long bm = __ballot(v);
-        if (lane == 0) s_wcnt[wave] = __popcll(bm);
-        __syncthreads();
-        int basei = 0;
-        for (int w = 0; w < wave; ++w) basei += s_wcnt[w];
-        M = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-        if (v) {
-            const int idx = basei + __popcll(bm & ((1ull << lane) - 1ull));
-            s_tok[idx] = tid;
-            s_id[idx] = (int)(sv < 0 ? 0 : (sv > a.n_item ? a.n_item : sv));
-            if (tid == p) {
-                s_q[0] = idx;
-                s_q[1] = (sv == 0) ? idx : -1; // the only pad a packed sequence can hold
-            }
-            if (blockIdx.x == 0) a.tok_out[idx] = tid;
-        }
-        __syncthreads();
-        if (blockIdx.x == 0 && tid == 0) {
-            a.cnt[0] = M, a.off[0] = 0, a.qrow[0] = s_q[0], a.padq[0] = s_q[1], a.mdev_out[0] = M;
-            float acc = 0.f; // r_u = user_mask_layer(user_embedder(user)) (influentialRS.py:180), 0 without the user factor
-            if (a.U) {
-                int64_t u = a.user[0];
-                if (u < 0) u = 0;
-                if (u >= a.n_user) u = a.n_user - 1;
-                const float *e = a.U + u * (int64_t)a.ud;
-                for (int c = 0; c < a.ud; ++c) acc = __fmaf_rn(e[c], a.uw[c], acc);
-                acc += a.ub[0];
-            }
-            a.r_u[0] = acc;
-            if (a.step_pair) a.step_pair[0] = a.step_pair[1];
-        }
+        M = small_plan_single(a, s_tok, s_id, s_wcnt, s_q);
     } else
         M = a.m_dev ? min(a.rows, a.m_dev[0]) : a.rows;
     const int m0 = blockIdx.x * 16;
@@ -3352,7 +3364,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     auto qkv_in = [&](int l) { return (!att_fused || ((ctx->dims.n_layers - 1 - l) & 1) == 0) ? ctx->act_qkv : ctx->act_qkv_b1; };
     float *xf = ctx->act_xf, *yf = ctx->act_yf;
     if (rows_only) {
-        if (small_plan && att_fused) {
+        const bool plan_in_embed = small_plan && B == 1 && L <= 256 && ctx->dims.n_layers > 1 && (att_fused || any_cfg);
+        if (plan_in_embed) {
             // one sequence: the embedding kernel below derives the plan itself
         } else if (small_plan) {
             const bool pif = ctx->dims.mask_mode == IRS_MASK_IRN && ctx->user_emb;
@@ -3403,11 +3416,22 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                           ctx->w_frag16 + small_any_win_off(d, F), ctx->layer[0].sa_in_b, ctx->act_qkv};
         irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
         const dim3 grid((rows + 15) / 16);
-        switch (small_any_dp(d)) {
-        case 32: hipLaunchKernelGGL(k_embed_qkv_small_any<2>, grid, dim3(256), 0, s, ea, d); break;
-        case 64: hipLaunchKernelGGL(k_embed_qkv_small_any<4>, grid, dim3(256), 0, s, ea, d); break;
-        default: hipLaunchKernelGGL(k_embed_qkv_small_any<6>, grid, dim3(256), 0, s, ea, d); break;
+        const bool plan1 = small_plan && B == 1 && L <= 256; // the plan of the one sequence is derived in the kernel
+        if (plan1) {
+            const bool pif = ctx->dims.mask_mode == IRS_MASK_IRN && ctx->user_emb;
+            ea.pos = pos, ea.cnt = ctx->seq_cnt, ea.off = ctx->seq_off, ea.qrow = ctx->seq_qrow, ea.tok_out = ctx->tok_row;
+            ea.padq = ctx->seq_padq, ea.mdev_out = ctx->m_dev, ea.user = user, ea.U = pif ? ctx->user_emb : nullptr;
+            ea.uw = ctx->um_w, ea.ub = ctx->um_b, ea.r_u = ctx->act_ru, ea.ud = ctx->dims.u_dim, ea.n_user = ctx->dims.n_user;
+            ea.step_pair = ctx->step_pair;
         }
+#define E_(T_) do { if (plan1) hipLaunchKernelGGL((k_embed_qkv_small_any<T_, true>), grid, dim3(256), 0, s, ea, d); \
+                    else hipLaunchKernelGGL((k_embed_qkv_small_any<T_, false>), grid, dim3(256), 0, s, ea, d); } while (0)
+        switch (small_any_dp(d)) {
+        case 32: E_(2); break;
+        case 64: E_(4); break;
+        default: E_(6); break;
+        }
+#undef E_
         irs_prof_end(ctx, IRS_PROF_LINEAR, s, 6.0 * rows * (double)d * d, 4.0 * 4.0 * rows * (double)d);
         qkv0_done = true;
     } else if (rows_only)
