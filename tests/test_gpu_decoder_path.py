@@ -159,6 +159,35 @@ def test_single_sequence_fused_attention_matches_batched_kernels(oracle, n_layer
             assert np.abs(ref - one.cpu().numpy()).max() < X_TOL, b
 
 
+@pytest.mark.parametrize("over", [{"emb_dim": 48, "n_heads": 4, "ffn_dim": 96}, {"emb_dim": 96, "n_heads": 4, "ffn_dim": 256},
+                                  {"emb_dim": 80, "n_heads": 4, "ffn_dim": 64}, {"emb_dim": 16, "n_heads": 2, "ffn_dim": 48},
+                                  {"emb_dim": 30, "n_heads": 6, "ffn_dim": 120}, {"emb_dim": 64, "n_heads": 4, "ffn_dim": 200}])
+@pytest.mark.parametrize("B", [1, 5])
+def test_generic_small_shapes_vs_oracle(oracle, over, B):
+    """The generic fused layer kernel (any d <= 96; padded widths 32 / 64 / 96, 1 / 2 / 4 k chunks of the FFN's second
+    GEMM, hidden widths that are not multiples of 16) and, for ffn 200, the per-GEMM fallback its shape test rejects:
+    consumed rows against the numpy oracle, one sequence (plan inside the embed kernel) and several."""
+    cfg = synth.make_config("c1", **over)
+    L = cfg.max_len
+    sd = synth.irn_state_dict(cfg, 55)
+    eng = make_engine(cfg, sd, max_rows=8)
+    hists = synth.user_histories(B, cfg.n_item, seed=61)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=63)
+    raws, seqs, users, targets, labels = synth.collate_eval_irs(rows, L, gap_len=0)
+    pos = np.full(B, L - 2, dtype=np.int32)
+    pos[0] = L // 3
+    seq, u, p = torch.from_numpy(seqs).cuda(), torch.from_numpy(users).cuda(), torch.from_numpy(pos).cuda()
+    _, xr, _ = eng.decode(seq, u, want_x=False, pos=p)
+    x_full, _, _ = eng.decode(seq, u, want_x=True)
+    xr = xr.cpu().numpy()
+    x_full = x_full.cpu().numpy()
+    for b in range(B):
+        ref = oracle.decode(sd, cfg, seqs[b], int(users[b]))[0]
+        assert np.abs(ref[pos[b]] - xr[b]).max() < X_TOL, (b, over)
+        ok = np.isfinite(ref)
+        assert np.abs(ref - x_full[b])[ok].max() < X_TOL, (b, over)
+
+
 @pytest.mark.parametrize("cfgname", ["tiny", "default", "c2"])
 def test_rows_only_decode_equals_full_decode(cfgname):
     """When only x[b, pos[b]] is requested the last layer is evaluated for that row alone
