@@ -2150,24 +2150,50 @@ __global__ void __launch_bounds__(256) k_block_small_any(SmallBlockArgs a, int d
     if (m0 >= M) return;
     const int KSF = Fp > 128 ? 2 : Fp > 64 ? 1 : 0, KCF = 1 << KSF; // k chunks of the FFN's second GEMM: 4 / 2 / 1
     {
+        // every global load of the fill is requested before the first LDS store: one round trip (two for the rows
+        // behind a.xidx), not one per loop
+        constexpr int NV = 4, NQ = 2; // 9 d <= 864, 3 d <= 288 values over 256 threads
         const float *src[9] = {a.bo, a.g1, a.b1n, a.c, a.g2, a.b2n, a.b2, a.g3, a.b3n};
-        for (int i = tid; i < 9 * d; i += 256) {
-            const int v = i / d;
+        float fv[NV], fb1 = 0.f, fq[NQ], fao[DPT], fx[DPT];
+        int xr[DPT];
+#pragma unroll
+        for (int u = 0; u < DPT; ++u) {
+            const int i = tid + 256 * u, row = m0 + i / dp;
+            xr[u] = (row < M && a.xidx) ? a.xidx[row] : row;
+        }
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int i = tid + 256 * u, v = i / d;
             const float *p = src[0];
 #pragma unroll
-            for (int u = 1; u < 9; ++u) p = (v == u) ? src[u] : p;
-            vecs[i] = p ? p[i - v * d] : 0.f;
+            for (int w = 1; w < 9; ++w) p = (v == w) ? src[w] : p;
+            fv[u] = (i < 9 * d && p) ? p[i - v * d] : 0.f;
         }
-        for (int i = tid; i < F; i += 256) vecs[9 * d + i] = a.b1[i];
-        if constexpr (QKV)
-            for (int i = tid; i < 3 * d; i += 256) vecs[9 * d + F + i] = a.bin[i];
-    }
-    for (int i = tid; i < 16 * dp; i += 256) {
-        const int rr = i / dp, c = i - rr * dp, row = m0 + rr;
-        const bool ok = row < M && c < d;
-        const int xr = (row < M && a.xidx) ? a.xidx[row] : row;
-        bufA[rr * lda + c] = ok ? a.AO[(int64_t)row * d + c] : 0.f;
-        bufZ[rr * lda + c] = ok ? a.X[(int64_t)xr * d + c] : 0.f; // + b_o below, once the vectors are visible
+        if (tid < F) fb1 = a.b1[tid];
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) fq[u] = (QKV && tid + 256 * u < 3 * d) ? a.bin[tid + 256 * u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < DPT; ++u) {
+            const int i = tid + 256 * u, rr = i / dp, c = i - rr * dp, row = m0 + rr;
+            const bool ok = row < M && c < d;
+            fao[u] = ok ? a.AO[(int64_t)row * d + c] : 0.f;
+            fx[u] = ok ? a.X[(int64_t)xr[u] * d + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < NV; ++u)
+            if (tid + 256 * u < 9 * d) vecs[tid + 256 * u] = fv[u];
+        if (tid < F) vecs[9 * d + tid] = fb1;
+        if constexpr (QKV) {
+#pragma unroll
+            for (int u = 0; u < NQ; ++u)
+                if (tid + 256 * u < 3 * d) vecs[9 * d + F + tid + 256 * u] = fq[u];
+        }
+#pragma unroll
+        for (int u = 0; u < DPT; ++u) {
+            const int i = tid + 256 * u, rr = i / dp, c = i - rr * dp;
+            bufA[rr * lda + c] = fao[u];
+            bufZ[rr * lda + c] = fx[u]; // + b_o below, once the vectors are visible
+        }
     }
     // acc(item) = W[16 nt .. +15][k range of chunk kc] . B[token][same k] on zero-padded, fragment-packed weights
     // (k_pack_frag16_any: float4 ((nt * Kp/16 + kg) * 64 + lane) = W[16nt + lq][16kg + 4gq .. +3], so a wave load is
