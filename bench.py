@@ -321,21 +321,28 @@ def main():
         roof["launches_per_step"] = f["launches"] / args.steps
         roof["family_ms_per_step"] = {k: v["ms"] / args.steps for k, v in fam.items()}
 
-        lat = lat128 = lat1024 = None
+        lat = lat128 = lat1024 = lat_tokens = None
         if not args.no_latency and world == 1:
             # path-gen p50: one user, 20 greedy steps, hipGraph-replayed step
             # the user whose window holds the median number of items of this workload (a window's length sets the
             # decoder's row count, i.e. the latency)
-            nvalid = (job.seqs != 0).sum(dim=1)
+            # fresh windows of the workload's shape (job.seqs has been advanced by every step above: by now those
+            # windows are full)
+            fresh = gpu_windows(job.B, cfg.max_len, cfg.n_item, device, seed=100 + rank)
+            nvalid = (fresh != 0).sum(dim=1)
             iu = int(torch.argsort(nvalid)[nvalid.numel() // 2].item())
-            s1 = job.seqs[iu:iu + 1].clone()
+            lat_tokens = int(nvalid[iu].item())
+            s1 = fresh[iu:iu + 1].clone()
             u1 = job.users[iu:iu + 1].clone()
             h1 = job.hep[iu:iu + 1].clone()
             p1 = torch.zeros((1, 20), dtype=torch.float32, device=device)
             st1 = torch.zeros(1, dtype=torch.int32, device=device)
             def p50(ss, uu, hh, pp, stt, warm, reps):
                 ts = []
+                ss0, hh0 = ss.clone(), hh.clone()
                 for it in range(warm + reps):
+                    ss.copy_(ss0)  # every repetition starts from the user's own window (a path search appends its
+                    hh.copy_(hh0)  # 20 items to the window it is given: without the reset the windows fill up)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     job.eng.generate_paths(ss, uu, hh, 20, k=100, sweep=job.sweep, use_graph=True, paths=pp, status=stt)
@@ -346,7 +353,7 @@ def main():
 
             lat = p50(s1, u1, h1, p1, st1, 20, 200)  # >= 200 repetitions after 20 warm-ups
             def per_user(nb, warm, reps):
-                return p50(job.seqs[:nb].clone(), job.users[:nb].clone(), job.hep[:nb].clone(),
+                return p50(fresh[:nb].clone(), job.users[:nb].clone(), job.hep[:nb].clone(),
                            torch.zeros((nb, 20), dtype=torch.float32, device=device),
                            torch.zeros(nb, dtype=torch.int32, device=device), warm, reps) / nb
 
@@ -382,6 +389,7 @@ def main():
                            if job.sharded else
                            f"users partitioned over {world} GPUs, catalog replicated ({cfg.n_item} items): no data-path collective")},
             "path_gen_p50_ms_b1": lat,
+            "path_gen_b1_window_tokens": lat_tokens,
             "path_gen_ms_per_user_b128": lat128,
             "path_gen_ms_per_user_b1024": lat1024,
             "roofline": roof,

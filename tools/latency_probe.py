@@ -13,9 +13,16 @@ SWEEP = {"bf16": IRS_SWEEP_BF16, "f32": IRS_SWEEP_F32, "exh": IRS_SWEEP_EXHAUSTI
 cfg = synth.make_config(cfgname)
 dev = torch.device("cuda:0")
 eng = Engine(n_item=cfg.n_item, n_user=cfg.n_user, d=cfg.emb_dim, max_len=cfg.max_len, n_heads=cfg.n_heads, ffn_dim=cfg.ffn_dim,
-             n_layers=cfg.n_layers, u_dim=cfg.u_emb_dim, mask_mode=IRS_MASK_IRN, device=dev, max_rows=max(B, 8), max_seqs=max(B, 8))
+             n_layers=cfg.n_layers, u_dim=cfg.u_emb_dim, mask_mode=IRS_MASK_IRN, device=dev, max_rows=max(B, int(os.environ.get("PROBE_MAX", "8"))), max_seqs=max(B, int(os.environ.get("PROBE_MAX", "8"))))
 eng.bind_state_dict({k: torch.from_numpy(v).to(dev) for k, v in synth.irn_state_dict(cfg, 1234).items()})
-seqs = torch.from_numpy(synth.random_windows(B, cfg.max_len, cfg.n_item, seed=3)).to(dev)
+wnd = synth.random_windows(B, cfg.max_len, cfg.n_item, seed=3)
+if os.environ.get("PROBE_NVALID"):  # windows with exactly this many items (pre-padded, target last)
+    nv = min(int(os.environ["PROBE_NVALID"]), cfg.max_len)
+    g = np.random.default_rng(5)
+    wnd[:] = 0
+    wnd[:, cfg.max_len - nv:] = g.integers(1, cfg.n_item + 1, size=(B, nv))
+seqs = torch.from_numpy(wnd).to(dev)
+print(f"valid tokens per window: {(wnd != 0).sum(axis=1).mean():.0f}")
 users = torch.zeros(B, dtype=torch.int64, device=dev)
 for graph in (False, True):
     ts = []
