@@ -118,10 +118,16 @@ __device__ __forceinline__ void emit_flush(const SweepArgs &a, EmitQ &q, int lan
 __device__ __forceinline__ void emit_candidates(const SweepArgs &a, const f32x16 &acc, float thr, int user, int t, int h,
                                                 EmitQ &q, int lane) {
     if (!__any(max16(acc) >= thr)) return;
+    // all sixteen compares first (each leaves the wave's hit mask in an SGPR pair), then scalar tests of the masks: a
+    // v_cmp followed at once by a branch on its result waits out the VALU -> SALU latency sixteen times
+    unsigned long long masks[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) masks[r] = __ballot(acc[r] >= thr);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const bool hit = acc[r] >= thr;
-        const unsigned long long mask = __ballot(hit);
+        const unsigned long long mask = masks[r];
         if (mask) { // wave-uniform
             const unsigned int n = (unsigned int)__popcll(mask);
             if (q.n + n > EMIT_Q) emit_flush(a, q, lane);
