@@ -380,3 +380,25 @@ def test_throughput_shape_evaluator_mask(oracle):
         assert np.array_equal(np.isnan(ref), np.isnan(got))
         fin = np.isfinite(ref) & np.isfinite(got)
         assert np.abs(ref - got)[fin].max() < X_TOL
+
+
+def test_single_sequence_fused_attention_evaluator_mask(oracle):
+    """The one-sequence path under the evaluator's mask (causal, no target column, no user factor, POST-padded
+    windows): consumed rows of single calls against the numpy oracle and against two-at-a-time calls."""
+    cfg = synth.make_config("c2", n_user=0)
+    L = cfg.max_len
+    sd = synth.irn_state_dict(cfg, 17, evaluator=True)
+    eng = make_engine(cfg, sd, evaluator=True, max_rows=8)
+    g = np.random.default_rng(9)
+    lens = [1, 17, 100, L]
+    seqs = np.zeros((len(lens), L), dtype=np.int64)
+    for b, n in enumerate(lens):
+        seqs[b, :n] = g.integers(1, cfg.n_item + 1, size=n)  # post-padded: zeros at the tail
+    pos = np.array([n - 1 for n in lens], dtype=np.int32)  # the last item's row
+    seq, p = torch.from_numpy(seqs).cuda(), torch.from_numpy(pos).cuda()
+    pair = torch.cat([eng.decode(seq[i:i + 2], None, want_x=False, pos=p[i:i + 2])[1] for i in range(0, 4, 2)])
+    for b in range(4):
+        one = eng.decode(seq[b:b + 1], None, want_x=False, pos=p[b:b + 1])[1][0]
+        assert (one - pair[b]).abs().max().item() < X_TOL, b
+        ref = oracle.decode(sd, cfg, seqs[b], None, evaluator=True)[0][pos[b]]
+        assert np.abs(ref - one.cpu().numpy()).max() < X_TOL, b
