@@ -892,22 +892,30 @@ __device__ unsigned long long g_direct_t[16];
 #else
 #define DSTAMP(i)
 #endif
+// MODE 0: as described (<= 32 rows: one launch).  More rows (<= 256) take two launches of the same code: MODE 1 scores
+// DIRECT_ROWS rows per workgroup against its W tile (the tile is staged once per 8 rows; wave w runs rows w and w + 4),
+// MODE 2 is the selection alone, one workgroup per row -- the last-arriver scheme would hand all 8 rows of a group to
+// the same workgroup, one after the other.
+#define DIRECT_ROWS 8
+template <int MODE>
 __global__ void __launch_bounds__(256) k_topk_direct(const float *__restrict__ x, int d, const float *__restrict__ W,
                                                      const float *__restrict__ bias, int n_local, int64_t item_lo, int k,
                                                      unsigned long long *__restrict__ gkeys, unsigned int *__restrict__ arrive,
                                                      float *__restrict__ val, int64_t *__restrict__ ids,
-                                                     int32_t *__restrict__ status, irs_path_args pa) {
+                                                     int32_t *__restrict__ status, irs_path_args pa, int M) {
     __shared__ __attribute__((aligned(16))) float tile[DIRECT_TILE * (DIRECT_MAX_D + 4)]; // W tile, later the key array
     __shared__ __attribute__((aligned(16))) unsigned long long rkeys[IRS_REFINE_CAP + 2];
-    __shared__ __attribute__((aligned(16))) float xs[DIRECT_MAX_D];
+    __shared__ __attribute__((aligned(16))) float xs[(MODE == 1 ? DIRECT_ROWS : 1) * DIRECT_MAX_D];
     __shared__ __attribute__((aligned(16))) unsigned long long tmax[256];
     __shared__ unsigned int wsum[4];
     __shared__ unsigned int s_last, s_thr;
-    const int row = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = MODE == 1 ? blockIdx.y * DIRECT_ROWS : blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef IRS_DIRECT_TIMING
     unsigned long long tstamp[10];
 #endif
     DSTAMP(0);
+    unsigned int *gk = reinterpret_cast<unsigned int *>(gkeys + (size_t)row * IRS_CAND_CAP);
+    if constexpr (MODE != 2) {
     const bool vec = (d & 3) == 0;
     // row stride: 4 mod 8 floats (conflict-free ds_read_b128 of one row per lane), or odd when d is not a multiple
     // of 4 (the reference's default d = 30: scalar staging and ds_read_b32)
@@ -926,11 +934,39 @@ __global__ void __launch_bounds__(256) k_topk_direct(const float *__restrict__ x
             tile[jj * S + c] = W[(size_t)j0 * d + i];
         }
     }
+    if constexpr (MODE == 1) {
+        for (int i = tid; i < DIRECT_ROWS * d; i += 256) {
+            const int rr = i / d, c = i - rr * d;
+            xs[rr * DIRECT_MAX_D + c] = (row + rr < M) ? x[(size_t)(row + rr) * d + c] : 0.f;
+        }
+        __syncthreads();
+        // two rows per wave against the same W row: one LDS read of W feeds two independent chains
+        if (lane < nj) {
+            const float b0 = bias[j0 + lane];
+            float acc0 = b0, acc1 = b0;
+            const float *x0 = xs + wave * DIRECT_MAX_D, *x1 = xs + (wave + 4) * DIRECT_MAX_D;
+            if (vec) {
+                const float4 *w4 = reinterpret_cast<const float4 *>(tile + lane * S);
+                for (int c = 0; c < d4; ++c) { // the k-ascending fma chain of irs_chain, twice
+                    const float4 wv = w4[c], xa = reinterpret_cast<const float4 *>(x0)[c], xb = reinterpret_cast<const float4 *>(x1)[c];
+                    acc0 = __fmaf_rn(xa.x, wv.x, acc0), acc1 = __fmaf_rn(xb.x, wv.x, acc1);
+                    acc0 = __fmaf_rn(xa.y, wv.y, acc0), acc1 = __fmaf_rn(xb.y, wv.y, acc1);
+                    acc0 = __fmaf_rn(xa.z, wv.z, acc0), acc1 = __fmaf_rn(xb.z, wv.z, acc1);
+                    acc0 = __fmaf_rn(xa.w, wv.w, acc0), acc1 = __fmaf_rn(xb.w, wv.w, acc1);
+                }
+            } else {
+                const float *wr = tile + lane * S;
+                for (int c = 0; c < d; ++c) acc0 = __fmaf_rn(x0[c], wr[c], acc0), acc1 = __fmaf_rn(x1[c], wr[c], acc1);
+            }
+            if (row + wave < M) gk[(size_t)wave * (IRS_CAND_CAP * 2) + j0 + lane] = irs_fkey(acc0);
+            if (row + wave + 4 < M) gk[(size_t)(wave + 4) * (IRS_CAND_CAP * 2) + j0 + lane] = irs_fkey(acc1);
+        }
+        return;
+    }
     for (int i = tid; i < d; i += 256) xs[i] = x[(size_t)row * d + i];
     __syncthreads();
     DSTAMP(1);
     // the row's score keys (32 bits per item, the item id is the position): 16 KB for the last workgroup to fetch
-    unsigned int *gk = reinterpret_cast<unsigned int *>(gkeys + (size_t)row * IRS_CAND_CAP);
     if (wave == 0 && lane < nj) {
         float acc = bias[j0 + lane];
         if (vec) {
@@ -958,10 +994,9 @@ __global__ void __launch_bounds__(256) k_topk_direct(const float *__restrict__ x
     if (!s_last) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // and are read from memory, not from a stale L2 line
     DSTAMP(4);
-    if (tid == 0) {
-        arrive[row] = 0u; // ready for the next call (graph replays included)
-        status[row] = 0;
-    }
+    if (tid == 0) arrive[row] = 0u; // ready for the next call (graph replays included)
+    } // MODE != 2
+    if (tid == 0) status[row] = 0;
     constexpr int KPT = DIRECT_MAX_ITEMS / 256;
     unsigned long long key[KPT]; // this thread's items: 1024 q + 4 tid + e, key = (score key, ~id); 0 where there is none
 #pragma unroll
@@ -1313,7 +1348,7 @@ int irs_launch_pack_w(irs_ctx *ctx, hipStream_t s) {
 }
 
 bool irs_topk_is_direct(const irs_ctx *ctx, int M, int k) {
-    return M <= 32 && ctx->n_local <= DIRECT_MAX_ITEMS && k <= 256 && ctx->dims.d <= DIRECT_MAX_D;
+    return M <= 256 && ctx->n_local <= DIRECT_MAX_ITEMS && k <= 256 && ctx->dims.d <= DIRECT_MAX_D;
 }
 
 int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, float *val, int64_t *ids0,
@@ -1322,9 +1357,19 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
     if (irs_topk_is_direct(ctx, M, k)) {
         // latency path on a small shard: one kernel, no fallback needed
         irs_prof_begin(ctx, IRS_PROF_REFINE, s);
-        hipLaunchKernelGGL(k_topk_direct, dim3((unsigned)((ctx->n_local + DIRECT_TILE - 1) / DIRECT_TILE), M), dim3(256), 0, s, xrows, ctx->dims.d,
-                           ctx->proj_w, ctx->proj_b, (int)ctx->n_local, ctx->shard.item_lo, k, ctx->cand,
-                           reinterpret_cast<unsigned int *>(ctx->step_ctr) + 8, val, ids0, status, path ? *path : irs_path_args{});
+        const unsigned int tiles = (unsigned)((ctx->n_local + DIRECT_TILE - 1) / DIRECT_TILE);
+        unsigned int *arrive = reinterpret_cast<unsigned int *>(ctx->step_ctr) + 8;
+        const irs_path_args pa = path ? *path : irs_path_args{};
+        if (M <= 32)
+            hipLaunchKernelGGL(k_topk_direct<0>, dim3(tiles, M), dim3(256), 0, s, xrows, ctx->dims.d, ctx->proj_w, ctx->proj_b,
+                               (int)ctx->n_local, ctx->shard.item_lo, k, ctx->cand, arrive, val, ids0, status, pa, M);
+        else {
+            hipLaunchKernelGGL(k_topk_direct<1>, dim3(tiles, (M + DIRECT_ROWS - 1) / DIRECT_ROWS), dim3(256), 0, s, xrows, ctx->dims.d,
+                               ctx->proj_w, ctx->proj_b, (int)ctx->n_local, ctx->shard.item_lo, k, ctx->cand, arrive, val, ids0,
+                               status, irs_path_args{}, M);
+            hipLaunchKernelGGL(k_topk_direct<2>, dim3(1, M), dim3(256), 0, s, xrows, ctx->dims.d, ctx->proj_w, ctx->proj_b,
+                               (int)ctx->n_local, ctx->shard.item_lo, k, ctx->cand, arrive, val, ids0, status, pa, M);
+        }
         irs_prof_end(ctx, IRS_PROF_REFINE, s, 2.0 * ctx->dims.d * (double)M * (double)ctx->n_local, 0.0);
         IRS_CHECK_HIP(ctx, hipGetLastError());
         return IRS_OK;

@@ -20,7 +20,7 @@ int main() {
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0, 0));
         for (int i = 0; i < 20; ++i)
-            hipLaunchKernelGGL(k_topk_direct, dim3((n + DIRECT_TILE - 1) / DIRECT_TILE, 1), dim3(256), 0, 0, x, d, W, bias, n, (int64_t)0, k, gk, arrive, val, ids, st);
+            hipLaunchKernelGGL(k_topk_direct<0>, dim3((n + DIRECT_TILE - 1) / DIRECT_TILE, 1), dim3(256), 0, 0, x, d, W, bias, n, (int64_t)0, k, gk, arrive, val, ids, st, irs_path_args{}, 1);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         unsigned long long t[16]; CK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_direct_t), sizeof t));
