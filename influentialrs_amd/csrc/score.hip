@@ -892,7 +892,7 @@ __device__ unsigned long long g_direct_t[16];
 #else
 #define DSTAMP(i)
 #endif
-// MODE 0: as described (<= 32 rows: one launch).  More rows (<= 256) take two launches of the same code: MODE 1 scores
+// MODE 0: as described (<= 32 rows: one launch).  More rows (<= 1024) take two launches of the same code: MODE 1 scores
 // DIRECT_ROWS rows per workgroup against its W tile (the tile is staged once per 8 rows; wave w runs rows w and w + 4),
 // MODE 2 is the selection alone, one workgroup per row -- the last-arriver scheme would hand all 8 rows of a group to
 // the same workgroup, one after the other.
@@ -1348,7 +1348,7 @@ int irs_launch_pack_w(irs_ctx *ctx, hipStream_t s) {
 }
 
 bool irs_topk_is_direct(const irs_ctx *ctx, int M, int k) {
-    return M <= 256 && ctx->n_local <= DIRECT_MAX_ITEMS && k <= 256 && ctx->dims.d <= DIRECT_MAX_D;
+    return M <= 1024 && ctx->n_local <= DIRECT_MAX_ITEMS && k <= 256 && ctx->dims.d <= DIRECT_MAX_D;
 }
 
 int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, float *val, int64_t *ids0,

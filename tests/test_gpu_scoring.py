@@ -79,7 +79,7 @@ def test_topk_ties_and_fallback(oracle):
             assert np.array_equal(val[m].cpu().numpy().view(np.uint32), ov.view(np.uint32))
 
 
-DIRECT_CASES = [  # the small-shard path (n_item <= 4096, k <= 256): one launch up to 32 rows, two up to 256
+DIRECT_CASES = [  # the small-shard path (n_item <= 4096, k <= 256): one launch up to 32 rows, two up to 1024
     (3415, 128, 1, 100),    # the single-user step
     (3415, 128, 8, 100),
     (4096, 64, 32, 256),    # every limit at once
@@ -91,7 +91,8 @@ DIRECT_CASES = [  # the small-shard path (n_item <= 4096, k <= 256): one launch 
     (700, 6, 3, 20),        # d = 2 mod 4
     (3415, 128, 33, 100),   # > 32 rows: scoring (8 rows per workgroup) and selection as two launches
     (3415, 128, 129, 100),  # ragged last row group
-    (4096, 64, 256, 256),   # the two-launch form's limits
+    (4096, 64, 256, 256),   # the two-launch form at the key-array and k limits
+    (3415, 128, 1000, 100),  # ... and near its row limit (1024)
     (3415, 30, 40, 100),    # scalar staging, two rows per wave
 ]
 
