@@ -570,25 +570,36 @@ __global__ void __launch_bounds__(256, 2) k_sweep_f32(SweepArgs a) {
 }
 
 // =============================== small kernels ===============================
-// 8 consecutive k of one row -> one 16-byte bf16 fragment piece (RNE, finite inputs)
-__device__ __forceinline__ uint4 pack8_bf16(const float *__restrict__ src, int k0, int d, bool row_ok, float &ss) {
+// 8 consecutive k of one row -> one 16-byte bf16 fragment piece (RNE, finite inputs).  Accumulates the squared
+// norms the error bound is made of: ss of the values, ssr of the rounded values, ssd of the rounding errors
+// (v - bf16(v) is exact in float32: both share an exponent range and the difference has <= 16 significant bits).
+__device__ __forceinline__ uint4 pack8_bf16(const float *__restrict__ src, int k0, int d, bool row_ok, float &ss, float &ssr,
+                                            float &ssd) {
     unsigned int h[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float v = (row_ok && k0 + j < d) ? src[k0 + j] : 0.f;
-        ss += v * v;
         unsigned int u = __float_as_uint(v);
         u += 0x7FFFu + ((u >> 16) & 1u);
         h[j] = u >> 16;
+        const float vr = __uint_as_float(h[j] << 16), dv = v - vr;
+        ss += v * v;
+        ssr += vr * vr;
+        ssd += dv * dv;
     }
     return make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
 }
 
 // rows -> bf16 fragments + eps.  One wave per row of the padded row block;
 // lane l < 2*KS packs k = 8l .. 8l+7 (ks = l>>1, half = l&1).
+// eps[row] bounds |bf16-MFMA score - exact chain| for EVERY item (DESIGN.md "Why the bf16 filter is exact"):
+//   x^ w^ - x w = (x^ - x) w^ + x (w^ - w)   =>   |sum| <= ||dx|| max||w^_j|| + ||x|| max||dw_j||   (Cauchy-Schwarz on the
+//   ACTUAL rounding-error vectors: rigorous, and ~0.6x the worst case 2u ||x|| ||w|| on ordinary data)
+//   + the float32 accumulation of both sides: (d_pad + 8) 2^-22 (max(||x||, ||x^||) max||w|| + max|b|).
+// wn = {max_j max(||w_j||, ||w^_j||), max_j ||w_j - w^_j||, max_j |b_j|}, each rounded up by k_pack_w.
 __global__ void __launch_bounds__(256) k_prep_x(const float *__restrict__ x, int M, int M_pad, int d, int KS,
                                                 uint4 *__restrict__ xb, float *__restrict__ eps,
-                                                const float *__restrict__ wnorm_max, float eps_factor,
+                                                const float *__restrict__ wn, float acc_factor,
                                                 unsigned int *__restrict__ cand_cnt, int32_t *__restrict__ status) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
@@ -597,14 +608,22 @@ __global__ void __launch_bounds__(256) k_prep_x(const float *__restrict__ x, int
     cand_cnt[(size_t)row * IRS_CAND_BUCKETS + lane] = 0u; // IRS_CAND_BUCKETS == 64 == wave size
     if (lane == 0 && row < M) status[row] = 0;
     const int ut = row >> 5, r = row & 31;
-    float ss = 0.f;
+    float ss = 0.f, ssr = 0.f, ssd = 0.f;
     if (lane < 2 * KS) {
-        uint4 v = pack8_bf16(x + (size_t)row * d, 8 * lane, d, row < M, ss);
+        uint4 v = pack8_bf16(x + (size_t)row * d, 8 * lane, d, row < M, ss, ssr, ssd);
         xb[((size_t)ut * KS + (lane >> 1)) * 64 + (lane & 1) * 32 + r] = v;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
-    if (lane == 0) eps[row] = (row < M) ? sqrtf(ss) * wnorm_max[0] * eps_factor : 0.f;
+    for (int off = 32; off > 0; off >>= 1) {
+        ss += __shfl_xor(ss, off, 64);
+        ssr += __shfl_xor(ssr, off, 64);
+        ssd += __shfl_xor(ssd, off, 64);
+    }
+    if (lane == 0) {
+        const float nx = sqrtf(fmaxf(ss, ssr)), ndx = sqrtf(ssd);
+        // 1.001: the float32 sums of squares / square roots above (relative error < d 2^-24 + 2^-23)
+        eps[row] = (row < M) ? 1.001f * (ndx * wn[0] + nx * wn[1]) + acc_factor * (1.001f * nx * wn[0] + wn[2]) : 0.f;
+    }
 }
 
 __global__ void k_zero_eps(float *eps, int n) {
@@ -612,25 +631,33 @@ __global__ void k_zero_eps(float *eps, int n) {
     if (i < n) eps[i] = 0.f;
 }
 
-// W -> bf16 fragments, padded bias, max row norm.  One wave per item row (padded).
+// W -> bf16 fragments, padded bias, and the three maxima of the error bound (see k_prep_x).  One wave per item row (padded).
 __global__ void __launch_bounds__(256) k_pack_w(const float *__restrict__ W, const float *__restrict__ b, int64_t n_local,
                                                 int n_tiles, int d, int KS, uint4 *__restrict__ wp,
-                                                float *__restrict__ bias_pad, unsigned int *__restrict__ wnorm_max_bits) {
+                                                float *__restrict__ bias_pad, unsigned int *__restrict__ wn_bits) {
     int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (row >= (int64_t)n_tiles * 32) return;
     const int64_t t = row >> 5;
     const int r = (int)(row & 31);
-    float ss = 0.f;
+    float ss = 0.f, ssr = 0.f, ssd = 0.f;
     if (lane < 2 * KS) {
-        uint4 v = pack8_bf16(W + (size_t)row * d, 8 * lane, d, row < n_local, ss);
+        uint4 v = pack8_bf16(W + (size_t)row * d, 8 * lane, d, row < n_local, ss, ssr, ssd);
         wp[((size_t)t * KS + (lane >> 1)) * 64 + (lane & 1) * 32 + r] = v;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    for (int off = 32; off > 0; off >>= 1) {
+        ss += __shfl_xor(ss, off, 64);
+        ssr += __shfl_xor(ssr, off, 64);
+        ssd += __shfl_xor(ssd, off, 64);
+    }
     if (lane == 0) {
         bias_pad[row] = (row < n_local) ? b[row] : -INFINITY;
-        if (row < n_local) atomicMax(wnorm_max_bits, __float_as_uint(sqrtf(ss) * 1.0001f));
+        if (row < n_local) { // non-negative floats order like their bit patterns
+            atomicMax(wn_bits + 0, __float_as_uint(sqrtf(fmaxf(ss, ssr)) * 1.001f));
+            atomicMax(wn_bits + 1, __float_as_uint(sqrtf(ssd) * 1.001f));
+            atomicMax(wn_bits + 2, __float_as_uint(fabsf(b[row])));
+        }
     }
 }
 
@@ -1338,7 +1365,7 @@ static void sweep_decompose(SweepArgs &a, int tile_begin, int tile_end, int n_ub
 }
 
 int irs_launch_pack_w(irs_ctx *ctx, hipStream_t s) {
-    IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->wnorm_max, 0, sizeof(float), s));
+    IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->wnorm_max, 0, 4 * sizeof(float), s));
     int64_t rows = (int64_t)ctx->n_tiles * 32;
     hipLaunchKernelGGL(k_pack_w, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, ctx->proj_w, ctx->proj_b,
                        ctx->n_local, ctx->n_tiles, ctx->dims.d, ctx->KS, ctx->wp,
@@ -1382,10 +1409,10 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
     int rc;
     static_assert(IRS_CAND_BUCKETS == 64, "k_prep_x resets one bucket counter per lane");
     if (sweep == IRS_SWEEP_BF16) {
-        // |approx - exact| <= ||x|| * max||W_j|| * (2u + u^2 + accumulation), u = 2^-9
-        float eps_factor = 0.00390625f * 1.01f + (float)(ctx->d_pad + 8) * 2.384185791015625e-07f;
+        // |approx - exact| <= eps[row] for every item of the shard: see k_prep_x
+        const float acc_factor = (float)(ctx->d_pad + 8) * 2.384185791015625e-07f; // (d_pad + 8) 2^-22
         hipLaunchKernelGGL(k_prep_x, dim3((M_pad + 3) / 4), dim3(256), 0, s, xrows, M, M_pad, d, ctx->KS,
-                           ctx->xb, ctx->eps, ctx->wnorm_max, eps_factor, ctx->cand_cnt, status);
+                           ctx->xb, ctx->eps, ctx->wnorm_max, acc_factor, ctx->cand_cnt, status);
     } else {
         IRS_CHECK_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t) * M, s));
         IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->cand_cnt, 0, sizeof(unsigned int) * (size_t)M_pad * IRS_CAND_BUCKETS, s));

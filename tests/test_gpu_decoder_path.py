@@ -10,10 +10,35 @@ import torch
 from influentialrs_amd import synth
 from influentialrs_amd._lib import IRS_SWEEP_BF16, IRS_SWEEP_F32
 from gpu_util import make_engine
+from rank_check import check_ranked
 
 pytestmark = pytest.mark.gpu
 
 X_TOL = 2e-5
+TAU = 2e-5  # two reference scores closer than this may swap (decoder tolerance propagated to the logits)
+GOLDENS = [("irn_tiny", "tiny"), ("irn_default", "default"), ("irn_c1", "c1"), ("irn_c2", "c2"), ("irn_c3", "c3")]
+_ENG = {}
+
+
+def _engine(cfgname):
+    """One engine per golden config for the whole module (the 1M-item catalog of c3 takes seconds to generate)."""
+    if cfgname not in _ENG:
+        cfg = synth.make_config(cfgname)
+        sd = synth.irn_state_dict(cfg, 1234)
+        _ENG.clear()  # at most one catalog resident
+        _ENG[cfgname] = (cfg, sd, make_engine(cfg, sd, max_rows=32, max_seqs=32))
+    return _ENG[cfgname]
+
+
+def _trim_after_target(paths, targets):
+    """The reference's post-processing (influentialRS.py:459-467): zero the path after the target's first occurrence."""
+    out, n = paths.copy(), 0
+    for i in range(out.shape[0]):
+        pos = np.where(out[i] == targets[i])[0]
+        if len(pos):
+            n += 1
+            out[i, pos[0] + 1:] = 0
+    return out, n
 
 
 def _irn_inputs(g):
@@ -22,12 +47,10 @@ def _irn_inputs(g):
     return raws, g["seqs"], g["users"], g["targets"], g["labels"]
 
 
-@pytest.mark.parametrize("name,cfgname", [("irn_tiny", "tiny"), ("irn_default", "default"), ("irn_c1", "c1"), ("irn_c2", "c2")])
+@pytest.mark.parametrize("name,cfgname", GOLDENS)
 def test_decoder_rows_vs_golden_and_oracle(oracle, golden, name, cfgname):
     g = golden(name)
-    cfg = synth.make_config(cfgname)
-    sd = synth.irn_state_dict(cfg, 1234)
-    eng = make_engine(cfg, sd, max_rows=8)
+    cfg, sd, eng = _engine(cfgname)
     raws, seqs, users, targets, labels = _irn_inputs(g)
     B, L = seqs.shape
     pos = torch.full((B,), L - 2, dtype=torch.int32, device="cuda")
@@ -50,14 +73,16 @@ def test_decoder_rows_vs_golden_and_oracle(oracle, golden, name, cfgname):
         assert np.abs(lg - ref).max() < 5e-5
 
 
-@pytest.mark.parametrize("name,cfgname", [("irn_tiny", "tiny"), ("irn_default", "default"), ("irn_c1", "c1"), ("irn_c2", "c2")])
+STRICT = {}
+
+
+@pytest.mark.parametrize("name,cfgname", GOLDENS)
 def test_topk_vs_reference_goldens(golden, name, cfgname):
-    """Top-100 ids of the reference (torch) reproduced wherever the recorded
-    adjacent margin exceeds the decoder tolerance propagated to the logits."""
+    """Top-100 ids of the reference (torch topk / sort of its own float32 logits) in order: every position holds the
+    reference's id, except inside a run of reference scores closer than TAU (rank_check.check_ranked).  The number of
+    users that are id-for-id identical is asserted per config and over all configs (test below)."""
     g = golden(name)
-    cfg = synth.make_config(cfgname)
-    sd = synth.irn_state_dict(cfg, 1234)
-    eng = make_engine(cfg, sd, max_rows=8)
+    cfg, sd, eng = _engine(cfgname)
     raws, seqs, users, targets, labels = _irn_inputs(g)
     B, L = seqs.shape
     pos = torch.full((B,), L - 2, dtype=torch.int32, device="cuda")
@@ -65,24 +90,29 @@ def test_topk_vs_reference_goldens(golden, name, cfgname):
     val, ids, st = eng.score_topk(xr, 100, IRS_SWEEP_BF16)
     ids = ids.cpu().numpy()
     val = val.cpu().numpy()
+    strict = 0
     for i in range(B):
-        ref_ids, ref_val = g["top100_ids0"][i], g["top100_vals"][i]
-        assert np.abs(val[i] - ref_val).max() < 5e-5
-        if g["min_margin_top101"][i] > 2e-5:
-            assert np.array_equal(ids[i], ref_ids), f"user {i}"
-        else:  # margin-aware: same set up to swaps of near-tied neighbours
-            assert set(ids[i][:99]) <= set(ref_ids) | set(ids[i][99:])
+        assert np.abs(val[i] - g["top_vals"][i][:100]).max() < 5e-5
+        strict += check_ranked(ids[i], g["top_ids0"][i], g["top_gaps"][i], TAU)
+    STRICT[name] = (strict, B)
+    assert strict >= 0.9 * B, f"{name}: only {strict} of {B} users id-for-id identical to the reference"
 
 
-@pytest.mark.parametrize("name,cfgname", [("irn_tiny", "tiny"), ("irn_default", "default"), ("irn_c1", "c1"), ("irn_c2", "c2")])
+def test_topk_vs_reference_goldens_coverage():
+    """>= 90 % of >= 100 reference-pinned users are compared (and equal) id for id, every config included."""
+    assert set(STRICT) == {n for n, _ in GOLDENS}, "run together with test_topk_vs_reference_goldens"
+    strict = sum(v[0] for v in STRICT.values())
+    users = sum(v[1] for v in STRICT.values())
+    assert users >= 100 and strict >= 0.9 * users, STRICT
+
+
+@pytest.mark.parametrize("name,cfgname", GOLDENS)
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_paths_vs_reference_goldens(golden, name, cfgname, use_graph):
     """20-step greedy persuasion paths (IRSNN.get_seq_in_batch) reproduce the
-    reference's paths id for id."""
+    reference's paths id for id, early successes (tail zeroed after the target) included."""
     g = golden(name)
-    cfg = synth.make_config(cfgname)
-    sd = synth.irn_state_dict(cfg, 1234)
-    eng = make_engine(cfg, sd, max_rows=8)
+    cfg, sd, eng = _engine(cfgname)
     raws, seqs, users, targets, labels = _irn_inputs(g)
     B, L = seqs.shape
     P = int(g["meta"][2])
@@ -92,24 +122,22 @@ def test_paths_vs_reference_goldens(golden, name, cfgname, use_graph):
     torch.cuda.synchronize()
     paths = paths.cpu().numpy()
     assert (st.cpu().numpy() & 2).sum() == 0
-    ref = g["paths"].copy()  # reference zeroes the tail after an early success; none in these goldens
-    assert int(g["n_early_success"]) == 0
-    assert np.array_equal(paths, ref), (paths, ref)
+    trimmed, n_early = _trim_after_target(paths, targets)  # the search itself never stops at the target (:459-467)
+    assert int(g["n_early_success"]) > 0 and n_early == int(g["n_early_success"])
+    assert np.array_equal(trimmed, g["paths"]), (trimmed, g["paths"])
     # final window = shifted history + path + target
     w = work.cpu().numpy()
     assert np.array_equal(w[:, -1], targets)
     assert np.array_equal(w[:, L - 1 - P:L - 1] if P < L - 1 else w[:, :L - 1], paths[:, -(L - 1):].astype(np.int64) if P >= L - 1 else paths.astype(np.int64))
 
 
-@pytest.mark.parametrize("name,cfgname", [("irn_tiny", "tiny"), ("irn_default", "default"), ("irn_c1", "c1"), ("irn_c2", "c2")])
+@pytest.mark.parametrize("name,cfgname", GOLDENS)
 def test_single_sequence_calls_match_goldens(golden, name, cfgname):
     """One sequence per call -- the reference IRN's own regime and the latency metric's.  At d = 128 / 4 heads that
     is a path of its own (self-attention inside the 16-token layer kernel, q | k | v ping-pong buffers): decoder
     rows, top-100 ids and 20-step paths of every golden sequence, one at a time, against the reference's outputs."""
     g = golden(name)
-    cfg = synth.make_config(cfgname)
-    sd = synth.irn_state_dict(cfg, 1234)
-    eng = make_engine(cfg, sd, max_rows=8)
+    cfg, sd, eng = _engine(cfgname)
     raws, seqs, users, targets, labels = _irn_inputs(g)
     B, L = seqs.shape
     P = int(g["meta"][2])
@@ -126,7 +154,7 @@ def test_single_sequence_calls_match_goldens(golden, name, cfgname):
             paths, st = eng.generate_paths(work, u1, hep, P, k=100, sweep=IRS_SWEEP_BF16, use_graph=use_graph)
             torch.cuda.synchronize()
             assert (st.cpu().numpy() & 2).sum() == 0
-            assert np.array_equal(paths.cpu().numpy()[0], g["paths"][b]), (b, use_graph)
+            assert np.array_equal(_trim_after_target(paths.cpu().numpy(), targets[b:b + 1])[0][0], g["paths"][b]), (b, use_graph)
 
 
 @pytest.mark.parametrize("n_layers", [2, 3])

