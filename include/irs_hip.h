@@ -20,7 +20,10 @@
  *    workspace sized by irs_workspace_bytes() and bound by irs_bind_workspace().
  *  - all work is enqueued on the caller's stream (a hipStream_t passed as
  *    void*); no call synchronises the device unless documented.
- *  - one context <-> one device, one stream at a time (not re-entrant).
+ *  - one context <-> one device, one stream at a time (not re-entrant).  Kernels
+ *    are launched on the CURRENT HIP device: the caller makes the device that
+ *    owns the context's pointers current around every call (the Python engine
+ *    does: influentialrs_amd/engine.py Engine._call).
  *  - item ids crossing the ABI in "ids0" arguments are 0-based GLOBAL catalog
  *    positions (reference item id = ids0 + 1, influentialRS.py:376,422;
  *    0 is the pad id in sequences, which carry 1-based ids like the reference).
@@ -65,6 +68,9 @@ extern "C" {
 #define IRS_ROW_NO_CANDIDATE 2 /* every one of the k candidates is in the window
                                   (the reference raises IndexError at influentialRS.py:429) */
 #define IRS_ROW_FEWER_THAN_K 4 /* catalog shard has fewer than k items; tail filled with (-inf, -1) */
+
+#define IRS_MAX_SAMPLE_K 8 /* sampled path steps draw among at most this many survivors (reference default: 3);
+                              larger sample_k -> IRS_E_UNSUPPORTED */
 
 typedef struct irs_ctx irs_ctx;
 

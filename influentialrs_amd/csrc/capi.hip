@@ -443,6 +443,8 @@ extern "C" int irs_path_step(irs_ctx *ctx, int64_t *seq, int32_t *hep, int32_t B
     if (!ctx) return IRS_E_INVALID;
     if (!seq || !hep || !val || !ids0 || !paths || !status || B < 1 || k < 1 || step < 0 || step >= path_ld)
         IRS_FAIL(ctx, IRS_E_INVALID, "irs_path_step: bad arguments");
+    if (sample && (sample_k < 1 || sample_k > IRS_MAX_SAMPLE_K))
+        IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "irs_path_step: sample_k must be in [1, %d]", IRS_MAX_SAMPLE_K);
     return irs_launch_path_step(ctx, seq, hep, B, val, ids0, k, step, nullptr, paths, path_ld, sample, sample_k, seed,
                                 status, (hipStream_t)stream);
 }
@@ -484,6 +486,8 @@ extern "C" int irs_generate_paths(irs_ctx *ctx, int64_t *seq, const int64_t *use
     if (B > ctx->max_seqs || B > ctx->max_rows) IRS_FAIL(ctx, IRS_E_INVALID, "irs_generate_paths: B too large");
     if (k < 1 || k > ctx->dims.max_k) IRS_FAIL(ctx, IRS_E_INVALID, "irs_generate_paths: bad k");
     if (sweep != IRS_SWEEP_BF16 && sweep != IRS_SWEEP_F32) IRS_FAIL(ctx, IRS_E_INVALID, "irs_generate_paths: bad sweep");
+    if (sample && (sample_k < 1 || sample_k > IRS_MAX_SAMPLE_K))
+        IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "irs_generate_paths: sample_k must be in [1, %d]", IRS_MAX_SAMPLE_K);
     hipStream_t s = (hipStream_t)stream;
     IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->step_ctr, 0, 2 * sizeof(int32_t), s));
     IRS_CHECK_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t) * B, s));
@@ -493,7 +497,7 @@ extern "C" int irs_generate_paths(irs_ctx *ctx, int64_t *seq, const int64_t *use
                 return rc;
         return IRS_OK;
     }
-    bool reuse = ctx->graph_exec && ctx->graph_B == B && ctx->graph_k == k && ctx->graph_sweep == sweep &&
+    bool reuse = ctx->graph_exec && ctx->graph_B == B && ctx->graph_P == max_path_len && ctx->graph_k == k && ctx->graph_sweep == sweep &&
                  ctx->graph_sample == sample && ctx->graph_sample_k == sample_k && ctx->graph_seq == seq &&
                  ctx->graph_user == user && ctx->graph_hep == hep && ctx->graph_paths == paths &&
                  ctx->graph_status == status && ctx->graph_seed == seed && ctx->prof_family == IRS_PROF_NONE;
@@ -528,6 +532,7 @@ extern "C" int irs_generate_paths(irs_ctx *ctx, int64_t *seq, const int64_t *use
             IRS_FAIL(ctx, IRS_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
         }
         ctx->graph_B = B;
+        ctx->graph_P = max_path_len;
         ctx->graph_k = k;
         ctx->graph_sweep = sweep;
         ctx->graph_sample = sample;
@@ -598,7 +603,7 @@ extern "C" int irs_beam_search(irs_ctx *ctx, const int64_t *seq0, const int64_t 
         // NOTE: `status` is baked into the captured graph, so it is part of the cache key via its address below
         static_assert(sizeof(void *) == 8, "64-bit only");
         bool reuse = ctx->beam_graph && ctx->beam_B == B && ctx->beam_W == W && ctx->beam_k == k &&
-                     ctx->beam_sweep == sweep && ctx->beam_P == P && ctx->graph_status == (void *)status;
+                     ctx->beam_sweep == sweep && ctx->beam_P == P && ctx->beam_status == (void *)status;
         if (!reuse) {
             if (ctx->beam_graph) {
                 hipGraphExecDestroy(ctx->beam_graph);
@@ -627,7 +632,7 @@ extern "C" int irs_beam_search(irs_ctx *ctx, const int64_t *seq0, const int64_t 
             ctx->beam_k = k;
             ctx->beam_sweep = sweep;
             ctx->beam_P = P;
-            ctx->graph_status = status;
+            ctx->beam_status = status;
         }
         for (; done + 2 <= P; done += 2) IRS_CHECK_HIP(ctx, hipGraphLaunch(ctx->beam_graph, s));
     }

@@ -47,7 +47,7 @@ struct irs_ctx {
     uint4 *wp;        // bf16 fragments [n_tiles][KS][64] x 16 B
     float *bias_pad;  // [n_tiles*32], -inf beyond n_local
     float *c_l;       // [n_layers][d] cross-attention constants
-    float *wnorm_max; // [1] max_j ||W_j||_2
+    float *wnorm_max; // [3] max_j max(||W_j||, ||bf16(W_j)||), max_j ||W_j - bf16(W_j)||, max_j |b_j| (k_prep_x)
     float *w_frag16;  // fragment-packed layer weights of the 16-token latency kernel (d = 128, F = 256), or null
     bool finalized;
 
@@ -91,10 +91,11 @@ struct irs_ctx {
     float *lse_max, *lse_sum; // [max_rows]
     hipGraphExec_t beam_graph;
     int beam_B, beam_W, beam_k, beam_sweep, beam_P;
+    void *beam_status; // the status buffer baked into the captured beam steps
 
     // graph cache for irs_generate_paths
     hipGraphExec_t graph_exec;
-    int graph_B, graph_k, graph_sweep, graph_sample, graph_sample_k;
+    int graph_B, graph_P, graph_k, graph_sweep, graph_sample, graph_sample_k;
     void *graph_seq, *graph_user, *graph_hep, *graph_paths, *graph_status;
     uint64_t graph_seed;
 
@@ -237,9 +238,9 @@ __device__ __forceinline__ void irs_path_step_row(const irs_path_args &p_, int r
     }
     int64_t chosen = 0;
     int found = 0;
-    float surv_val[8];
-    int64_t surv_id[8];
-    if (sample_k > 8) sample_k = 8;
+    float surv_val[IRS_MAX_SAMPLE_K];
+    int64_t surv_id[IRS_MAX_SAMPLE_K];
+    if (sample_k > IRS_MAX_SAMPLE_K) sample_k = IRS_MAX_SAMPLE_K; // the entry points reject larger values
     const int want = sample ? sample_k : 1;
     for (int c = 0; c < k && found < want; ++c) {
         int64_t id0 = ids0[(size_t)row * k + c];
@@ -267,7 +268,7 @@ __device__ __forceinline__ void irs_path_step_row(const irs_path_args &p_, int r
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
         z = z ^ (z >> 31);
         float u = (float)((z >> 40) & 0xFFFFFF) * (1.0f / 16777216.0f);
-        float mx = surv_val[0], tot = 0.f, p[8];
+        float mx = surv_val[0], tot = 0.f, p[IRS_MAX_SAMPLE_K];
         for (int i = 0; i < found; ++i) {
             p[i] = __expf(surv_val[i] - mx);
             tot += p[i];

@@ -58,12 +58,12 @@ class Engine:
                        self.max_seqs)
         shard = IrsShard(rank, world, lo, hi)
         h = ctypes.c_void_p()
-        rc = self.lib.irs_create(ctypes.byref(h), ctypes.byref(dims), ctypes.byref(shard))
-        if rc != 0:
-            raise IrsError(f"irs_create failed ({rc}): {self.lib.irs_last_error(None).decode()}")
-        self.h = h
         self._weights: Dict[str, torch.Tensor] = {}
         with torch.cuda.device(self.device):
+            rc = self.lib.irs_create(ctypes.byref(h), ctypes.byref(dims), ctypes.byref(shard))
+            if rc != 0:
+                raise IrsError(f"irs_create failed ({rc}): {self.lib.irs_last_error(None).decode()}")
+            self.h = h
             self._ws = torch.empty(self.lib.irs_workspace_bytes(self.h) + 256, dtype=torch.uint8, device=self.device)
             self._check(self.lib.irs_bind_workspace(self.h, _ptr(self._ws), self._ws.numel()))
         self._arena = None
@@ -80,6 +80,20 @@ class Engine:
     def _check(self, rc: int):
         if rc != 0:
             raise IrsError(f"libirs_hip error {rc}: {self.lib.irs_last_error(self.h).decode()}")
+
+    def _call(self, fn, *args):
+        """Every library entry point launches on the CURRENT HIP device (include/irs_hip.h): make the engine's
+        device current around the call, whatever the caller's current device is."""
+        with torch.cuda.device(self.device):
+            self._check(fn(self.h, *args, self._stream()))
+
+    def _inplace(self, t: torch.Tensor, dtype, what: str) -> torch.Tensor:
+        """A buffer the library updates in place: it must already be what the kernels assume (a copy would
+        silently drop the update)."""
+        if t.device != self.device or t.dtype != dtype or not t.is_contiguous():
+            raise IrsError(f"{what}: need a contiguous {dtype} tensor on {self.device}, got {t.dtype} on {t.device}"
+                           f"{'' if t.is_contiguous() else ' (non-contiguous)'}")
+        return t
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -120,7 +134,7 @@ class Engine:
     def pif(self, users: torch.Tensor) -> torch.Tensor:
         users = self._dev(users, torch.int64)
         out = torch.empty(users.shape[0], dtype=torch.float32, device=self.device)
-        self._check(self.lib.irs_pif(self.h, _ptr(users), users.shape[0], _ptr(out), self._stream()))
+        self._call(self.lib.irs_pif, _ptr(users), users.shape[0], _ptr(out))
         return out
 
     def decode(self, seqs: torch.Tensor, users: Optional[torch.Tensor], *, want_x: bool = True,
@@ -138,8 +152,7 @@ class Engine:
             pos = self._dev(pos, torch.int32)
             xr = torch.empty((B, self.d), dtype=torch.float32, device=self.device)
         ru = torch.empty(B, dtype=torch.float32, device=self.device) if want_r_u else None
-        self._check(self.lib.irs_decode(self.h, _ptr(seqs), _ptr(users), B, _ptr(x), _ptr(pos), _ptr(xr), _ptr(ru),
-                                        self._stream()))
+        self._call(self.lib.irs_decode, _ptr(seqs), _ptr(users), B, _ptr(x), _ptr(pos), _ptr(xr), _ptr(ru))
         return x, xr, ru
 
     # ------------------------------------------------------------------ scoring
@@ -150,8 +163,7 @@ class Engine:
         val = torch.empty((M, k), dtype=torch.float32, device=self.device)
         ids = torch.empty((M, k), dtype=torch.int64, device=self.device)
         st = torch.empty(M, dtype=torch.int32, device=self.device)
-        self._check(self.lib.irs_score_topk(self.h, _ptr(xrows), M, k, sweep, _ptr(val), _ptr(ids), _ptr(st),
-                                            self._stream()))
+        self._call(self.lib.irs_score_topk, _ptr(xrows), M, k, sweep, _ptr(val), _ptr(ids), _ptr(st))
         return val, ids, st
 
     def score_gather(self, xrows: torch.Tensor, ids0: torch.Tensor) -> torch.Tensor:
@@ -159,7 +171,7 @@ class Engine:
         ids0 = self._dev(ids0, torch.int64)
         M, g = ids0.shape
         out = torch.empty((M, g), dtype=torch.float32, device=self.device)
-        self._check(self.lib.irs_score_gather(self.h, _ptr(xrows), M, _ptr(ids0), g, _ptr(out), self._stream()))
+        self._call(self.lib.irs_score_gather, _ptr(xrows), M, _ptr(ids0), g, _ptr(out))
         return out
 
     def score_count_before(self, xrows, ref_score, ref_id0, excl_ids0: Optional[torch.Tensor]) -> torch.Tensor:
@@ -172,8 +184,8 @@ class Engine:
             excl_ids0 = self._dev(excl_ids0, torch.int64)
             n_ex = excl_ids0.shape[1]
         out = torch.empty(M, dtype=torch.int64, device=self.device)
-        self._check(self.lib.irs_score_count_before(self.h, _ptr(xrows), M, _ptr(ref_score), _ptr(ref_id0),
-                                                    _ptr(excl_ids0) if n_ex else None, n_ex, _ptr(out), self._stream()))
+        self._call(self.lib.irs_score_count_before, _ptr(xrows), M, _ptr(ref_score), _ptr(ref_id0),
+                                                    _ptr(excl_ids0) if n_ex else None, n_ex, _ptr(out))
         return out
 
     def score_dense(self, xrows: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -181,7 +193,7 @@ class Engine:
         M = xrows.shape[0]
         if out is None:
             out = torch.empty((M, self.n_local), dtype=torch.float32, device=self.device)
-        self._check(self.lib.irs_score_dense(self.h, _ptr(xrows), M, _ptr(out), out.stride(0), self._stream()))
+        self._call(self.lib.irs_score_dense, _ptr(xrows), M, _ptr(out), out.stride(0))
         return out
 
     def score_lse(self, xrows: torch.Tensor):
@@ -189,7 +201,7 @@ class Engine:
         M = xrows.shape[0]
         mx = torch.empty(M, dtype=torch.float32, device=self.device)
         sm = torch.empty(M, dtype=torch.float32, device=self.device)
-        self._check(self.lib.irs_score_lse(self.h, _ptr(xrows), M, _ptr(mx), _ptr(sm), self._stream()))
+        self._call(self.lib.irs_score_lse, _ptr(xrows), M, _ptr(mx), _ptr(sm))
         return mx, sm
 
     def merge_topk(self, val_in: torch.Tensor, ids_in: torch.Tensor):
@@ -199,8 +211,7 @@ class Engine:
         W, M, k = val_in.shape
         val = torch.empty((M, k), dtype=torch.float32, device=self.device)
         ids = torch.empty((M, k), dtype=torch.int64, device=self.device)
-        self._check(self.lib.irs_merge_topk(self.h, _ptr(val_in), _ptr(ids_in), W, M, k, _ptr(val), _ptr(ids),
-                                            self._stream()))
+        self._call(self.lib.irs_merge_topk, _ptr(val_in), _ptr(ids_in), W, M, k, _ptr(val), _ptr(ids))
         return val, ids
 
     # ------------------------------------------------------------------ evaluation batch (device-side loader)
@@ -222,18 +233,23 @@ class Engine:
         raw = torch.empty((B, raw_len), dtype=torch.int64, device=self.device)
         raw_n = torch.empty(B, dtype=torch.int32, device=self.device)
         status = torch.zeros(B, dtype=torch.int32, device=self.device)
-        self._check(self.lib.irs_build_eval_batch(self.h, _ptr(items), _ptr(offsets), B, raw_len, gap_len, _ptr(targets),
+        self._call(self.lib.irs_build_eval_batch, _ptr(items), _ptr(offsets), B, raw_len, gap_len, _ptr(targets),
                                                   _ptr(pool), 0 if pool is None else pool.shape[0], seed & (2 ** 64 - 1),
-                                                  _ptr(seq), _ptr(tgt), _ptr(lab), _ptr(raw), _ptr(raw_n), _ptr(status),
-                                                  self._stream()))
+                                                  _ptr(seq), _ptr(tgt), _ptr(lab), _ptr(raw), _ptr(raw_n), _ptr(status))
         return seq, tgt, lab, raw, raw_n, status
 
     # ------------------------------------------------------------------ path search
     def path_step(self, seqs, hep, val, ids0, step: int, paths, status, sample=False, sample_k=3, seed=0):
+        seqs = self._inplace(seqs, torch.int64, "path_step: seqs")
+        hep = self._inplace(hep, torch.int32, "path_step: hep")
+        paths = self._inplace(paths, torch.float32, "path_step: paths")
+        status = self._inplace(status, torch.int32, "path_step: status")
+        val, ids0 = self._dev(val, torch.float32), self._dev(ids0, torch.int64)
         B = seqs.shape[0]
-        self._check(self.lib.irs_path_step(self.h, _ptr(seqs), _ptr(hep), B, _ptr(val), _ptr(ids0), val.shape[1], step,
-                                           _ptr(paths), paths.shape[1], int(sample), sample_k, seed, _ptr(status),
-                                           self._stream()))
+        if seqs.shape[1] != self.L or hep.shape[0] != B or val.shape != ids0.shape or val.shape[0] != B:
+            raise IrsError("path_step: inconsistent shapes")
+        self._call(self.lib.irs_path_step, _ptr(seqs), _ptr(hep), B, _ptr(val), _ptr(ids0), val.shape[1], step,
+                                           _ptr(paths), paths.shape[1], int(sample), sample_k, seed, _ptr(status))
 
     def generate_paths(self, seqs: torch.Tensor, users: Optional[torch.Tensor], hep: torch.Tensor, max_path_len: int,
                        k: int = 100, sweep: int = IRS_SWEEP_BF16, sample=False, sample_k=3, seed=0,
@@ -241,27 +257,41 @@ class Engine:
                        status: Optional[torch.Tensor] = None):
         """Runs the whole search loop on the device.  `seqs` and `hep` are the
         working window state and are modified in place."""
+        seqs = self._inplace(seqs, torch.int64, "generate_paths: seqs")
+        hep = self._inplace(hep, torch.int32, "generate_paths: hep")
+        if users is not None:
+            users = self._dev(users, torch.int64)
         B = seqs.shape[0]
+        if seqs.shape[1] != self.L or hep.shape[0] != B or (users is not None and users.shape[0] != B):
+            raise IrsError("generate_paths: inconsistent shapes")
         if paths is None:
             paths = torch.zeros((B, max_path_len), dtype=torch.float32, device=self.device)
         if status is None:
             status = torch.zeros(B, dtype=torch.int32, device=self.device)
-        self._check(self.lib.irs_generate_paths(self.h, _ptr(seqs), _ptr(users), _ptr(hep), B, max_path_len, k, sweep,
-                                                int(sample), sample_k, seed, int(use_graph), _ptr(paths), _ptr(status),
-                                                self._stream()))
+        paths = self._inplace(paths, torch.float32, "generate_paths: paths")
+        status = self._inplace(status, torch.int32, "generate_paths: status")
+        if paths.shape != (B, max_path_len):
+            raise IrsError("generate_paths: paths must be [B, max_path_len]")
+        self._call(self.lib.irs_generate_paths, _ptr(seqs), _ptr(users), _ptr(hep), B, max_path_len, k, sweep,
+                                                int(sample), sample_k, seed, int(use_graph), _ptr(paths), _ptr(status))
         return paths, status
 
     # ------------------------------------------------------------------ beam search (build-defined extension)
     def beam_step(self, state_in, val, ids0, lse, step: int, state_out, status):
         """One beam step; state = (seq[B,W,L] i64, hep[B,W] i32, cum[B,W] f64, paths[B,W,P] f32)."""
-        seq_i, hep_i, cum_i, paths_i = state_in
-        seq_o, hep_o, cum_o, paths_o = state_out
+        kinds = (torch.int64, torch.int32, torch.float64, torch.float32)
+        seq_i, hep_i, cum_i, paths_i = (self._inplace(t, k, "beam_step: state_in") for t, k in zip(state_in, kinds))
+        seq_o, hep_o, cum_o, paths_o = (self._inplace(t, k, "beam_step: state_out") for t, k in zip(state_out, kinds))
+        status = self._inplace(status, torch.int32, "beam_step: status")
+        val, ids0 = self._dev(val, torch.float32), self._dev(ids0, torch.int64)
         B, W, _ = seq_i.shape
         lmax, lsum = lse if lse is not None else (None, None)
-        self._check(self.lib.irs_beam_step(self.h, _ptr(seq_i), _ptr(hep_i), _ptr(cum_i), _ptr(paths_i), _ptr(val),
+        if lmax is not None:
+            lmax, lsum = self._dev(lmax, torch.float32), self._dev(lsum, torch.float32)
+        self._call(self.lib.irs_beam_step, _ptr(seq_i), _ptr(hep_i), _ptr(cum_i), _ptr(paths_i), _ptr(val),
                                            _ptr(ids0), _ptr(lmax), _ptr(lsum), B, W, val.shape[1], step,
                                            paths_i.shape[2], _ptr(seq_o), _ptr(hep_o), _ptr(cum_o), _ptr(paths_o),
-                                           _ptr(status), self._stream()))
+                                           _ptr(status))
 
     def beam_search(self, seqs: torch.Tensor, users: Optional[torch.Tensor], hep: torch.Tensor, max_path_len: int,
                     beam: int, k: int = 100, sweep: int = IRS_SWEEP_BF16, use_graph: bool = False,
@@ -269,22 +299,25 @@ class Engine:
         """(paths[B,W,P] f32, scores[B,W] f64, status[B] i32[, windows[B,W,L]]); beam 0 is the best."""
         seqs = self._dev(seqs, torch.int64)
         hep = self._dev(hep, torch.int32)
+        if users is not None:
+            users = self._dev(users, torch.int64)
         B = seqs.shape[0]
         paths = torch.zeros((B, beam, max_path_len), dtype=torch.float32, device=self.device)
         scores = torch.zeros((B, beam), dtype=torch.float64, device=self.device)
         status = torch.zeros(B, dtype=torch.int32, device=self.device)
         fin = torch.empty((B, beam, self.L), dtype=torch.int64, device=self.device) if want_windows else None
-        self._check(self.lib.irs_beam_search(self.h, _ptr(seqs), _ptr(users), _ptr(hep), B, beam, max_path_len, k, sweep,
-                                             int(use_graph), _ptr(paths), _ptr(scores), _ptr(fin), _ptr(status),
-                                             self._stream()))
+        self._call(self.lib.irs_beam_search, _ptr(seqs), _ptr(users), _ptr(hep), B, beam, max_path_len, k, sweep,
+                                             int(use_graph), _ptr(paths), _ptr(scores), _ptr(fin), _ptr(status))
         return (paths, scores, status, fin) if want_windows else (paths, scores, status)
 
     # ------------------------------------------------------------------ measurement
     def prof_enable(self, family: int):
-        self._check(self.lib.irs_prof_enable(self.h, family))
+        with torch.cuda.device(self.device):
+            self._check(self.lib.irs_prof_enable(self.h, family))
 
     def prof_read(self):
         n = ctypes.c_int32()
         ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-        self._check(self.lib.irs_prof_read(self.h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
+        with torch.cuda.device(self.device):
+            self._check(self.lib.irs_prof_read(self.h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
         return n.value, ms.value, fl.value, by.value

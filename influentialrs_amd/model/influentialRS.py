@@ -171,9 +171,6 @@ class IRSNN(nn.Module):
         self.optimizer.step()
         return loss.item()
 
-    def _delete_item_in_history(self, tensor, indices):
-        return tensor[~tensor.unsqueeze(1).eq(indices).any(1)]
-
     # ---- inference hot path
     def get_pif_in_batch(self, seqs, users):
         """r_u [B, 1] float32 (reference :325-338; the reference runs the whole
@@ -273,7 +270,9 @@ class IRSNN(nn.Module):
         B, L = seqs.shape
         dev = seqs.device
         hip = self.net._hip
-        work = seqs.clone()
+        if sample and sample_k > 8:
+            raise ValueError("sample_k > 8 is not supported by the HIP path step (include/irs_hip.h)")
+        work = seqs.to(torch.int64).clone(memory_format=torch.contiguous_format)  # the search updates it in place
         hep = torch.full((B,), L - (gap_len + 1) - 1, dtype=torch.int32, device=dev)
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if sample else 0
         if beam_width > 1:

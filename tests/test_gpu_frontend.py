@@ -43,7 +43,31 @@ def test_irsnn_handlers_match_reference(golden, name, cfgname):
         hit, rr = irn.get_accuracy_metrics_in_batch(raw, seq, u, t, l, 20, 0, True)
         assert hit == int(g["hit_count"]) and hit > 0  # the Hit@k branch (:383-385) with real hits
         ref_rr = g["rr"][g["rr"] > 0]
-        assert rr.shape == ref_rr.shape and np.array_equal(rr, ref_rr)  # ranks are integers: exact
+        assert rr.shape == ref_rr.shape
+        if not np.array_equal(rr, ref_rr):
+            # Ranks are integers, and identical on the ml-1m-sized catalogs.  Deep in a 1M-item ranking adjacent
+            # scores are ~1e-6 apart, closer than the float32 reordering noise between torch's GEMM and the fixed
+            # chain, so the reference's own rank is only defined up to the items within TAU of the label's score:
+            # bracket it with two exact counts of the HIP path (scores > s + TAU, scores >= s - TAU).
+            TAU = 2e-5
+            assert cfg.n_item > 100_000, (rr, ref_rr)
+            kept = [i for i in range(B) if int(g["labels"][i]) not in set(g["raw"][i, :g["raw_len"][i]].tolist())]
+            assert len(kept) == len(ref_rr)
+            hip = net._hip
+            pos = torch.full((B,), cfg.max_len - 2, dtype=torch.int32, device=DEV)
+            xr = net.decode_rows(seq.clone(), u, pos)
+            lab0 = (l - 1).view(B)
+            sc = hip.gather(xr, lab0.view(B, 1))[:, 0].contiguous()
+            excl = torch.from_numpy(np.where(g["raw"] > 0, g["raw"] - 1, -1)).to(DEV)
+            far = torch.full_like(lab0, -1)  # no id tie-break: pure score thresholds
+            lo = hip.count_before(xr, sc + TAU, far, excl).cpu().numpy() + 1
+            hi = hip.count_before(xr, sc - TAU, torch.full_like(lab0, cfg.n_item + 1), excl).cpu().numpy() + 1
+            for j, i in enumerate(kept):
+                ref_rank = int(round(1.0 / ref_rr[j]))
+                assert lo[i] <= ref_rank <= hi[i], (i, lo[i], ref_rank, hi[i])
+                assert lo[i] <= int(round(1.0 / rr[j])) <= hi[i]
+                if hi[i] - lo[i] == 0:
+                    assert rr[j] == ref_rr[j]
         P = int(g["meta"][2])
         paths, tt, hh, early = irn.get_seq_in_batch(seq, u, t, P, 0, False, 3)
         assert paths.dtype == np.float32 and paths.shape == (B, P)

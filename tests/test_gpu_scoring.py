@@ -207,3 +207,50 @@ def test_sharded_merge_equals_unsharded(oracle, world):
         ov, oi = oracle.topk(s, k)
         assert np.array_equal(mi[m], oi)
         assert np.array_equal(mv[m].view(np.uint32), ov.view(np.uint32))
+
+
+def test_bf16_filter_survives_worst_case_rounding(oracle):
+    """Adversarial inputs for the bf16 filter's error bound (DESIGN.md "Why the bf16 filter is exact"): every entry
+    of x and of the 'hot' item rows sits exactly on a bf16 rounding midpoint, with the signs of the rounding errors
+    aligned -- coordinates 0..63 of x round DOWN, 64..127 round UP; 'down' items live on the first half (their
+    weights round down too), 'up' items on the second half (weights round up).  The bf16 scores of the up items are
+    then 2^-7 relative ABOVE their exact scores and those of the down items 2^-7 BELOW, the full 2u of the worst
+    case.  Biases make the down items the TRUE top-k by a small margin while every one of them scores below every up
+    item in bf16 -- by more than the (half-width) bound the first version used, which silently returned up items.
+    The up items sit in even tiles (the tiles the sampled pre-pass sees), so the emission threshold is set by them."""
+    n_item, d, M, k = 70_001, 128, 3, 100
+    g = np.random.default_rng(21)
+    W = ((g.random((n_item, d), dtype=np.float32) * 2 - 1) * 0.05).astype(np.float32)
+    b = (g.standard_normal(n_item) * 0.1).astype(np.float32)
+    lo, hi = np.float32(1 + 2.0 ** -8), np.float32(1 + 3 * 2.0 ** -8)  # midpoints: RNE -> 1.0 (down), 1 + 2^-6 (up)
+    assert oracle.bf16_round(np.array([lo, hi]))[0] == 1.0 and oracle.bf16_round(np.array([lo, hi]))[1] == np.float32(1 + 2.0 ** -6)
+    x = np.zeros((M, d), dtype=np.float32)
+    x[:, :64], x[:, 64:] = lo, hi
+    tiles = g.permutation(n_item // 32 - 1)
+    up_tiles = [t for t in tiles if t % 2 == 0][:300]
+    dn_tiles = [t for t in tiles if t % 2 == 1][:300]
+    up = np.array([t * 32 + int(g.integers(0, 32)) for t in up_tiles])
+    dn = np.array([t * 32 + int(g.integers(0, 32)) for t in dn_tiles])
+    W[up] = 0
+    W[up, 64:] = hi
+    W[dn] = 0
+    W[dn, :64] = lo
+    base_up, base_dn = 64.0 * float(hi) * float(hi), 64.0 * float(lo) * float(lo)
+    b[up] = 0.0
+    b[dn] = np.float32(base_up - base_dn + 0.13) + (np.arange(300) * 1e-4).astype(np.float32)
+    eng = scoring_only_engine(n_item, d, W, b, max_rows=M)
+    xt = torch.from_numpy(x).cuda()
+    val, ids, st = eng.score_topk(xt, k, IRS_SWEEP_BF16)
+    ev, ei, _ = eng.score_topk(xt, k, IRS_SWEEP_EXHAUSTIVE)
+    torch.cuda.synchronize()
+    val, ids, st = val.cpu().numpy(), ids.cpu().numpy(), st.cpu().numpy()
+    s = oracle.score_chain(x[0], W, b)
+    ov, oi = oracle.topk(s, k)
+    assert set(oi.tolist()) <= set(dn.tolist()), "construction: the true top-k are 'down' items"
+    a_up = 64.0 * (1 + 2.0 ** -6) ** 2
+    a_dn_max = 64.0 + float(b[dn].max())
+    assert a_dn_max < a_up - 0.8, "construction: in bf16 every down item scores well below every up item"
+    for m in range(M):
+        assert np.array_equal(ids[m], oi) and np.array_equal(val[m].view(np.uint32), ov.view(np.uint32)), f"row {m}"
+        assert np.array_equal(ei[m].cpu().numpy(), oi)
+    assert (st & 1).sum() == 0, "handled by the filter itself, not by the exhaustive fallback"
