@@ -99,6 +99,8 @@ struct irs_ctx {
     void *graph_seq, *graph_user, *graph_hep, *graph_paths, *graph_status;
     uint64_t graph_seed;
 
+    int sweep_variant; // 0 = production kernels; 1 = the previous compute-bound bf16 sweep (development A/B only)
+
     // profiling
     int prof_family;
     irs_prof_ev *prof_ev;

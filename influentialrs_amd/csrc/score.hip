@@ -50,6 +50,8 @@ struct SweepArgs {
     // tile range and decomposition
     int tile_begin, tile_end, tiles_per_wave, n_strips, n_ublocks;
     int tile_stride; // PRE samples tiles tile_begin + i * tile_stride
+    int no_stagger;   // ring kernel, development switch: all waves take the step barrier at the same k-step
+    int tiles_per_wg; // ring kernel, EMIT: tiles per workgroup strip (0: 4 * tiles_per_wave, the PRE group structure)
     // outputs
     float *gm;                   // PRE  [n_groups][M_pad]
     const float *thr;            // EMIT [M_pad]
@@ -64,13 +66,17 @@ struct SweepArgs {
     float *lse_part;             // LSE [slots][M_pad][2]
 };
 
+// IEEE-754-2019 maximum (llvm.maximum -> v_maximum3_f32 on gfx950): unlike fmaxf / maxnum it needs no canonicalising
+// self-maxima in front (hipcc adds 6 of them per 16-way maximum in IEEE mode), and unlike inline asm it keeps the
+// compiler's MFMA -> VALU hazard handling (an asm v_max3_f32 on fresh MFMA results read stale registers).  A NaN
+// score propagates, compares false against every threshold and is never emitted.
+__device__ __forceinline__ float vmax2(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { return vmax2(vmax2(a, b), c); }
+// maximum of registers 4i .. 4i+3 (the four consecutive items 8i + 4h .. 8i + 4h + 3 of a lane)
+__device__ __forceinline__ float quad_max(const f32x16 &a, int i) { return vmax2(vmax3(a[4 * i], a[4 * i + 1], a[4 * i + 2]), a[4 * i + 3]); }
 __device__ __forceinline__ float max16(const f32x16 &a) {
-    float m0 = fmaxf(fmaxf(a[0], a[1]), a[2]);
-    float m1 = fmaxf(fmaxf(a[3], a[4]), a[5]);
-    float m2 = fmaxf(fmaxf(a[6], a[7]), a[8]);
-    float m3 = fmaxf(fmaxf(a[9], a[10]), a[11]);
-    float m4 = fmaxf(fmaxf(a[12], a[13]), a[14]);
-    return fmaxf(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)), fmaxf(m4, a[15]));
+    return vmax2(vmax3(vmax3(a[0], a[1], a[2]), vmax3(a[3], a[4], a[5]), vmax3(a[6], a[7], a[8])),
+                 vmax3(vmax3(a[9], a[10], a[11]), vmax3(a[12], a[13], a[14]), a[15]));
 }
 
 // workgroup -> (strip, ublock): the n_ublocks workgroups that stream the same
@@ -85,18 +91,25 @@ __device__ __forceinline__ bool sweep_map(const SweepArgs &a, int &strip, int &u
 
 // ---- epilogues (lane = scored row `user`, regs = 16 items of tile `t`, half h)
 // In-kernel timing (s_memtime) of the first version showed the emission epilogue at ~680 cycles per 32x32 tile
-// against ~260 cycles of MFMA: every hit paid a returning LDS atomic inside a divergent branch.  Now
+// against ~260 cycles of MFMA: every hit paid a returning LDS atomic inside a divergent branch.  The second version
+// (ballot-compacted wave-private queue) still cost ~560 cycles per tile with a hit (a third of all tiles at ~450
+// emitted items per row): its queue fill count lived in a VGPR, so each of the 16 per-register segments carried a
+// vector compare, an exec save and two branches for the overflow test, and every hit built its order key in place.
+// Now
 //   * a tile whose 16-register maximum is below the threshold in every lane is skipped after one v_max3 tree
-//     and one ballot (with ~300 emitted items per row that is ~3 tiles in 4),
-//   * otherwise one v_cmp per accumulator register yields the wave's hit mask in SGPRs and only non-empty
-//     masks enter the handler, which compacts the hits with mbcnt into a wave-private LDS queue whose fill
-//     count lives in a scalar register (nobody else touches the queue: no atomics),
+//     (no canonicalising self-maxima) and one ballot (~2 tiles in 3),
+//   * otherwise the four quad maxima the tree produced on the way are tested first (4 ballots); only the
+//     registers of a quad with a hit are compared one by one (a tile with one hit: 8 ballots, not 16),
+//   * the queue fill count is a SCALAR (readfirstlane after every update), room for the whole tile is checked
+//     once (16 entries per lane with a hit) and a hit costs two mbcnt, one address shift and three LDS stores of
+//     registers that already exist (score bits, item, row) -- the order key is formed at flush time,
 //   * a full queue is flushed with all its global atomics in flight together.
 #define EMIT_Q 128
 struct EmitQ {
-    unsigned long long *keys; // [EMIT_Q]
-    unsigned int *users;      // [EMIT_Q]
-    unsigned int n;           // entries queued (wave-uniform)
+    float *score;        // [EMIT_Q] approximate scores (raw float bits)
+    unsigned int *item;  // [EMIT_Q] local item ids
+    unsigned int *users; // [EMIT_Q] scored rows
+    int n;               // entries queued (wave-uniform, kept in an SGPR)
 };
 
 // candidate lists are bucketed by item tile (bucket = tile mod 64): 64 counters per row keep the
@@ -110,43 +123,62 @@ __device__ __forceinline__ void emit_append_global(const SweepArgs &a, unsigned 
 
 __device__ __forceinline__ void emit_flush(const SweepArgs &a, EmitQ &q, int lane) {
     __builtin_amdgcn_wave_barrier();
-    for (unsigned int i = lane; i < q.n; i += 64) emit_append_global(a, q.users[i], q.keys[i]);
+    for (int i = lane; i < q.n; i += 64)
+        emit_append_global(a, q.users[i], ((unsigned long long)irs_fkey(q.score[i]) << 32) | q.item[i]);
     __builtin_amdgcn_wave_barrier();
     q.n = 0;
 }
 
+__device__ __forceinline__ void emit_one(EmitQ &q, float v, float thr, unsigned int item, unsigned int user) {
+    const unsigned long long mask = __ballot(v >= thr);
+    if (mask) { // wave-uniform
+        if (v >= thr) {
+            const unsigned int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, (unsigned int)q.n));
+            q.score[pos] = v;
+            q.item[pos] = item;
+            q.users[pos] = user;
+        }
+        q.n = __builtin_amdgcn_readfirstlane(q.n + (int)__popcll(mask));
+    }
+}
+
 __device__ __forceinline__ void emit_candidates(const SweepArgs &a, const f32x16 &acc, float thr, int user, int t, int h,
                                                 EmitQ &q, int lane) {
-    if (!__any(max16(acc) >= thr)) return;
-    // all sixteen compares first (each leaves the wave's hit mask in an SGPR pair), then scalar tests of the masks: a
-    // v_cmp followed at once by a branch on its result waits out the VALU -> SALU latency sixteen times
-    unsigned long long masks[16];
+    q.n = __builtin_amdgcn_readfirstlane(q.n);
+    float qm[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) masks[r] = __ballot(acc[r] >= thr);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < 4; ++i) qm[i] = quad_max(acc, i);
+    const float m = vmax2(vmax3(qm[0], qm[1], qm[2]), qm[3]);
+    const unsigned long long lanes = __ballot(m >= thr);
+    if (!lanes) return;
+    const int need = 16 * (int)__popcll(lanes); // upper bound of this tile's hits
+    const unsigned int item0 = (unsigned int)(t * 32 + 4 * h);
+    if (q.n + need > EMIT_Q) {
+        emit_flush(a, q, lane);
+        if (need > EMIT_Q) { // more than 8 lanes with a hit (dense ties): room is checked register by register
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const bool hit = acc[r] >= thr;
-        const unsigned long long mask = masks[r];
-        if (mask) { // wave-uniform
-            const unsigned int n = (unsigned int)__popcll(mask);
-            if (q.n + n > EMIT_Q) emit_flush(a, q, lane);
-            if (hit) {
-                const unsigned int item = (unsigned int)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
-                const unsigned int pos = q.n + __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
-                q.keys[pos] = ((unsigned long long)irs_fkey(acc[r]) << 32) | item;
-                q.users[pos] = (unsigned int)user;
+            for (int r = 0; r < 16; ++r) {
+                if (q.n + 64 > EMIT_Q) emit_flush(a, q, lane);
+                emit_one(q, acc[r], thr, item0 + (r & 3) + 8 * (r >> 2), (unsigned int)user);
             }
-            q.n += n;
+            return;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (__ballot(qm[i] >= thr)) { // wave-uniform
+#pragma unroll
+            for (int e = 0; e < 4; ++e) emit_one(q, acc[4 * i + e], thr, item0 + e + 8 * i, (unsigned int)user);
         }
     }
 }
 
 __device__ __forceinline__ EmitQ emit_queue(char *base, int wave) {
-    // per wave: 128 x 8 B keys, 128 x 4 B users, 16 B counter
+    // per wave: 128 x (4 B score, 4 B item, 4 B row), 16 B pad
     char *p = base + wave * (EMIT_Q * 12 + 16);
     EmitQ q;
-    q.keys = reinterpret_cast<unsigned long long *>(p);
+    q.score = reinterpret_cast<float *>(p);
+    q.item = reinterpret_cast<unsigned int *>(p + EMIT_Q * 4);
     q.users = reinterpret_cast<unsigned int *>(p + EMIT_Q * 8);
     q.n = 0;
     return q;
@@ -160,7 +192,8 @@ __global__ void __launch_bounds__(256, 2) k_sweep_bf16(SweepArgs a) {
     uint4 *xs = reinterpret_cast<uint4 *>(smem); // [UB][KS][64]
     int strip, ublock;
     if (!sweep_map(a, strip, ublock)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // uniform for the compiler too: the emission queue's fill count stays scalar
     const int r = lane & 31, h = lane >> 5;
     const int ut0 = ublock * UB;
     const int ubc = min(UB, a.UT - ut0);
@@ -269,7 +302,8 @@ __global__ void __launch_bounds__(256, 2) k_sweep_bf16_rs(SweepArgs a) {
     float *bs = reinterpret_cast<float *>(smem + (size_t)2 * STAGE_U4 * 16);      // [2][ST][32] bias
     int strip, ublock;
     if (!sweep_map(a, strip, ublock)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // uniform for the compiler too: the emission queue's fill count stays scalar
     const int r = lane & 31, h = lane >> 5;
     const int ut0 = ublock * 4 * RT + wave * RT; // this wave's first row tile
     EmitQ eq = emit_queue(smem + (size_t)2 * STAGE_U4 * 16 + 2 * ST * 32 * 4, wave);
@@ -395,6 +429,345 @@ __global__ void __launch_bounds__(256, 2) k_sweep_bf16_rs(SweepArgs a) {
     if (MODE == MODE_EMIT) emit_flush(a, eq, lane);
 }
 
+// =============================== bf16 sweep, LDS-DMA ring (compute-bound form) ===============================
+// What bounded k_sweep_bf16_rs (lab: tools/sweep_lab.hip, 1M x 128, 1024 rows): a bare MFMA stream with every
+// operand in registers takes 170-190 us on this chip (it holds ~1.5 GHz under dense bf16 MFMA work: ~60 % of the
+// 2.4 GHz peak is the ceiling); LDS fragment reads the compiler issues one k-step ahead add ~15 %, the 16-way maxima
+// of four accumulator sets, each followed at once by its own compare + branch, another ~15 %, and the emission
+// ~20 % more.  This kernel keeps the row-stationary blocking and changes everything around the MFMAs:
+//   * W tiles stream HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write pass) into a ring
+//     of NSLOT steps; ONE raw s_barrier per step, placed in the MIDDLE of a step's MFMAs, publishes step s + 1 and
+//     frees the slot of step s - 1 for the DMA of step s + NSLOT - 1 -- no wave ever waits at it for its own operands;
+//   * the fragment reads are inline-asm ds_read_b128 with hand-counted lgkmcnt waits, issued two k-steps ahead and,
+//     for the first k-steps of the NEXT step, before the epilogue of this one.  (Compiler-visible LDS reads made
+//     hipcc put an s_waitcnt vmcnt(0) in front of the first read after every DMA issue: it cannot prove that the
+//     slot being filled is not the slot being read, so each step waited for the load it had just started.)
+//   * the epilogue is split: the quad / tile maxima and threshold ballots of ALL accumulator sets of a step form one
+//     branch-free block (their latencies overlap); only then are the sets with a hit handled;
+//   * hits go to the wave-private LDS queue of the other sweeps (ballot-compacted, scalar fill count), written
+//     with inline-asm stores.
+// Tiles, PRE groups and accumulated values are those of k_sweep_bf16 / k_sweep_bf16_rs (bit-identical output).
+typedef __attribute__((address_space(3))) void irs_lds_void;
+typedef const __attribute__((address_space(1))) void irs_glb_void;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read16(unsigned int addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+// s_waitcnt lgkmcnt(N) that the listed registers depend on (keeps their consumers behind the wait)
+template <int N>
+__device__ __forceinline__ void lds_wait(u32x4 &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+template <int N>
+__device__ __forceinline__ void lds_wait(u32x4 &a, u32x4 &b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+
+// one candidate into the wave's LDS queue; the stores are inline asm for the same reason as the reads (a
+// compiler-visible LDS store behind an LDS-DMA issue gets an s_waitcnt vmcnt(0) in front)
+__device__ __forceinline__ void ring_emit_one(EmitQ &q, unsigned int q_addr, float v, float thr, unsigned int item, unsigned int row) {
+    const unsigned long long mask = __ballot(v >= thr);
+    if (mask) { // wave-uniform
+        if (v >= thr) {
+            const unsigned int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, (unsigned int)q.n));
+            const unsigned int ad = q_addr + 4u * pos;
+            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:%4\n\tds_write_b32 %0, %3 offset:%5"
+                         :: "v"(ad), "v"(v), "v"(item), "v"(row), "n"(EMIT_Q * 4), "n"(EMIT_Q * 8) : "memory");
+        }
+        q.n = __builtin_amdgcn_readfirstlane(q.n + (int)__popcll(mask));
+    }
+}
+
+template <int KS, int RT, int TPS, int NW, int WPS, int NSLOT, int MODE, int DBG = 0>
+__global__ void __launch_bounds__(NW * 64, WPS) k_sweep_ring(SweepArgs a) {
+    static_assert(MODE == MODE_PRE || MODE == MODE_EMIT, "top-k modes only");
+    constexpr int SLOT_B = TPS * KS * 1024;  // fragment bytes per ring slot
+    constexpr int NP = TPS * KS + TPS;       // DMA pieces per step: KiB fragment pieces + one 256-B bias piece per tile
+    constexpr int PPW = (NP + NW - 1) / NW;  // pieces per wave (the tail repeats the last piece)
+    constexpr int D = NSLOT - 1;             // steps resident beyond the one being multiplied
+    static_assert(NSLOT >= 3, "the ring advances in the middle of a step: at least three slots");
+    constexpr int KSYNC = KS >= 2 ? KS / 2 : 0; // k-step in front of which the ring advances
+    constexpr int PD = KS >= 3 ? ((KS * TPS >= 32 || (DBG & 2)) ? 1 : 2) : KS - 1; // fragment prefetch distance in k-steps (registers at d_pad = 256)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int strip, ublock;
+    if (!sweep_map(a, strip, ublock)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int ut0 = ublock * NW * RT + wave * RT; // this wave's first row tile
+    const int ts = a.tile_stride, tpw = a.tiles_per_wave;
+    int ntile = a.tiles_per_wg ? a.tiles_per_wg : 4 * tpw; // tiles of this workgroup: t(i) = tfirst + i * ts, while < tile_end
+    const int tfirst = a.tile_begin + strip * ntile * ts;
+    {
+        const int avail = (a.tile_end - tfirst + ts - 1) / ts;
+        if (avail < ntile) ntile = avail;
+    }
+    if (ntile <= 0) return;
+    const int nstep = (ntile + TPS - 1) / TPS;
+    const unsigned int lds0 = (unsigned int)(size_t)(__attribute__((address_space(3))) char *)smem;
+    const unsigned int frag_addr = lds0 + lane * 16;                           // + slot * SLOT_B + (ti * KS + ks) * 1024
+    const unsigned int bias_addr = lds0 + NSLOT * SLOT_B + h * 16;             // + (slot * TPS + ti) * 256 + 32 q
+    // this wave's rows: fragments in registers for the whole kernel (ordinary loads, complete before the first DMA)
+    uint4 xr[RT][KS];
+    float aux[RT];
+#pragma unroll
+    for (int u = 0; u < RT; ++u) {
+        const bool live = ut0 + u < a.UT;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            xr[u][ks] = live ? a.xb[((size_t)(ut0 + u) * KS + ks) * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
+        if (MODE == MODE_PRE) aux[u] = -INFINITY;
+        else aux[u] = live ? fmaxf(a.thr[(ut0 + u) * 32 + r], -3.0e38f) : INFINITY;
+    }
+    // a waitcnt the compiler's own counter model sees (vmcnt(0), other counters untouched): with an inline-asm wait it
+    // keeps the row loads above on its scoreboard and puts a vmcnt(0) -- draining the ring -- in front of their first
+    // use in EVERY iteration of the step loop
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    auto issue = [&](int s) { // DMA of step s into slot s % NSLOT (tiles beyond the end repeat the last one: never consumed)
+        const int slot = s % NSLOT;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            int p = wave + j * NW;
+            if (p > NP - 1) p = NP - 1;
+            if (p < TPS * KS) {
+                const int tl = p / KS, ks = p - tl * KS;
+                const int t = tfirst + min(s * TPS + tl, ntile - 1) * ts;
+                __builtin_amdgcn_global_load_lds((irs_glb_void *)(a.wp + ((size_t)t * KS + ks) * 64 + lane),
+                                                 (irs_lds_void *)(smem + slot * SLOT_B + p * 1024), 16, 0, 0);
+            } else {
+                const int tl = p - TPS * KS;
+                const int t = tfirst + min(s * TPS + tl, ntile - 1) * ts;
+                __builtin_amdgcn_global_load_lds((irs_glb_void *)(a.bias + (size_t)t * 32 + r),
+                                                 (irs_lds_void *)(smem + NSLOT * SLOT_B + (slot * TPS + tl) * 256), 4, 0, 0);
+            }
+        }
+    };
+    EmitQ eq = emit_queue(smem + NSLOT * SLOT_B + NSLOT * TPS * 256, wave);
+    const unsigned int q_addr = lds0 + NSLOT * SLOT_B + NSLOT * TPS * 256 + wave * (EMIT_Q * 12 + 16);
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < nstep) issue(s);
+    // step 0 visible to every wave
+    if (D - 1 < nstep) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x16 bv[TPS];          // bias vectors of the step's tiles = C operand of each chain's first MFMA
+    u32x4 af[PD + 1][TPS];   // fragment ring over k-steps (slot = ks % (PD + 1))
+    auto prefetch_head = [&](int s) { // bias and the first PD k-steps of step s (already published)
+        const unsigned int fa = frag_addr + (s % NSLOT) * SLOT_B, ba = bias_addr + (s % NSLOT) * TPS * 256;
+#pragma unroll
+        for (int ti = 0; ti < TPS; ++ti) {
+            const u32x4 q0 = ti == 0 ? lds_read16<0>(ba) : lds_read16<256>(ba);
+            const u32x4 q1 = ti == 0 ? lds_read16<32>(ba) : lds_read16<256 + 32>(ba);
+            const u32x4 q2 = ti == 0 ? lds_read16<64>(ba) : lds_read16<256 + 64>(ba);
+            const u32x4 q3 = ti == 0 ? lds_read16<96>(ba) : lds_read16<256 + 96>(ba);
+            typedef __attribute__((ext_vector_type(16))) unsigned int u32x16;
+            const u32x16 w = __builtin_shufflevector(__builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7),
+                                                     __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7, 8,
+                                                     9, 10, 11, 12, 13, 14, 15);
+            bv[ti] = __builtin_bit_cast(f32x16, w); // valid once k-step 0's wait has passed
+        }
+#pragma unroll
+        for (int ks = 0; ks < PD; ++ks) {
+            af[ks][0] = ks == 0 ? lds_read16<0>(fa) : lds_read16<1024>(fa);
+            if (TPS > 1) af[ks][TPS - 1] = ks == 0 ? lds_read16<KS * 1024>(fa) : lds_read16<(KS + 1) * 1024>(fa);
+        }
+    };
+    static_assert(TPS == 1 || TPS == 2, "one or two tiles per step");
+    static_assert(PD <= 2, "prefetch_head is written for a distance of at most two k-steps");
+    // The head registers are carried around the loop (requested in the prologue / before an epilogue, consumed in the
+    // next iteration).  Registers with an LDS return still pending must not meet a compiler-made copy: it would
+    // copy stale contents (seen: the prologue's head landed in other registers than the loop's, and the first tile
+    // of every workgroup was multiplied with whatever those held).  So every head is WAITED for -- with all its
+    // registers tied to the wait -- before control leaves the straight-line code that requested it: after the
+    // prologue and at the end of an iteration, behind the epilogue that hid its latency.
+    auto head_landed = [&]() {
+#pragma unroll
+        for (int ti = 0; ti < TPS; ++ti) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[ti]));
+#pragma unroll
+        for (int ks = 0; ks < PD; ++ks)
+#pragma unroll
+            for (int ti = 0; ti < TPS; ++ti) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[ks][ti]));
+    };
+    prefetch_head(0);
+    head_landed();
+    int gcount = 0, gw = strip * 4; // PRE: tiles seen in the current group; group (= wave id of k_sweep_bf16)
+    // Eight waves = two per SIMD running the same program between the same barriers would march in lockstep (MFMA
+    // phases together, epilogues together).  The second half of the workgroup takes the step's barrier in front
+    // of k-step 0 instead of k-step KSYNC: it then runs half a step behind the first half for the whole kernel,
+    // so a SIMD's two waves alternate between matrix work and epilogue.
+    const bool late = NW == 8 && wave >= NW / 2 && !a.no_stagger;
+    for (int s = 0; s < nstep; ++s) {
+        const unsigned int fa = frag_addr + (s % NSLOT) * SLOT_B;
+        f32x16 acc[TPS][RT];
+        // ---- MFMAs of step s; LDS reads run PD k-steps ahead; the ring advances in front of k-step KSYNC
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (KS > 1 && s + 1 < nstep && (late ? ks == 0 : ks == KSYNC)) {
+                // this wave's pieces of step s + 1 have landed: steps s + 1 .. s + D - 1 are in flight in a full
+                // pipeline (step s + D is issued behind the barrier), so all but the (D - 2) * PPW youngest DMAs
+                if (s + D <= nstep) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * PPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier(); // step s + 1 is visible to all; every wave has left step s - 1
+                if (s + D < nstep) issue(s + D); // into the slot of step s - 1
+            }
+            if (DBG & 4) {
+                asm volatile("s_nop 15");
+                asm volatile("s_nop 15");
+                asm volatile("s_nop 15");
+                asm volatile("s_nop 15");
+            }
+            if (ks + PD < KS) {
+                switch (ks + PD) { // compile-time after unrolling
+#define IRS_RD_(K_)                                                                                        \
+    case K_:                                                                                               \
+        af[K_ % (PD + 1)][0] = lds_read16<(K_)*1024>(fa);                                                  \
+        if (TPS > 1) af[K_ % (PD + 1)][TPS - 1] = lds_read16<(KS + (K_)) * 1024>(fa);                      \
+        break;
+                    IRS_RD_(0) IRS_RD_(1) IRS_RD_(2) IRS_RD_(3) IRS_RD_(4) IRS_RD_(5) IRS_RD_(6) IRS_RD_(7) IRS_RD_(8) IRS_RD_(9)
+                    IRS_RD_(10) IRS_RD_(11) IRS_RD_(12) IRS_RD_(13) IRS_RD_(14) IRS_RD_(15)
+#undef IRS_RD_
+                default: break;
+                }
+            }
+            // k-steps < PD arrived with the head; reads younger than k-step ks's: those of the next min(PD, KS - 1 - ks) k-steps
+            if (ks >= PD) {
+                u32x4 &f0 = af[ks % (PD + 1)][0];
+                const int younger = (DBG & 1) ? 0 : (KS - 1 - ks < PD ? KS - 1 - ks : PD) * TPS;
+                if constexpr (TPS == 1) {
+                    if (younger >= 2 * TPS) lds_wait<2 * TPS>(f0);
+                    else if (younger >= TPS) lds_wait<TPS>(f0);
+                    else lds_wait<0>(f0);
+                } else {
+                    u32x4 &f1 = af[ks % (PD + 1)][TPS - 1];
+                    if (younger >= 2 * TPS) lds_wait<2 * TPS>(f0, f1);
+                    else if (younger >= TPS) lds_wait<TPS>(f0, f1);
+                    else lds_wait<0>(f0, f1);
+                }
+            }
+#pragma unroll
+            for (int ti = 0; ti < TPS; ++ti) {
+                const u32x4 av = af[ks % (PD + 1)][ti];
+                if (ks == 0) {
+#pragma unroll
+                    for (int u = 0; u < RT; ++u) // the bias vector is the C operand of each chain's first MFMA
+                        acc[ti][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
+                                                                             __builtin_bit_cast(bf16x8, xr[u][0]), bv[ti], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < RT; ++u)
+                        acc[ti][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
+                                                                             __builtin_bit_cast(bf16x8, xr[u][ks]), acc[ti][u], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0); // keep the k-steps (their waits and MFMAs) in program order
+        }
+        if (KS == 1 && s + 1 < nstep) { // (no interior k-step to hang the ring advance on)
+            if (s + D <= nstep) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (s + D < nstep) issue(s + D);
+        }
+        // the head of step s + 1 is requested before this step's epilogue runs
+        if (DBG & 8) {
+            asm volatile("s_nop 15");
+            asm volatile("s_nop 15");
+            asm volatile("s_nop 15");
+            asm volatile("s_nop 15");
+        }
+        if (s + 1 < nstep) prefetch_head(s + 1);
+        // ---- epilogue of step s
+        if (MODE == MODE_PRE) {
+#pragma unroll
+            for (int ti = 0; ti < TPS; ++ti) {
+                if (s * TPS + ti < ntile) {
+#pragma unroll
+                    for (int u = 0; u < RT; ++u)
+                        if (ut0 + u < a.UT) aux[u] = vmax2(aux[u], max16(acc[ti][u]));
+                    ++gcount;
+                    if (gcount == tpw || s * TPS + ti + 1 == ntile) { // end of a group: publish, restart
+#pragma unroll
+                        for (int u = 0; u < RT; ++u) {
+                            if (ut0 + u < a.UT) a.gm[(size_t)(gw * 2 + h) * a.M_pad + (ut0 + u) * 32 + r] = aux[u];
+                            aux[u] = -INFINITY;
+                        }
+                        gcount = 0;
+                        ++gw;
+                    }
+                }
+            }
+        } else {
+            unsigned long long hit[TPS][RT];
+#pragma unroll
+            for (int ti = 0; ti < TPS; ++ti)
+#pragma unroll
+                for (int u = 0; u < RT; ++u) {
+                    const unsigned long long b = __ballot(max16(acc[ti][u]) >= aux[u]);
+                    hit[ti][u] = (s * TPS + ti < ntile && ut0 + u < a.UT) ? b : 0ull;
+                }
+#pragma unroll
+            for (int ti = 0; ti < TPS; ++ti)
+#pragma unroll
+                for (int u = 0; u < RT; ++u) {
+                    if (hit[ti][u]) { // wave-uniform, no VALU result awaited
+                        const unsigned int item0 = (unsigned int)((tfirst + (s * TPS + ti) * ts) * 32 + 4 * h);
+                        const unsigned int row = (unsigned int)((ut0 + u) * 32 + r);
+                        const float thr = aux[u];
+                        eq.n = __builtin_amdgcn_readfirstlane(eq.n);
+                        // room for the whole tile (16 entries per lane with a hit), else flush; dense ties go register by register
+                        const int need = 16 * (int)__popcll(hit[ti][u]);
+                        bool dense = false;
+                        if (eq.n + need > EMIT_Q) {
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the queue's asm stores
+                            emit_flush(a, eq, lane);
+                            dense = need > EMIT_Q;
+                        }
+                        if (dense) {
+#pragma unroll
+                            for (int rr = 0; rr < 16; ++rr) {
+                                if (eq.n + 64 > EMIT_Q) {
+                                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                                    emit_flush(a, eq, lane);
+                                }
+                                ring_emit_one(eq, q_addr, acc[ti][u][rr], thr, item0 + (rr & 3) + 8 * (rr >> 2), row);
+                            }
+                        } else {
+                            // compares in batches of four, each batch ahead of the scalar tests of its masks: a
+                            // v_cmp followed at once by a branch on its result waits out the VALU -> SALU latency
+                            unsigned long long qmask[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) qmask[i] = __ballot(quad_max(acc[ti][u], i) >= thr);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                if (qmask[i]) {
+                                    unsigned long long rmask[4];
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) rmask[e] = __ballot(acc[ti][u][4 * i + e] >= thr);
+                                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        if (rmask[e]) ring_emit_one(eq, q_addr, acc[ti][u][4 * i + e], thr, item0 + e + 8 * i, row);
+                                }
+                            }
+                        }
+                    }
+                }
+        }
+        if (s + 1 < nstep) head_landed();
+    }
+    if (MODE == MODE_PRE) { // the last strip may hold fewer than four groups: the selection reads all of them
+        for (; gw < strip * 4 + 4; ++gw)
+#pragma unroll
+            for (int u = 0; u < RT; ++u)
+                if (ut0 + u < a.UT) a.gm[(size_t)(gw * 2 + h) * a.M_pad + (ut0 + u) * 32 + r] = -INFINITY;
+    }
+    if (MODE == MODE_EMIT) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        emit_flush(a, eq, lane);
+    }
+}
+
 // =============================== fp32 sweep ===============================
 // v_mfma_f32_32x32x2_f32: lane (r, h) supplies A[r][k=h] and B[k=h][r]; one
 // instruction is fma(a_k1, b_k1, fma(a_k0, b_k0, C)), so issuing k pairs in
@@ -407,7 +780,8 @@ __global__ void __launch_bounds__(256, 2) k_sweep_f32(SweepArgs a) {
     float4 *xs4 = reinterpret_cast<float4 *>(smem); // [UB][QN][64]
     int strip, ublock;
     if (!sweep_map(a, strip, ublock)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // uniform for the compiler too: the emission queue's fill count stays scalar
     const int r = lane & 31, h = lane >> 5;
     const int ut0 = ublock * UB;
     const int ubc = min(UB, a.UT - ut0);
@@ -1270,14 +1644,73 @@ __global__ void k_lse_reduce(const float *__restrict__ part, int slots, int M_pa
 static inline int ub_bf16(int KS) { return KS >= 16 ? 4 : 8; }
 static inline int ub_f32(int KS) { return KS >= 16 ? 2 : KS >= 8 ? 4 : 8; }
 
+// tiles per wave (a workgroup of the blocked kernels walks 4 of them) for a grid of about `target_wgs` workgroups
+static void sweep_decompose(SweepArgs &a, int tile_begin, int tile_end, int n_ublocks_hint, int force_tpw, int stride = 1,
+                            int target_wgs = 2048, int max_tpw = 16);
+
+// Workgroups that can be resident at once (occupancy x CUs), per kernel instantiation.
+template <typename K>
+static int resident_workgroups(K kern, int threads, size_t lds) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256 * per_cu;
+    return prop.multiProcessorCount * per_cu;
+}
+
+template <int KS, int RT, int TPS, int NW, int MODE>
+static void launch_ring(SweepArgs &a, hipStream_t s) {
+    constexpr int NSLOT = 4; // two steps of DMA in flight behind the one being multiplied
+    a.n_ublocks = (a.UT + NW * RT - 1) / (NW * RT);
+    const size_t lds = (size_t)NSLOT * TPS * KS * 1024 + (size_t)NSLOT * TPS * 256 + (size_t)NW * (EMIT_Q * 12 + 16);
+    auto kern = k_sweep_ring<KS, RT, TPS, NW, 2, NSLOT, MODE>;
+    static int slots = 0; // per instantiation
+    if (!slots) {
+        if (lds > 65536)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        slots = resident_workgroups(kern, NW * 64, lds);
+    }
+    if (MODE == MODE_EMIT) {
+        // Equal strips, sized so that the grid is just under a whole number of rounds of resident workgroups: the
+        // time of a sweep is rounds x strip length, and a grid of 2.06 rounds costs 3 (measured: 322 vs 264 us).
+        const int nt = a.tile_end - a.tile_begin;
+        int rounds = 3;
+        while (rounds > 1 && (long long)nt * a.n_ublocks < (long long)rounds * slots * 16) --rounds; // >= 16 tiles per strip
+        int strips = (int)((long long)rounds * slots / a.n_ublocks) & ~7; // strips of one XCD class are multiples of 8
+        if (strips < 8) strips = 8;
+        a.tiles_per_wg = (nt + strips - 1) / strips;
+        if (a.tiles_per_wg < 1) a.tiles_per_wg = 1;
+        a.n_strips = (nt + a.tiles_per_wg - 1) / a.tiles_per_wg;
+        a.tile_stride = 1;
+    } else
+        a.tiles_per_wg = 0;
+    dim3 grid(((a.n_strips + 7) / 8) * 8 * a.n_ublocks);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
+}
+
 template <int MODE>
 static int launch_sweep_bf16(irs_ctx *ctx, SweepArgs &a, hipStream_t s) {
     const int KS = ctx->KS, UB = ub_bf16(KS);
+    // compute-bound regime (>= 256 rows): the ring kernel, rows in registers.  512 rows per workgroup (4 row tiles x
+    // 4 waves, or 2 x 8 waves at d_pad = 256) unless 256 (2 x 4) wastes fewer dead row tiles.
+    if (a.UT >= 8 && ctx->sweep_variant != 1 && ctx->sweep_variant != 3) {
+        a.no_stagger = ctx->sweep_variant == 2;
+        const int w512 = (a.UT + 15) / 16 * 16 - a.UT, w256 = (a.UT + 7) / 8 * 8 - a.UT;
+        const bool big = w512 <= w256;
+        switch (KS) {
+        case 1: big ? launch_ring<1, 4, 1, 4, MODE>(a, s) : launch_ring<1, 2, 2, 4, MODE>(a, s); break;
+        case 2: big ? launch_ring<2, 4, 1, 4, MODE>(a, s) : launch_ring<2, 2, 2, 4, MODE>(a, s); break;
+        case 4: big ? launch_ring<4, 4, 1, 4, MODE>(a, s) : launch_ring<4, 2, 2, 4, MODE>(a, s); break;
+        case 8: big ? launch_ring<8, 4, 1, 4, MODE>(a, s) : launch_ring<8, 2, 2, 4, MODE>(a, s); break;
+        case 16: launch_ring<16, 2, 1, 4, MODE>(a, s); break; // 256 rows per workgroup: two row tiles per wave is all the register file holds
+        default: IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "unsupported d_pad %d", ctx->d_pad);
+        }
+        IRS_CHECK_HIP(ctx, hipGetLastError());
+        return IRS_OK;
+    }
     a.n_ublocks = (a.UT + UB - 1) / UB;
     dim3 grid(((a.n_strips + 7) / 8) * 8 * a.n_ublocks);
-    // compute-bound regime (at least one full row block, d_pad <= 128): rows stay in registers, W tiles are shared
-    // through LDS.  At d_pad = 256 only one row tile per wave fits the register file and the streaming form wins.
-    if (a.UT >= UB && KS <= 8) {
+    if (a.UT >= UB && KS <= 8 && ctx->sweep_variant == 1) { // previous compute-bound form (kept for A/B measurements)
         const int ST = KS >= 16 ? 2 : 4; // as in the kernel
         const size_t lds_rs = (size_t)2 * ST * KS * 1024 + 2 * ST * 32 * 4 + EMIT_Q_BYTES;
 #define R_(KS_, RT_) hipLaunchKernelGGL((k_sweep_bf16_rs<KS_, RT_, MODE>), grid, dim3(256), lds_rs, s, a)
@@ -1348,16 +1781,17 @@ static void sweep_common(irs_ctx *ctx, SweepArgs &a, const float *xrows, int M) 
     a.cap = IRS_CAND_CAP;
 }
 
-// choose tiles per wave so that the grid has >= ~2048 workgroups when the catalog allows it
-static void sweep_decompose(SweepArgs &a, int tile_begin, int tile_end, int n_ublocks_hint, int force_tpw, int stride = 1) {
+// choose tiles per wave so that the grid has >= ~target_wgs workgroups when the catalog allows it
+static void sweep_decompose(SweepArgs &a, int tile_begin, int tile_end, int n_ublocks_hint, int force_tpw, int stride,
+                            int target_wgs, int max_tpw) {
     a.tile_begin = tile_begin;
     a.tile_end = tile_end;
     a.tile_stride = stride;
     int nt = (tile_end - tile_begin + stride - 1) / stride;
     int tpw = force_tpw;
     if (tpw <= 0) {
-        long long t = ((long long)nt * n_ublocks_hint) / (4LL * 2048);
-        tpw = (int)(t < 1 ? 1 : t > 16 ? 16 : t);
+        long long t = ((long long)nt * n_ublocks_hint) / (4LL * target_wgs);
+        tpw = (int)(t < 1 ? 1 : t > max_tpw ? max_tpw : t);
     }
     a.tiles_per_wave = tpw;
     a.n_strips = (nt + 4 * tpw - 1) / (4 * tpw);

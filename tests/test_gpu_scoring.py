@@ -254,3 +254,53 @@ def test_bf16_filter_survives_worst_case_rounding(oracle):
         assert np.array_equal(ids[m], oi) and np.array_equal(val[m].view(np.uint32), ov.view(np.uint32)), f"row {m}"
         assert np.array_equal(ei[m].cpu().numpy(), oi)
     assert (st & 1).sum() == 0, "handled by the filter itself, not by the exhaustive fallback"
+
+
+RING_CASES = [  # >= 256 rows: the compute-bound LDS-DMA ring sweep (PRE and EMIT), both row-block sizes, ragged row counts
+    (50_000, 128, 300, 100),    # 10 row tiles: 512-row blocks waste more than 256-row ones -> RT = 2, two tiles per step
+    (50_000, 128, 513, 100),    # 17 row tiles: one dead row tile short of two 512-row blocks... ragged both ways
+    (70_001, 256, 260, 50),     # d_pad = 256: two row tiles per wave, one tile per step
+    (20_000, 64, 1024, 100),    # d_pad = 64
+    (9_000, 30, 256, 100),      # the reference's default d (padded to 32), exactly one 256-row block
+    (40_000, 16, 1000, 7),      # a single k-step per tile: the ring advances behind the step, not inside it
+    (300_000, 128, 1024, 100),  # long strips, several rounds of workgroups
+]
+
+
+@pytest.mark.parametrize("n_item,d,M,k", RING_CASES)
+def test_topk_many_rows_ring_kernel(oracle, n_item, d, M, k):
+    """The ring kernel against the exhaustive exact kernel (every row, bit for bit) and the CPU oracle (a few rows)."""
+    W, b = _weights(n_item, d, 31)
+    x = _rows(M, d, 32)
+    eng = scoring_only_engine(n_item, d, W, b, max_rows=M, max_k=k)
+    xt = torch.from_numpy(x).cuda()
+    for rep in range(2):
+        val, ids, st = eng.score_topk(xt, k, IRS_SWEEP_BF16)
+    ev, ei, _ = eng.score_topk(xt, k, IRS_SWEEP_EXHAUSTIVE)
+    torch.cuda.synchronize()
+    assert torch.equal(ids, ei) and torch.equal(val.view(torch.int32), ev.view(torch.int32))
+    assert (st.cpu().numpy() & 1).sum() == 0, "unexpected fallback rows on benign data"
+    val, ids = val.cpu().numpy(), ids.cpu().numpy()
+    for m in (0, M // 2, M - 1):
+        ov, oi = oracle.topk(oracle.score_chain(x[m], W, b), k)
+        assert np.array_equal(ids[m], oi) and np.array_equal(val[m].view(np.uint32), ov.view(np.uint32)), f"row {m}"
+
+
+def test_topk_many_rows_ties_and_dense_hits(oracle):
+    """The ring kernel's dense-hit path (more than 8 lanes of a tile above the threshold: duplicate item rows make whole
+    tiles tie) and the overflow fallback behind it, at 256+ rows."""
+    n_item, d, M, k = 20_000, 32, 288, 100
+    W, b = _weights(n_item, d, 3)
+    W[:] = W[:7][np.arange(n_item) % 7]  # only 7 distinct rows
+    b[:] = 0.25
+    x = _rows(M, d, 4)
+    x[5] = x[4]  # identical rows too
+    eng = scoring_only_engine(n_item, d, W, b, max_rows=M)
+    xt = torch.from_numpy(x).cuda()
+    val, ids, st = eng.score_topk(xt, k, IRS_SWEEP_BF16)
+    ev, ei, _ = eng.score_topk(xt, k, IRS_SWEEP_EXHAUSTIVE)
+    torch.cuda.synchronize()
+    assert (st.cpu().numpy() & 1).all(), "expected the fallback to trigger"
+    assert torch.equal(ids, ei) and torch.equal(val.view(torch.int32), ev.view(torch.int32))
+    ov, oi = oracle.topk(oracle.score_chain(x[4], W, b), k)
+    assert np.array_equal(ids[4].cpu().numpy(), oi) and np.array_equal(ids[5].cpu().numpy(), oi)
