@@ -6,16 +6,22 @@
 
 (IRSNN.get_seq_in_batch's loop body, reference model/influentialRS.py:412-450).
 Metric (BASELINE.json): scored user-item pairs/sec = users x n_item / time, whole job.
-Default workload = BASELINE.json configs[1]: ml-1m-shaped, d=128, L=200, H=4,
+Headline workload = BASELINE.json configs[1] (C2): ml-1m-shaped, d=128, L=200, H=4,
 6 layers, F=256, N=3415, synthetic weights and windows, inputs resident in HBM.
 
-    python bench.py                       # 1 GPU, C2
+    python bench.py                       # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1 (weak scaling): every rank decodes its own B users, rows are all-gathered
-(RCCL), each rank scores all N*B rows against ITS item shard, per-shard top-100
-lists are all-gathered and merged identically on every rank.
+Besides the headline line items the JSON carries
+  * `scoring`: irs_score_topk and its emission sweep alone on the catalog-scale shapes (1M x 128 = C3,
+    1.25M x 256 = C4's per-GPU shard) for 1 / 32 / 1024 rows, each with its fraction of the bf16 MFMA peak
+    (>= 315 rows) or of the HBM floor of streaming the bf16 catalog once (small row counts);
+  * `c4_item_sharded`: BASELINE configs[3] -- a 10M-item, d=256 catalog cut into N item shards (one GPU: the whole
+    catalog = the N=1 anchor): rows all-gathered over RCCL, every rank sweeps its shard, ONE all_to_all of packed
+    64-bit top-100 keys, merge, path step.  The C2 headline itself replicates its 1.7 MB catalog and
+    partitions the users (no data-path collective);
+  * `cpu_baseline`: the CPU restatement timed on this box's host cores (B-equiv and B-row).
 """
 from __future__ import annotations
 
@@ -26,44 +32,178 @@ import sys
 import time
 
 import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
-
-from influentialrs_amd import synth  # noqa: E402
-from influentialrs_amd._lib import (IRS_MASK_IRN, IRS_PROF_ATTN, IRS_PROF_LINEAR, IRS_PROF_NONE,  # noqa: E402
-                                    IRS_PROF_REFINE, IRS_PROF_SWEEP, IRS_SWEEP_BF16, IRS_SWEEP_F32)
-from influentialrs_amd.engine import Engine  # noqa: E402
 
 PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (exact f32) dense peak
 PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0           # HBM3E spec
 
 
-def gpu_state_dict(cfg, device, seed=1234):
-    """Same init families as synth.irn_state_dict, generated on the device
-    (large catalogs: no host round trip)."""
+# ---------------------------------------------------------------------------------------------------- CPU baselines
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_row_worker(job):
+    """One worker of the B-row leg: greedy path steps for its users, consumed row only (single-threaded numpy + C)."""
+    cfg_name, seqs, users, steps, seed = job
+    from threadpoolctl import threadpool_limits
+    from influentialrs_amd import synth
+    from oracle import oracle_np as O
+    O.lib().orc_set_threads(1)
+    cfg = synth.make_config(cfg_name)
+    sd = _CPU_SD
+    W, b = sd["project.weight"], sd["project.bias"]
+    hep = cfg.max_len - 2
+    with threadpool_limits(limits=1):
+        for _ in range(steps):
+            for r in range(seqs.shape[0]):
+                x, _ = O.decode(sd, cfg, seqs[r], users[r])
+                s = O.score_chain(x[hep], W, b)
+                vals, ids0 = O.topk(s, 100)
+                nxt = O.select_next(ids0 + 1, vals, seqs[r][:hep + 1])
+                seqs[r][:-2] = seqs[r][1:-1].copy()
+                seqs[r][-2] = nxt
+    return seqs.shape[0] * steps
+
+
+_CPU_SD = None
+
+
+def cpu_baseline(cfg_name, budget_s=10.0):
+    """The oracle (CPU restatement, kind "port") on this box's host cores, bounded samples of the headline workload.
+    Runs BEFORE the process touches the GPU (it forks workers).  Checker code used as a yard-stick, never shipped.
+
+    B-equiv (`value`): what the reference does per path step (influentialRS.py:412-434) -- decoder, logits of ALL L
+      rows against the catalog, softmax over N for every row, top-100 of the consumed row, window filter, shift --
+      one user at a time (the only batch size the published IRN runs at), numpy on `threads` BLAS threads.
+    B-row: the fair algorithmic baseline -- consumed row only, 128 users per step spread over single-threaded
+      worker processes on all cores (numpy float32 decoder + C fma-chain scoring / top-100)."""
+    global _CPU_SD
+    import multiprocessing as mp
+    import subprocess
+    from threadpoolctl import threadpool_limits
+    so = os.path.join(REPO, "oracle", "_build", "liboracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle")], stdout=subprocess.DEVNULL)
+    from influentialrs_amd import synth
+    from oracle import oracle_np as O
+    cfg = synth.make_config(cfg_name)
+    sd = synth.irn_state_dict(cfg, 1234)
+    _CPU_SD = sd
+    cores = os.cpu_count() or 1
+    W, b = sd["project.weight"], sd["project.bias"]
+    hep = cfg.max_len - 2
+    # ---- B-equiv: torch CPU operators, like the reference itself (oracle/oracle_torch.py); thread count = the
+    #      fastest of a short calibration (tiny operators do not scale to hundreds of threads)
+    import torch
+    from oracle import oracle_torch as OT
+    irn = OT.TorchIRN(sd, cfg)
+    seqs = [torch.from_numpy(s_) for s_ in synth.random_windows(4, cfg.max_len, cfg.n_item, seed=3)]
+    prev_threads = torch.get_num_threads()
+    best = None
+    for cand in sorted({min(cores, c) for c in (4, 8, 16, 32, 64)}):
+        torch.set_num_threads(cand)
+        irn.path_step_like_reference(seqs[0], 0, hep)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            irn.path_step_like_reference(seqs[0], 0, hep)
+        t = (time.perf_counter() - t0) / 3
+        if best is None or t < best[0]:
+            best = (t, cand)
+    thr = best[1]
+    torch.set_num_threads(thr)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        for r in range(4):
+            _, seqs[r] = irn.path_step_like_reference(seqs[r], r, hep)
+            done += 1
+        if time.perf_counter() - t0 > budget_s or done >= 4000:
+            break
+    dt_e = time.perf_counter() - t0
+    torch.set_num_threads(prev_threads)
+    equiv = done * cfg.n_item / dt_e
+    # ---- B-row
+    nproc = min(cores, 128)
+    B = 128
+    seqs = synth.random_windows(B, cfg.max_len, cfg.n_item, seed=5)
+    users = np.arange(B)
+    per = (B + nproc - 1) // nproc
+    steps = 2
+    # size the sample from the B-equiv step time (a consumed-row step costs about the same decoder work)
+    est = 2.5 * (dt_e / max(done, 1)) * per  # numpy decoder: ~2.5x the torch step
+    steps = int(max(1, min(40, budget_s / max(est, 1e-3))))
+    jobs = [(cfg_name, seqs[i:i + per].copy(), users[i:i + per], steps, i) for i in range(0, B, per)]
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    with ctx.Pool(len(jobs)) as pool:
+        n_done = sum(pool.map(_cpu_row_worker, jobs))
+    dt_r = time.perf_counter() - t0
+    row = n_done * cfg.n_item / dt_r
+    return {"value": equiv, "unit": "pairs/s", "cores": thr, "kind": "port",
+            "sample": f"B-equiv: {done} greedy path steps (4 users, B=1 loop; all {cfg.max_len} rows scored, softmax over "
+                      f"{cfg.n_item} items per row, top-100, filter, shift; torch CPU operators like the reference) in {dt_e:.1f}s on "
+                      f"{thr} threads (fastest of a 4..64-thread calibration)",
+            "b_row": {"value": row, "unit": "pairs/s", "cores": len(jobs),
+                      "sample": f"{steps} steps x {B} users (consumed row only) over {len(jobs)} single-threaded worker "
+                                f"processes in {dt_r:.1f}s (fork + pool start-up included)"},
+            "ms_per_user_step_b_equiv": dt_e / max(done, 1) * 1e3,
+            "host": {"cpu_model": _cpu_model(), "logical_cpus": cores},
+            "b_ref_note": "B-ref (the unmodified reference's pipeline.test_model timed in the build container) is recorded in "
+                          "BASELINE.md section 4 (tools/time_reference.py)"}
+
+
+# ---------------------------------------------------------------------------------------------------- GPU side
+def gpu_state_dict(cfg, device, seed=1234, item_lo=0, item_hi=None, with_embedding=True):
+    """Same init families as synth.irn_state_dict, generated on the device (large catalogs: no host round trip).
+    project.weight / project.bias hold only rows [item_lo, item_hi): an item-sharded rank never materialises the
+    rest of the table.  Rows come from per-chunk generators (1M rows each), so every shard layout of the same
+    catalog draws identical numbers."""
+    import torch
+    from influentialrs_amd import synth
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     d, F, N = cfg.emb_dim, cfg.ffn_dim, cfg.n_item
+    item_hi = N if item_hi is None else item_hi
 
-    def normal(*shape, std=1.0):
-        return torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * std
+    def normal(*shape, std=1.0, gen=g):
+        return torch.randn(*shape, generator=gen, device=device, dtype=torch.float32) * std
 
-    def uniform(*shape, bound):
-        return (torch.rand(*shape, generator=g, device=device, dtype=torch.float32) * 2 - 1) * bound
+    def uniform(*shape, bound, gen=g):
+        return (torch.rand(*shape, generator=gen, device=device, dtype=torch.float32) * 2 - 1) * bound
 
     sd = {}
-    E = normal(N + 1, d)
-    E[0] = 0
-    sd["item_embedder.weight"] = E
+    if with_embedding:
+        E = normal(N + 1, d)
+        E[0] = 0
+        sd["item_embedder.weight"] = E
     sd["user_embedder.weight"] = normal(cfg.n_user, cfg.u_emb_dim)
     sd["user_mask_layer.weight"] = uniform(1, cfg.u_emb_dim, bound=cfg.u_emb_dim ** -0.5)
     sd["user_mask_layer.bias"] = normal(1, std=0.1)
     sd["pos_embedder.pe"] = torch.from_numpy(synth.positional_encoding(d, cfg.max_len)).to(device)
-    sd["project.weight"] = uniform(N, d, bound=d ** -0.5)
-    sd["project.bias"] = normal(N, std=0.1)
+    CH = 1 << 20
+    pw = torch.empty((item_hi - item_lo, d), dtype=torch.float32, device=device)
+    pb = torch.empty((item_hi - item_lo,), dtype=torch.float32, device=device)
+    for c in range(item_lo // CH, (item_hi + CH - 1) // CH):
+        gc = torch.Generator(device=device)
+        gc.manual_seed(seed * 100003 + c)
+        lo, hi = c * CH, min((c + 1) * CH, N)
+        w = uniform(hi - lo, d, bound=d ** -0.5, gen=gc)
+        bb = normal(hi - lo, std=0.1, gen=gc)
+        a, e = max(lo, item_lo), min(hi, item_hi)
+        pw[a - item_lo:e - item_lo] = w[a - lo:e - lo]
+        pb[a - item_lo:e - item_lo] = bb[a - lo:e - lo]
+        del w, bb
+    sd["project.weight"], sd["project.bias"] = pw, pb
     xav = (6.0 / (4 * d)) ** 0.5
     for l in range(cfg.n_layers):
         p = f"decoder.layers.{l}."
@@ -86,6 +226,7 @@ def gpu_windows(B, L, n_item, device, seed):
     """ml-1m-shaped evaluation windows: history length log-normal (median 95, sigma 0.95)
     clipped to [18, 2276]; the window keeps the last L-1 history items, pre-padded, target last
     (DataLoaderEvalIRS layout, reference data_provider.py:591-617)."""
+    import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     seqs = torch.randint(1, n_item + 1, (B, L), generator=g, device=device, dtype=torch.int64)
@@ -99,27 +240,33 @@ def gpu_windows(B, L, n_item, device, seed):
 def packed_fraction(job):
     """Fraction of the B*L window slots the decoder actually computes (non-pad tokens; the consumed row
     always counts).  The decoder packs them, so executed work scales with this."""
+    import torch
     s = job.seqs
-    L = s.shape[1]
     valid = (s != 0)
     valid[torch.arange(s.shape[0], device=s.device), job.hep.long()] = True
     return float(valid.sum().item()) / float(s.numel())
 
 
 class Job:
-    def __init__(self, args, rank, world, device):
-        self.args, self.rank, self.world, self.device = args, rank, world, device
-        self.cfg = synth.make_config(args.workload)
-        if args.n_item:
-            self.cfg.n_item = args.n_item
+    """One workload on this rank: engine, weights (the local item shard only when sharded), windows, one step."""
+
+    def __init__(self, workload, batch, rank, world, device, shard, sweep, n_item=0):
+        import torch
+        from influentialrs_amd import synth
+        from influentialrs_amd._lib import IRS_MASK_IRN, IRS_SWEEP_BF16, IRS_SWEEP_F32
+        from influentialrs_amd.engine import Engine, shard_bounds
+        self.rank, self.world, self.device = rank, world, device
+        self.cfg = synth.make_config(workload)
+        if n_item:
+            self.cfg.n_item = n_item
         cfg = self.cfg
-        self.B = args.batch
+        self.B = batch
         self.k = 100
-        self.sweep = IRS_SWEEP_F32 if args.sweep == "f32" else IRS_SWEEP_BF16
+        self.sweep = IRS_SWEEP_F32 if sweep == "f32" else IRS_SWEEP_BF16
         # Where the path shards (SURVEY 8e): a large catalog is cut into item shards (one exchange step per search
         # step); a catalog that fits every GPU many times over is replicated and the USERS are partitioned, with no
         # data-path collective at all.
-        self.sharded = world > 1 and (args.shard == "items" or (args.shard == "auto" and cfg.n_item >= 262144))
+        self.sharded = world > 1 and (shard == "items" or (shard == "auto" and cfg.n_item >= 262144))
         rows = self.B * world if self.sharded else self.B
         self.eng = Engine(n_item=cfg.n_item, n_user=cfg.n_user, d=cfg.emb_dim, max_len=cfg.max_len,
                           n_heads=cfg.n_heads, ffn_dim=cfg.ffn_dim, n_layers=cfg.n_layers, u_dim=cfg.u_emb_dim,
@@ -127,8 +274,13 @@ class Job:
                           rank=rank if self.sharded else 0, world=world if self.sharded else 1)
         if cfg.n_item <= 100_000:
             sd = {k: torch.from_numpy(v).to(device) for k, v in synth.irn_state_dict(cfg, 1234).items()}
+            if self.sharded:  # keep this rank's rows only
+                lo, hi = shard_bounds(cfg.n_item, world, rank)
+                sd["project.weight"] = sd["project.weight"][lo:hi].clone()
+                sd["project.bias"] = sd["project.bias"][lo:hi].clone()
         else:
-            sd = gpu_state_dict(cfg, device, 1234)
+            lo, hi = shard_bounds(cfg.n_item, world, rank) if self.sharded else (0, cfg.n_item)
+            sd = gpu_state_dict(cfg, device, 1234, lo, hi)
         self.eng.bind_state_dict(sd)
         self.seqs = gpu_windows(self.B, cfg.max_len, cfg.n_item, device, seed=100 + rank)
         self.users = torch.randint(0, cfg.n_user, (self.B,), device=device, dtype=torch.int64)
@@ -137,11 +289,17 @@ class Job:
         self.status = torch.zeros(self.B, dtype=torch.int32, device=device)
         if self.sharded:
             self.x_all = torch.empty((rows, cfg.emb_dim), dtype=torch.float32, device=device)
-            # exchange of per-shard top-k lists: each rank only needs the lists of ITS rows -> all_to_all of
-            # [world, B, k] (score f32 + id i32) instead of all-gathering every row's list on every rank
-            self.v_recv = torch.empty((world, self.B, self.k), dtype=torch.float32, device=device)
-            self.i_recv = torch.empty((world, self.B, self.k), dtype=torch.int32, device=device)
-            self.exchange = args.exchange
+            self.k_recv = torch.empty((world, self.B, self.k), dtype=torch.int64, device=device)
+
+    def _collect(self, fn, out, inp):
+        """RCCL works on device tensors; the gloo rehearsal backend (several ranks on ONE GPU) goes through the host."""
+        import torch.distributed as dist
+        if dist.get_backend() == "gloo":
+            o, i = out.cpu(), inp.cpu()
+            fn(o.view(-1), i.view(-1))
+            out.copy_(o)
+        else:
+            fn(out.view(-1), inp.view(-1))
 
     def step(self):
         eng = self.eng
@@ -150,25 +308,16 @@ class Job:
             val, ids, _ = eng.score_topk(xr, self.k, self.sweep)
         else:
             import torch.distributed as dist
-            dist.all_gather_into_tensor(self.x_all.view(-1), xr.view(-1))
-            v, i, _ = eng.score_topk(self.x_all, self.k, self.sweep)  # all rows x this rank's item shard
-            i32 = i.to(torch.int32)
-            if self.exchange == "all_to_all":
-                dist.all_to_all_single(self.v_recv.view(-1), v.view(-1))
-                dist.all_to_all_single(self.i_recv.view(-1), i32.view(-1))
-            else:  # rehearsal backends without all_to_all: gather everything, keep the own slice
-                vg = torch.empty((self.world,) + tuple(v.shape), dtype=v.dtype, device=v.device)
-                ig = torch.empty((self.world,) + tuple(i32.shape), dtype=i32.dtype, device=v.device)
-                dist.all_gather_into_tensor(vg.view(-1), v.view(-1))
-                dist.all_gather_into_tensor(ig.view(-1), i32.view(-1))
-                lo = self.rank * self.B
-                self.v_recv.copy_(vg[:, lo:lo + self.B])
-                self.i_recv.copy_(ig[:, lo:lo + self.B])
-            val, ids = eng.merge_topk(self.v_recv, self.i_recv.to(torch.int64))
+            self._collect(dist.all_gather_into_tensor, self.x_all, xr)
+            v, i, _ = eng.score_topk(self.x_all, self.k, self.sweep)    # all rows x this rank's item shard
+            keys = eng.pack_topk(v, i)                                   # one 64-bit key per entry (irs_hip.h)
+            self._collect(dist.all_to_all_single, self.k_recv, keys)     # the world's lists of THIS rank's rows
+            val, ids = eng.merge_topk_keys(self.k_recv)
         eng.path_step(self.seqs, self.hep, val, ids, 0, self.paths, self.status)
 
 
 def timed(job, steps, world):
+    import torch
     import torch.distributed as dist
     if world > 1:
         dist.barrier()
@@ -187,37 +336,57 @@ def timed(job, steps, world):
     return dt
 
 
-def cpu_baseline(cfg, budget_s=20.0):
-    """The oracle (CPU restatement, 'port') timed on this box's host cores on a
-    bounded sample of the same workload: greedy path steps for a few users, one
-    user at a time (the only batch size the published IRN runs at), scoring the
-    consumed row only.  Checker code used as a yard-stick, never shipped."""
-    import subprocess
-    so = os.path.join(REPO, "oracle", "_build", "liboracle.so")
-    if not os.path.exists(so):
-        subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle")], stdout=subprocess.DEVNULL)
-    from oracle import oracle_np as O
-    sd = synth.irn_state_dict(cfg, 1234)
-    seqs = synth.random_windows(4, cfg.max_len, cfg.n_item, seed=3)
-    users = np.arange(4)
-    hep = cfg.max_len - 2
-    W, b = sd["project.weight"], sd["project.bias"]
-    done, t0 = 0, time.perf_counter()
-    while True:
-        for r in range(4):
-            x, _ = O.decode(sd, cfg, seqs[r], users[r])
-            s = O.score_chain(x[hep], W, b)
-            vals, ids0 = O.topk(s, 100)
-            nxt = O.select_next(ids0 + 1, vals, seqs[r][:hep + 1])
-            seqs[r][:-2] = seqs[r][1:-1].copy()
-            seqs[r][-2] = nxt
-            done += 1
-        if time.perf_counter() - t0 > budget_s or done >= 400:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": done * cfg.n_item / dt, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{done} greedy path steps (4 users, B=1 loop, consumed row only) in {dt:.1f}s: numpy float32 "
-                      f"decoder (BLAS threads) + C fma-chain scoring/top-100 (OpenMP)"}
+def scoring_legs(device, reps=10):
+    """irs_score_topk and its emission sweep alone on the catalog-scale shapes ('also report the scoring
+    kernel in isolation'; the north star's 60 % MFMA target is quoted on this kernel)."""
+    import torch
+    from influentialrs_amd import synth
+    from influentialrs_amd._lib import IRS_MASK_IRN, IRS_PROF_NONE, IRS_PROF_SWEEP_EMIT, IRS_SWEEP_BF16
+    from influentialrs_amd.engine import Engine
+    out = {}
+    for name, N, d in (("1Mx128", 1_000_000, 128), ("1.25Mx256", 1_250_000, 256)):
+        nh = d // 32
+        cfg = synth.make_config("tiny", n_item=N, emb_dim=d, n_heads=nh, n_layers=1, max_len=4, ffn_dim=8, n_user=2)
+        eng = Engine(n_item=N, n_user=2, d=d, max_len=4, n_heads=nh, ffn_dim=8, n_layers=1, u_dim=10, mask_mode=IRS_MASK_IRN,
+                     device=device, max_rows=1024, max_seqs=1)
+        sd = gpu_state_dict(cfg, device, 1)
+        eng.bind_state_dict(sd)
+        g = torch.Generator(device=device)
+        g.manual_seed(7)
+        legs = {}
+        for M in (1, 32, 1024):
+            x = torch.randn((M, d), generator=g, device=device)
+            for _ in range(2):
+                eng.score_topk(x, 100, IRS_SWEEP_BF16)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                eng.score_topk(x, 100, IRS_SWEEP_BF16)
+            torch.cuda.synchronize()
+            total_us = (time.perf_counter() - t0) / reps * 1e6
+            eng.prof_enable(IRS_PROF_SWEEP_EMIT)
+            for _ in range(reps):
+                eng.score_topk(x, 100, IRS_SWEEP_BF16)
+            torch.cuda.synchronize()
+            n, ms, fl, by = eng.prof_read()
+            eng.prof_enable(IRS_PROF_NONE)
+            sweep_us = ms / max(n, 1) * 1e3
+            flops = 2.0 * d * M * N
+            wbytes = N * d * 2.0
+            leg = {"rows": M, "score_topk_us": total_us, "emit_sweep_us": sweep_us}
+            if M >= 315:
+                leg.update(bound="mfma", emit_sweep_tflops=flops / sweep_us / 1e6,
+                           emit_sweep_frac_bf16_peak=flops / sweep_us / 1e6 / PEAK_BF16_TFLOPS,
+                           score_topk_frac_bf16_peak=flops / total_us / 1e6 / PEAK_BF16_TFLOPS)
+            else:
+                leg.update(bound="hbm", w_stream_floor_us=wbytes / PEAK_HBM_GBS / 1e3,
+                           emit_sweep_frac_hbm=wbytes / sweep_us / 1e3 / PEAK_HBM_GBS,
+                           score_topk_frac_hbm=wbytes / total_us / 1e3 / PEAK_HBM_GBS)
+            legs[f"M={M}"] = leg
+        out[name] = legs
+        del eng, sd
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -231,6 +400,10 @@ def main():
     ap.add_argument("--sweep", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-scoring", action="store_true", help="skip the catalog-scale scoring legs")
+    ap.add_argument("--no-c4", action="store_true", help="skip the 10M-item item-sharded leg")
+    ap.add_argument("--c4-batch", type=int, default=1024, help="users per rank per step of the c4_item_sharded leg")
+    ap.add_argument("--c4-steps", type=int, default=5)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N > 1 code path with several ranks on ONE GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -238,18 +411,23 @@ def main():
                     help="N > 1: 'items' = every rank holds a slice of the catalog (rows all-gathered, per-shard top-k "
                          "exchanged, merged); 'replicate' = every rank holds the whole catalog and scores its own users, no "
                          "data-path collective; 'auto' = items from 262144 catalog entries up (a 3415-item catalog is 1.7 MB)")
-    ap.add_argument("--exchange", default=None, choices=["all_to_all", "all_gather"],
-                    help="how per-shard top-k lists travel (default: all_to_all on nccl, all_gather otherwise)")
     args = ap.parse_args()
 
-    if args.exchange is None:
-        args.exchange = "all_to_all" if args.backend == "nccl" else "all_gather"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+
+    # the CPU legs run first: they fork worker processes, which must happen before this process touches the GPU
+    cpu = None
+    if not args.no_cpu_baseline and world == 1 and rank == 0:
+        cpu = cpu_baseline(args.workload if args.workload in ("c1", "c2", "default", "tiny") else "c2")
+
+    import torch
+    from influentialrs_amd._lib import (IRS_PROF_ATTN, IRS_PROF_LINEAR, IRS_PROF_NONE, IRS_PROF_REFINE, IRS_PROF_SWEEP,
+                                        IRS_SWEEP_BF16)
     device = torch.device("cuda", 0 if args.same_device else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
@@ -259,7 +437,7 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    job = Job(args, rank, world, device)
+    job = Job(args.workload, args.batch, rank, world, device, args.shard, args.sweep, args.n_item)
     cfg = job.cfg
     for _ in range(args.warmup):
         job.step()
@@ -282,21 +460,21 @@ def main():
         fam[name] = dict(launches=n, ms=ms, flops=fl * scale, bytes=by, packed_fraction=scale)
     job.eng.prof_enable(IRS_PROF_NONE)
 
-    out = None
+    roof = None
     if rank == 0:
         dom = max(fam, key=lambda k: fam[k]["ms"])
         f = fam[dom]
         per_launch_ms = f["ms"] / max(f["launches"], 1)
         if dom in ("linear", "attn"):
             ach = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
-            roof = {"kernel": {"linear": "k_block + k_linear (decoder fp32 MFMA GEMM family: fused layer kernel, layer-0 QKV)", "attn": "k_attn (decoder attention, fp32 VALU)"}[dom],
+            roof = {"kernel": {"linear": "k_block + k_linear (decoder fp32 MFMA GEMM family: fused layer kernel, layer-0 QKV)",
+                               "attn": "k_attn16 / k_attn_mfma (decoder self-attention, fp32 MFMA)"}[dom],
                     "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_F32_MATRIX_TFLOPS, "traffic": None}
         else:
-            Mrows = users_total
-            if dom == "sweep" and Mrows >= 315 and job.sweep == IRS_SWEEP_BF16:
+            if dom == "sweep" and users_total >= 315 and job.sweep == IRS_SWEEP_BF16:
                 ach = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
-                roof = {"kernel": "k_sweep_bf16 (catalog sweep, bf16 MFMA)", "bound": "mfma", "achieved": ach,
+                roof = {"kernel": "k_sweep_ring / k_sweep_bf16 (catalog sweep, bf16 MFMA)", "bound": "mfma", "achieved": ach,
                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None}
             else:
                 ach = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f["ms"] > 0 else 0.0
@@ -304,16 +482,21 @@ def main():
                         "frac": ach / PEAK_HBM_GBS, "traffic": None}
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the number is the
         # per-launch mean of the committed rocprofv3 passes of this same command (FETCH_SIZE doubled per the gfx950
-        # note + WRITE_SIZE, separate --pmc passes), valid for the default workload only
+        # note + WRITE_SIZE, separate --pmc passes), valid for the default workload only.  It is reported together with
+        # the packed row count it was measured at; `algorithmic_bytes_per_launch` is quoted at that SAME row count.
         pmc_file = os.path.join(REPO, "profiles", "r01", "c2_b4096_pmc_v7.json")
         if dom == "linear" and world == 1 and args.workload == "c2" and args.batch == 4096 and not args.n_item and os.path.exists(pmc_file):
             try:
                 with open(pmc_file) as fh:
                     der = json.load(fh)["_derived"]
                 roof["traffic"] = float(next(v for k, v in der.items() if "HBM bytes per launch" in k))
+                rows_pmc = 463.5e3  # packed rows of the profiled run (its window law: VERDICT r01 recomputation)
+                roof["traffic_measured_at_packed_rows"] = rows_pmc
                 roof["traffic_source"] = ("profiles/r01/c2_b4096_pmc_v7.json: k_block<true,true> (5 of the family's 6 launches per "
-                                          "step), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2 x FETCH_SIZE + WRITE_SIZE")
-                roof["algorithmic_bytes_per_launch"] = 4.0 * 128 * (2 + 1 + 3) * fam[dom]["packed_fraction"] * job.B * cfg.max_len
+                                          "step), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2 x FETCH_SIZE + WRITE_SIZE; "
+                                          "the kernel is unchanged since")
+                roof["algorithmic_bytes_per_launch"] = 4.0 * 128 * (2 + 1 + 3) * rows_pmc
+                roof["packed_rows_this_run"] = fam[dom]["packed_fraction"] * job.B * cfg.max_len
             except Exception:
                 pass
         roof["flops_counted"] = "executed (dense-shape flops x packed non-pad row fraction %.3f)" % fam[dom].get("packed_fraction", 1.0)
@@ -321,50 +504,81 @@ def main():
         roof["launches_per_step"] = f["launches"] / args.steps
         roof["family_ms_per_step"] = {k: v["ms"] / args.steps for k, v in fam.items()}
 
-        lat = lat128 = lat1024 = lat_tokens = None
-        if not args.no_latency and world == 1:
-            # path-gen p50: one user, 20 greedy steps through irs_generate_paths, stream launches (as the front-end
-            # calls it; on ROCm 7.2 the hipGraph replay of the same 180 nodes measures ~3 % slower: 2.82 vs 2.74 ms)
-            # the user whose window holds the median number of items of this workload (a window's length sets the
-            # decoder's row count, i.e. the latency)
-            # fresh windows of the workload's shape (job.seqs has been advanced by every step above: by now those
-            # windows are full)
-            fresh = gpu_windows(job.B, cfg.max_len, cfg.n_item, device, seed=100 + rank)
-            nvalid = (fresh != 0).sum(dim=1)
-            iu = int(torch.argsort(nvalid)[nvalid.numel() // 2].item())
-            lat_tokens = int(nvalid[iu].item())
-            s1 = fresh[iu:iu + 1].clone()
-            u1 = job.users[iu:iu + 1].clone()
-            h1 = job.hep[iu:iu + 1].clone()
-            p1 = torch.zeros((1, 20), dtype=torch.float32, device=device)
-            st1 = torch.zeros(1, dtype=torch.int32, device=device)
-            def p50(ss, uu, hh, pp, stt, warm, reps):
-                ts = []
-                ss0, hh0 = ss.clone(), hh.clone()
-                for it in range(warm + reps):
-                    ss.copy_(ss0)  # every repetition starts from the user's own window (a path search appends its
-                    hh.copy_(hh0)  # 20 items to the window it is given: without the reset the windows fill up)
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    job.eng.generate_paths(ss, uu, hh, 20, k=100, sweep=job.sweep, use_graph=False, paths=pp, status=stt)
-                    torch.cuda.synchronize()
-                    if it >= warm:
-                        ts.append((time.perf_counter() - t0) * 1e3)
-                return float(np.median(ts))
+    lat = lat128 = lat1024 = lat_tokens = None
+    if rank == 0 and not args.no_latency and world == 1:
+        # path-gen p50: one user, 20 greedy steps through irs_generate_paths, stream launches (as the front-end
+        # calls it), on the user whose window holds the median number of items of this workload (a window's length
+        # sets the decoder's row count, i.e. the latency); fresh windows of the workload's shape (job.seqs has been
+        # advanced by every step above: by now those windows are full)
+        fresh = gpu_windows(job.B, cfg.max_len, cfg.n_item, device, seed=100 + rank)
+        nvalid = (fresh != 0).sum(dim=1)
+        iu = int(torch.argsort(nvalid)[nvalid.numel() // 2].item())
+        lat_tokens = int(nvalid[iu].item())
 
-            lat = p50(s1, u1, h1, p1, st1, 20, 200)  # >= 200 repetitions after 20 warm-ups
-            def per_user(nb, warm, reps):
-                return p50(fresh[:nb].clone(), job.users[:nb].clone(), job.hep[:nb].clone(),
-                           torch.zeros((nb, 20), dtype=torch.float32, device=device),
-                           torch.zeros(nb, dtype=torch.int32, device=device), warm, reps) / nb
+        def p50(ss, uu, hh, pp, stt, warm, reps):
+            ts = []
+            ss0, hh0 = ss.clone(), hh.clone()
+            for it in range(warm + reps):
+                ss.copy_(ss0)  # every repetition starts from the user's own window (a path search appends its
+                hh.copy_(hh0)  # 20 items to the window it is given: without the reset the windows fill up)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                job.eng.generate_paths(ss, uu, hh, 20, k=100, sweep=job.sweep, use_graph=False, paths=pp, status=stt)
+                torch.cuda.synchronize()
+                if it >= warm:
+                    ts.append((time.perf_counter() - t0) * 1e3)
+            return float(np.median(ts))
 
-            lat128 = per_user(min(128, job.B), 5, 30)
-            lat1024 = per_user(min(1024, job.B), 3, 10)
+        lat = p50(fresh[iu:iu + 1].clone(), job.users[iu:iu + 1].clone(), job.hep[iu:iu + 1].clone(),
+                  torch.zeros((1, 20), dtype=torch.float32, device=device), torch.zeros(1, dtype=torch.int32, device=device),
+                  20, 200)  # >= 200 repetitions after 20 warm-ups
 
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(cfg)
+        def per_user(nb, warm, reps):
+            return p50(fresh[:nb].clone(), job.users[:nb].clone(), job.hep[:nb].clone(),
+                       torch.zeros((nb, 20), dtype=torch.float32, device=device),
+                       torch.zeros(nb, dtype=torch.int32, device=device), warm, reps) / nb
 
+        lat128 = per_user(min(128, job.B), 5, 30)
+        lat1024 = per_user(min(1024, job.B), 3, 10)
+
+    out_cfg = {"workload": f"{args.workload}: n_item={cfg.n_item}, d={cfg.emb_dim}, L={cfg.max_len}, H={cfg.n_heads}, "
+                           f"layers={cfg.n_layers}, ffn={cfg.ffn_dim}; one greedy path-search step",
+               "users_per_step": users_total, "users_per_gpu": job.B, "top_k": 100,
+               "windows": "ml-1m-shaped history lengths (log-normal, median 95), pre-padded; decoder skips pad tokens "
+                          "(packed rows), results identical",
+               "packed_row_fraction": fam["linear"]["packed_fraction"],
+               "sweep": args.sweep + (" filter + exact f32 re-score" if args.sweep == "bf16" else ""),
+               "parallelism": "single GPU" if world == 1 else (
+                   f"rows data-parallel + item-sharded x{world}: RCCL all-gather of rows, one all_to_all of packed 64-bit top-100 keys"
+                   if job.sharded else
+                   f"users partitioned over {world} GPUs, catalog replicated ({cfg.n_item} items): no data-path collective")}
+    del job
+    torch.cuda.empty_cache()
+
+    scoring = None
+    if rank == 0 and world == 1 and not args.no_scoring:
+        scoring = scoring_legs(device)
+
+    # ---- BASELINE configs[3]: the 10M-item catalog, item-sharded over the N GPUs (N = 1: the whole catalog, the anchor)
+    c4 = None
+    if not args.no_c4:
+        j4 = Job("c4", args.c4_batch, rank, world, device, "items", args.sweep)
+        for _ in range(2):
+            j4.step()
+        dt4 = timed(j4, args.c4_steps, world)
+        u4 = j4.B * world
+        c4 = {"metric": "scored user-item pairs/sec (whole node)", "value": u4 * j4.cfg.n_item * args.c4_steps / dt4,
+              "unit": "pairs/s", "n_gpus": world, "steps": args.c4_steps, "ms_per_step": dt4 / args.c4_steps * 1e3,
+              "scaling": "weak", "users_per_gpu": j4.B, "items_per_gpu": j4.eng.n_local,
+              "workload": f"c4: n_item={j4.cfg.n_item}, d={j4.cfg.emb_dim}, L={j4.cfg.max_len}, H={j4.cfg.n_heads}; one greedy "
+                          f"path-search step, top-100",
+              "parallelism": "single GPU holds the whole catalog" if world == 1 else
+                             f"item shards of {j4.eng.n_local} rows x {world}; per step: all-gather of {u4} x {j4.cfg.emb_dim} f32 rows, "
+                             f"one all_to_all of {u4} x 100 packed 64-bit keys per rank, merge"}
+        del j4
+        torch.cuda.empty_cache()
+
+    if rank == 0:
         out = {
             "metric": "scored user-item pairs/sec (whole node)",
             "value": value,
@@ -378,22 +592,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: n_item={cfg.n_item}, d={cfg.emb_dim}, L={cfg.max_len}, H={cfg.n_heads}, "
-                                   f"layers={cfg.n_layers}, ffn={cfg.ffn_dim}; one greedy path-search step",
-                       "users_per_step": users_total, "users_per_gpu": job.B, "top_k": 100,
-                       "windows": "ml-1m-shaped history lengths (log-normal, median 95), pre-padded; decoder skips pad tokens "
-                                  "(packed rows), results identical",
-                       "packed_row_fraction": fam["linear"]["packed_fraction"],
-                       "sweep": args.sweep + (" filter + exact f32 re-score" if args.sweep == "bf16" else ""),
-                       "parallelism": "single GPU" if world == 1 else (
-                           f"rows data-parallel + item-sharded x{world}: RCCL all-gather of rows, {args.exchange} of per-shard top-100"
-                           if job.sharded else
-                           f"users partitioned over {world} GPUs, catalog replicated ({cfg.n_item} items): no data-path collective")},
+            "config": out_cfg,
             "path_gen_p50_ms_b1": lat,
             "path_gen_b1_window_tokens": lat_tokens,
             "path_gen_ms_per_user_b128": lat128,
             "path_gen_ms_per_user_b1024": lat1024,
             "roofline": roof,
+            "scoring": scoring,
+            "c4_item_sharded": c4,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

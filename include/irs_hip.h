@@ -190,6 +190,16 @@ int irs_score_lse(irs_ctx *ctx, const float *dev_xrows, int32_t M, float *dev_ma
 int irs_merge_topk(irs_ctx *ctx, const float *dev_val_in, const int64_t *dev_ids_in, int32_t W, int32_t M, int32_t k,
                    float *dev_val, int64_t *dev_ids0, void *stream);
 
+/* Wire format of a per-shard list for the exchange step (SURVEY 8e budgets 8 bytes per entry): ONE unsigned 64-bit
+ * key per entry = (order key of the float32 score << 32) | (0xFFFFFFFF - global id0); 0 = no entry (id -1).
+ * Unsigned key order IS the selection order (score descending, id ascending), so a merge is a sort of keys.
+ * irs_pack_topk: n = M * k entries -> dev_keys uint64 [n].
+ * irs_merge_topk_keys: dev_keys_in uint64 [W, M, k] (what an all-gather / all-to-all of packed lists delivers)
+ *                      -> the merged top-k as (dev_val float [M, k], dev_ids0 int64 [M, k]); W * k <= 2048. */
+int irs_pack_topk(irs_ctx *ctx, const float *dev_val, const int64_t *dev_ids0, int64_t n, uint64_t *dev_keys, void *stream);
+int irs_merge_topk_keys(irs_ctx *ctx, const uint64_t *dev_keys_in, int32_t W, int32_t M, int32_t k, float *dev_val,
+                        int64_t *dev_ids0, void *stream);
+
 /* ---- evaluation batch construction on the device (replaces the per-user Python of
  *      DataProvider.get_random_evaluate_data, data_provider.py:398-449, and
  *      DataLoaderEvalIRS._collate_fn, data_provider.py:591-617) -------------
@@ -265,6 +275,7 @@ int irs_beam_search(irs_ctx *ctx, const int64_t *dev_seq0, const int64_t *dev_us
 #define IRS_PROF_ATTN 2    /* decoder attention */
 #define IRS_PROF_SWEEP 3   /* catalog sweep (pre-pass + emit) */
 #define IRS_PROF_REFINE 4  /* candidate refine / exact re-score / sort */
+#define IRS_PROF_SWEEP_EMIT 5 /* the emission sweep of irs_score_topk alone (the kernel the bf16 MFMA roofline is quoted on) */
 int irs_prof_enable(irs_ctx *ctx, int32_t family);
 int irs_prof_read(irs_ctx *ctx, int32_t *launches, double *total_ms, double *total_flops, double *total_bytes);
 

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "libirs_hip.so")
 IRS_MASK_IRN, IRS_MASK_CAUSAL = 0, 1
 IRS_SWEEP_BF16, IRS_SWEEP_F32, IRS_SWEEP_EXHAUSTIVE = 0, 1, 2
 IRS_ROW_FALLBACK, IRS_ROW_NO_CANDIDATE, IRS_ROW_FEWER_THAN_K = 1, 2, 4
-IRS_PROF_NONE, IRS_PROF_LINEAR, IRS_PROF_ATTN, IRS_PROF_SWEEP, IRS_PROF_REFINE = 0, 1, 2, 3, 4
+IRS_PROF_NONE, IRS_PROF_LINEAR, IRS_PROF_ATTN, IRS_PROF_SWEEP, IRS_PROF_REFINE, IRS_PROF_SWEEP_EMIT = 0, 1, 2, 3, 4, 5
 
 
 class IrsDims(ctypes.Structure):
@@ -50,6 +50,8 @@ SIGNATURES = {
     "irs_build_eval_batch": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64,
                                        c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "irs_merge_topk": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "irs_pack_topk": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "irs_merge_topk_keys": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "irs_path_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p,
                                 c_int32, c_int32, c_int32, c_uint64, c_void_p, c_void_p]),
     "irs_generate_paths": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,

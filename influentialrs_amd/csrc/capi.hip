@@ -426,6 +426,19 @@ extern "C" int irs_merge_topk(irs_ctx *ctx, const float *val_in, const int64_t *
     return irs_launch_merge(ctx, val_in, ids_in, W, M, k, val, ids0, (hipStream_t)stream);
 }
 
+extern "C" int irs_pack_topk(irs_ctx *ctx, const float *val, const int64_t *ids0, int64_t n, uint64_t *keys, void *stream) {
+    if (!ctx) return IRS_E_INVALID;
+    if (!val || !ids0 || !keys || n < 1) IRS_FAIL(ctx, IRS_E_INVALID, "irs_pack_topk: bad arguments");
+    return irs_launch_pack_topk(ctx, val, ids0, n, keys, (hipStream_t)stream);
+}
+
+extern "C" int irs_merge_topk_keys(irs_ctx *ctx, const uint64_t *keys_in, int32_t W, int32_t M, int32_t k, float *val,
+                                   int64_t *ids0, void *stream) {
+    if (!ctx) return IRS_E_INVALID;
+    if (!keys_in || !val || !ids0 || W < 1 || M < 1 || k < 1) IRS_FAIL(ctx, IRS_E_INVALID, "irs_merge_topk_keys: bad arguments");
+    return irs_launch_merge_keys(ctx, keys_in, W, M, k, val, ids0, (hipStream_t)stream);
+}
+
 extern "C" int irs_build_eval_batch(irs_ctx *ctx, const int64_t *items, const int64_t *offsets, int32_t B, int32_t raw_len,
                                     int32_t gap_len, const int64_t *targets_in, const int64_t *pool, int64_t n_pool,
                                     uint64_t seed, int64_t *seq, int64_t *target, int64_t *label, int64_t *raw,

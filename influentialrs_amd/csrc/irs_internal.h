@@ -153,6 +153,8 @@ int irs_launch_lse(irs_ctx *ctx, const float *xrows, int M, float *out_max, floa
 // ---- path.hip ----
 int irs_launch_merge(irs_ctx *ctx, const float *val_in, const int64_t *ids_in, int W, int M, int k, float *val,
                      int64_t *ids0, hipStream_t s);
+int irs_launch_merge_keys(irs_ctx *ctx, const uint64_t *keys_in, int W, int M, int k, float *val, int64_t *ids0, hipStream_t s);
+int irs_launch_pack_topk(irs_ctx *ctx, const float *val, const int64_t *ids0, int64_t n, uint64_t *keys, hipStream_t s);
 int irs_launch_path_step(irs_ctx *ctx, int64_t *seq, int32_t *hep, int B, const float *val, const int64_t *ids0, int k,
                          int step, const int32_t *step_ptr, float *paths, int path_ld, int sample, int sample_k,
                          uint64_t seed, int32_t *status, hipStream_t s, int32_t *step_next = nullptr);

@@ -25,9 +25,22 @@ __global__ void k_inc(int32_t *ctr) {
     if (threadIdx.x == 0 && blockIdx.x == 0) ctr[0] += 1;
 }
 
-// merge W lists of k entries per row: one workgroup per row, bitonic sort of <= 2048 keys
+// merge W lists of k entries per row: one workgroup per row, bitonic sort of <= 2048 keys.
+// PACKED: the lists arrive as the exchange step's 64-bit keys (irs_hip.h: irs_pack_topk).
+__device__ __forceinline__ unsigned long long irs_topk_key(float v, int64_t id) {
+    return id >= 0 ? (((unsigned long long)irs_fkey(v) << 32) | (0xFFFFFFFFu - (unsigned int)id)) : 0ull;
+}
+
+__global__ void __launch_bounds__(256) k_pack_topk(const float *__restrict__ val, const int64_t *__restrict__ ids, int64_t n,
+                                                   unsigned long long *__restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keys[i] = irs_topk_key(val[i], ids[i]);
+}
+
+template <bool PACKED>
 __global__ void __launch_bounds__(256) k_merge(const float *__restrict__ val_in, const int64_t *__restrict__ ids_in,
-                                               int W, int M, int k, float *__restrict__ val, int64_t *__restrict__ ids) {
+                                               const unsigned long long *__restrict__ keys_in, int W, int M, int k,
+                                               float *__restrict__ val, int64_t *__restrict__ ids) {
     __shared__ unsigned long long keys[2048];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int n = W * k;
@@ -36,10 +49,9 @@ __global__ void __launch_bounds__(256) k_merge(const float *__restrict__ val_in,
     for (int i = tid; i < n2; i += 256) {
         unsigned long long key = 0ull;
         if (i < n) {
-            int w = i / k, c = i % k;
-            int64_t id = ids_in[((size_t)w * M + row) * k + c];
-            float v = val_in[((size_t)w * M + row) * k + c];
-            if (id >= 0) key = ((unsigned long long)irs_fkey(v) << 32) | (0xFFFFFFFFu - (unsigned int)id);
+            const int w = i / k, c = i % k;
+            const size_t at = ((size_t)w * M + row) * k + c;
+            key = PACKED ? keys_in[at] : irs_topk_key(val_in[at], ids_in[at]);
         }
         keys[i] = key;
     }
@@ -238,7 +250,22 @@ int irs_launch_beam_step(irs_ctx *ctx, const int64_t *seq_in, const int32_t *hep
 int irs_launch_merge(irs_ctx *ctx, const float *val_in, const int64_t *ids_in, int W, int M, int k, float *val,
                      int64_t *ids0, hipStream_t s) {
     if (W * k > 2048) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "merge of %d x %d entries exceeds 2048", W, k);
-    hipLaunchKernelGGL(k_merge, dim3(M), dim3(256), 0, s, val_in, ids_in, W, M, k, val, ids0);
+    hipLaunchKernelGGL(k_merge<false>, dim3(M), dim3(256), 0, s, val_in, ids_in, (const unsigned long long *)nullptr, W, M, k, val, ids0);
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}
+
+int irs_launch_merge_keys(irs_ctx *ctx, const uint64_t *keys_in, int W, int M, int k, float *val, int64_t *ids0, hipStream_t s) {
+    if (W * k > 2048) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "merge of %d x %d entries exceeds 2048", W, k);
+    hipLaunchKernelGGL(k_merge<true>, dim3(M), dim3(256), 0, s, (const float *)nullptr, (const int64_t *)nullptr,
+                       reinterpret_cast<const unsigned long long *>(keys_in), W, M, k, val, ids0);
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}
+
+int irs_launch_pack_topk(irs_ctx *ctx, const float *val, const int64_t *ids0, int64_t n, uint64_t *keys, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_topk, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, val, ids0, n,
+                       reinterpret_cast<unsigned long long *>(keys));
     IRS_CHECK_HIP(ctx, hipGetLastError());
     return IRS_OK;
 }

@@ -1037,16 +1037,18 @@ __global__ void __launch_bounds__(256) k_pack_w(const float *__restrict__ W, con
 
 // thr[row] = (k-th largest of gm[0..G)[row]) - 2 eps ; traw[row] = that order statistic itself
 // (-inf when G < k; +inf for padding rows so that they never emit).
-// 1024 threads = 32 rows x 32 threads per row; a wave's lanes read 32 consecutive rows of one group
-// (coalesced 128-byte lines of gm[G][M_pad]).  8-bit radix select, per-row LDS histograms; the 256-bin
-// scan of a row is done by its 32 threads (8 bins each + a 32-lane suffix sum).
-__global__ void __launch_bounds__(1024) k_select_thr(const float *__restrict__ gm, int G, int M, int M_pad, int k,
-                                                     const float *__restrict__ eps, float *__restrict__ thr,
-                                                     float *__restrict__ traw) {
-    __shared__ unsigned int hist[32][257];
-    __shared__ unsigned int s_prefix[32], s_k[32];
-    const int rl = threadIdx.x & 31, tq = threadIdx.x >> 5; // row within block, thread within row
-    const int row = blockIdx.x * 32 + rl;
+// ROWS rows x 32 threads per row per workgroup; consecutive lanes read consecutive rows of one group (gm[G][M_pad]:
+// 128-byte lines at ROWS = 32, 32-byte pieces at ROWS = 8).  8-bit radix select, per-row LDS histograms; the
+// 256-bin scan of a row is done by its 32 threads (8 bins each + a 32-lane suffix sum).  ROWS = 32 left a
+// 1024-row call on 32 CUs (59 us, as long as a fifth of the sweep); ROWS = 8 spreads it over 128.
+template <int ROWS>
+__global__ void __launch_bounds__(ROWS * 32) k_select_thr(const float *__restrict__ gm, int G, int M, int M_pad, int k,
+                                                          const float *__restrict__ eps, float *__restrict__ thr,
+                                                          float *__restrict__ traw) {
+    __shared__ unsigned int hist[ROWS][257];
+    __shared__ unsigned int s_prefix[ROWS], s_k[ROWS];
+    const int rl = threadIdx.x % ROWS, tq = threadIdx.x / ROWS; // row within block, thread within row
+    const int row = blockIdx.x * ROWS + rl;
     if (G < k) {
         if (tq == 0 && row < M_pad) {
             thr[row] = (row < M) ? -INFINITY : INFINITY;
@@ -1060,7 +1062,7 @@ __global__ void __launch_bounds__(1024) k_select_thr(const float *__restrict__ g
     }
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
-        for (int i = threadIdx.x; i < 32 * 257; i += 1024) (&hist[0][0])[i] = 0;
+        for (int i = threadIdx.x; i < ROWS * 257; i += ROWS * 32) (&hist[0][0])[i] = 0;
         __syncthreads();
         const unsigned int prefix = s_prefix[rl];
         if (row < M) {
@@ -1080,7 +1082,7 @@ __global__ void __launch_bounds__(1024) k_select_thr(const float *__restrict__ g
             // suffix sum over tq (threads of one row are 32 apart in threadIdx: go through LDS)
             hist[rl][256] = 0; // unused pad word, keeps the row stride odd
             __syncthreads();
-            __shared__ unsigned int part[32][33];
+            __shared__ unsigned int part[ROWS][33];
             part[rl][tq] = own;
             __syncthreads();
             unsigned int above = 0; // count in bins owned by higher tq
@@ -1884,8 +1886,12 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
         if (r_sel < 8) r_sel = 8;
         if (r_sel > k) r_sel = k;
     }
-    hipLaunchKernelGGL(k_select_thr, dim3((M_pad + 31) / 32), dim3(1024), 0, s, ctx->gm, G, M, M_pad, r_sel, ctx->eps,
-                       ctx->thr, ctx->ref_tmp);
+    if (M_pad >= 8192)
+        hipLaunchKernelGGL(k_select_thr<32>, dim3((M_pad + 31) / 32), dim3(1024), 0, s, ctx->gm, G, M, M_pad, r_sel, ctx->eps,
+                           ctx->thr, ctx->ref_tmp);
+    else
+        hipLaunchKernelGGL(k_select_thr<8>, dim3((M_pad + 7) / 8), dim3(256), 0, s, ctx->gm, G, M, M_pad, r_sel, ctx->eps,
+                           ctx->thr, ctx->ref_tmp);
     IRS_CHECK_HIP(ctx, hipGetLastError());
 
     // emission sweep over the whole shard
@@ -1894,9 +1900,12 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
     a.cnt = ctx->cand_cnt;
     a.cand = ctx->cand;
     irs_prof_begin(ctx, IRS_PROF_SWEEP, s);
+    irs_prof_begin(ctx, IRS_PROF_SWEEP_EMIT, s); // (one family is enabled at a time)
     if (sweep == IRS_SWEEP_BF16) rc = launch_sweep_bf16<MODE_EMIT>(ctx, a, s);
     else rc = launch_sweep_f32<MODE_EMIT>(ctx, a, s);
     irs_prof_end(ctx, IRS_PROF_SWEEP, s, 2.0 * d * (double)M * (double)ctx->n_local,
+                 (double)nt * 32.0 * ctx->d_pad * (sweep == IRS_SWEEP_BF16 ? 2.0 : 4.0));
+    irs_prof_end(ctx, IRS_PROF_SWEEP_EMIT, s, 2.0 * d * (double)M * (double)ctx->n_local,
                  (double)nt * 32.0 * ctx->d_pad * (sweep == IRS_SWEEP_BF16 ? 2.0 : 4.0));
     if (rc) return rc;
 

@@ -5,14 +5,15 @@ holds rows [lo_r, hi_r) of project.weight / project.bias.  Per scoring call:
 
     rows (data-parallel)  --all_gather-->  every rank has all rows
     local sweep over the rank's item shard  ->  per-shard top-k / counts / (max, sumexp) / scores
-    --all_gather-->  identical deterministic combine on every rank
+    per-shard top-k lists, packed to ONE 64-bit key per entry (include/irs_hip.h: irs_pack_topk),
+    --all_to_all-->  every rank receives the world's lists of ITS OWN rows and merges them
+    (`topk_own`; `topk` = the all-gather form that leaves every row's merged list on every rank)
 
-so every rank advances the same windows with no further broadcast.  The payloads
-are tiny (M*k*12 bytes per rank), i.e. latency bound; nothing here is reduced
-at bandwidth scale.  The reference has no counterpart (it only knows
+The payloads are small (M*k*8 bytes per rank), i.e. latency bound; nothing here is
+reduced at bandwidth scale.  The reference has no counterpart (it only knows
 nn.DataParallel, pipeline.py:43-44); this is the MI355X-native replacement.
 
-`scorer` is anything with the Engine scoring methods (score_topk, merge_topk,
+`scorer` is anything with the Engine scoring methods (score_topk, pack_topk, merge_topk_keys,
 score_gather, score_count_before, score_lse); in the product it is an
 influentialrs_amd.engine.Engine.  The CPU rehearsal tests (gloo, world 2) pass
 an oracle-backed stand-in to exercise exactly this collective logic.
@@ -34,6 +35,7 @@ class ShardGroup:
         # gloo (the CPU rehearsal backend) is only dependable on host tensors: with device tensors and several
         # ranks sharing one GPU its collectives were seen to hang now and then.  Its payloads go through the host.
         self._via_host = self.world > 1 and dist.get_backend(group) == "gloo"
+        self._a2a = None  # None: all_to_all untried; True / False: supported or not by the backend
 
     # -- plumbing ---------------------------------------------------------
     def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
@@ -67,14 +69,44 @@ class ShardGroup:
     def my_slice(self, rows_per_rank: int) -> slice:
         return slice(self.rank * rows_per_rank, (self.rank + 1) * rows_per_rank)
 
+    def _all_to_all(self, t: torch.Tensor) -> torch.Tensor:
+        """[world, ...] -> [world, ...]: slice j goes to rank j; slice i of the result came from rank i."""
+        t = t.contiguous()
+        src = t.cpu() if (self._via_host and t.is_cuda) else t
+        out = torch.empty_like(src)
+        if self._a2a is not False:
+            try:
+                dist.all_to_all_single(out.view(-1), src.view(-1), group=self.group)
+                self._a2a = True
+            except (RuntimeError, NotImplementedError):
+                if self._a2a is True:
+                    raise
+                self._a2a = False  # backend without all_to_all: all-gather, keep the own column
+        if self._a2a is False:
+            allt = torch.empty((self.world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
+            dist.all_gather_into_tensor(allt.view(-1), src.view(-1), group=self.group)
+            out = allt[:, self.rank].contiguous()
+        return out.to(t.device)
+
     # -- combines ---------------------------------------------------------
-    def topk(self, xrows: torch.Tensor, k: int, sweep: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    def topk_own(self, xrows: torch.Tensor, k: int, sweep: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Global top-k of THIS rank's rows.  `xrows` = all rows, rank-major ([world * B, d], from gather_rows); every
+        rank sweeps them over its item shard, and one all_to_all of packed keys hands each rank the world's lists
+        of its own B rows.  Returns (val[B,k], ids0[B,k], status[B])."""
         val, ids, st = self.scorer.score_topk(xrows, k, sweep)
         if self.world == 1:
             return val, ids, st
-        v_all = self._all_gather(val)
-        i_all = self._all_gather(ids)
-        mv, mi = self.scorer.merge_topk(v_all, i_all)
+        B = xrows.shape[0] // self.world
+        keys = self.scorer.pack_topk(val, ids).view(self.world, B, k)
+        mv, mi = self.scorer.merge_topk_keys(self._all_to_all(keys))
+        return mv, mi, (mi[:, -1] < 0).to(torch.int32) * 4
+
+    def topk(self, xrows: torch.Tensor, k: int, sweep: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Global top-k of ALL rows on every rank (one all_gather of packed keys)."""
+        val, ids, st = self.scorer.score_topk(xrows, k, sweep)
+        if self.world == 1:
+            return val, ids, st
+        mv, mi = self.scorer.merge_topk_keys(self._all_gather(self.scorer.pack_topk(val, ids)))
         # fallback bit is informational per shard; FEWER_THAN_K only if the merged list is short
         st = (mi[:, -1] < 0).to(torch.int32) * 4
         return mv, mi, st

@@ -214,6 +214,23 @@ class Engine:
         self._call(self.lib.irs_merge_topk, _ptr(val_in), _ptr(ids_in), W, M, k, _ptr(val), _ptr(ids))
         return val, ids
 
+    def pack_topk(self, val: torch.Tensor, ids0: torch.Tensor) -> torch.Tensor:
+        """(val, ids0) lists -> the exchange step's 64-bit keys (include/irs_hip.h), same shape, int64 storage."""
+        val = self._dev(val, torch.float32)
+        ids0 = self._dev(ids0, torch.int64)
+        keys = torch.empty(val.shape, dtype=torch.int64, device=self.device)
+        self._call(self.lib.irs_pack_topk, _ptr(val), _ptr(ids0), val.numel(), _ptr(keys))
+        return keys
+
+    def merge_topk_keys(self, keys_in: torch.Tensor):
+        """[W, M, k] packed per-shard lists -> global (val[M,k], ids0[M,k])."""
+        keys_in = self._dev(keys_in, torch.int64)
+        W, M, k = keys_in.shape
+        val = torch.empty((M, k), dtype=torch.float32, device=self.device)
+        ids = torch.empty((M, k), dtype=torch.int64, device=self.device)
+        self._call(self.lib.irs_merge_topk_keys, _ptr(keys_in), W, M, k, _ptr(val), _ptr(ids))
+        return val, ids
+
     # ------------------------------------------------------------------ evaluation batch (device-side loader)
     def build_eval_batch(self, items: torch.Tensor, offsets: torch.Tensor, *, raw_len: int = 100, gap_len: int = 0,
                          targets: Optional[torch.Tensor] = None, pool: Optional[torch.Tensor] = None, seed: int = 0):

@@ -25,12 +25,21 @@ class HipBackend:
         self.sweep = IRS_SWEEP_BF16
         self.rank, self.world = 0, 1
 
-    def set_sharding(self, rank: int, world: int):
+    def set_sharding(self, rank: int, world: int, drop_full: bool = True):
         """Item-dimension sharding over `world` ranks (torch.distributed must be
-        initialised by the caller when world > 1)."""
+        initialised by the caller when world > 1).  drop_full: keep only the shard's rows of
+        project.weight / project.bias in the module (the engine binds local rows either way)."""
         if (rank, world) != (self.rank, self.world):
             self.rank, self.world = rank, world
             self.engine = None
+        proj = getattr(self.net, "project", None)
+        if drop_full and world > 1 and proj is not None and proj.weight.shape[0] == self.net.n_item:
+            from ..engine import shard_bounds
+            lo, hi = shard_bounds(self.net.n_item, world, rank)
+            with torch.no_grad():
+                proj.weight = nn.Parameter(proj.weight[lo:hi].detach().clone(), requires_grad=proj.weight.requires_grad)
+                proj.bias = nn.Parameter(proj.bias[lo:hi].detach().clone(), requires_grad=proj.bias.requires_grad)
+            self._fp = None
 
     def _fingerprint(self):
         return tuple((t.data_ptr(), t._version) for t in self.net.state_dict(keep_vars=True).values())

@@ -71,9 +71,12 @@ class InfluentialNet(nn.Module):
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
         return super().load_state_dict(sd, strict=strict, **kw)
 
-    def shard_items(self, rank: int, world: int):
-        """Hold only rows [lo, hi) of the catalog on this GPU."""
-        self._hip.set_sharding(rank, world)
+    def shard_items(self, rank: int, world: int, drop_full: bool = True):
+        """Hold only rows [lo, hi) of the catalog on this GPU.  With drop_full (default) the
+        module's own project.weight / project.bias are cut down to the shard -- call it after
+        load_state_dict: from then on this rank's state_dict() carries the LOCAL rows only and the
+        training-mode forward (a full nn.Linear) is not available on it."""
+        self._hip.set_sharding(rank, world, drop_full)
 
     # ---- training-mode path: stock PyTorch autograd, per-row as-called mask
     def _generate_square_subsequent_mask(self, size, pi_factor):
@@ -251,12 +254,12 @@ class IRSNN(nn.Module):
                 cur, nxt = st[i & 1], st[(i & 1) ^ 1]
                 _, xr, _ = eng.decode(cur[0].view(B * W, L), urep, want_x=False, pos=cur[1].view(-1))
                 allrows = g.gather_rows(xr)
-                val, ids, _ = g.topk(allrows, 100, hip.sweep)
+                val, ids, _ = g.topk_own(allrows, 100, hip.sweep)
                 lse = None
                 if W > 1:
                     m, sm = g.lse(allrows)
                     lse = (m[sl].contiguous(), sm[sl].contiguous())
-                eng.beam_step(cur, val[sl].contiguous(), ids[sl].contiguous(), lse, i, nxt, status)
+                eng.beam_step(cur, val, ids, lse, i, nxt, status)
             paths, scores = st[max_path_len & 1][3], st[max_path_len & 1][2]
         self.last_beams = (paths.detach().cpu().numpy(), scores.detach().cpu().numpy())
         return paths[:, 0].contiguous(), status
@@ -289,8 +292,8 @@ class IRSNN(nn.Module):
             for i in range(max_path_len):
                 _, xr, _ = eng.decode(work, users, want_x=False, pos=hep)
                 allrows = hip.group.gather_rows(xr)
-                val, ids, _ = hip.group.topk(allrows, 100, hip.sweep)
-                eng.path_step(work, hep, val[sl].contiguous(), ids[sl].contiguous(), i, paths_t, status, sample, sample_k, seed)
+                val, ids, _ = hip.group.topk_own(allrows, 100, hip.sweep)
+                eng.path_step(work, hep, val, ids, i, paths_t, status, sample, sample_k, seed)
         if int((status & IRS_ROW_NO_CANDIDATE).sum().item()) > 0:
             raise IndexError("index 0 is out of bounds: every top-100 candidate is already in the window "
                              "(same condition as reference influentialRS.py:429)")

@@ -41,8 +41,9 @@ class SampleNet(nn.Module):
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
         return super().load_state_dict(sd, strict=strict, **kw)
 
-    def shard_items(self, rank: int, world: int):
-        self._hip.set_sharding(rank, world)
+    def shard_items(self, rank: int, world: int, drop_full: bool = True):
+        """Item shard [lo, hi) of the catalog on this GPU; see InfluentialNet.shard_items."""
+        self._hip.set_sharding(rank, world, drop_full)
 
     def _generate_square_subsequent_mask(self, sz):
         mask = (torch.triu(torch.ones(sz, sz)) == 1).transpose(0, 1)

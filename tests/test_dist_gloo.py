@@ -2,7 +2,7 @@
 The product's ShardGroup (influentialrs_amd/dist.py) runs unchanged; the
 per-shard scorer is an oracle-backed stand-in for the Engine (test
 infrastructure), so this checks exactly the collective logic: row all-gather,
-per-shard top-k all-gather + merge, max/sum combines."""
+per-shard top-k exchange (packed 64-bit keys: all-gather and all_to_all forms) + merge, max/sum combines."""
 import os
 import socket
 
@@ -41,17 +41,31 @@ class OracleShardScorer:
             ids[m, :len(i)] = torch.from_numpy(i)
         return val, ids, torch.zeros(M, dtype=torch.int32)
 
-    def merge_topk(self, v_all, i_all):
-        W, M, k = v_all.shape
+    # the exchange step's wire format (include/irs_hip.h: irs_pack_topk / irs_merge_topk_keys), restated in numpy
+    @staticmethod
+    def _fkey(v):
+        u = np.ascontiguousarray(v, dtype=np.float32).view(np.uint32).astype(np.uint64)
+        u = np.where(u == 0x80000000, 0, u)
+        return np.where(u & 0x80000000, ~u & 0xFFFFFFFF, u | 0x80000000)
+
+    def pack_topk(self, val, ids):
+        v, i = val.numpy(), ids.numpy()
+        key = (self._fkey(v) << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - i.astype(np.uint64) & np.uint64(0xFFFFFFFF))
+        key = np.where(i >= 0, key, np.uint64(0))
+        return torch.from_numpy(key.view(np.int64).reshape(v.shape))
+
+    def merge_topk_keys(self, keys):
+        W, M, k = keys.shape
+        ku = keys.numpy().view(np.uint64)
         ov = torch.full((M, k), float("-inf"))
         oi = torch.full((M, k), -1, dtype=torch.int64)
         for m in range(M):
-            v = v_all[:, m].reshape(-1).numpy()
-            i = i_all[:, m].reshape(-1).numpy()
-            keep = i >= 0
-            order = np.lexsort((i[keep], -v[keep].astype(np.float64)))[:k]
-            ov[m, :len(order)] = torch.from_numpy(v[keep][order])
-            oi[m, :len(order)] = torch.from_numpy(i[keep][order])
+            srt = np.sort(ku[:, m].reshape(-1))[::-1][:k]
+            srt = srt[srt != 0]
+            f = (srt >> np.uint64(32)).astype(np.uint32)
+            bits = np.where(f & 0x80000000, f & 0x7FFFFFFF, ~f)
+            ov[m, :len(srt)] = torch.from_numpy(bits.astype(np.uint32).view(np.float32).copy())
+            oi[m, :len(srt)] = torch.from_numpy((np.uint64(0xFFFFFFFF) - (srt & np.uint64(0xFFFFFFFF))).astype(np.int64))
         return ov, oi
 
     def score_gather(self, xrows, ids0):
@@ -103,6 +117,14 @@ def _worker(rank, world, port, n_item, d, ret):
         fv, fi, _ = full.score_topk(rows, k, 0)
         assert torch.equal(ids, fi) and torch.equal(val, fv)
         assert torch.equal(ids[grp.my_slice(rows_per_rank)], fi[rank * rows_per_rank:(rank + 1) * rows_per_rank])
+        # the exchange the path-search loops use: one all_to_all of packed keys, own rows only
+        ov, oi, _ = grp.topk_own(rows, k, 0)
+        sl = grp.my_slice(rows_per_rank)
+        assert torch.equal(oi, fi[sl]) and torch.equal(ov, fv[sl])
+        kk = 1200  # more entries than the shard holds on some ranks: (-inf, -1) tails survive the packing
+        tv, ti, _ = grp.topk_own(rows, kk, 0)
+        gv, gi, _ = full.score_topk(rows, kk, 0)
+        assert torch.equal(ti, gi[sl]) and torch.equal(tv, gv[sl])
         probe = torch.from_numpy(g.integers(0, n_item, size=(rows.shape[0], 5)).astype(np.int64))
         assert torch.equal(grp.gather(rows, probe), full.score_gather(rows, probe))
         lab = probe[:, 0].contiguous()

@@ -1,7 +1,9 @@
 """-m gpu: item-sharded front-end handlers with world_size 2 (two processes on the one
 GPU of the test box, gloo for the collectives; on a node it is one process per GPU
-over RCCL).  Each rank holds half of the catalog and its own rows; results must equal
-the reference goldens exactly like the single-GPU run."""
+over RCCL).  Each rank holds half of the catalog and its own rows; greedy paths and
+accuracy metrics must equal the reference goldens exactly like the single-GPU run
+(SURVEY 8e), the sharded beam search must equal the single-device one, and the sharded
+evaluator handlers must equal the evaluator goldens."""
 import os
 import socket
 
@@ -17,7 +19,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _worker(rank, world, port, ret):
     import faulthandler
     import sys
-    faulthandler.dump_traceback_later(150, exit=True)  # a stuck rank reports where, and dies
+    faulthandler.dump_traceback_later(170, exit=True)  # a stuck rank reports where, and dies
     sys.path.insert(0, REPO)
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -49,6 +51,47 @@ def _worker(rank, world, port, ret):
             paths, tt, hh, early = irn.get_seq_in_batch(seq, u, t, P, 0, False, 3)
             assert np.array_equal(paths, g["paths"][sl]), (rank, paths, g["paths"][sl])
         assert net._hip.engine.n_local < cfg.n_item
+        assert net.project.weight.shape[0] == net._hip.engine.n_local, "the module keeps only its shard of project.weight"
+        # ---- beam search, item-sharded (row all-gather, packed top-100 all_to_all, log-sum-exp all-reduce per step)
+        #      against the same search on ONE device holding the whole catalog
+        full = InfluentialNet(cfg)
+        full.load_state_dict({k: torch.from_numpy(v) for k, v in synth.irn_state_dict(cfg, 1234).items()})
+        full.to(dev)
+        irn1 = IRSNN(cfg, full, dev)
+        irn1.eval()
+        nb, Wb, Pb = 4, 3, 6
+        with torch.no_grad():
+            pb, _, _, _ = irn.get_seq_in_batch(seq[:nb], u[:nb], t[:nb], Pb, 0, beam_width=Wb)
+            sp, ss = irn.last_beams
+            p1, _, _, _ = irn1.get_seq_in_batch(seq[:nb], u[:nb], t[:nb], Pb, 0, beam_width=Wb)
+            fp, fs = irn1.last_beams
+        assert np.allclose(ss, fs, rtol=0, atol=2e-4), (ss, fs)
+        for b_ in range(nb):  # ids exact wherever consecutive beam scores are separated by more than the float32 LSE noise
+            gaps = np.abs(np.diff(fs[b_]))
+            n_safe = Wb if gaps.min() > 1e-4 else int(np.argmax(gaps <= 1e-4)) + 1
+            assert np.array_equal(sp[b_, :n_safe], fp[b_, :n_safe]), (b_, sp[b_], fp[b_])
+        assert np.array_equal(pb, sp[:, 0])
+        # ---- evaluator handlers with an item-sharded SampleNet: every rank feeds the SAME batch, the shards'
+        #      counts / maxima / exp-sums / label scores are all-reduced; results equal the reference goldens
+        from influentialrs_amd.model.evaluator import Evaluator
+        from influentialrs_amd.model.uRS import SampleNet
+        ge = np.load(os.path.join(REPO, "tests", "golden", "eval_default.npz"))
+        ecfg = synth.make_config("eval_default")
+        snet = SampleNet(ecfg)
+        snet.load_state_dict({k: torch.from_numpy(v) for k, v in synth.irn_state_dict(ecfg, 17, evaluator=True).items()})
+        snet.to(dev)
+        snet.shard_items(rank, world)
+        ev = Evaluator(ecfg, snet, dev)
+        ev.eval()
+        h, d_, tt_, sp_, lp_ = (torch.from_numpy(ge[k]).to(dev) for k in ("histories", "new_seqs", "targets", "start_pos", "l_paths"))
+        with torch.no_grad():
+            pp = ev.get_pp_in_batch(d_, sp_, lp_)
+            assert np.allclose(pp, ge["pp"], rtol=1e-5, atol=1e-5)
+            irr, ir = ev.get_rr_increase_in_batch(h, d_, tt_)
+            assert np.array_equal(ir, ge["ir"]) and np.allclose(irr, ge["irr"], atol=1e-12)
+            tp, ppb, avg, ioi = ev.get_grad_in_batch(h, d_, tt_, sp_, lp_)
+            assert np.allclose(tp, ge["t_probs"], rtol=1e-5, atol=2e-5) and np.allclose(ppb, ge["p_probs"], rtol=1e-5, atol=2e-5)
+        assert snet._hip.engine.n_local < ecfg.n_item
         ret[rank] = 1
     finally:
         dist.destroy_process_group()

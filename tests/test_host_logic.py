@@ -104,3 +104,25 @@ def test_eval_mode_needs_the_hip_engine():
     ev = Evaluator(synth.make_config("eval_tiny"), SampleNet(synth.make_config("eval_tiny")).eval(), "cpu")
     with pytest.raises(IrsError):
         ev.get_pp_in_batch(torch.ones((2, 13), dtype=torch.int64), torch.tensor([3, 3]), torch.tensor([2, 2]))
+
+
+def test_torch_restatement_matches_numpy_oracle(oracle):
+    """oracle/oracle_torch.py (the restatement bench.py times as the reference-equivalent CPU baseline) against
+    oracle_np.py, which the reference's goldens pin: decoder rows within 2e-5, same greedy step."""
+    import torch
+    from oracle import oracle_torch as OT
+    for name in ("tiny", "c1"):
+        cfg = synth.make_config(name)
+        sd = synth.irn_state_dict(cfg, 1234)
+        irn = OT.TorchIRN(sd, cfg)
+        seqs = synth.random_windows(3, cfg.max_len, cfg.n_item, seed=3)
+        hep = cfg.max_len - 2
+        for r in range(3):
+            x, _ = oracle.decode(sd, cfg, seqs[r], r)
+            xt = irn.decode(torch.from_numpy(seqs[r]), r).numpy()
+            assert np.abs(x - xt).max() < 2e-5
+            s = oracle.score_chain(x[hep], sd["project.weight"], sd["project.bias"])
+            vals, ids0 = oracle.topk(s, 100)
+            nxt = oracle.select_next(ids0 + 1, vals, seqs[r][:hep + 1])
+            got, new = irn.path_step_like_reference(torch.from_numpy(seqs[r]), r, hep)
+            assert got == nxt and new[-2] == nxt and new[-1] == seqs[r][-1]
