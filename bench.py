@@ -65,6 +65,8 @@ def _cpu_row_worker(job):
     W, b = sd["project.weight"], sd["project.bias"]
     hep = cfg.max_len - 2
     with threadpool_limits(limits=1):
+        x, _ = O.decode(sd, cfg, seqs[0], users[0])  # warm-up (page in the weights, BLAS initialisation after the fork)
+        t0 = time.perf_counter()
         for _ in range(steps):
             for r in range(seqs.shape[0]):
                 x, _ = O.decode(sd, cfg, seqs[r], users[r])
@@ -73,7 +75,7 @@ def _cpu_row_worker(job):
                 nxt = O.select_next(ids0 + 1, vals, seqs[r][:hep + 1])
                 seqs[r][:-2] = seqs[r][1:-1].copy()
                 seqs[r][-2] = nxt
-    return seqs.shape[0] * steps
+    return seqs.shape[0] * steps, time.perf_counter() - t0
 
 
 _CPU_SD = None
@@ -146,8 +148,10 @@ def cpu_baseline(cfg_name, budget_s=10.0):
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     with ctx.Pool(len(jobs)) as pool:
-        n_done = sum(pool.map(_cpu_row_worker, jobs))
-    dt_r = time.perf_counter() - t0
+        res = pool.map(_cpu_row_worker, jobs)
+    dt_wall = time.perf_counter() - t0
+    n_done = sum(r_[0] for r_ in res)
+    dt_r = max(r_[1] for r_ in res)  # the slowest worker's compute time (pool start-up excluded)
     row = n_done * cfg.n_item / dt_r
     return {"value": equiv, "unit": "pairs/s", "cores": thr, "kind": "port",
             "sample": f"B-equiv: {done} greedy path steps (4 users, B=1 loop; all {cfg.max_len} rows scored, softmax over "
@@ -155,7 +159,7 @@ def cpu_baseline(cfg_name, budget_s=10.0):
                       f"{thr} threads (fastest of a 4..64-thread calibration)",
             "b_row": {"value": row, "unit": "pairs/s", "cores": len(jobs),
                       "sample": f"{steps} steps x {B} users (consumed row only) over {len(jobs)} single-threaded worker "
-                                f"processes in {dt_r:.1f}s (fork + pool start-up included)"},
+                                f"processes: slowest worker {dt_r:.1f}s ({dt_wall:.1f}s with fork + pool start-up)"},
             "ms_per_user_step_b_equiv": dt_e / max(done, 1) * 1e3,
             "host": {"cpu_model": _cpu_model(), "logical_cpus": cores},
             "b_ref_note": "B-ref (the unmodified reference's pipeline.test_model timed in the build container) is recorded in "
