@@ -185,12 +185,28 @@ __device__ __forceinline__ float irs_unkey(unsigned int k) {
     unsigned int u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
     return __uint_as_float(u);
 }
-// exact score: k-ascending float32 fma chain seeded with the bias
+// exact score: k-ascending float32 fma chain seeded with the bias.  The chain itself is serial; the LOADS of the item
+// row are not: they are requested eight float4 at a time ahead of the fmas that consume them (with one load per
+// loop trip a 128-float row cost 32 dependent memory round trips -- most of k_refine's time).
 __device__ __forceinline__ float irs_chain(const float *__restrict__ x, const float *__restrict__ w, float b, int d) {
     float acc = b;
     if ((d & 3) == 0 && ((((uintptr_t)w) & 15) == 0)) {
         const float4 *w4 = reinterpret_cast<const float4 *>(w);
-        for (int k = 0; k < d / 4; ++k) {
+        const int n4 = d >> 2;
+        int k = 0;
+        for (; k + 8 <= n4; k += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = w4[k + j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc = __fmaf_rn(x[4 * (k + j) + 0], v[j].x, acc);
+                acc = __fmaf_rn(x[4 * (k + j) + 1], v[j].y, acc);
+                acc = __fmaf_rn(x[4 * (k + j) + 2], v[j].z, acc);
+                acc = __fmaf_rn(x[4 * (k + j) + 3], v[j].w, acc);
+            }
+        }
+        for (; k < n4; ++k) {
             float4 v = w4[k];
             acc = __fmaf_rn(x[4 * k + 0], v.x, acc);
             acc = __fmaf_rn(x[4 * k + 1], v.y, acc);

@@ -1041,7 +1041,11 @@ __global__ void __launch_bounds__(256) k_pack_w(const float *__restrict__ W, con
 // 128-byte lines at ROWS = 32, 32-byte pieces at ROWS = 8).  8-bit radix select, per-row LDS histograms; the
 // 256-bin scan of a row is done by its 32 threads (8 bins each + a 32-lane suffix sum).  ROWS = 32 left a
 // 1024-row call on 32 CUs (59 us, as long as a fifth of the sweep); ROWS = 8 spreads it over 128.
-template <int ROWS>
+// REG: G <= 32 * SEL_VPT group maxima per row -> each thread keeps its share in registers for the four radix passes.
+// (The first version re-read gm in every pass with one dependent load per loop trip: ~245 L2 round trips = 58 us
+// whatever the row count -- the largest item of a 32-row irs_score_topk.)
+#define SEL_VPT 64
+template <int ROWS, bool REG>
 __global__ void __launch_bounds__(ROWS * 32) k_select_thr(const float *__restrict__ gm, int G, int M, int M_pad, int k,
                                                           const float *__restrict__ eps, float *__restrict__ thr,
                                                           float *__restrict__ traw) {
@@ -1060,16 +1064,46 @@ __global__ void __launch_bounds__(ROWS * 32) k_select_thr(const float *__restric
         s_prefix[rl] = 0;
         s_k[rl] = k;
     }
+    unsigned int keys[REG ? SEL_VPT : 1];
+    if (REG) {
+#pragma unroll
+        for (int i = 0; i < SEL_VPT; ++i) {
+            const int g = tq + 32 * i;
+            keys[i] = (g < G && row < M) ? irs_fkey(gm[(size_t)g * M_pad + row]) : 0u;
+        }
+    }
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
         for (int i = threadIdx.x; i < ROWS * 257; i += ROWS * 32) (&hist[0][0])[i] = 0;
         __syncthreads();
         const unsigned int prefix = s_prefix[rl];
         if (row < M) {
-            for (int g = tq; g < G; g += 32) {
-                unsigned int key = irs_fkey(gm[(size_t)g * M_pad + row]);
-                bool match = (pass == 0) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
-                if (match) atomicAdd(&hist[rl][(key >> shift) & 255], 1u);
+            if (REG) { // the thread's keys were loaded once, all loads in flight together
+                // Group maxima of one row share their leading digits: in the first passes every key of the row falls
+                // into the same bin, and 2000 LDS atomics on one address serialise (36 us of the kernel).  Runs of equal
+                // bins are counted in registers and added once.
+                unsigned int cur = 0xFFFFFFFFu, run = 0u;
+#pragma unroll
+                for (int i = 0; i < SEL_VPT; ++i) {
+                    const unsigned int key = keys[i];
+                    const bool match = (tq + 32 * i < G) && ((pass == 0) || ((key >> (shift + 8)) == (prefix >> (shift + 8))));
+                    if (match) {
+                        const unsigned int bin = (key >> shift) & 255;
+                        if (bin == cur) ++run;
+                        else {
+                            if (run) atomicAdd(&hist[rl][cur], run);
+                            cur = bin;
+                            run = 1u;
+                        }
+                    }
+                }
+                if (run) atomicAdd(&hist[rl][cur], run);
+            } else {
+                for (int g = tq; g < G; g += 32) {
+                    unsigned int key = irs_fkey(gm[(size_t)g * M_pad + row]);
+                    bool match = (pass == 0) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+                    if (match) atomicAdd(&hist[rl][(key >> shift) & 255], 1u);
+                }
             }
         }
         __syncthreads();
@@ -1171,8 +1205,8 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
                                                 const float *__restrict__ eps, const float *__restrict__ traw, int k,
                                                 int64_t item_lo, int64_t n_local, float *__restrict__ val,
                                                 int64_t *__restrict__ ids, int32_t *__restrict__ status) {
-    __shared__ unsigned long long ckeys[IRS_CAND_CAP];
-    __shared__ unsigned long long rkeys[IRS_REFINE_CAP];
+    __shared__ __attribute__((aligned(16))) unsigned long long ckeys[IRS_CAND_CAP + 2];
+    __shared__ __attribute__((aligned(16))) unsigned long long rkeys[IRS_REFINE_CAP + 2];
     __shared__ unsigned int hist[256];
     __shared__ float xs[256];
     __shared__ unsigned int boff[IRS_CAND_BUCKETS + 1];
@@ -1180,20 +1214,25 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
     const int row = blockIdx.x, tid = threadIdx.x;
     if (tid < IRS_CAND_BUCKETS) hist[tid] = cnt[(size_t)row * IRS_CAND_BUCKETS + tid];
     __syncthreads();
-    if (tid == 0) {
-        unsigned int off = 0, over = 0;
-        for (int b = 0; b < IRS_CAND_BUCKETS; ++b) {
-            unsigned int c = hist[b];
-            if (c > IRS_CAND_SLOTS) over = 1;
-            boff[b] = off;
-            off += (c > IRS_CAND_SLOTS) ? IRS_CAND_SLOTS : c;
+    if (tid < 64) { // exclusive scan of the (clamped) bucket counts by one wave (IRS_CAND_BUCKETS == 64)
+        const unsigned int cb = hist[tid];
+        const unsigned int cl = cb > IRS_CAND_SLOTS ? IRS_CAND_SLOTS : cb;
+        unsigned int incl = cl;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int t = __shfl_up(incl, o, 64);
+            if (tid >= o) incl += t;
         }
-        boff[IRS_CAND_BUCKETS] = off;
-        s_over = over;
-        s_prefix = 0;
-        s_k = k;
-        s_nr = 0;
-        s_above = 0;
+        boff[tid] = incl - cl;
+        if (tid == 63) boff[IRS_CAND_BUCKETS] = incl;
+        const unsigned long long ov = __ballot(cb > IRS_CAND_SLOTS);
+        if (tid == 0) {
+            s_over = ov ? 1u : 0u;
+            s_prefix = 0;
+            s_k = k;
+            s_nr = 0;
+            s_above = 0;
+        }
     }
     __syncthreads();
     if (s_over) { // a bucket overflowed -> the exhaustive kernel redoes the row
@@ -1201,10 +1240,22 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
         return;
     }
     const unsigned int c = boff[IRS_CAND_BUCKETS];
-    for (int idx = tid; idx < IRS_CAND_BUCKETS * IRS_CAND_SLOTS; idx += 256) {
-        const int b = idx / IRS_CAND_SLOTS, sl = idx % IRS_CAND_SLOTS;
-        if ((unsigned int)sl < boff[b + 1] - boff[b])
-            ckeys[boff[b] + sl] = cand[((size_t)row * IRS_CAND_BUCKETS + b) * IRS_CAND_SLOTS + sl];
+    {   // all of a thread's candidate loads are requested before the first is stored (one memory round trip instead of
+        // IRS_CAND_CAP / 256 dependent ones)
+        constexpr int PER = IRS_CAND_BUCKETS * IRS_CAND_SLOTS / 256;
+        unsigned long long v[PER];
+        unsigned int dst[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int idx = tid + 256 * j;
+            const int b = idx / IRS_CAND_SLOTS, sl = idx % IRS_CAND_SLOTS;
+            const bool live = (unsigned int)sl < boff[b + 1] - boff[b];
+            dst[j] = live ? boff[b] + sl : 0xFFFFFFFFu;
+            v[j] = live ? cand[((size_t)row * IRS_CAND_BUCKETS + b) * IRS_CAND_SLOTS + sl] : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            if (dst[j] != 0xFFFFFFFFu) ckeys[dst[j]] = v[j];
     }
     for (int i = tid; i < d; i += 256) xs[i] = x[(size_t)row * d + i];
     __syncthreads();
@@ -1228,10 +1279,21 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
             hist[tid] = 0;
             __syncthreads();
             const unsigned int prefix = s_prefix;
-            for (int i = tid; i < (int)c; i += 256) {
-                unsigned int key = (unsigned int)(ckeys[i] >> 32);
-                bool match = (pass == 0) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
-                if (match) atomicAdd(&hist[(key >> shift) & 255], 1u);
+            for (int i0 = 0; i0 < (int)c; i0 += 256) { // (trip count uniform over the workgroup)
+                const int i = i0 + tid;
+                const unsigned int key = i < (int)c ? (unsigned int)(ckeys[i] >> 32) : 0u;
+                const bool match = i < (int)c && ((pass == 0) || ((key >> (shift + 8)) == (prefix >> (shift + 8))));
+                const unsigned int bin = (key >> shift) & 255;
+                // near-equal scores share their leading digits: when every matching lane of the wave holds the same
+                // bin, one lane adds the count (hundreds of atomics on one LDS address serialise otherwise)
+                const unsigned long long m = __ballot(match);
+                if (m) {
+                    const unsigned int first = __builtin_amdgcn_readlane(bin, __builtin_ctzll(m));
+                    if (__ballot(match && bin == first) == m) {
+                        if ((tid & 63) == __builtin_ctzll(m)) atomicAdd(&hist[first], (unsigned int)__popcll(m));
+                    } else if (match)
+                        atomicAdd(&hist[bin], 1u);
+                }
             }
             __syncthreads();
             if (tid < 64) radix_find_bin(hist, s_k, tid, shift, &s_prefix, &s_k);
@@ -1259,16 +1321,24 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
         float e = irs_chain(xs, W + (size_t)j * d, bias[j], d);
         rkeys[i] = ((unsigned long long)irs_fkey(e) << 32) | (0xFFFFFFFFu - j);
     }
-    int n2 = 2;
-    while (n2 < (int)nr) n2 <<= 1;
-    for (int i = nr + tid; i < n2; i += 256) rkeys[i] = 0ull;
-    bitonic_desc(rkeys, n2);
-    for (int i = tid; i < k; i += 256) {
-        if (i < (int)nr) {
-            unsigned long long kk = rkeys[i];
-            val[(size_t)row * k + i] = irs_unkey((unsigned int)(kk >> 32));
-            ids[(size_t)row * k + i] = item_lo + (int64_t)(0xFFFFFFFFu - (unsigned int)kk);
-        } else {
+    if ((nr & 1) && tid == 0) rkeys[nr] = 0ull; // rkeys has IRS_REFINE_CAP + 2 slots
+    __syncthreads();
+    // final order by rank counting as well (keys distinct): winners go straight to their slots
+    {
+        const ulonglong2 *r2 = reinterpret_cast<const ulonglong2 *>(rkeys);
+        for (int i = tid; i < (int)nr; i += 256) {
+            const unsigned long long me = rkeys[i];
+            int above = 0;
+            for (int j = 0; j < (int)(nr + 1) / 2; ++j) {
+                const ulonglong2 v = r2[j];
+                above += (v.x > me) + (v.y > me);
+            }
+            if (above < k) {
+                val[(size_t)row * k + above] = irs_unkey((unsigned int)(me >> 32));
+                ids[(size_t)row * k + above] = item_lo + (int64_t)(0xFFFFFFFFu - (unsigned int)me);
+            }
+        }
+        for (int i = (int)nr + tid; i < k; i += 256) {
             val[(size_t)row * k + i] = -INFINITY;
             ids[(size_t)row * k + i] = -1;
         }
@@ -1886,12 +1956,21 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
         if (r_sel < 8) r_sel = 8;
         if (r_sel > k) r_sel = k;
     }
-    if (M_pad >= 8192)
-        hipLaunchKernelGGL(k_select_thr<32>, dim3((M_pad + 31) / 32), dim3(1024), 0, s, ctx->gm, G, M, M_pad, r_sel, ctx->eps,
-                           ctx->thr, ctx->ref_tmp);
-    else
-        hipLaunchKernelGGL(k_select_thr<8>, dim3((M_pad + 7) / 8), dim3(256), 0, s, ctx->gm, G, M, M_pad, r_sel, ctx->eps,
-                           ctx->thr, ctx->ref_tmp);
+    {
+        const bool reg = G <= 32 * SEL_VPT;
+        const dim3 g32((M_pad + 31) / 32), g8((M_pad + 7) / 8);
+#define SEL_(ROWS_, REG_, GRID_)                                                                                         \
+    hipLaunchKernelGGL((k_select_thr<ROWS_, REG_>), GRID_, dim3(ROWS_ * 32), 0, s, ctx->gm, G, M, M_pad, r_sel, ctx->eps, \
+                       ctx->thr, ctx->ref_tmp)
+        if (M_pad >= 8192) {
+            if (reg) SEL_(32, true, g32);
+            else SEL_(32, false, g32);
+        } else {
+            if (reg) SEL_(8, true, g8);
+            else SEL_(8, false, g8);
+        }
+#undef SEL_
+    }
     IRS_CHECK_HIP(ctx, hipGetLastError());
 
     // emission sweep over the whole shard
