@@ -579,6 +579,27 @@ def main():
               "parallelism": "single GPU holds the whole catalog" if world == 1 else
                              f"item shards of {j4.eng.n_local} rows x {world}; per step: all-gather of {u4} x {j4.cfg.emb_dim} f32 rows, "
                              f"one all_to_all of {u4} x 100 packed 64-bit keys per rank, merge"}
+        if world == 1 and rank == 0 and not args.no_latency:
+            # BASELINE configs[4] (C5), D1 (ii): beam-width-32 persuasion-path search over the 10M-item catalog for one
+            # user -- 32 windows decoded, scored (top-100 + exact log-sum-exp over the catalog) and re-ranked per step,
+            # 20 steps; p50 over 10 repetitions after 2 warm-ups, stream launches and the captured two-step hipGraph
+            fresh = gpu_windows(4, j4.cfg.max_len, j4.cfg.n_item, device, seed=7)
+            b_seq, b_usr, b_hep = fresh[:1].contiguous(), j4.users[:1].contiguous(), j4.hep[:1].contiguous()
+            c5 = {"workload": "c5: beam 32 x 20 steps, 1 user, n_item=10000000, d=256 (one GPU holds the whole catalog)"}
+            for label, graph in (("stream", False), ("hipgraph", True)):
+                ts = []
+                for it in range(12):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    j4.eng.beam_search(b_seq, b_usr, b_hep, 20, 32, k=100, sweep=j4.sweep, use_graph=graph)
+                    torch.cuda.synchronize()
+                    if it >= 2:
+                        ts.append((time.perf_counter() - t0) * 1e3)
+                c5[f"search_p50_ms_{label}"] = float(np.median(ts))
+                c5[f"step_p50_ms_{label}"] = float(np.median(ts)) / 20
+            # HBM floor of a step: the bf16 catalog once (top-100 sweep) + the fp32 catalog once (exact log-sum-exp)
+            c5["step_hbm_floor_ms"] = (j4.cfg.n_item * j4.cfg.emb_dim * (2.0 + 4.0)) / (PEAK_HBM_GBS * 1e9) * 1e3
+            c4["c5_beam32"] = c5
         del j4
         torch.cuda.empty_cache()
 

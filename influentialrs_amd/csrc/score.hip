@@ -1066,11 +1066,16 @@ __global__ void __launch_bounds__(ROWS * 32) k_select_thr(const float *__restric
     }
     unsigned int keys[REG ? SEL_VPT : 1];
     if (REG) {
+        float raw[SEL_VPT]; // unconditional loads at clamped indices: all in flight together (a load inside a
+                            // conditional gets its own wait: 64 dependent round trips, 32 of this kernel's 37 us)
+        const int rowc = row < M_pad ? row : M_pad - 1;
 #pragma unroll
         for (int i = 0; i < SEL_VPT; ++i) {
             const int g = tq + 32 * i;
-            keys[i] = (g < G && row < M) ? irs_fkey(gm[(size_t)g * M_pad + row]) : 0u;
+            raw[i] = gm[(size_t)(g < G ? g : G - 1) * M_pad + rowc];
         }
+#pragma unroll
+        for (int i = 0; i < SEL_VPT; ++i) keys[i] = (tq + 32 * i < G && row < M) ? irs_fkey(raw[i]) : 0u;
     }
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
@@ -1197,6 +1202,63 @@ __device__ __forceinline__ void radix_find_bin(const unsigned int *hist, unsigne
     }
 }
 
+// Exhaustive exact top-k of one row over the whole shard, by one 256-thread workgroup (fallback of the filter
+// pipeline -- k_refine calls it for a row whose buffers overflowed -- and GPU-side yard-stick): streams every item
+// through the exact chain; keeps the best k by (score desc, id asc).  `buf`: EXH_BUF keys of LDS, `xs`: 256 floats.
+#define EXH_BUF 2048
+__device__ void exhaustive_row(const float *__restrict__ x, int d, const float *__restrict__ W, const float *__restrict__ bias,
+                               int64_t n_local, int64_t item_lo, int k, int row, float *__restrict__ val,
+                               int64_t *__restrict__ ids, int32_t *__restrict__ status, unsigned long long *buf, float *xs,
+                               bool load_x) {
+    __shared__ unsigned int s_n;
+    __shared__ unsigned long long s_thr;
+    const int tid = threadIdx.x;
+    __syncthreads(); // callers may still be reading the LDS this reuses
+    if (load_x)
+        for (int i = tid; i < d; i += 256) xs[i] = x[(size_t)row * d + i];
+    if (tid == 0) {
+        s_n = 0;
+        s_thr = 0ull;
+    }
+    __syncthreads();
+    for (int64_t base = 0; base < n_local; base += 256) {
+        int64_t j = base + tid;
+        if (j < n_local) {
+            float e = irs_chain(xs, W + (size_t)j * d, bias[j], d);
+            unsigned long long key = ((unsigned long long)irs_fkey(e) << 32) | (0xFFFFFFFFu - (unsigned int)j);
+            if (key > s_thr) {
+                unsigned int slot = atomicAdd(&s_n, 1u);
+                buf[slot] = key; // slot < EXH_BUF: compaction below keeps s_n <= EXH_BUF - 256 at loop top
+            }
+        }
+        __syncthreads();
+        if (s_n > EXH_BUF - 256) {
+            unsigned int n = s_n;
+            for (int i = n + tid; i < EXH_BUF; i += 256) buf[i] = 0ull;
+            bitonic_desc(buf, EXH_BUF);
+            if (tid == 0) {
+                s_n = (n < (unsigned int)k) ? n : k;
+                if (n >= (unsigned int)k) s_thr = buf[k - 1];
+            }
+            __syncthreads();
+        }
+    }
+    unsigned int n = s_n;
+    for (int i = n + tid; i < EXH_BUF; i += 256) buf[i] = 0ull;
+    bitonic_desc(buf, EXH_BUF);
+    for (int i = tid; i < k; i += 256) {
+        if (i < (int)n) {
+            unsigned long long kk = buf[i];
+            val[(size_t)row * k + i] = irs_unkey((unsigned int)(kk >> 32));
+            ids[(size_t)row * k + i] = item_lo + (int64_t)(0xFFFFFFFFu - (unsigned int)kk);
+        } else {
+            val[(size_t)row * k + i] = -INFINITY;
+            ids[(size_t)row * k + i] = -1;
+        }
+    }
+    if (tid == 0 && (int)n < k) status[row] |= IRS_ROW_FEWER_THAN_K;
+}
+
 // One workgroup per row: gather the row's bucketed candidates, validate the emission threshold,
 // refine, re-score exactly, sort, write top-k.
 __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int d, const float *__restrict__ W,
@@ -1235,8 +1297,9 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
         }
     }
     __syncthreads();
-    if (s_over) { // a bucket overflowed -> the exhaustive kernel redoes the row
+    if (s_over) { // a bucket overflowed -> the row is redone exhaustively, here
         if (tid == 0) status[row] |= IRS_ROW_FALLBACK;
+        exhaustive_row(x, d, W, bias, n_local, item_lo, k, row, val, ids, status, ckeys, xs, true);
         return;
     }
     const unsigned int c = boff[IRS_CAND_BUCKETS];
@@ -1251,7 +1314,8 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
             const int b = idx / IRS_CAND_SLOTS, sl = idx % IRS_CAND_SLOTS;
             const bool live = (unsigned int)sl < boff[b + 1] - boff[b];
             dst[j] = live ? boff[b] + sl : 0xFFFFFFFFu;
-            v[j] = live ? cand[((size_t)row * IRS_CAND_BUCKETS + b) * IRS_CAND_SLOTS + sl] : 0ull;
+            v[j] = cand[((size_t)row * IRS_CAND_BUCKETS + b) * IRS_CAND_SLOTS + sl]; // every slot is valid memory: unconditional,
+                                                                                       // so the loads are not fenced one by one
         }
 #pragma unroll
         for (int j = 0; j < PER; ++j)
@@ -1269,6 +1333,7 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
         __syncthreads();
         if (s_above < (unsigned int)k) {
             if (tid == 0) status[row] |= IRS_ROW_FALLBACK;
+            exhaustive_row(x, d, W, bias, n_local, item_lo, k, row, val, ids, status, ckeys, xs, false);
             return;
         }
     }
@@ -1313,6 +1378,7 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
     const unsigned int nr = s_nr;
     if (nr > IRS_REFINE_CAP) {
         if (tid == 0) status[row] |= IRS_ROW_FALLBACK;
+        exhaustive_row(x, d, W, bias, n_local, item_lo, k, row, val, ids, status, ckeys, xs, false);
         return;
     }
     // exact re-score
@@ -1346,9 +1412,6 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
     if (tid == 0 && (int)nr < k) status[row] |= IRS_ROW_FEWER_THAN_K;
 }
 
-// Exhaustive exact top-k of one row over the whole shard (fallback and GPU-side yard-stick).
-// Streams every item through the exact chain; keeps the best k by (score desc, id asc).
-#define EXH_BUF 2048
 // Small shard x few rows (the single-user latency path on an ml-1m-sized catalog): the five-kernel filter pipeline
 // costs ~50 us of launches for ~2 us of work.  Here a workgroup scores 64 items of a row with the exact chain into a
 // global key array; the LAST workgroup of the row to finish (arrival counter) selects the k-th largest key and sorts
@@ -1598,52 +1661,9 @@ __global__ void __launch_bounds__(256) k_exhaustive(const float *__restrict__ x,
                                                     int64_t *__restrict__ ids, int32_t *__restrict__ status) {
     __shared__ unsigned long long buf[EXH_BUF];
     __shared__ float xs[256];
-    __shared__ unsigned int s_n;
-    __shared__ unsigned long long s_thr;
-    const int row = blockIdx.x, tid = threadIdx.x;
+    const int row = blockIdx.x;
     if (only_flagged && !(status[row] & IRS_ROW_FALLBACK)) return;
-    for (int i = tid; i < d; i += 256) xs[i] = x[(size_t)row * d + i];
-    if (tid == 0) {
-        s_n = 0;
-        s_thr = 0ull;
-    }
-    __syncthreads();
-    for (int64_t base = 0; base < n_local; base += 256) {
-        int64_t j = base + tid;
-        if (j < n_local) {
-            float e = irs_chain(xs, W + (size_t)j * d, bias[j], d);
-            unsigned long long key = ((unsigned long long)irs_fkey(e) << 32) | (0xFFFFFFFFu - (unsigned int)j);
-            if (key > s_thr) {
-                unsigned int slot = atomicAdd(&s_n, 1u);
-                buf[slot] = key; // slot < EXH_BUF: compaction below keeps s_n <= EXH_BUF - 256 at loop top
-            }
-        }
-        __syncthreads();
-        if (s_n > EXH_BUF - 256) {
-            unsigned int n = s_n;
-            for (int i = n + tid; i < EXH_BUF; i += 256) buf[i] = 0ull;
-            bitonic_desc(buf, EXH_BUF);
-            if (tid == 0) {
-                s_n = (n < (unsigned int)k) ? n : k;
-                if (n >= (unsigned int)k) s_thr = buf[k - 1];
-            }
-            __syncthreads();
-        }
-    }
-    unsigned int n = s_n;
-    for (int i = n + tid; i < EXH_BUF; i += 256) buf[i] = 0ull;
-    bitonic_desc(buf, EXH_BUF);
-    for (int i = tid; i < k; i += 256) {
-        if (i < (int)n) {
-            unsigned long long kk = buf[i];
-            val[(size_t)row * k + i] = irs_unkey((unsigned int)(kk >> 32));
-            ids[(size_t)row * k + i] = item_lo + (int64_t)(0xFFFFFFFFu - (unsigned int)kk);
-        } else {
-            val[(size_t)row * k + i] = -INFINITY;
-            ids[(size_t)row * k + i] = -1;
-        }
-    }
-    if (tid == 0 && (int)n < k) status[row] |= IRS_ROW_FEWER_THAN_K;
+    exhaustive_row(x, d, W, bias, n_local, item_lo, k, row, val, ids, status, buf, xs, true);
 }
 
 // exact scores at chosen items; -inf outside the shard
@@ -1991,9 +2011,7 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
     irs_prof_begin(ctx, IRS_PROF_REFINE, s);
     hipLaunchKernelGGL(k_refine, dim3(M), dim3(256), 0, s, xrows, d, ctx->proj_w, ctx->proj_b, ctx->cand_cnt, ctx->cand,
                        ctx->eps, ctx->ref_tmp, k, ctx->shard.item_lo, ctx->n_local, val, ids0, status);
-    irs_prof_end(ctx, IRS_PROF_REFINE, s, 0.0, 0.0);
-    hipLaunchKernelGGL(k_exhaustive, dim3(M), dim3(256), 0, s, xrows, d, ctx->proj_w, ctx->proj_b, ctx->n_local,
-                       ctx->shard.item_lo, k, 1, val, ids0, status);
+    irs_prof_end(ctx, IRS_PROF_REFINE, s, 0.0, 0.0); // (rows flagged IRS_ROW_FALLBACK were redone exhaustively inside k_refine)
     IRS_CHECK_HIP(ctx, hipGetLastError());
     return IRS_OK;
 }

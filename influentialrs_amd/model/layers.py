@@ -1,6 +1,4 @@
 """Counterpart of the reference's model/layers.py (same names and semantics)."""
-import math
-
 import numpy as np
 import torch
 import torch.nn as nn
@@ -12,12 +10,8 @@ class PositionalEncoding(nn.Module):
 
     def __init__(self, d_model, max_len):
         super().__init__()
-        pe = torch.zeros((max_len, d_model))
-        position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
-        div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
-        pe[:, 0::2] = torch.sin(position * div_term)
-        pe[:, 1::2] = torch.cos(position * div_term)
-        self.register_buffer("pe", pe.unsqueeze(0))
+        from ..synth import positional_encoding  # the package's one definition of the table (float32, [1, max_len, d])
+        self.register_buffer("pe", torch.from_numpy(positional_encoding(d_model, max_len).copy()))
 
     def forward(self, x):
         return self.pe[:, :x.size(1)]
