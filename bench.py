@@ -115,11 +115,14 @@ def cpu_baseline(cfg_name, budget_s=10.0):
     best = None
     for cand in sorted({min(cores, c) for c in (4, 8, 16, 32, 64)}):
         torch.set_num_threads(cand)
-        irn.path_step_like_reference(seqs[0], 0, hep)
-        t0 = time.perf_counter()
         for _ in range(3):
             irn.path_step_like_reference(seqs[0], 0, hep)
-        t = (time.perf_counter() - t0) / 3
+        ts = []
+        for _ in range(12):
+            t0 = time.perf_counter()
+            irn.path_step_like_reference(seqs[0], 0, hep)
+            ts.append(time.perf_counter() - t0)
+        t = float(np.median(ts))
         if best is None or t < best[0]:
             best = (t, cand)
     thr = best[1]

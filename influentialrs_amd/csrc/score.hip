@@ -1147,6 +1147,81 @@ __global__ void __launch_bounds__(ROWS * 32) k_select_thr(const float *__restric
     }
 }
 
+// The same selection for G <= 2048 group maxima per row without histograms: 8 rows per 256-thread workgroup; the
+// rows' keys are transposed through LDS (coalesced global reads, then 32 consecutive lanes own a row, 64 keys per
+// lane in registers) and the r-th largest key is found bit by bit -- count(keys >= candidate) is 64 compares per
+// lane and a five-step shuffle reduction over the row's 32 lanes; the leading bits every key of the row shares are
+// skipped.  (The radix form spent 34 us of a 1024-row call and ~25 us of a 32-row call in LDS atomics on the
+// handful of bins near-equal maxima fall into.)
+#define SEL2_G 2048
+__global__ void __launch_bounds__(256) k_select_thr_bits(const float *__restrict__ gm, int G, int M, int M_pad, int k,
+                                                         const float *__restrict__ eps, float *__restrict__ thr,
+                                                         float *__restrict__ traw) {
+    constexpr int STRIDE = SEL2_G + 8; // row stride = 8 mod 32 words: the transposing stores are at most 2-way conflicted
+    extern __shared__ unsigned int sel_lds[]; // [8][STRIDE]
+    const int tid = threadIdx.x;
+    {
+        const int rl = tid & 7, tq = tid >> 3; // consecutive lanes read consecutive rows of one group
+        const int row = blockIdx.x * 8 + rl;
+        const int rowc = row < M_pad ? row : M_pad - 1;
+        float raw[SEL2_G / 32];
+#pragma unroll
+        for (int i = 0; i < SEL2_G / 32; ++i) {
+            const int g = tq + 32 * i;
+            raw[i] = gm[(size_t)(g < G ? g : G - 1) * M_pad + rowc];
+        }
+#pragma unroll
+        for (int i = 0; i < SEL2_G / 32; ++i) {
+            const int g = tq + 32 * i;
+            sel_lds[rl * STRIDE + g] = (g < G && row < M) ? irs_fkey(raw[i]) : 0u;
+        }
+    }
+    __syncthreads();
+    const int rr = tid >> 5, l = tid & 31; // row of this half-wave, lane within the row
+    const int row = blockIdx.x * 8 + rr;
+    unsigned int key[SEL2_G / 32];
+    unsigned int mx = 0u, mn = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < SEL2_G / 32; ++i) {
+        key[i] = sel_lds[rr * STRIDE + l + 32 * i];
+        mx = key[i] > mx ? key[i] : mx;
+        if (l + 32 * i < G) mn = key[i] < mn ? key[i] : mn;
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        const unsigned int a = __shfl_xor(mx, o, 32), b = __shfl_xor(mn, o, 32);
+        mx = a > mx ? a : mx;
+        mn = b < mn ? b : mn;
+    }
+    // keys of the row agree on their bits above `top`; the answer carries those bits too
+    // (tried: ballots + scalar popcounts instead of the shuffle reduction -- 64 v_cmp -> s_bcnt1 pairs per bit: slower)
+    const unsigned int diff = mx ^ mn;
+    const int top = diff ? 31 - __builtin_clz(diff) : -1;
+    unsigned int prefix = top >= 31 ? 0u : (mx & ~((2u << top) - 1u));
+    if (top < 0) prefix = mx;
+    for (int bit = top; bit >= 0; --bit) {
+        const unsigned int cand = prefix | (1u << bit);
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0; // four partial counts: shorter dependent add chains
+#pragma unroll
+        for (int i = 0; i < SEL2_G / 32; i += 4) {
+            c0 += key[i] >= cand ? 1 : 0;
+            c1 += key[i + 1] >= cand ? 1 : 0;
+            c2 += key[i + 2] >= cand ? 1 : 0;
+            c3 += key[i + 3] >= cand ? 1 : 0;
+        }
+        int cnt = (c0 + c1) + (c2 + c3);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 32);
+        if (cnt >= k) prefix = cand;
+    }
+    if (l == 0 && row < M_pad) {
+        const bool enough = G >= k;
+        const float t = enough ? irs_unkey(prefix) : -INFINITY;
+        thr[row] = (row < M) ? (enough ? t - 2.0f * eps[row] : -INFINITY) : INFINITY;
+        traw[row] = (row < M) ? t : INFINITY;
+    }
+}
+
 // in-LDS bitonic sort, descending, n a power of two, 256 threads
 __device__ __forceinline__ void bitonic_desc(unsigned long long *keys, int n) {
     for (int size = 2; size <= n; size <<= 1) {
@@ -1764,9 +1839,10 @@ static void launch_ring(SweepArgs &a, hipStream_t s) {
     }
     if (MODE == MODE_EMIT) {
         // Equal strips, sized so that the grid is just under a whole number of rounds of resident workgroups: the
-        // time of a sweep is rounds x strip length, and a grid of 2.06 rounds costs 3 (measured: 322 vs 264 us).
+        // time of a sweep is rounds x strip length, and a grid of 2.06 rounds costs 3 (measured: 322 vs 264 us).  Four rounds of shorter strips balance a little
+        // better than two or three of longer ones (lab: -4 % at both catalog shapes).
         const int nt = a.tile_end - a.tile_begin;
-        int rounds = 3;
+        int rounds = 4;
         while (rounds > 1 && (long long)nt * a.n_ublocks < (long long)rounds * slots * 16) --rounds; // >= 16 tiles per strip
         int strips = (int)((long long)rounds * slots / a.n_ublocks) & ~7; // strips of one XCD class are multiples of 8
         if (strips < 8) strips = 8;
@@ -1976,7 +2052,16 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
         if (r_sel < 8) r_sel = 8;
         if (r_sel > k) r_sel = k;
     }
-    {
+    if (G <= SEL2_G && M_pad < 8192) {
+        const size_t lds = (size_t)8 * (SEL2_G + 8) * sizeof(unsigned int);
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_select_thr_bits), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(k_select_thr_bits, dim3((M_pad + 7) / 8), dim3(256), lds, s, ctx->gm, G, M, M_pad, r_sel, ctx->eps,
+                           ctx->thr, ctx->ref_tmp);
+    } else {
         const bool reg = G <= 32 * SEL_VPT;
         const dim3 g32((M_pad + 31) / 32), g8((M_pad + 7) / 8);
 #define SEL_(ROWS_, REG_, GRID_)                                                                                         \
