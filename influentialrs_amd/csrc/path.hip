@@ -93,30 +93,34 @@ __global__ void __launch_bounds__(256) k_merge(const float *__restrict__ val_in,
 //   new beams: window grown / shifted exactly like the greedy step, path extended.
 // W == 1 reduces to the greedy step of k_path_step bit for bit (the single live beam's first
 // survivor wins whatever its score; lse_* may then be null).
-// One workgroup (256 threads) per user; state is ping-ponged (in -> out).
+// One workgroup (one wave per beam, at most 16 waves) per user; state is ping-ponged (in -> out).
+// A beam's candidates are taken 64 at a time into registers (one per lane) before the survivor scan, so the
+// scan is a chain of v_readlane + ballot, not of dependent global loads; the W best of the W*W candidates are ordered
+// by rank counting (no barriers) instead of a full sort.
 #define BEAM_MAXW 32
-__global__ void __launch_bounds__(256) k_beam_step(const int64_t *__restrict__ seq_in, const int32_t *__restrict__ hep_in,
-                                                   const double *__restrict__ cum_in, const float *__restrict__ paths_in,
-                                                   const float *__restrict__ val, const int64_t *__restrict__ ids0,
-                                                   const float *__restrict__ lse_max, const float *__restrict__ lse_sum,
-                                                   int W, int L, int k, int step_arg, const int32_t *__restrict__ step_ptr,
-                                                   int P, int64_t *__restrict__ seq_out, int32_t *__restrict__ hep_out,
-                                                   double *__restrict__ cum_out, float *__restrict__ paths_out,
-                                                   int32_t *__restrict__ status) {
+__global__ void __launch_bounds__(1024) k_beam_step(const int64_t *__restrict__ seq_in, const int32_t *__restrict__ hep_in,
+                                                    const double *__restrict__ cum_in, const float *__restrict__ paths_in,
+                                                    const float *__restrict__ val, const int64_t *__restrict__ ids0,
+                                                    const float *__restrict__ lse_max, const float *__restrict__ lse_sum,
+                                                    int W, int L, int k, int step_arg, const int32_t *__restrict__ step_ptr,
+                                                    int P, int64_t *__restrict__ seq_out, int32_t *__restrict__ hep_out,
+                                                    double *__restrict__ cum_out, float *__restrict__ paths_out,
+                                                    int32_t *__restrict__ status) {
     __shared__ double c_score[BEAM_MAXW * BEAM_MAXW];
     __shared__ int64_t c_item[BEAM_MAXW * BEAM_MAXW];
-    __shared__ int c_order[BEAM_MAXW * BEAM_MAXW];
-    __shared__ int c_count[BEAM_MAXW];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int c_order[BEAM_MAXW];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6;
     const int step = step_ptr ? step_ptr[0] : step_arg;
     const int WW = W * W;
-    for (int i = tid; i < WW; i += 256) {
+    for (int i = tid; i < WW; i += nthr) {
         c_score[i] = -INFINITY;
         c_item[i] = 0;
     }
+    if (tid < BEAM_MAXW) c_order[tid] = WW; // "no candidate of this rank"
     __syncthreads();
     // phase 1: survivors of every live beam (one wave per beam)
-    for (int j = wave; j < W; j += 4) {
+    for (int j = wave; j < W; j += nwave) {
         const int row = b * W + j;
         const double cj = cum_in[row];
         int found = 0;
@@ -131,53 +135,50 @@ __global__ void __launch_bounds__(256) k_beam_step(const int64_t *__restrict__ s
             }
             double norm = 0.0;
             if (lse_max) norm = (double)lse_max[row] + log((double)lse_sum[row]);
-            for (int c = 0; c < k && found < W; ++c) {
-                int64_t id0 = ids0[(size_t)row * k + c];
-                if (id0 < 0) break;
-                int64_t item = id0 + 1;
-                bool hit = false;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) hit |= (wv[i] == item);
-                if (!__any(hit)) {
-                    if (lane == 0) {
-                        c_score[j * W + found] = cj + ((double)val[(size_t)row * k + c] - norm);
-                        c_item[j * W + found] = item;
+            bool more = true;
+            for (int c0 = 0; c0 < k && found < W && more; c0 += 64) { // 64 candidates per round, one per lane
+                const int cl = c0 + lane;
+                const int64_t cid = cl < k ? ids0[(size_t)row * k + cl] : (int64_t)-1;
+                const float cv = cl < k ? val[(size_t)row * k + cl] : 0.f;
+                for (int c = 0; c < 64 && c0 + c < k && found < W; ++c) {
+                    const int64_t id0 = __shfl(cid, c, 64);
+                    if (id0 < 0) { // end of the list (fewer than k items on this shard / excluded)
+                        more = false;
+                        break;
                     }
-                    ++found;
+                    const int64_t item = id0 + 1;
+                    bool hit = false;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) hit |= (wv[q] == item);
+                    if (!__any(hit)) {
+                        const float v = __shfl(cv, c, 64);
+                        if (lane == 0) {
+                            c_score[j * W + found] = cj + ((double)v - norm);
+                            c_item[j * W + found] = item;
+                        }
+                        ++found;
+                    }
                 }
             }
             if (found == 0 && lane == 0) atomicOr(&status[b], IRS_ROW_NO_CANDIDATE);
         }
-        if (lane == 0) c_count[j] = found;
     }
     __syncthreads();
-    // phase 2: order candidates by (score desc, index asc); index = parent * W + rank
-    int n2 = 2;
-    while (n2 < WW) n2 <<= 1;
-    for (int i = tid; i < n2; i += 256) c_order[i] = i;
-    // indices >= WW compare as -inf with a larger index: they sink to the end
-    auto before = [&](int x, int y) {
-        double sx = x < WW ? c_score[x] : -INFINITY, sy = y < WW ? c_score[y] : -INFINITY;
-        return sx > sy || (sx == sy && x < y);
-    };
-    for (int size = 2; size <= n2; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int i = tid; i < n2 / 2; i += 256) {
-                int lo = 2 * i - (i & (stride - 1));
-                int hi = lo + stride;
-                bool asc = ((lo & size) == 0); // "ascending rank" = best first
-                int x = c_order[lo], y = c_order[hi];
-                if (before(y, x) == asc) {
-                    c_order[lo] = y;
-                    c_order[hi] = x;
-                }
+    // phase 2: rank of every candidate by (score desc, index asc), index = parent * W + rank in parent; ranks < W survive
+    for (int x = tid; x < WW; x += nthr) {
+        const double sx = c_score[x];
+        if (sx > -INFINITY) {
+            int rank = 0;
+            for (int y = 0; y < WW; ++y) {
+                const double sy = c_score[y];
+                rank += (sy > sx || (sy == sx && y < x)) ? 1 : 0;
             }
+            if (rank < W) c_order[rank] = x;
         }
     }
     __syncthreads();
     // phase 3: materialise the new beams (one wave per new beam)
-    for (int t = wave; t < W; t += 4) {
+    for (int t = wave; t < W; t += nwave) {
         const int ci = c_order[t];
         const double sc = ci < WW ? c_score[ci] : -INFINITY;
         const int orow = b * W + t;
@@ -241,7 +242,9 @@ int irs_launch_beam_step(irs_ctx *ctx, const int64_t *seq_in, const int32_t *hep
                          int64_t *seq_out, int32_t *hep_out, double *cum_out, float *paths_out, int32_t *status,
                          hipStream_t s) {
     if (W < 1 || W > BEAM_MAXW) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "beam width %d outside [1, %d]", W, BEAM_MAXW);
-    hipLaunchKernelGGL(k_beam_step, dim3(B), dim3(256), 0, s, seq_in, hep_in, cum_in, paths_in, val, ids0, lse_max,
+    if (ctx->dims.max_len > 256) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "beam step: window length %d > 256", ctx->dims.max_len);
+    const int waves = W < 4 ? 4 : (W > 16 ? 16 : W);
+    hipLaunchKernelGGL(k_beam_step, dim3(B), dim3(64 * waves), 0, s, seq_in, hep_in, cum_in, paths_in, val, ids0, lse_max,
                        lse_sum, W, ctx->dims.max_len, k, step, step_ptr, P, seq_out, hep_out, cum_out, paths_out, status);
     IRS_CHECK_HIP(ctx, hipGetLastError());
     return IRS_OK;

@@ -776,6 +776,9 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_sweep_ring(SweepArgs a) {
 template <int KS, int UB, int MODE, bool VEC>
 __global__ void __launch_bounds__(256, 2) k_sweep_f32(SweepArgs a) {
     constexpr int QN = 2 * KS; // float4 groups per row (d_pad / 8)
+    // The log-sum-exp is a float32 sum of exp() over the catalog in no particular order: it does not need the chain's
+    // summation order, so each lane loads ONE float4 per 8 k (its half's four consecutive k) instead of two.
+    constexpr bool PERM = MODE == MODE_LSE && VEC;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *xs4 = reinterpret_cast<float4 *>(smem); // [UB][QN][64]
     int strip, ublock;
@@ -792,11 +795,19 @@ __global__ void __launch_bounds__(256, 2) k_sweep_f32(SweepArgs a) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < a.M) {
             const float *xr = a.x32 + (size_t)row * a.d;
-            int k = 8 * q + hh;
-            if (k < a.d) v.x = xr[k];
-            if (k + 2 < a.d) v.y = xr[k + 2];
-            if (k + 4 < a.d) v.z = xr[k + 4];
-            if (k + 6 < a.d) v.w = xr[k + 6];
+            if (PERM) { // half h holds k = 8q + 4h + c: same pairing on both operands, another summation order
+                int k = 8 * q + 4 * hh;
+                if (k < a.d) v.x = xr[k];
+                if (k + 1 < a.d) v.y = xr[k + 1];
+                if (k + 2 < a.d) v.z = xr[k + 2];
+                if (k + 3 < a.d) v.w = xr[k + 3];
+            } else {
+                int k = 8 * q + hh;
+                if (k < a.d) v.x = xr[k];
+                if (k + 2 < a.d) v.y = xr[k + 2];
+                if (k + 4 < a.d) v.z = xr[k + 4];
+                if (k + 6 < a.d) v.w = xr[k + 6];
+            }
         }
         xs4[i] = v;
     }
@@ -827,7 +838,15 @@ __global__ void __launch_bounds__(256, 2) k_sweep_f32(SweepArgs a) {
         // A fragments for the whole tile
         float4 af[QN];
         const int64_t item = (int64_t)t * 32 + r;
-        if (VEC) {
+        if (PERM) {
+            const float *wr = a.w32 + (size_t)(item < a.n_local ? item : 0) * a.d + 4 * h;
+#pragma unroll
+            for (int q = 0; q < QN; ++q) {
+                float4 s = *reinterpret_cast<const float4 *>(wr + 8 * q);
+                if (item >= a.n_local) s = make_float4(0.f, 0.f, 0.f, 0.f);
+                af[q] = s;
+            }
+        } else if (VEC) {
             const float *wr = a.w32 + (size_t)(item < a.n_local ? item : 0) * a.d;
 #pragma unroll
             for (int q = 0; q < QN; ++q) {
@@ -1792,19 +1811,39 @@ __global__ void k_localize_ref(const int64_t *__restrict__ ref_id0, int64_t item
     if (i < M) out[i] = ref_id0[i] - item_lo; // may be negative / >= n_local: then only the score decides
 }
 
-__global__ void k_lse_reduce(const float *__restrict__ part, int slots, int M_pad, int M, float *__restrict__ out_max,
-                             float *__restrict__ out_sum) {
-    int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= M) return;
-    float m = -INFINITY;
-    for (int s = 0; s < slots; ++s) m = fmaxf(m, part[((size_t)s * M_pad + row) * 2]);
-    float acc = 0.f;
-    for (int s = 0; s < slots; ++s) {
-        float pm = part[((size_t)s * M_pad + row) * 2], ps = part[((size_t)s * M_pad + row) * 2 + 1];
-        if (pm > -INFINITY) acc += ps * __expf(pm - m);
+// one workgroup per row: threads stride over the partial (max, sum) pairs with an online rescale, then a fixed tree
+__global__ void __launch_bounds__(256) k_lse_reduce(const float *__restrict__ part, int slots, int M_pad, int M,
+                                                    float *__restrict__ out_max, float *__restrict__ out_sum) {
+    __shared__ float sm[4], ss[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    float m = -INFINITY, acc = 0.f;
+    for (int s = tid; s < slots; s += 256) {
+        const float2 p = *reinterpret_cast<const float2 *>(part + ((size_t)s * M_pad + row) * 2);
+        if (p.x > -INFINITY) {
+            const float nm = fmaxf(m, p.x);
+            acc = acc * __expf(m - nm) + p.y * __expf(p.x - nm);
+            m = nm;
+        }
     }
-    out_max[row] = m;
-    out_sum[row] = acc;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float om = __shfl_xor(m, off, 64), oa = __shfl_xor(acc, off, 64);
+        const float nm = fmaxf(m, om);
+        acc = (nm > -INFINITY) ? acc * __expf(m - nm) + oa * __expf(om - nm) : 0.f;
+        m = nm;
+    }
+    if ((tid & 63) == 0) {
+        sm[tid >> 6] = m;
+        ss[tid >> 6] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float fm = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])), fa = 0.f;
+        for (int w = 0; w < 4; ++w)
+            if (sm[w] > -INFINITY) fa += ss[w] * __expf(sm[w] - fm);
+        out_max[row] = fm;
+        out_sum[row] = fa;
+    }
 }
 
 // =============================== host side ===============================
@@ -2175,7 +2214,7 @@ int irs_launch_lse(irs_ctx *ctx, const float *xrows, int M, float *out_max, floa
     irs_prof_end(ctx, IRS_PROF_SWEEP, s, 2.0 * ctx->dims.d * (double)M * (double)ctx->n_local,
                  (double)ctx->n_local * ctx->dims.d * 4.0);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_lse_reduce, dim3((M + 255) / 256), dim3(256), 0, s, ctx->lse_part, slots, a.M_pad, M, out_max,
+    hipLaunchKernelGGL(k_lse_reduce, dim3(M), dim3(256), 0, s, ctx->lse_part, slots, a.M_pad, M, out_max,
                        out_sum);
     IRS_CHECK_HIP(ctx, hipGetLastError());
     return IRS_OK;
