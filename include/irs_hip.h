@@ -184,6 +184,14 @@ int irs_score_dense(irs_ctx *ctx, const float *dev_xrows, int32_t M, float *dev_
  * (max of maxes, rescaled sum). */
 int irs_score_lse(irs_ctx *ctx, const float *dev_xrows, int32_t M, float *dev_max, float *dev_sumexp, void *stream);
 
+/* irs_score_topk and irs_score_lse of the same rows out of ONE call: what a beam-search step needs (candidates +
+ * the log-softmax normaliser, influentialRS.py:418-421 with LogSoftmax instead of Softmax).  On the swept path
+ * with IRS_SWEEP_BF16 the threshold still comes from the bf16 pre-pass, but candidates and (max, sum exp) come
+ * out of a single pass over the float32 catalog; results equal the two separate calls' (ids and values bit for
+ * bit; the pair (max, sum) to float32 rounding). */
+int irs_score_topk_lse(irs_ctx *ctx, const float *dev_xrows, int32_t M, int32_t k, int32_t sweep, float *dev_val,
+                       int64_t *dev_ids0, int32_t *dev_status, float *dev_max, float *dev_sumexp, void *stream);
+
 /* Merge W per-shard top-k lists (after the RCCL all-gather) into
  * the global top-k with the same total order.
  *  dev_val_in float [W, M, k], dev_ids_in int64 [W, M, k] (ids -1 ignored) */

@@ -47,6 +47,8 @@ SIGNATURES = {
     "irs_score_count_before": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "irs_score_dense": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
     "irs_score_lse": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "irs_score_topk_lse": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p]),
     "irs_build_eval_batch": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64,
                                        c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "irs_merge_topk": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),

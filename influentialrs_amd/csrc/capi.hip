@@ -419,6 +419,17 @@ extern "C" int irs_score_lse(irs_ctx *ctx, const float *xrows, int32_t M, float 
     return irs_launch_lse(ctx, xrows, M, omax, osum, (hipStream_t)stream);
 }
 
+extern "C" int irs_score_topk_lse(irs_ctx *ctx, const float *xrows, int32_t M, int32_t k, int32_t sweep, float *val,
+                                  int64_t *ids0, int32_t *status, float *omax, float *osum, void *stream) {
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if ((rc = check_rows(ctx, "irs_score_topk_lse", xrows, M))) return rc;
+    if (k < 1 || k > ctx->dims.max_k || !val || !ids0 || !status || !omax || !osum)
+        IRS_FAIL(ctx, IRS_E_INVALID, "irs_score_topk_lse: bad k / outputs");
+    if (sweep != IRS_SWEEP_BF16 && sweep != IRS_SWEEP_F32) IRS_FAIL(ctx, IRS_E_INVALID, "irs_score_topk_lse: bad sweep");
+    return irs_launch_topk(ctx, xrows, M, k, sweep, val, ids0, status, (hipStream_t)stream, nullptr, omax, osum);
+}
+
 extern "C" int irs_merge_topk(irs_ctx *ctx, const float *val_in, const int64_t *ids_in, int32_t W, int32_t M, int32_t k,
                               float *val, int64_t *ids0, void *stream) {
     if (!ctx) return IRS_E_INVALID;
@@ -581,8 +592,10 @@ static int enqueue_beam_step(irs_ctx *ctx, int in, int B, int W, int k, int swee
     const int out = in ^ 1, rows = B * W;
     int rc;
     if ((rc = irs_launch_decode(ctx, ctx->bm_seq[in], ctx->bm_user, rows, nullptr, ctx->bm_hep[in], ctx->xrows, nullptr, s))) return rc;
-    if ((rc = irs_launch_topk(ctx, ctx->xrows, rows, k, sweep, ctx->top_val, ctx->top_ids, ctx->row_status, s))) return rc;
-    if (W > 1 && (rc = irs_launch_lse(ctx, ctx->xrows, rows, ctx->lse_max, ctx->lse_sum, s))) return rc;
+    // W > 1: top-k and log-sum-exp out of one call (one pass over the float32 catalog on the swept path)
+    if ((rc = irs_launch_topk(ctx, ctx->xrows, rows, k, sweep, ctx->top_val, ctx->top_ids, ctx->row_status, s, nullptr,
+                              W > 1 ? ctx->lse_max : nullptr, W > 1 ? ctx->lse_sum : nullptr)))
+        return rc;
     if ((rc = irs_launch_beam_step(ctx, ctx->bm_seq[in], ctx->bm_hep[in], ctx->bm_cum[in], ctx->bm_paths[in], ctx->top_val,
                                    ctx->top_ids, W > 1 ? ctx->lse_max : nullptr, W > 1 ? ctx->lse_sum : nullptr, B, W, k, 0,
                                    ctx->step_ctr, P, ctx->bm_seq[out], ctx->bm_hep[out], ctx->bm_cum[out],

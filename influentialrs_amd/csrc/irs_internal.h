@@ -143,7 +143,8 @@ int irs_launch_pack_w(irs_ctx *ctx, hipStream_t s);
 struct irs_path_args;
 bool irs_topk_is_direct(const irs_ctx *ctx, int M, int k);
 int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, float *val, int64_t *ids0,
-                    int32_t *status, hipStream_t s, const irs_path_args *path = nullptr);
+                    int32_t *status, hipStream_t s, const irs_path_args *path = nullptr, float *lse_max = nullptr,
+                    float *lse_sum = nullptr);
 int irs_launch_gather(irs_ctx *ctx, const float *xrows, int M, const int64_t *ids0, int g, float *out, hipStream_t s);
 int irs_launch_count_before(irs_ctx *ctx, const float *xrows, int M, const float *ref_score, const int64_t *ref_id0,
                             const int64_t *excl, int n_excl, int64_t *count, hipStream_t s);

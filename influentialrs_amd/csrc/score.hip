@@ -962,6 +962,111 @@ __global__ void __launch_bounds__(256, 2) k_sweep_f32(SweepArgs a) {
     }
 }
 
+// Log-sum-exp over the catalog, one wave per SIMD (512 registers): a tile's 32 W rows go row-major from global
+// memory straight into MFMA A fragments (lane (r, h): row r, four consecutive k of half h per 8 k -- the pairing of
+// k is the same on both operands, the summation order is not the chain's, which a sum of exp() does not need), the
+// next tile's fragments are requested before the current tile's MFMAs start.  The x image sits in LDS.
+// EMIT: the same pass also emits every item whose float32 score reaches the row's emission threshold (a.thr, from the
+// bf16 pre-pass) -- a search that needs both the top-k and the log-sum-exp (beam search) then reads the float32
+// catalog once and the bf16 one not at all.  The scores here differ from the chain's by < eps[row] (a different
+// float32 summation order is within the accumulation term of eps), so k_refine's validity test holds unchanged.
+template <int KS, int UB, bool EMIT>
+__global__ void __launch_bounds__(256, 1) k_lse_f32(SweepArgs a) {
+    constexpr int QN = 2 * KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *xs4 = reinterpret_cast<float4 *>(smem); // [UB][QN][64]
+    int strip, ublock;
+    if (!sweep_map(a, strip, ublock)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int ut0 = ublock * UB;
+    const int ubc = min(UB, a.UT - ut0);
+    EmitQ eq = emit_queue(smem + (size_t)UB * KS * 2048, wave);
+    for (int i = tid; i < ubc * QN * 64; i += 256) {
+        const int ln = i & 63, q = (i >> 6) % QN, u = (i >> 6) / QN;
+        const int row = (ut0 + u) * 32 + (ln & 31);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < a.M) v = *reinterpret_cast<const float4 *>(a.x32 + (size_t)row * a.d + 8 * q + 4 * (ln >> 5));
+        xs4[i] = v;
+    }
+    __syncthreads();
+    const int gw = strip * 4 + wave;
+    const int ts = a.tile_stride;
+    const int t0 = a.tile_begin + gw * a.tiles_per_wave * ts;
+    const int t1 = min(t0 + a.tiles_per_wave * ts, a.tile_end);
+    float mx[UB], sm[UB], thr[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+        mx[u] = -INFINITY;
+        sm[u] = 0.f;
+        thr[u] = (EMIT && u < ubc) ? fmaxf(a.thr[(ut0 + u) * 32 + r], -3.0e38f) : INFINITY;
+    }
+    if (t0 < t1) {
+        const int tlast = t0 + ((t1 - 1 - t0) / ts) * ts;
+        // loads are unconditional (a request past the strip re-reads its last tile): a load under a branch costs a
+        // full vmcnt(0) where the branches meet.  Pad items read row 0; their bias is -inf, so is their score.
+        auto load = [&](float4(&af)[QN], float4(&bc)[4], int t) {
+            const int tc = min(t, tlast);
+            const int64_t item = (int64_t)tc * 32 + r;
+            const float *wr = a.w32 + (size_t)(item < a.n_local ? item : 0) * a.d + 4 * h;
+#pragma unroll
+            for (int q = 0; q < QN; ++q) af[q] = *reinterpret_cast<const float4 *>(wr + 8 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bc[q] = *reinterpret_cast<const float4 *>(a.bias + (size_t)tc * 32 + 8 * q + 4 * h);
+        };
+        auto compute = [&](const float4(&af)[QN], const float4(&bc)[4], int t) {
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (u < ubc) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[4 * q + 0] = bc[q].x;
+                        acc[4 * q + 1] = bc[q].y;
+                        acc[4 * q + 2] = bc[q].z;
+                        acc[4 * q + 3] = bc[q].w;
+                    }
+#pragma unroll
+                    for (int q = 0; q < QN; ++q) {
+                        const float4 bv = xs4[(u * QN + q) * 64 + lane];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].x, bv.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].y, bv.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].z, bv.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].w, bv.w, acc, 0, 0, 0);
+                    }
+                    if (EMIT) emit_candidates(a, acc, thr[u], (ut0 + u) * 32 + r, t, h, eq, lane);
+                    const float m = fmaxf(mx[u], max16(acc));
+                    if (m > -INFINITY) {
+                        float sacc = sm[u] * __expf(mx[u] - m);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) sacc += __expf(acc[i] - m);
+                        mx[u] = m;
+                        sm[u] = sacc;
+                    }
+                }
+            }
+        };
+        float4 fa[QN], fb[QN], ba[4], bb[4];
+        load(fa, ba, t0);
+        for (int t = t0; t < t1; t += 2 * ts) {
+            load(fb, bb, t + ts);
+            compute(fa, ba, t);
+            if (t + ts >= t1) break;
+            load(fa, ba, t + 2 * ts);
+            compute(fb, bb, t + ts);
+        }
+    }
+    if (EMIT) emit_flush(a, eq, lane);
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+        if (u >= ubc) continue;
+        float *p = a.lse_part + ((size_t)(gw * 2 + h) * a.M_pad + (ut0 + u) * 32 + r) * 2;
+        p[0] = mx[u];
+        p[1] = sm[u];
+    }
+}
+
 // =============================== small kernels ===============================
 // 8 consecutive k of one row -> one 16-byte bf16 fragment piece (RNE, finite inputs).  Accumulates the squared
 // norms the error bound is made of: ss of the values, ssr of the rounded values, ssd of the rounding errors
@@ -2005,6 +2110,39 @@ static void sweep_decompose(SweepArgs &a, int tile_begin, int tile_end, int n_ub
     if (a.n_strips < 1) a.n_strips = 1;
 }
 
+// the double-buffered log-sum-exp kernel loads 16-byte fragments: d = d_pad and aligned operands
+static bool lse_fast_ok(const irs_ctx *ctx, const SweepArgs &a) {
+    return ctx->KS >= 2 && a.d == ctx->KS * 16 && ((((uintptr_t)a.w32) & 15) == 0) && ((((uintptr_t)a.x32) & 15) == 0);
+}
+
+template <bool EMIT>
+static int launch_lse_f32(irs_ctx *ctx, SweepArgs &a, hipStream_t s) {
+    const int KS = ctx->KS, UB = ub_f32(KS);
+    a.n_ublocks = (a.UT + UB - 1) / UB;
+    dim3 grid(((a.n_strips + 7) / 8) * 8 * a.n_ublocks);
+    const size_t lds = (size_t)UB * KS * 2048 + EMIT_Q_BYTES;
+#define L_(KS_, UB_)                                                                                                      \
+    do {                                                                                                                  \
+        static bool attr = false;                                                                                         \
+        if (!attr) {                                                                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lse_f32<KS_, UB_, EMIT>),                          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+            attr = true;                                                                                                  \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((k_lse_f32<KS_, UB_, EMIT>), grid, dim3(256), lds, s, a);                                      \
+    } while (0)
+    switch (KS) {
+    case 2: L_(2, 8); break;
+    case 4: L_(4, 8); break;
+    case 8: L_(8, 4); break;
+    case 16: L_(16, 2); break;
+    default: IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "unsupported d_pad %d", ctx->d_pad);
+    }
+#undef L_
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}
+
 int irs_launch_pack_w(irs_ctx *ctx, hipStream_t s) {
     IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->wnorm_max, 0, 4 * sizeof(float), s));
     int64_t rows = (int64_t)ctx->n_tiles * 32;
@@ -2019,8 +2157,11 @@ bool irs_topk_is_direct(const irs_ctx *ctx, int M, int k) {
     return M <= 1024 && ctx->n_local <= DIRECT_MAX_ITEMS && k <= 256 && ctx->dims.d <= DIRECT_MAX_D;
 }
 
+// lse_max / lse_sum non-null: the rows' log-sum-exp over the shard as well (beam search).  On the swept path with the
+// bf16 filter it comes out of the SAME pass as the candidates: pre-pass and threshold on the bf16 catalog sample as
+// usual, then one sweep of the float32 catalog that emits against the threshold and accumulates (max, sum exp).
 int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, float *val, int64_t *ids0,
-                    int32_t *status, hipStream_t s, const irs_path_args *path) {
+                    int32_t *status, hipStream_t s, const irs_path_args *path, float *lse_max, float *lse_sum) {
     if (path && !irs_topk_is_direct(ctx, M, k)) IRS_FAIL(ctx, IRS_E_STATE, "fused path step needs the one-launch top-k");
     if (irs_topk_is_direct(ctx, M, k)) {
         // latency path on a small shard: one kernel, no fallback needed
@@ -2040,11 +2181,12 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
         }
         irs_prof_end(ctx, IRS_PROF_REFINE, s, 2.0 * ctx->dims.d * (double)M * (double)ctx->n_local, 0.0);
         IRS_CHECK_HIP(ctx, hipGetLastError());
-        return IRS_OK;
+        return lse_max ? irs_launch_lse(ctx, xrows, M, lse_max, lse_sum, s) : IRS_OK;
     }
     SweepArgs a;
     sweep_common(ctx, a, xrows, M);
     const int M_pad = a.M_pad;
+    const bool fused_lse = lse_max && sweep == IRS_SWEEP_BF16 && lse_fast_ok(ctx, a);
     const int d = ctx->dims.d;
     const int nt = ctx->n_tiles;
     int rc;
@@ -2118,25 +2260,40 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
     IRS_CHECK_HIP(ctx, hipGetLastError());
 
     // emission sweep over the whole shard
-    sweep_decompose(a, 0, nt, nub, 0);
     a.thr = ctx->thr;
     a.cnt = ctx->cand_cnt;
     a.cand = ctx->cand;
+    int lse_slots = 0;
+    if (fused_lse) { // bounded number of (max, sum) partials: tiles per wave from the slot budget, like irs_launch_lse
+        const int max_waves = ctx->lse_slots / 2;
+        int tpw = (nt + max_waves - 1) / max_waves;
+        if (tpw < 1) tpw = 1;
+        sweep_decompose(a, 0, nt, 1, tpw);
+        lse_slots = a.n_strips * 4 * 2;
+        if (lse_slots > ctx->lse_slots) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "lse slots %d > %d", lse_slots, ctx->lse_slots);
+        a.lse_part = ctx->lse_part;
+    } else
+        sweep_decompose(a, 0, nt, nub, 0);
+    const double emit_bytes = (double)nt * 32.0 * ctx->d_pad * ((sweep == IRS_SWEEP_BF16 && !fused_lse) ? 2.0 : 4.0);
     irs_prof_begin(ctx, IRS_PROF_SWEEP, s);
     irs_prof_begin(ctx, IRS_PROF_SWEEP_EMIT, s); // (one family is enabled at a time)
-    if (sweep == IRS_SWEEP_BF16) rc = launch_sweep_bf16<MODE_EMIT>(ctx, a, s);
+    if (fused_lse) rc = launch_lse_f32<true>(ctx, a, s);
+    else if (sweep == IRS_SWEEP_BF16) rc = launch_sweep_bf16<MODE_EMIT>(ctx, a, s);
     else rc = launch_sweep_f32<MODE_EMIT>(ctx, a, s);
-    irs_prof_end(ctx, IRS_PROF_SWEEP, s, 2.0 * d * (double)M * (double)ctx->n_local,
-                 (double)nt * 32.0 * ctx->d_pad * (sweep == IRS_SWEEP_BF16 ? 2.0 : 4.0));
-    irs_prof_end(ctx, IRS_PROF_SWEEP_EMIT, s, 2.0 * d * (double)M * (double)ctx->n_local,
-                 (double)nt * 32.0 * ctx->d_pad * (sweep == IRS_SWEEP_BF16 ? 2.0 : 4.0));
+    irs_prof_end(ctx, IRS_PROF_SWEEP, s, 2.0 * d * (double)M * (double)ctx->n_local, emit_bytes);
+    irs_prof_end(ctx, IRS_PROF_SWEEP_EMIT, s, 2.0 * d * (double)M * (double)ctx->n_local, emit_bytes);
     if (rc) return rc;
+    if (fused_lse) {
+        hipLaunchKernelGGL(k_lse_reduce, dim3(M), dim3(256), 0, s, ctx->lse_part, lse_slots, M_pad, M, lse_max, lse_sum);
+        IRS_CHECK_HIP(ctx, hipGetLastError());
+    }
 
     irs_prof_begin(ctx, IRS_PROF_REFINE, s);
     hipLaunchKernelGGL(k_refine, dim3(M), dim3(256), 0, s, xrows, d, ctx->proj_w, ctx->proj_b, ctx->cand_cnt, ctx->cand,
                        ctx->eps, ctx->ref_tmp, k, ctx->shard.item_lo, ctx->n_local, val, ids0, status);
     irs_prof_end(ctx, IRS_PROF_REFINE, s, 0.0, 0.0); // (rows flagged IRS_ROW_FALLBACK were redone exhaustively inside k_refine)
     IRS_CHECK_HIP(ctx, hipGetLastError());
+    if (lse_max && !fused_lse) return irs_launch_lse(ctx, xrows, M, lse_max, lse_sum, s);
     return IRS_OK;
 }
 
@@ -2210,7 +2367,9 @@ int irs_launch_lse(irs_ctx *ctx, const float *xrows, int M, float *out_max, floa
     if (slots > ctx->lse_slots) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "lse slots %d > %d", slots, ctx->lse_slots);
     a.lse_part = ctx->lse_part;
     irs_prof_begin(ctx, IRS_PROF_SWEEP, s);
-    int rc = launch_sweep_f32<MODE_LSE>(ctx, a, s);
+    int rc = IRS_OK;
+    if (lse_fast_ok(ctx, a)) rc = launch_lse_f32<false>(ctx, a, s);
+    else rc = launch_sweep_f32<MODE_LSE>(ctx, a, s);
     irs_prof_end(ctx, IRS_PROF_SWEEP, s, 2.0 * ctx->dims.d * (double)M * (double)ctx->n_local,
                  (double)ctx->n_local * ctx->dims.d * 4.0);
     if (rc) return rc;

@@ -101,6 +101,25 @@ class ShardGroup:
         mv, mi = self.scorer.merge_topk_keys(self._all_to_all(keys))
         return mv, mi, (mi[:, -1] < 0).to(torch.int32) * 4
 
+    def topk_own_lse(self, xrows: torch.Tensor, k: int, sweep: int):
+        """topk_own plus the rows' global (max, sum exp) -- a beam step's scoring: the shard is swept ONCE for both
+        (Engine.score_topk_lse).  Returns (val[B,k], ids0[B,k], status[B], max[world*B], sumexp[world*B])."""
+        if not hasattr(self.scorer, "score_topk_lse"):
+            v, i, st = self.topk_own(xrows, k, sweep)
+            return (v, i, st) + tuple(self.lse(xrows))
+        val, ids, st, m, s = self.scorer.score_topk_lse(xrows, k, sweep)
+        if self.world == 1:
+            return val, ids, st, m, s
+        B = xrows.shape[0] // self.world
+        keys = self.scorer.pack_topk(val, ids).view(self.world, B, k)
+        mv, mi = self.scorer.merge_topk_keys(self._all_to_all(keys))
+        gm = m.clone()
+        self._all_reduce(gm, dist.ReduceOp.MAX)
+        s = s * torch.exp(m - gm)
+        s = torch.where(torch.isfinite(m), s, torch.zeros_like(s))
+        self._all_reduce(s, dist.ReduceOp.SUM)
+        return mv, mi, (mi[:, -1] < 0).to(torch.int32) * 4, gm, s
+
     def topk(self, xrows: torch.Tensor, k: int, sweep: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """Global top-k of ALL rows on every rank (one all_gather of packed keys)."""
         val, ids, st = self.scorer.score_topk(xrows, k, sweep)

@@ -166,6 +166,19 @@ class Engine:
         self._call(self.lib.irs_score_topk, _ptr(xrows), M, k, sweep, _ptr(val), _ptr(ids), _ptr(st))
         return val, ids, st
 
+    def score_topk_lse(self, xrows: torch.Tensor, k: int = 100, sweep: int = IRS_SWEEP_BF16):
+        """score_topk and score_lse out of one call (one pass over the float32 catalog on the swept path):
+        (val, ids0, status, max[M], sumexp[M]) of this shard."""
+        xrows = self._dev(xrows, torch.float32)
+        M = xrows.shape[0]
+        val = torch.empty((M, k), dtype=torch.float32, device=self.device)
+        ids = torch.empty((M, k), dtype=torch.int64, device=self.device)
+        st = torch.empty(M, dtype=torch.int32, device=self.device)
+        mx = torch.empty(M, dtype=torch.float32, device=self.device)
+        sm = torch.empty(M, dtype=torch.float32, device=self.device)
+        self._call(self.lib.irs_score_topk_lse, _ptr(xrows), M, k, sweep, _ptr(val), _ptr(ids), _ptr(st), _ptr(mx), _ptr(sm))
+        return val, ids, st, mx, sm
+
     def score_gather(self, xrows: torch.Tensor, ids0: torch.Tensor) -> torch.Tensor:
         xrows = self._dev(xrows, torch.float32)
         ids0 = self._dev(ids0, torch.int64)

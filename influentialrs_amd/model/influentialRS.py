@@ -254,11 +254,12 @@ class IRSNN(nn.Module):
                 cur, nxt = st[i & 1], st[(i & 1) ^ 1]
                 _, xr, _ = eng.decode(cur[0].view(B * W, L), urep, want_x=False, pos=cur[1].view(-1))
                 allrows = g.gather_rows(xr)
-                val, ids, _ = g.topk_own(allrows, 100, hip.sweep)
                 lse = None
-                if W > 1:
-                    m, sm = g.lse(allrows)
+                if W > 1:  # candidates and the log-softmax normaliser out of one sweep of the shard
+                    val, ids, _, m, sm = g.topk_own_lse(allrows, 100, hip.sweep)
                     lse = (m[sl].contiguous(), sm[sl].contiguous())
+                else:
+                    val, ids, _ = g.topk_own(allrows, 100, hip.sweep)
                 eng.beam_step(cur, val, ids, lse, i, nxt, status)
             paths, scores = st[max_path_len & 1][3], st[max_path_len & 1][2]
         self.last_beams = (paths.detach().cpu().numpy(), scores.detach().cpu().numpy())

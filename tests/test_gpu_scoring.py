@@ -188,6 +188,32 @@ def test_lse(oracle, n_item, d, M):
         assert abs((mx[m] + np.log(sm[m])) - (om + np.log(osum))) <= 4e-6 * max(1.0, abs(om))
 
 
+@pytest.mark.parametrize("n_item,d,M", [(3415, 128, 10), (200_000, 64, 3), (300_017, 128, 70), (150_000, 256, 33), (120_000, 40, 5)])
+def test_topk_lse_fused_equals_separate_calls(oracle, n_item, d, M):
+    """irs_score_topk_lse (one pass over the float32 catalog emits candidates AND accumulates max / sum exp on the
+    swept path) == irs_score_topk + irs_score_lse: ids and values bit for bit, the log-sum-exp to float32 rounding;
+    row 0 also against the oracle."""
+    W, b = _weights(n_item, d, 21)
+    x = _rows(M, d, 22)
+    eng = scoring_only_engine(n_item, d, W, b, max_rows=M)
+    xt = torch.from_numpy(x).cuda()
+    for sweep in (IRS_SWEEP_BF16, IRS_SWEEP_F32):
+        v0, i0, s0 = eng.score_topk(xt, 100, sweep)
+        m0, e0 = eng.score_lse(xt)
+        v1, i1, s1, m1, e1 = eng.score_topk_lse(xt, 100, sweep)
+        torch.cuda.synchronize()
+        assert torch.equal(i0, i1) and torch.equal(v0.view(torch.int32), v1.view(torch.int32))
+        assert not (s1.cpu().numpy() & 1).any()
+        l0 = (m0.double() + e0.double().log()).cpu().numpy()
+        l1 = (m1.double() + e1.double().log()).cpu().numpy()
+        assert np.abs(l0 - l1).max() <= 4e-6 * max(1.0, np.abs(l0).max())
+    s = oracle.score_chain(x[0], W, b)
+    ov, oi = oracle.topk(s, 100)
+    assert np.array_equal(i1[0].cpu().numpy(), oi) and np.array_equal(v1[0].cpu().numpy().view(np.uint32), ov.view(np.uint32))
+    om, osum = oracle.max_sumexp(s)
+    assert abs(l1[0] - (om + np.log(osum))) <= 4e-6 * max(1.0, abs(om))
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_merge_equals_unsharded(oracle, world):
     """Item-sharded top-k + merge == single-shard top-k, bit for bit."""
