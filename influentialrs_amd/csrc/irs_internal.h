@@ -14,7 +14,7 @@
 #define IRS_CAND_SLOTS 64   // entries per bucket
 #define IRS_CAND_CAP (IRS_CAND_BUCKETS * IRS_CAND_SLOTS) // emitted candidates kept per row by the sweep
 #define IRS_REFINE_CAP 1024 // candidates exactly re-scored per row
-#define IRS_MAX_GROUPS 8192 // pre-pass group maxima per row (upper bound)
+#define IRS_MAX_GROUPS 2048 // pre-pass group maxima per row (upper bound: the pre-pass is decomposed to stay below it)
 #define IRS_MAX_PATH 64     // beam-search path length bound
 
 struct irs_layer_w {
@@ -67,7 +67,7 @@ struct irs_ctx {
     uint4 *xb;          // packed bf16 rows [m_pad/32][KS][64] x 16 B
     float *eps;         // [m_pad]
     float *thr;         // [m_pad]
-    float *gm;          // [IRS_MAX_GROUPS][m_pad]
+    float *gm;          // [m_pad / 4][n_groups <= IRS_MAX_GROUPS][4]
     unsigned int *cand_cnt; // [m_pad][IRS_CAND_BUCKETS]
     unsigned long long *cand; // [m_pad][IRS_CAND_CAP]
     float *lse_part;    // [lse_slots][m_pad][2]

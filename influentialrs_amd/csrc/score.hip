@@ -53,7 +53,8 @@ struct SweepArgs {
     int no_stagger;   // ring kernel, development switch: all waves take the step barrier at the same k-step
     int tiles_per_wg; // ring kernel, EMIT: tiles per workgroup strip (0: 4 * tiles_per_wave, the PRE group structure)
     // outputs
-    float *gm;                   // PRE  [n_groups][M_pad]
+    float *gm;                   // PRE  [M_pad / 4][n_groups][4]: the four rows a selection workgroup owns are one contiguous block
+    int n_groups;                // PRE
     const float *thr;            // EMIT [M_pad]
     unsigned int *cnt;           // EMIT [M_pad][IRS_CAND_BUCKETS]
     unsigned long long *cand;    // EMIT [M_pad][IRS_CAND_BUCKETS][IRS_CAND_SLOTS]
@@ -65,6 +66,10 @@ struct SweepArgs {
     int64_t ld;
     float *lse_part;             // LSE [slots][M_pad][2]
 };
+
+__device__ __forceinline__ size_t gm_index(const SweepArgs &a, int group, int row) {
+    return ((size_t)(row >> 2) * a.n_groups + group) * 4 + (row & 3);
+}
 
 // IEEE-754-2019 maximum (llvm.maximum -> v_maximum3_f32 on gfx950): unlike fmaxf / maxnum it needs no canonicalising
 // self-maxima in front (hipcc adds 6 of them per 16-way maximum in IEEE mode), and unlike inline asm it keeps the
@@ -279,7 +284,7 @@ __global__ void __launch_bounds__(256, 2) k_sweep_bf16(SweepArgs a) {
     if (MODE == MODE_PRE) {
 #pragma unroll
         for (int u = 0; u < UB; ++u)
-            if (u < ubc) a.gm[(size_t)(gw * 2 + h) * a.M_pad + (ut0 + u) * 32 + r] = aux[u];
+            if (u < ubc) a.gm[gm_index(a, gw * 2 + h, (ut0 + u) * 32 + r)] = aux[u];
     }
 }
 
@@ -411,7 +416,7 @@ __global__ void __launch_bounds__(256, 2) k_sweep_bf16_rs(SweepArgs a) {
                             if (gcount == tpw || i + ti + 1 == ntile) { // end of a group: publish, restart
 #pragma unroll
                                 for (int u = 0; u < RT; ++u) {
-                                    if (ut0 + u < a.UT) a.gm[(size_t)(gw * 2 + h) * a.M_pad + (ut0 + u) * 32 + r] = aux[u];
+                                    if (ut0 + u < a.UT) a.gm[gm_index(a, gw * 2 + h, (ut0 + u) * 32 + r)] = aux[u];
                                     aux[u] = -INFINITY;
                                 }
                                 gcount = 0;
@@ -688,7 +693,7 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_sweep_ring(SweepArgs a) {
                     if (gcount == tpw || s * TPS + ti + 1 == ntile) { // end of a group: publish, restart
 #pragma unroll
                         for (int u = 0; u < RT; ++u) {
-                            if (ut0 + u < a.UT) a.gm[(size_t)(gw * 2 + h) * a.M_pad + (ut0 + u) * 32 + r] = aux[u];
+                            if (ut0 + u < a.UT) a.gm[gm_index(a, gw * 2 + h, (ut0 + u) * 32 + r)] = aux[u];
                             aux[u] = -INFINITY;
                         }
                         gcount = 0;
@@ -760,7 +765,7 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_sweep_ring(SweepArgs a) {
         for (; gw < strip * 4 + 4; ++gw)
 #pragma unroll
             for (int u = 0; u < RT; ++u)
-                if (ut0 + u < a.UT) a.gm[(size_t)(gw * 2 + h) * a.M_pad + (ut0 + u) * 32 + r] = -INFINITY;
+                if (ut0 + u < a.UT) a.gm[gm_index(a, gw * 2 + h, (ut0 + u) * 32 + r)] = -INFINITY;
     }
     if (MODE == MODE_EMIT) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -950,7 +955,7 @@ __global__ void __launch_bounds__(256, 2) k_sweep_f32(SweepArgs a) {
     for (int u = 0; u < UB; ++u) {
         if (u >= ubc) continue;
         const int user = (ut0 + u) * 32 + r;
-        if (MODE == MODE_PRE) a.gm[(size_t)(gw * 2 + h) * a.M_pad + user] = aux[u];
+        if (MODE == MODE_PRE) a.gm[gm_index(a, gw * 2 + h, user)] = aux[u];
         if (MODE == MODE_COUNT) {
             if (user < a.M && cnt[u]) atomicAdd(&a.count[user], (unsigned long long)cnt[u]);
         }
@@ -1159,186 +1164,101 @@ __global__ void __launch_bounds__(256) k_pack_w(const float *__restrict__ W, con
     }
 }
 
-// thr[row] = (k-th largest of gm[0..G)[row]) - 2 eps ; traw[row] = that order statistic itself
-// (-inf when G < k; +inf for padding rows so that they never emit).
-// ROWS rows x 32 threads per row per workgroup; consecutive lanes read consecutive rows of one group (gm[G][M_pad]:
-// 128-byte lines at ROWS = 32, 32-byte pieces at ROWS = 8).  8-bit radix select, per-row LDS histograms; the
-// 256-bin scan of a row is done by its 32 threads (8 bins each + a 32-lane suffix sum).  ROWS = 32 left a
-// 1024-row call on 32 CUs (59 us, as long as a fifth of the sweep); ROWS = 8 spreads it over 128.
-// REG: G <= 32 * SEL_VPT group maxima per row -> each thread keeps its share in registers for the four radix passes.
-// (The first version re-read gm in every pass with one dependent load per loop trip: ~245 L2 round trips = 58 us
-// whatever the row count -- the largest item of a 32-row irs_score_topk.)
-#define SEL_VPT 64
-template <int ROWS, bool REG>
-__global__ void __launch_bounds__(ROWS * 32) k_select_thr(const float *__restrict__ gm, int G, int M, int M_pad, int k,
-                                                          const float *__restrict__ eps, float *__restrict__ thr,
-                                                          float *__restrict__ traw) {
-    __shared__ unsigned int hist[ROWS][257];
-    __shared__ unsigned int s_prefix[ROWS], s_k[ROWS];
-    const int rl = threadIdx.x % ROWS, tq = threadIdx.x / ROWS; // row within block, thread within row
-    const int row = blockIdx.x * ROWS + rl;
-    if (G < k) {
-        if (tq == 0 && row < M_pad) {
-            thr[row] = (row < M) ? -INFINITY : INFINITY;
-            traw[row] = (row < M) ? -INFINITY : INFINITY;
-        }
-        return;
-    }
-    if (tq == 0) {
-        s_prefix[rl] = 0;
-        s_k[rl] = k;
-    }
-    unsigned int keys[REG ? SEL_VPT : 1];
-    if (REG) {
-        float raw[SEL_VPT]; // unconditional loads at clamped indices: all in flight together (a load inside a
-                            // conditional gets its own wait: 64 dependent round trips, 32 of this kernel's 37 us)
-        const int rowc = row < M_pad ? row : M_pad - 1;
-#pragma unroll
-        for (int i = 0; i < SEL_VPT; ++i) {
-            const int g = tq + 32 * i;
-            raw[i] = gm[(size_t)(g < G ? g : G - 1) * M_pad + rowc];
-        }
-#pragma unroll
-        for (int i = 0; i < SEL_VPT; ++i) keys[i] = (tq + 32 * i < G && row < M) ? irs_fkey(raw[i]) : 0u;
-    }
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        for (int i = threadIdx.x; i < ROWS * 257; i += ROWS * 32) (&hist[0][0])[i] = 0;
-        __syncthreads();
-        const unsigned int prefix = s_prefix[rl];
-        if (row < M) {
-            if (REG) { // the thread's keys were loaded once, all loads in flight together
-                // Group maxima of one row share their leading digits: in the first passes every key of the row falls
-                // into the same bin, and 2000 LDS atomics on one address serialise (36 us of the kernel).  Runs of equal
-                // bins are counted in registers and added once.
-                unsigned int cur = 0xFFFFFFFFu, run = 0u;
-#pragma unroll
-                for (int i = 0; i < SEL_VPT; ++i) {
-                    const unsigned int key = keys[i];
-                    const bool match = (tq + 32 * i < G) && ((pass == 0) || ((key >> (shift + 8)) == (prefix >> (shift + 8))));
-                    if (match) {
-                        const unsigned int bin = (key >> shift) & 255;
-                        if (bin == cur) ++run;
-                        else {
-                            if (run) atomicAdd(&hist[rl][cur], run);
-                            cur = bin;
-                            run = 1u;
-                        }
-                    }
-                }
-                if (run) atomicAdd(&hist[rl][cur], run);
-            } else {
-                for (int g = tq; g < G; g += 32) {
-                    unsigned int key = irs_fkey(gm[(size_t)g * M_pad + row]);
-                    bool match = (pass == 0) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
-                    if (match) atomicAdd(&hist[rl][(key >> shift) & 255], 1u);
-                }
-            }
-        }
-        __syncthreads();
-        // thread tq of row rl owns bins [8 tq, 8 tq + 8); find the bin where the descending cumulative count reaches need
-        {
-            const unsigned int need = s_k[rl];
-            unsigned int own = 0;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) own += hist[rl][8 * tq + b];
-            // suffix sum over tq (threads of one row are 32 apart in threadIdx: go through LDS)
-            hist[rl][256] = 0; // unused pad word, keeps the row stride odd
-            __syncthreads();
-            __shared__ unsigned int part[ROWS][33];
-            part[rl][tq] = own;
-            __syncthreads();
-            unsigned int above = 0; // count in bins owned by higher tq
-            for (int j = tq + 1; j < 32; ++j) above += part[rl][j];
-            if (above < need && above + own >= need) { // the target bin is mine
-                unsigned int cum = above;
-                int bin = 8 * tq + 7;
-                for (; bin > 8 * tq; --bin) {
-                    unsigned int c = hist[rl][bin];
-                    if (cum + c >= need) break;
-                    cum += c;
-                }
-                s_k[rl] = need - cum;
-                s_prefix[rl] = prefix | (((unsigned int)bin) << shift);
-            }
-        }
-        __syncthreads();
-    }
-    if (tq == 0 && row < M_pad) {
-        const float t = irs_unkey(s_prefix[rl]);
-        thr[row] = (row < M) ? t - 2.0f * eps[row] : INFINITY;
-        traw[row] = (row < M) ? t : INFINITY;
-    }
+// thr[row] = (k-th largest of the row's G group maxima) - 2 eps ; traw[row] = that order statistic itself
+// (-inf when G < k; +inf for padding rows so that they never emit).  G <= 2048 by construction of the pre-pass.
+// ONE WAVE PER ROW, four rows per workgroup, no histograms.  The pre-pass leaves the four rows' maxima as one
+// contiguous [G][4] block (coalesced 16-byte reads); they are transposed through LDS (each lane ends up with 32 keys
+// of its wave's row in registers) and the r-th largest key is found bit by bit: count(keys >= candidate) is 32 compare + add-carry pairs
+// per lane against a SCALAR candidate, a four-step DPP reduction inside the 16-lane rows and four v_readlane -- the
+// count, the decision and the prefix all live in SGPRs.  The leading bits every key of the row shares are skipped.
+// History: the radix form spent ~34 us of a 1024-row call in LDS atomics on the handful of bins near-equal maxima
+// fall into; a form with 8 rows per workgroup and 32 lanes per row (64 keys per lane, ds_bpermute reductions) still
+// took 28-32 us whatever the row count: 128 workgroups at 1024 rows, each a long chain.
+#define SEL2_G IRS_MAX_GROUPS
+static_assert(SEL2_G == 2048, "k_select_thr_bits: 32 keys per lane");
+template <int CTRL>
+__device__ __forceinline__ unsigned int dpp_u32(unsigned int v) {
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
-
-// The same selection for G <= 2048 group maxima per row without histograms: 8 rows per 256-thread workgroup; the
-// rows' keys are transposed through LDS (coalesced global reads, then 32 consecutive lanes own a row, 64 keys per
-// lane in registers) and the r-th largest key is found bit by bit -- count(keys >= candidate) is 64 compares per
-// lane and a five-step shuffle reduction over the row's 32 lanes; the leading bits every key of the row shares are
-// skipped.  (The radix form spent 34 us of a 1024-row call and ~25 us of a 32-row call in LDS atomics on the
-// handful of bins near-equal maxima fall into.)
-#define SEL2_G 2048
+// all lanes of the wave contribute; result is wave-uniform (SGPR)
+__device__ __forceinline__ unsigned int wave_sum_u32(unsigned int v) {
+    v += dpp_u32<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_u32<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dpp_u32<0x141>(v); // row_half_mirror: the other quad of the 8
+    v += dpp_u32<0x140>(v); // row_mirror: the other 8 of the 16
+    return (unsigned int)__builtin_amdgcn_readlane((int)v, 0) + (unsigned int)__builtin_amdgcn_readlane((int)v, 16) +
+           (unsigned int)__builtin_amdgcn_readlane((int)v, 32) + (unsigned int)__builtin_amdgcn_readlane((int)v, 48);
+}
+__device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
+    unsigned int o;
+    o = dpp_u32<0xB1>(v), v = o > v ? o : v;
+    o = dpp_u32<0x4E>(v), v = o > v ? o : v;
+    o = dpp_u32<0x141>(v), v = o > v ? o : v;
+    o = dpp_u32<0x140>(v), v = o > v ? o : v;
+    const unsigned int a = (unsigned int)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned int)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned int c = (unsigned int)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned int)__builtin_amdgcn_readlane((int)v, 48);
+    const unsigned int ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
 __global__ void __launch_bounds__(256) k_select_thr_bits(const float *__restrict__ gm, int G, int M, int M_pad, int k,
                                                          const float *__restrict__ eps, float *__restrict__ thr,
                                                          float *__restrict__ traw) {
-    constexpr int STRIDE = SEL2_G + 8; // row stride = 8 mod 32 words: the transposing stores are at most 2-way conflicted
-    extern __shared__ unsigned int sel_lds[]; // [8][STRIDE]
+    constexpr int STRIDE = SEL2_G + 16; // row stride = 16 mod 64 words: the transposing stores of a wave hit 64 banks once
+    constexpr int KPL = SEL2_G / 64;    // keys per lane
+    __shared__ unsigned int sel_lds[4 * STRIDE];
     const int tid = threadIdx.x;
     {
-        const int rl = tid & 7, tq = tid >> 3; // consecutive lanes read consecutive rows of one group
-        const int row = blockIdx.x * 8 + rl;
-        const int rowc = row < M_pad ? row : M_pad - 1;
-        float raw[SEL2_G / 32];
+        const int rl = tid & 3, tq = tid >> 2; // four consecutive lanes read the four rows of one group (16 bytes)
+        const int row = blockIdx.x * 4 + rl;
+        const float *blk = gm + (size_t)blockIdx.x * G * 4 + rl; // M_pad is a multiple of 32: the block exists
+        float raw[KPL]; // unconditional loads at clamped indices: all in flight together
 #pragma unroll
-        for (int i = 0; i < SEL2_G / 32; ++i) {
-            const int g = tq + 32 * i;
-            raw[i] = gm[(size_t)(g < G ? g : G - 1) * M_pad + rowc];
+        for (int i = 0; i < KPL; ++i) {
+            const int g = tq + 64 * i;
+            raw[i] = blk[(size_t)(g < G ? g : G - 1) * 4];
         }
 #pragma unroll
-        for (int i = 0; i < SEL2_G / 32; ++i) {
-            const int g = tq + 32 * i;
-            sel_lds[rl * STRIDE + g] = (g < G && row < M) ? irs_fkey(raw[i]) : 0u;
+        for (int i = 0; i < KPL; ++i) asm volatile("" : "+v"(raw[i])); // keep every load in front of the selects below
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            const int g = tq + 64 * i;
+            const unsigned int kk = irs_fkey(raw[i]);
+            sel_lds[rl * STRIDE + g] = (g < G && row < M) ? kk : 0u;
         }
     }
     __syncthreads();
-    const int rr = tid >> 5, l = tid & 31; // row of this half-wave, lane within the row
-    const int row = blockIdx.x * 8 + rr;
-    unsigned int key[SEL2_G / 32];
-    unsigned int mx = 0u, mn = 0xFFFFFFFFu;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = blockIdx.x * 4 + wave;
+    unsigned int key[KPL];
+    unsigned int mx = 0u, mnc = 0u; // mnc = max of the complements = complement of the min over the real groups
 #pragma unroll
-    for (int i = 0; i < SEL2_G / 32; ++i) {
-        key[i] = sel_lds[rr * STRIDE + l + 32 * i];
+    for (int i = 0; i < KPL; ++i) {
+        key[i] = sel_lds[wave * STRIDE + lane + 64 * i];
         mx = key[i] > mx ? key[i] : mx;
-        if (l + 32 * i < G) mn = key[i] < mn ? key[i] : mn;
+        const unsigned int c = (lane + 64 * i < G) ? ~key[i] : 0u;
+        mnc = c > mnc ? c : mnc;
     }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
-        const unsigned int a = __shfl_xor(mx, o, 32), b = __shfl_xor(mn, o, 32);
-        mx = a > mx ? a : mx;
-        mn = b < mn ? b : mn;
-    }
+    const unsigned int smx = wave_max_u32(mx), smn = ~wave_max_u32(mnc);
     // keys of the row agree on their bits above `top`; the answer carries those bits too
-    // (tried: ballots + scalar popcounts instead of the shuffle reduction -- 64 v_cmp -> s_bcnt1 pairs per bit: slower)
-    const unsigned int diff = mx ^ mn;
+    const unsigned int diff = smx ^ smn;
     const int top = diff ? 31 - __builtin_clz(diff) : -1;
-    unsigned int prefix = top >= 31 ? 0u : (mx & ~((2u << top) - 1u));
-    if (top < 0) prefix = mx;
+    unsigned int prefix = top >= 31 ? 0u : (smx & ~((2u << top) - 1u));
+    if (top < 0) prefix = smx;
     for (int bit = top; bit >= 0; --bit) {
         const unsigned int cand = prefix | (1u << bit);
-        int c0 = 0, c1 = 0, c2 = 0, c3 = 0; // four partial counts: shorter dependent add chains
+        unsigned int c0 = 0, c1 = 0, c2 = 0, c3 = 0; // four partial counts: shorter dependent add chains
 #pragma unroll
-        for (int i = 0; i < SEL2_G / 32; i += 4) {
-            c0 += key[i] >= cand ? 1 : 0;
-            c1 += key[i + 1] >= cand ? 1 : 0;
-            c2 += key[i + 2] >= cand ? 1 : 0;
-            c3 += key[i + 3] >= cand ? 1 : 0;
+        for (int i = 0; i < KPL; i += 4) {
+            c0 += key[i] >= cand ? 1u : 0u;
+            c1 += key[i + 1] >= cand ? 1u : 0u;
+            c2 += key[i + 2] >= cand ? 1u : 0u;
+            c3 += key[i + 3] >= cand ? 1u : 0u;
         }
-        int cnt = (c0 + c1) + (c2 + c3);
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 32);
-        if (cnt >= k) prefix = cand;
+        const unsigned int cnt = wave_sum_u32((c0 + c1) + (c2 + c3));
+        if (cnt >= (unsigned int)k) prefix = cand;
     }
-    if (l == 0 && row < M_pad) {
+    if (lane == 0 && row < M_pad) {
         const bool enough = G >= k;
         const float t = enough ? irs_unkey(prefix) : -INFINITY;
         thr[row] = (row < M) ? (enough ? t - 2.0f * eps[row] : -INFINITY) : INFINITY;
@@ -2215,8 +2135,9 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
     sweep_decompose(a, 0, nt, nub, tpw0, stride);
     int n_waves0 = a.n_strips * 4;
     int G = 2 * n_waves0;
-    if (G > IRS_MAX_GROUPS) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "pre-pass groups %d > %d", G, IRS_MAX_GROUPS);
+    if (G > SEL2_G) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "pre-pass groups %d > %d", G, SEL2_G);
     a.gm = ctx->gm;
+    a.n_groups = G;
     irs_prof_begin(ctx, IRS_PROF_SWEEP, s);
     if (sweep == IRS_SWEEP_BF16) rc = launch_sweep_bf16<MODE_PRE>(ctx, a, s);
     else rc = launch_sweep_f32<MODE_PRE>(ctx, a, s);
@@ -2233,30 +2154,8 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
         if (r_sel < 8) r_sel = 8;
         if (r_sel > k) r_sel = k;
     }
-    if (G <= SEL2_G && M_pad < 8192) {
-        const size_t lds = (size_t)8 * (SEL2_G + 8) * sizeof(unsigned int);
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_select_thr_bits), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(k_select_thr_bits, dim3((M_pad + 7) / 8), dim3(256), lds, s, ctx->gm, G, M, M_pad, r_sel, ctx->eps,
-                           ctx->thr, ctx->ref_tmp);
-    } else {
-        const bool reg = G <= 32 * SEL_VPT;
-        const dim3 g32((M_pad + 31) / 32), g8((M_pad + 7) / 8);
-#define SEL_(ROWS_, REG_, GRID_)                                                                                         \
-    hipLaunchKernelGGL((k_select_thr<ROWS_, REG_>), GRID_, dim3(ROWS_ * 32), 0, s, ctx->gm, G, M, M_pad, r_sel, ctx->eps, \
-                       ctx->thr, ctx->ref_tmp)
-        if (M_pad >= 8192) {
-            if (reg) SEL_(32, true, g32);
-            else SEL_(32, false, g32);
-        } else {
-            if (reg) SEL_(8, true, g8);
-            else SEL_(8, false, g8);
-        }
-#undef SEL_
-    }
+    hipLaunchKernelGGL(k_select_thr_bits, dim3((M_pad + 3) / 4), dim3(256), 0, s, ctx->gm, G, M, M_pad, r_sel, ctx->eps,
+                       ctx->thr, ctx->ref_tmp);
     IRS_CHECK_HIP(ctx, hipGetLastError());
 
     // emission sweep over the whole shard

@@ -35,6 +35,7 @@ static void launch_ring_lab(SweepArgs a, int nt, int rounds_x10, hipStream_t s) 
             printf("   (PRE variant skipped: %d groups > %d)\n", 8 * a.n_strips, IRS_MAX_GROUPS);
             return;
         }
+        a.n_groups = 8 * a.n_strips;
     } else {
         a.tiles_per_wg = (nt + strips - 1) / strips;
         a.n_strips = (nt + a.tiles_per_wg - 1) / a.tiles_per_wg;
@@ -50,6 +51,7 @@ static void check_pre(irs_ctx *ctx, SweepArgs a, int nt, int stride, int tpw, hi
     const int nts = (nt + stride - 1) / stride;
     a.n_strips = (nts + 4 * tpw - 1) / (4 * tpw);
     const size_t G = (size_t)8 * a.n_strips, n = G * a.M_pad;
+    a.n_groups = (int)G;
     std::vector<float> ref(n), got(n);
     CK(hipMemset(ctx->gm, 0xFF, n * 4));
     SweepArgs b = a;
