@@ -192,6 +192,21 @@ int irs_score_lse(irs_ctx *ctx, const float *dev_xrows, int32_t M, float *dev_ma
 int irs_score_topk_lse(irs_ctx *ctx, const float *dev_xrows, int32_t M, int32_t k, int32_t sweep, float *dev_val,
                        int64_t *dev_ids0, int32_t *dev_status, float *dev_max, float *dev_sumexp, void *stream);
 
+/* Training side: CrossEntropyLoss(project(x)[valid], label - 1) of IRSNN.train_batch /
+ * get_loss_on_eval_data (influentialRS.py:252-310) and Evaluator.train_batch (evaluator.py:53-92) WITHOUT the
+ * [M, n_item] logits the reference materialises.  One device holds the whole catalog.  project.weight / bias are
+ * read where they were bound: an optimizer step that updates them in place needs no re-finalisation for these two.
+ *  irs_ce_forward:  dev_labels0 int64 [M] 0-based, -1 = row ignored (a pad target);
+ *                   dev_lse float [M] = log sum_j exp(logit_mj); dev_label_score float [M];
+ *                   dev_loss double [2] = { sum over valid rows of (lse - label score), number of valid rows }.
+ *  irs_ce_grad_logits: dL/dlogits of rows [0, M) (a chunk the caller sizes: M x ld floats), written ONCE by the
+ *                   fp32-MFMA sweep's epilogue: scale * (exp(logit - lse) - [item == label]); ignored rows 0.
+ *                   The caller finishes with two plain GEMMs (dX = G W, dW = G^T X) and a column sum (db). */
+int irs_ce_forward(irs_ctx *ctx, const float *dev_xrows, const int64_t *dev_labels0, int32_t M, float *dev_lse,
+                   float *dev_label_score, double *dev_loss, void *stream);
+int irs_ce_grad_logits(irs_ctx *ctx, const float *dev_xrows, const int64_t *dev_labels0, const float *dev_lse, int32_t M,
+                       float scale, float *dev_out, int64_t ld, void *stream);
+
 /* Merge W per-shard top-k lists (after the RCCL all-gather) into
  * the global top-k with the same total order.
  *  dev_val_in float [W, M, k], dev_ids_in int64 [W, M, k] (ids -1 ignored) */

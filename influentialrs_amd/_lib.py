@@ -49,6 +49,8 @@ SIGNATURES = {
     "irs_score_lse": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "irs_score_topk_lse": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
+    "irs_ce_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "irs_ce_grad_logits": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, ctypes.c_float, c_void_p, c_int64, c_void_p]),
     "irs_build_eval_batch": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64,
                                        c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "irs_merge_topk": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),

@@ -430,6 +430,34 @@ extern "C" int irs_score_topk_lse(irs_ctx *ctx, const float *xrows, int32_t M, i
     return irs_launch_topk(ctx, xrows, M, k, sweep, val, ids0, status, (hipStream_t)stream, nullptr, omax, osum);
 }
 
+// ---- projection + cross entropy, training side
+extern "C" int irs_ce_forward(irs_ctx *ctx, const float *xrows, const int64_t *labels0, int32_t M, float *lse,
+                              float *label_score, double *loss, void *stream) {
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if ((rc = check_rows(ctx, "irs_ce_forward", xrows, M))) return rc;
+    if (!labels0 || !lse || !label_score || !loss) IRS_FAIL(ctx, IRS_E_INVALID, "irs_ce_forward: null arguments");
+    if (ctx->shard.world != 1) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "irs_ce_forward needs the whole catalog on one device");
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = irs_launch_refresh_bias(ctx, s))) return rc;
+    if ((rc = irs_launch_lse(ctx, xrows, M, ctx->lse_max, ctx->lse_sum, s))) return rc;
+    if ((rc = irs_launch_lse_combine(ctx, ctx->lse_max, ctx->lse_sum, lse, M, s))) return rc;
+    if ((rc = irs_launch_gather(ctx, xrows, M, labels0, 1, label_score, s))) return rc;
+    return irs_launch_ce_reduce(ctx, lse, label_score, labels0, M, loss, s);
+}
+
+extern "C" int irs_ce_grad_logits(irs_ctx *ctx, const float *xrows, const int64_t *labels0, const float *lse, int32_t M,
+                                  float scale, float *out, int64_t ld, void *stream) {
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if ((rc = check_rows(ctx, "irs_ce_grad_logits", xrows, M))) return rc;
+    if (!labels0 || !lse || !out || ld < ctx->n_local) IRS_FAIL(ctx, IRS_E_INVALID, "irs_ce_grad_logits: bad arguments");
+    if (ctx->shard.world != 1) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "irs_ce_grad_logits needs the whole catalog on one device");
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = irs_launch_refresh_bias(ctx, s))) return rc;
+    return irs_launch_ce_grad(ctx, xrows, labels0, lse, M, scale, out, ld, s);
+}
+
 extern "C" int irs_merge_topk(irs_ctx *ctx, const float *val_in, const int64_t *ids_in, int32_t W, int32_t M, int32_t k,
                               float *val, int64_t *ids0, void *stream) {
     if (!ctx) return IRS_E_INVALID;

@@ -150,6 +150,12 @@ int irs_launch_count_before(irs_ctx *ctx, const float *xrows, int M, const float
                             const int64_t *excl, int n_excl, int64_t *count, hipStream_t s);
 int irs_launch_dense(irs_ctx *ctx, const float *xrows, int M, float *out, int64_t ld, hipStream_t s);
 int irs_launch_lse(irs_ctx *ctx, const float *xrows, int M, float *out_max, float *out_sum, hipStream_t s);
+int irs_launch_refresh_bias(irs_ctx *ctx, hipStream_t s);
+int irs_launch_lse_combine(irs_ctx *ctx, const float *mx, const float *sm, float *lse, int M, hipStream_t s);
+int irs_launch_ce_reduce(irs_ctx *ctx, const float *lse, const float *lab_score, const int64_t *labels0, int M, double *out,
+                         hipStream_t s);
+int irs_launch_ce_grad(irs_ctx *ctx, const float *xrows, const int64_t *labels0, const float *lse, int M, float scale,
+                       float *out, int64_t ld, hipStream_t s);
 
 // ---- path.hip ----
 int irs_launch_merge(irs_ctx *ctx, const float *val_in, const int64_t *ids_in, int W, int M, int k, float *val,

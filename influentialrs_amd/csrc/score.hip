@@ -37,6 +37,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 #define MODE_COUNT 2
 #define MODE_DENSE 3
 #define MODE_LSE 4
+#define MODE_CEGRAD 5 // DENSE's orientation; writes scale * (softmax - onehot(label)) instead of the logits
 
 struct SweepArgs {
     // operands
@@ -65,6 +66,9 @@ struct SweepArgs {
     float *dense;                // DENSE [M][ld]
     int64_t ld;
     float *lse_part;             // LSE [slots][M_pad][2]
+    const float *ce_lse;         // CEGRAD [M] log-sum-exp of each row over the WHOLE catalog
+    const int64_t *ce_label;     // CEGRAD [M] local 0-based label (outside [0, n_local): no one-hot on this shard); < -2^62: row ignored
+    float ce_scale;              // CEGRAD dL/dloss / n_valid
 };
 
 __device__ __forceinline__ size_t gm_index(const SweepArgs &a, int group, int row) {
@@ -878,7 +882,7 @@ __global__ void __launch_bounds__(256, 2) k_sweep_f32(SweepArgs a) {
         }
         float4 bc[4];
         float bd = 0.f;
-        if (MODE == MODE_DENSE) bd = a.bias[(size_t)t * 32 + r];
+        if (MODE == MODE_DENSE || MODE == MODE_CEGRAD) bd = a.bias[(size_t)t * 32 + r];
         else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) bc[q] = *reinterpret_cast<const float4 *>(a.bias + (size_t)t * 32 + 8 * q + 4 * h);
@@ -887,7 +891,7 @@ __global__ void __launch_bounds__(256, 2) k_sweep_f32(SweepArgs a) {
         for (int u = 0; u < UB; ++u) {
             if (u < ubc) {
                 f32x16 acc;
-                if (MODE == MODE_DENSE) {
+                if (MODE == MODE_DENSE || MODE == MODE_CEGRAD) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc[i] = bd;
                 } else {
@@ -902,7 +906,7 @@ __global__ void __launch_bounds__(256, 2) k_sweep_f32(SweepArgs a) {
 #pragma unroll
                 for (int q = 0; q < QN; ++q) {
                     float4 bv = xs4[(u * QN + q) * 64 + lane];
-                    if (MODE == MODE_DENSE) { // D[row][item]: rows on registers, items on lanes
+                    if (MODE == MODE_DENSE || MODE == MODE_CEGRAD) { // D[row][item]: rows on registers, items on lanes
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.x, af[q].x, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.y, af[q].y, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.z, af[q].z, acc, 0, 0, 0);
@@ -937,6 +941,24 @@ __global__ void __launch_bounds__(256, 2) k_sweep_f32(SweepArgs a) {
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0); // one row tile's accumulators live at a time
+                } else if (MODE == MODE_CEGRAD) {
+                    // dL/dlogit[row][item] = scale * (exp(logit - lse[row]) - [item == label[row]]); ignored rows: 0
+                    const int64_t col = (int64_t)t * 32 + r;
+                    if (col < a.n_local) {
+                        int row0 = (ut0 + u) * 32 + 4 * h;
+                        asm volatile("" : "+v"(row0));
+                        float *dst = a.dense + (size_t)row0 * a.ld + col;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int dr = (i & 3) + 8 * (i >> 2);
+                            if (row0 + dr < a.M) {
+                                const int64_t lab = a.ce_label[row0 + dr];
+                                const float p = __expf(acc[i] - a.ce_lse[row0 + dr]);
+                                dst[(size_t)dr * a.ld] = (lab < -(1ll << 62)) ? 0.f : a.ce_scale * (p - (lab == col ? 1.f : 0.f));
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 } else if (MODE == MODE_LSE) {
                     float m = fmaxf(aux[u], max16(acc));
                     if (m > -INFINITY) {
@@ -2248,6 +2270,92 @@ int irs_launch_dense(irs_ctx *ctx, const float *xrows, int M, float *out, int64_
     a.ld = ld;
     irs_prof_begin(ctx, IRS_PROF_SWEEP, s);
     int rc = launch_sweep_f32<MODE_DENSE>(ctx, a, s);
+    irs_prof_end(ctx, IRS_PROF_SWEEP, s, 2.0 * ctx->dims.d * (double)M * (double)ctx->n_local,
+                 (double)ctx->n_local * (ctx->dims.d + (double)M) * 4.0);
+    return rc;
+}
+
+// ---- projection + cross entropy without the [M, n_item] logits (training side: reference influentialRS.py:252-310,
+// evaluator.py:53-92).  The float32 sweeps read project.weight where the caller bound it, so an optimizer step
+// that updates it in place is seen at once; the one derived operand they need, the padded bias, is refreshed here.
+__global__ void k_refresh_bias(const float *__restrict__ b, int64_t n_local, int64_t n_pad, float *__restrict__ bias_pad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pad) bias_pad[i] = i < n_local ? b[i] : -INFINITY;
+}
+
+int irs_launch_refresh_bias(irs_ctx *ctx, hipStream_t s) {
+    const int64_t n_pad = (int64_t)ctx->n_tiles * 32;
+    hipLaunchKernelGGL(k_refresh_bias, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, ctx->proj_b, ctx->n_local, n_pad,
+                       ctx->bias_pad);
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}
+
+// labels0 global 0-based (-1: row ignored) -> local; ignored rows get the sentinel the sweep tests for
+__global__ void k_ce_localize(const int64_t *__restrict__ labels0, int64_t item_lo, int64_t *__restrict__ out, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) out[i] = labels0[i] < 0 ? INT64_MIN : labels0[i] - item_lo;
+}
+
+// loss[0] = sum over valid rows of (lse - label score), loss[1] = number of valid rows (one workgroup; M is a batch)
+__global__ void __launch_bounds__(256) k_ce_reduce(const float *__restrict__ lse, const float *__restrict__ lab_score,
+                                                   const int64_t *__restrict__ labels0, int M, double *__restrict__ out) {
+    __shared__ double ssum[4], scnt[4];
+    double acc = 0.0, cnt = 0.0;
+    for (int i = threadIdx.x; i < M; i += 256)
+        if (labels0[i] >= 0) {
+            acc += (double)lse[i] - (double)lab_score[i];
+            cnt += 1.0;
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        acc += __shfl_xor(acc, off, 64);
+        cnt += __shfl_xor(cnt, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        ssum[threadIdx.x >> 6] = acc;
+        scnt[threadIdx.x >> 6] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+        out[1] = (scnt[0] + scnt[1]) + (scnt[2] + scnt[3]);
+    }
+}
+
+__global__ void k_lse_combine(const float *__restrict__ mx, const float *__restrict__ sm, float *__restrict__ lse, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) lse[i] = mx[i] + logf(sm[i]);
+}
+
+int irs_launch_lse_combine(irs_ctx *ctx, const float *mx, const float *sm, float *lse, int M, hipStream_t s) {
+    hipLaunchKernelGGL(k_lse_combine, dim3((M + 255) / 256), dim3(256), 0, s, mx, sm, lse, M);
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}
+
+int irs_launch_ce_reduce(irs_ctx *ctx, const float *lse, const float *lab_score, const int64_t *labels0, int M, double *out,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(k_ce_reduce, dim3(1), dim3(256), 0, s, lse, lab_score, labels0, M, out);
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}
+
+int irs_launch_ce_grad(irs_ctx *ctx, const float *xrows, const int64_t *labels0, const float *lse, int M, float scale,
+                       float *out, int64_t ld, hipStream_t s) {
+    SweepArgs a;
+    sweep_common(ctx, a, xrows, M);
+    int64_t *lab_local = reinterpret_cast<int64_t *>(ctx->cand); // scratch: [M] int64
+    hipLaunchKernelGGL(k_ce_localize, dim3((M + 255) / 256), dim3(256), 0, s, labels0, ctx->shard.item_lo, lab_local, M);
+    const int nub = (a.UT + ub_f32(ctx->KS) - 1) / ub_f32(ctx->KS);
+    sweep_decompose(a, 0, ctx->n_tiles, nub, 0);
+    a.dense = out;
+    a.ld = ld;
+    a.ce_lse = lse;
+    a.ce_label = lab_local;
+    a.ce_scale = scale;
+    irs_prof_begin(ctx, IRS_PROF_SWEEP, s);
+    int rc = launch_sweep_f32<MODE_CEGRAD>(ctx, a, s);
     irs_prof_end(ctx, IRS_PROF_SWEEP, s, 2.0 * ctx->dims.d * (double)M * (double)ctx->n_local,
                  (double)ctx->n_local * (ctx->dims.d + (double)M) * 4.0);
     return rc;

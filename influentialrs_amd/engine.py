@@ -217,6 +217,32 @@ class Engine:
         self._call(self.lib.irs_score_lse, _ptr(xrows), M, _ptr(mx), _ptr(sm))
         return mx, sm
 
+    # ---- projection + cross entropy without the logits (training side)
+    def ce_forward(self, xrows: torch.Tensor, labels0: torch.Tensor):
+        """(lse[M] float32, label_score[M] float32, loss[2] float64 = {sum over valid rows of lse - label score,
+        number of valid rows}); labels0 int64 0-based, -1 = row ignored."""
+        xrows = self._dev(xrows, torch.float32)
+        labels0 = self._dev(labels0, torch.int64)
+        M = xrows.shape[0]
+        lse = torch.empty(M, dtype=torch.float32, device=self.device)
+        ls = torch.empty(M, dtype=torch.float32, device=self.device)
+        loss = torch.empty(2, dtype=torch.float64, device=self.device)
+        self._call(self.lib.irs_ce_forward, _ptr(xrows), _ptr(labels0), M, _ptr(lse), _ptr(ls), _ptr(loss))
+        return lse, ls, loss
+
+    def ce_grad_logits(self, xrows: torch.Tensor, labels0: torch.Tensor, lse: torch.Tensor, scale: float, out: torch.Tensor):
+        """out[M, ld >= n_local] = scale * (softmax(logits) - onehot(label)); ignored rows 0.  Written in place."""
+        xrows = self._dev(xrows, torch.float32)
+        labels0 = self._dev(labels0, torch.int64)
+        lse = self._dev(lse, torch.float32)
+        M = xrows.shape[0]
+        if out.dtype != torch.float32 or out.device != self.device or out.dim() != 2 or out.stride(1) != 1 \
+                or out.shape[0] < M or out.shape[1] < self.n_local:
+            raise IrsError("ce_grad_logits: out must be a float32 [>= M, >= n_local] row-major tensor on the engine's device")
+        self._call(self.lib.irs_ce_grad_logits, _ptr(xrows), _ptr(labels0), _ptr(lse), M, float(scale), _ptr(out),
+                   int(out.stride(0)))
+        return out
+
     def merge_topk(self, val_in: torch.Tensor, ids_in: torch.Tensor):
         """[W, M, k] gathered per-shard lists -> global (val[M,k], ids0[M,k])."""
         val_in = self._dev(val_in, torch.float32)

@@ -44,7 +44,7 @@ class HipBackend:
     def _fingerprint(self):
         return tuple((t.data_ptr(), t._version) for t in self.net.state_dict(keep_vars=True).values())
 
-    def get(self, n_seqs: int, n_rows: int) -> Engine:
+    def get(self, n_seqs: int, n_rows: int, for_training: bool = False) -> Engine:
         net = self.net
         dev = next(net.parameters()).device
         if dev.type != "cuda":
@@ -65,6 +65,8 @@ class HipBackend:
             self._fp = None
             self.group = ShardGroup(self.engine) if self.world > 1 else None
         fp = self._fingerprint()
+        if for_training and self._fp is not None and [a for a, _ in fp] == [a for a, _ in self._fp]:
+            return self.engine  # same storage: the CE entry points read project.* in place, nothing derived is used
         if fp != self._fp:
             sd = {k: v.detach() for k, v in net.state_dict(keep_vars=True).items() if v.dtype == torch.float32}
             self.engine.bind_state_dict(sd)
@@ -87,6 +89,56 @@ class HipBackend:
 
     def lse(self, xrows):
         return self.group.lse(xrows) if self.group is not None else self.engine.score_lse(xrows)
+
+
+class _ProjectCE(torch.autograd.Function):
+    """mean over valid rows of CrossEntropy(project(x), label) -- nn.Linear + nn.CrossEntropyLoss of the reference's
+    train_batch (influentialRS.py:278-310, evaluator.py:53-68) -- without the [M, n_item] logits: forward =
+    irs_ce_forward (float32 log-sum-exp sweep + label gather), backward = irs_ce_grad_logits per row chunk (the
+    softmax gradient written once by the sweep's epilogue) followed by the two plain GEMMs dX = G W, dW = G^T X."""
+    ROWS = 8192          # rows per engine call
+    CHUNK_BYTES = 1 << 30  # budget of the dL/dlogits chunk
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, labels0, backend):
+        M = x.shape[0]
+        eng = backend.get(1, min(M, _ProjectCE.ROWS), for_training=True)
+        xd = x.detach().contiguous()
+        lse = torch.empty(M, dtype=torch.float32, device=x.device)
+        tot = torch.zeros(2, dtype=torch.float64, device=x.device)
+        for c0 in range(0, M, _ProjectCE.ROWS):
+            c1 = min(M, c0 + _ProjectCE.ROWS)
+            l, _, t = eng.ce_forward(xd[c0:c1], labels0[c0:c1])
+            lse[c0:c1] = l
+            tot += t
+        ctx.save_for_backward(xd, weight, labels0, lse, tot)
+        ctx.backend = backend
+        return (tot[0] / tot[1]).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        xd, weight, labels0, lse, tot = ctx.saved_tensors
+        M, d = xd.shape
+        N = weight.shape[0]
+        eng = ctx.backend.get(1, min(M, _ProjectCE.ROWS), for_training=True)
+        mc = max(32, min(_ProjectCE.ROWS, M, (_ProjectCE.CHUNK_BYTES // (4 * N)) // 32 * 32))
+        G = torch.empty((mc, N), dtype=torch.float32, device=xd.device)
+        dx = torch.empty_like(xd)
+        dW = torch.zeros_like(weight)
+        db = torch.zeros(N, dtype=torch.float32, device=xd.device)
+        for c0 in range(0, M, mc):
+            c1 = min(M, c0 + mc)
+            Gc = eng.ce_grad_logits(xd[c0:c1], labels0[c0:c1], lse[c0:c1], 1.0, G)[:c1 - c0]
+            torch.mm(Gc, weight, out=dx[c0:c1])
+            dW.addmm_(Gc.t(), xd[c0:c1])
+            db += Gc.sum(0)
+        sc = (g.double() / tot[1]).to(torch.float32)  # dL/dloss / n_valid, kept on the device
+        return dx * sc, dW * sc, db * sc, None, None
+
+
+def project_ce(x: torch.Tensor, project: nn.Linear, labels0: torch.Tensor, backend: "HipBackend") -> torch.Tensor:
+    """Scalar loss; x [M, d] rows of the decoder, labels0 [M] 0-based with -1 = ignored."""
+    return _ProjectCE.apply(x, project.weight, project.bias, labels0, backend)
 
 
 def pad_ragged_ids(lists: Sequence, device, minus: int = 1) -> torch.Tensor:

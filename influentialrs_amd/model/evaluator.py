@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 import torch.optim as optim
 
-from ._backend import make_scheduler
+from ._backend import make_scheduler, project_ce
 from .layers import get_end_index
 
 
@@ -28,12 +28,19 @@ class Evaluator(nn.Module):
                                     eps=1e-09, lr=config.lr1)
         self.pla_lr_scheduler = make_scheduler(self.optimizer)
 
-    # ---- training side (stock autograd; reference :53-92)
+    # ---- training side (reference :53-92): decoder trunk = stock autograd (train) / HIP engine (eval); projection +
+    #      cross entropy on the HIP engine in both, without the [B (L-1), n_item] logits
     def _masked_loss(self, target):
-        output = self.net.forward(target[:, :-1]).reshape(-1, self.vocab_size)
-        tgt = target[:, 1:].contiguous().view(-1)
-        mask = tgt.gt(self.PAD_ID)
-        return self.loss_function(output[mask], tgt[mask] - 1)
+        net = self.net
+        x = net.decoding(target[:, :-1])
+        rows = x.reshape(-1, net.embed_dim)
+        tgt = target[:, 1:].reshape(-1)
+        labels0 = torch.where(tgt.gt(self.PAD_ID), tgt - 1, torch.full_like(tgt, -1)).to(torch.int64)
+        if net._hip.world != 1 or rows.device.type != "cuda":  # sharded or CPU module: the reference's own formulation
+            out = net.project(rows)
+            mask = labels0.ge(0)
+            return self.loss_function(out[mask], labels0[mask])
+        return project_ce(rows, net.project, labels0, net._hip)
 
     def train_batch(self, target):
         self.net.train()

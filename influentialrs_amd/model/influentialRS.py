@@ -27,7 +27,7 @@ import torch.nn.functional as F
 import torch.optim as optim
 
 from .._lib import IRS_MASK_IRN, IRS_ROW_NO_CANDIDATE
-from ._backend import HipBackend, make_scheduler, pad_ragged_ids
+from ._backend import HipBackend, make_scheduler, pad_ragged_ids, project_ce
 from .layers import PositionalEncoding, get_item_index
 
 
@@ -151,16 +151,25 @@ class IRSNN(nn.Module):
         self.pla_lr_scheduler = make_scheduler(self.optimizer)
         self.softmax = nn.Softmax(dim=2)
 
-    # ---- training side (stock autograd; out of the inference hot path)
+    # ---- training side: the decoder trunk is stock autograd (train mode) or the HIP engine (eval mode); projection +
+    #      cross entropy go through the HIP engine in both, never materialising [B (L-1), n_item]
     def _masked_loss(self, seqs, users):
-        output = self.net.forward(seqs.clone(), users)[:, :-1, :].contiguous().view(-1, self.n_item)
-        tgt = seqs[:, 1:].contiguous().view(-1)
-        mask = tgt.gt(self.PAD_ID)
-        return self.loss_function(output[mask], tgt[mask] - 1)
+        net = self.net
+        if net.training:
+            x, _ = net._decoding_autograd(seqs.clone(), users)
+        else:
+            x = net.decoding(seqs.clone(), users)
+        rows = x[:, :-1, :].reshape(-1, net.embed_dim)
+        tgt = seqs[:, 1:].reshape(-1)
+        labels0 = torch.where(tgt.gt(self.PAD_ID), tgt - 1, torch.full_like(tgt, -1)).to(torch.int64)
+        if net._hip.world != 1 or rows.device.type != "cuda":  # sharded or CPU module: the reference's own formulation
+            out = net.project(rows)
+            mask = labels0.ge(0)
+            return self.loss_function(out[mask], labels0[mask])
+        return project_ce(rows, net.project, labels0, net._hip)
 
     def get_loss_on_eval_data(self, seqs, users):
-        """Mean next-item cross entropy over non-pad targets (reference :252-276).
-        Eval mode: logits come from the HIP path; the loss reduction is torch."""
+        """Mean next-item cross entropy over non-pad targets (reference :252-276)."""
         self.net.eval()
         with torch.no_grad():
             return self._masked_loss(seqs, users).item()

@@ -1,0 +1,172 @@
+"""-m gpu: the training side -- IRSNN.train_batch / get_loss_on_eval_data (reference
+influentialRS.py:252-310) and Evaluator.train_batch (evaluator.py:53-92) with projection + cross entropy on the
+HIP engine (irs_ce_forward / irs_ce_grad_logits: no [M, n_item] logits) against the reference's own formulation,
+nn.Linear + nn.CrossEntropyLoss under stock autograd, in float32 and float64."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from influentialrs_amd import synth
+from influentialrs_amd.model import _backend
+from influentialrs_amd.model.evaluator import Evaluator
+from influentialrs_amd.model.influentialRS import IRSNN, InfluentialNet
+from influentialrs_amd.model.uRS import SampleNet
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _reference_loss(x, W, b, labels0):
+    """What the reference computes: CrossEntropyLoss(project(x)[mask], label) (mean over the valid rows)."""
+    mask = labels0.ge(0)
+    return F.cross_entropy(F.linear(x, W, b)[mask], labels0[mask])
+
+
+@pytest.mark.parametrize("M,d,N,chunk_bytes", [(300, 64, 3415, 1 << 30), (70, 128, 100_003, 100_003 * 4 * 32),
+                                               (9000, 128, 3415, 1 << 30), (45, 40, 5000, 1 << 30), (33, 256, 70_001, 1 << 30)])
+def test_project_ce_loss_and_gradients_match_autograd(M, d, N, chunk_bytes, monkeypatch):
+    monkeypatch.setattr(_backend._ProjectCE, "CHUNK_BYTES", chunk_bytes)  # the second case walks 3 row chunks
+    g = torch.Generator(device=DEV)
+    g.manual_seed(M + N)
+    nh = d // 32 if d % 32 == 0 else 1
+    cfg = synth.make_config("tiny", n_item=N, emb_dim=d, n_heads=nh, n_layers=1, max_len=4, ffn_dim=8, n_user=2)
+    net = InfluentialNet(cfg).to(DEV)
+    with torch.no_grad():
+        net.project.weight.copy_((torch.rand((N, d), generator=g, device=DEV) * 2 - 1) * d ** -0.5)
+        net.project.bias.copy_(torch.randn((N,), generator=g, device=DEV) * 0.1)
+    x = torch.randn((M, d), generator=g, device=DEV, requires_grad=True)
+    labels0 = torch.randint(0, N, (M,), generator=g, device=DEV)
+    labels0[torch.rand((M,), generator=g, device=DEV) < 0.3] = -1  # pad targets
+    labels0[0], labels0[1] = N - 1, 0
+    loss = _backend.project_ce(x, net.project, labels0, net._hip)
+    loss.backward()
+    got = (loss.item(), x.grad.clone(), net.project.weight.grad.clone(), net.project.bias.grad.clone())
+    # float64 reference (the yard-stick) and the reference's own float32 formulation (whose error sets the tolerance)
+    x64 = x.detach().double().requires_grad_(True)
+    W64 = net.project.weight.detach().double().requires_grad_(True)
+    b64 = net.project.bias.detach().double().requires_grad_(True)
+    l64 = _reference_loss(x64, W64, b64, labels0)
+    l64.backward()
+    x32 = x.detach().clone().requires_grad_(True)
+    W32 = net.project.weight.detach().clone().requires_grad_(True)
+    b32 = net.project.bias.detach().clone().requires_grad_(True)
+    l32 = _reference_loss(x32, W32, b32, labels0)
+    l32.backward()
+    assert abs(got[0] - l64.item()) <= 2e-6 * abs(l64.item())
+    for name, mine, r64, r32 in (("dx", got[1], x64.grad, x32.grad), ("dW", got[2], W64.grad, W32.grad),
+                                 ("db", got[3], b64.grad, b32.grad)):
+        scale = r64.abs().max().item()
+        err = (mine.double() - r64).abs().max().item()
+        err32 = (r32.double() - r64).abs().max().item()
+        assert err <= max(4 * err32, 2e-6 * scale), (name, err, err32, scale)
+    # ignored rows carry no gradient
+    assert (got[1][labels0 < 0] == 0).all()
+
+
+def _train_pair(cfgname, n, **over):
+    cfg = synth.make_config(cfgname, dropout=0.0, **over)
+    sd = {k: torch.from_numpy(v) for k, v in synth.irn_state_dict(cfg, 1234).items()}
+    net = InfluentialNet(cfg)
+    net.load_state_dict(sd)
+    net.to(DEV)
+    hists = synth.user_histories(max(n, 8), cfg.n_item, seed=7)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=11)[:n]
+    raws, seqs, users, targets, labels = synth.collate_eval_irs(rows, cfg.max_len, gap_len=0)
+    return cfg, net, torch.from_numpy(seqs).to(DEV), torch.from_numpy(users).to(DEV)
+
+
+def _stock_loss(net, seqs, users):
+    """The reference's train_batch body (influentialRS.py:292-303) on the same module, all torch."""
+    out = net.project(net._decoding_autograd(seqs.clone(), users)[0])[:, :-1, :].contiguous().view(-1, net.n_item)
+    tgt = seqs[:, 1:].contiguous().view(-1)
+    mask = tgt.gt(0)
+    return nn.CrossEntropyLoss()(out[mask], tgt[mask] - 1)
+
+
+@pytest.mark.parametrize("cfgname,n", [("tiny", 6), ("default", 8)])
+def test_irsnn_train_batch_equals_the_reference_formulation(cfgname, n):
+    cfg, net, seqs, users = _train_pair(cfgname, n)
+    twin = copy.deepcopy(net)
+    irn = IRSNN(cfg, net, DEV)
+    # gradients of one step, parameter by parameter
+    net.train()
+    twin.train()
+    l_hip = irn._masked_loss(seqs, users)
+    l_hip.backward()
+    l_ref = _stock_loss(twin, seqs, users)
+    l_ref.backward()
+    assert abs(l_hip.item() - l_ref.item()) <= 2e-6 * abs(l_ref.item())
+    for (name, p), (_, q) in zip(net.named_parameters(), twin.named_parameters()):
+        if q.grad is None:
+            assert p.grad is None or not p.grad.abs().max() > 0, name
+            continue
+        sc = q.grad.abs().max().item()
+        assert (p.grad - q.grad).abs().max().item() <= 2e-4 * sc + 1e-9, name
+    # the handler: Adam steps bring the loss down, the eval-mode loss (decoder on the HIP engine too) follows
+    net.zero_grad()
+    l0 = irn.train_batch(seqs, users)
+    l1 = irn.train_batch(seqs, users)
+    l2 = irn.train_batch(seqs, users)
+    assert abs(l0 - l_ref.item()) <= 2e-6 * abs(l0) and l2 < l1 < l0
+    le = irn.get_loss_on_eval_data(seqs, users)
+    net.train()
+    with torch.no_grad():
+        ls = _stock_loss(net, seqs, users).item()  # dropout 0: train-mode torch trunk == eval-mode HIP trunk
+    assert abs(le - ls) <= 2e-5 * abs(ls)
+
+
+def test_eval_loss_matches_reference_logits(golden):
+    """get_loss_on_eval_data == CrossEntropyLoss over the REFERENCE's own logits of the tiny golden."""
+    g = golden("irn_tiny")
+    cfg = synth.make_config("tiny")
+    net = InfluentialNet(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.irn_state_dict(cfg, 1234).items()})
+    net.to(DEV)
+    irn = IRSNN(cfg, net, DEV)
+    seqs = torch.from_numpy(g["seqs"]).to(DEV)
+    loss = irn.get_loss_on_eval_data(seqs, torch.from_numpy(g["users"]).to(DEV))
+    ref = torch.from_numpy(g["logits_full"])[:, :-1, :].reshape(-1, cfg.n_item)
+    tgt = torch.from_numpy(g["seqs"])[:, 1:].reshape(-1)
+    mask = tgt.gt(0)
+    want = F.cross_entropy(ref[mask].double(), tgt[mask] - 1).item()
+    assert abs(loss - want) <= 1e-5 * abs(want)
+
+
+def test_evaluator_train_batch_equals_the_reference_formulation():
+    cfg = synth.make_config("eval_default", dropout=0.0)
+    net = SampleNet(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.irn_state_dict(cfg, 17, evaluator=True).items()})
+    net.to(DEV)
+    twin = copy.deepcopy(net)
+    ev = Evaluator(cfg, net, DEV)
+    g = np.random.default_rng(3)
+    B, L = 6, cfg.max_len
+    tgt = np.zeros((B, L), dtype=np.int64)
+    for i in range(B):  # post-padded sequences, as the evaluator's loader emits them
+        n = int(g.integers(5, L + 1))
+        tgt[i, :n] = g.integers(1, cfg.n_item + 1, size=n)
+    target = torch.from_numpy(tgt).to(DEV)
+    net.train()
+    twin.train()
+    l_hip = ev._masked_loss(target)
+    l_hip.backward()
+    out = twin.forward(target[:, :-1]).reshape(-1, cfg.n_item)
+    t1 = target[:, 1:].contiguous().view(-1)
+    mask = t1.gt(0)
+    l_ref = nn.CrossEntropyLoss()(out[mask], t1[mask] - 1)
+    l_ref.backward()
+    assert abs(l_hip.item() - l_ref.item()) <= 2e-6 * abs(l_ref.item())
+    for (name, p), (_, q) in zip(net.named_parameters(), twin.named_parameters()):
+        if q.grad is None:
+            continue
+        assert (p.grad - q.grad).abs().max().item() <= 2e-4 * q.grad.abs().max().item() + 1e-9, name
+    net.zero_grad()
+    l0 = ev.train_batch(target)
+    l1 = ev.train_batch(target)
+    assert l1 < l0
+    le = ev.get_loss_on_eval_data(target)
+    assert np.isfinite(le) and le < l0
