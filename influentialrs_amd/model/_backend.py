@@ -25,6 +25,18 @@ class HipBackend:
         self.sweep = IRS_SWEEP_BF16
         self.rank, self.world = 0, 1
 
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(net): the copy gets its own backend and builds its own engine on first use (an engine is a
+        handle to device state bound to THIS module's parameter storage; it is never shared or copied)."""
+        import copy
+        new = HipBackend.__new__(HipBackend)
+        memo[id(self)] = new
+        new.net = copy.deepcopy(self.net, memo)
+        new.mask_mode, new.sweep = self.mask_mode, self.sweep
+        new.engine, new._fp, new.group = None, None, None
+        new.rank, new.world = self.rank, self.world
+        return new
+
     def set_sharding(self, rank: int, world: int, drop_full: bool = True):
         """Item-dimension sharding over `world` ranks (torch.distributed must be
         initialised by the caller when world > 1).  drop_full: keep only the shard's rows of
