@@ -2828,8 +2828,12 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
                 }
             };
             const unsigned int pm_diag = (padbits[qb >> 1] >> (16 * (qb & 1))) & 0xFFFFu;
+            // (pairs in groups of two under one guard: a block of few tiles does not walk every pair's own comparisons)
 #pragma unroll
-            for (int kp = 0; kp < MAXT / 2; ++kp) {
+            for (int kg = 0; kg < MAXT / 4; ++kg) {
+            if (4 * kg <= qb) {
+#pragma unroll
+            for (int kp = 2 * kg; kp < 2 * kg + 2; ++kp) {
                 const int k0t = 2 * kp, k1t = 2 * kp + 1;
                 if (k1t <= qb) { // two independent MFMA chains; tile k0t lies below the diagonal
                     score_tile(k0t, sacc[k0t]);
@@ -2845,6 +2849,8 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
                     score_tile(k0t, sacc[k0t]);
                     mask_tile(k0t, pm_diag, sacc[k0t]);
                 }
+            }
+            }
             }
             live = (2u << qb) - 1u;
         } else {
@@ -2913,7 +2919,10 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
                 for (int r = 0; r < 4; ++r) o[0][ct][r] = pt * Vt[(16 * ct + 4 * gq + r) * S + L - 1];
         }
 #pragma unroll
-        for (int kt = 0; kt < MAXT; ++kt) {
+        for (int kg = 0; kg < MAXT / 4; ++kg) {
+        if (!FAST || 4 * kg <= qb) { // FAST: tiles in groups of four under one guard
+#pragma unroll
+        for (int kt = 4 * kg; kt < 4 * kg + 4; ++kt) {
             if (FAST ? (kt <= qb) : ((live >> kt) & 1u) != 0u) { // wave-uniform; tiles beyond qb are never live
                 f32x4 pa;
 #pragma unroll
@@ -2933,6 +2942,8 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
                     o[kt & 1][ct] = oo;
                 }
             }
+        }
+        }
         }
         float lt = l + __shfl_xor(l, 16, 64);
         lt += __shfl_xor(lt, 32, 64);
