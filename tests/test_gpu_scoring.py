@@ -1,6 +1,8 @@
 """-m gpu: the HIP scoring path (through the C ABI) against the oracle.
 Bar: bit-exact ids AND values for every selection (integer/index work and the
 fixed-order float chain), 1e-6 relative for log-sum-exp."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -331,3 +333,41 @@ def test_topk_many_rows_ties_and_dense_hits(oracle):
     assert torch.equal(ids, ei) and torch.equal(val.view(torch.int32), ev.view(torch.int32))
     ov, oi = oracle.topk(oracle.score_chain(x[4], W, b), k)
     assert np.array_equal(ids[4].cpu().numpy(), oi) and np.array_equal(ids[5].cpu().numpy(), oi)
+
+
+def _random_shapes(n, seed):
+    g = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        n_item = int(np.exp(g.uniform(np.log(40), np.log(400_000))))
+        d = int(g.choice([8, 16, 24, 30, 32, 40, 64, 96, 128, 160, 192, 256]))
+        M = int(np.exp(g.uniform(0, np.log(600))))
+        k = int(g.integers(1, 101))
+        out.append((n_item, d, M, k))
+    return out
+
+
+@pytest.mark.parametrize("n_item,d,M,k", _random_shapes(int(os.environ.get("IRS_RANDOM_SHAPES", "28")),
+                                                        int(os.environ.get("IRS_RANDOM_SHAPES_SEED", "20261004"))))
+def test_topk_random_shapes_against_exhaustive(n_item, d, M, k):
+    """Randomly drawn (catalog, width, rows, k): launch geometry, ragged tiles, strip counts, direct / streaming / ring
+    paths as they fall -- the filtered top-k (bf16 and fused with the log-sum-exp) equals the exhaustive exact kernel
+    bit for bit on every row; scores are heavy-tailed (a tenth of the rows scaled by 8, a few items with a large bias)."""
+    W, b = _weights(n_item, d, n_item + d)
+    g = np.random.default_rng(M + k)
+    b[g.integers(0, n_item, size=max(1, n_item // 5000))] += 3.0
+    x = _rows(M, d, M + 7 * k)
+    x[g.random(M) < 0.1] *= 8.0
+    eng = scoring_only_engine(n_item, d, W, b, max_rows=M, max_k=k)
+    xt = torch.from_numpy(x).cuda()
+    ev, ei, es = eng.score_topk(xt, k, IRS_SWEEP_EXHAUSTIVE)
+    val, ids, st = eng.score_topk(xt, k, IRS_SWEEP_BF16)
+    v2, i2, s2, mx, sm = eng.score_topk_lse(xt, k, IRS_SWEEP_BF16)
+    m0, e0 = eng.score_lse(xt)
+    torch.cuda.synchronize()
+    assert torch.equal(ids, ei) and torch.equal(val.view(torch.int32), ev.view(torch.int32))
+    assert torch.equal(i2, ei) and torch.equal(v2.view(torch.int32), ev.view(torch.int32))
+    assert torch.equal(st & 4, es & 4) and torch.equal(s2 & 4, es & 4)  # "fewer than k items" agrees
+    l0 = (m0.double() + e0.double().log()).cpu().numpy()
+    l1 = (mx.double() + sm.double().log()).cpu().numpy()
+    assert np.abs(l0 - l1).max() <= 4e-6 * max(1.0, np.abs(l0).max())
