@@ -82,6 +82,7 @@ class InfluentialNet(nn.Module):
     def _generate_square_subsequent_mask(self, size, pi_factor):
         """[B*H, L, L] float mask: allowed = r_u[b], future = -inf, last column = 1.0
         (the as-called semantics of reference :120-155 / :183-184, per row)."""
+        pi_factor = pi_factor.detach()  # the reference calls float() on it (:141): no gradient reaches the user tensors
         B = pi_factor.size(0)
         dev = pi_factor.device
         tril = torch.ones(size, size, device=dev).tril().bool()

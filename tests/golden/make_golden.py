@@ -373,6 +373,45 @@ def harness_case():
     print("[golden] harness_tiny: printed =", g["printed"], "paths", g["paths"].shape, g["paths"].dtype)
 
 
+def train_case():
+    """The training side as the unmodified reference runs it, dropout 0 (the only source of randomness):
+    IRSNN.train_batch looped at B = 1 over four users (sequential Adam steps, influentialRS.py:278-310) with
+    get_loss_on_eval_data before and after; Evaluator.train_batch at B = 4 (evaluator.py:53-68), three steps."""
+    g = {}
+    cfg = synth.make_config("tiny", dropout=0.0)
+    torch.manual_seed(0)
+    net = _load(InfluentialNet(cfg), synth.irn_state_dict(cfg, 1234))
+    irn = IRSNN(cfg, net, "cpu")
+    hists = synth.user_histories(8, cfg.n_item, seed=7)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=11)[:4]
+    raws, seqs, users, targets, labels = synth.collate_eval_irs(rows, cfg.max_len, gap_len=0)
+    g["irn_seqs"], g["irn_users"] = seqs, users
+    ev0 = [irn.get_loss_on_eval_data(torch.from_numpy(seqs[i:i + 1]), torch.from_numpy(users[i:i + 1])) for i in range(4)]
+    tr = [irn.train_batch(torch.from_numpy(seqs[i:i + 1]), torch.from_numpy(users[i:i + 1])) for i in range(4)]
+    ev1 = [irn.get_loss_on_eval_data(torch.from_numpy(seqs[i:i + 1]), torch.from_numpy(users[i:i + 1])) for i in range(4)]
+    g["irn_eval_before"], g["irn_train"], g["irn_eval_after"] = np.array(ev0), np.array(tr), np.array(ev1)
+    g["irn_bias_after"] = net.project.bias.detach().numpy().copy()
+
+    ecfg = synth.make_config("eval_tiny", dropout=0.0)
+    torch.manual_seed(0)
+    snet = _load(SampleNet(ecfg), synth.irn_state_dict(ecfg, 17, evaluator=True))
+    ev = Evaluator(ecfg, snet, "cpu")
+    rng = np.random.default_rng(3)
+    B, L = 4, ecfg.max_len
+    tgt = np.zeros((B, L), dtype=np.int64)
+    for i in range(B):  # post-padded sequences, as the evaluator's loader emits them
+        n = int(rng.integers(5, L + 1))
+        tgt[i, :n] = rng.integers(1, ecfg.n_item + 1, size=n)
+    g["ev_target"] = tgt
+    t = torch.from_numpy(tgt)
+    g["ev_eval_before"] = np.array([ev.get_loss_on_eval_data(t)])
+    g["ev_train"] = np.array([ev.train_batch(t) for _ in range(3)])
+    g["ev_eval_after"] = np.array([ev.get_loss_on_eval_data(t)])
+    g["meta"] = np.array([torch.__version__])
+    np.savez_compressed(os.path.join(OUT, "train_tiny.npz"), **g)
+    print(f"[golden] train_tiny: irn train {g['irn_train']} eval {ev0[0]:.5f} -> {ev1[0]:.5f}; evaluator {g['ev_train']}")
+
+
 CASES = {
     "irn_tiny": lambda: irn_case("irn_tiny", "tiny", 12, full_logits=True, save_x_full=True),
     "irn_default": lambda: irn_case("irn_default", "default", 32),
@@ -383,6 +422,7 @@ CASES = {
     "eval_default": lambda: eval_case("eval_default", "eval_default", 6),
     "contract": contract_case,
     "harness_tiny": harness_case,
+    "train_tiny": train_case,
 }
 
 if __name__ == "__main__":

@@ -170,3 +170,37 @@ def test_evaluator_train_batch_equals_the_reference_formulation():
     assert l1 < l0
     le = ev.get_loss_on_eval_data(target)
     assert np.isfinite(le) and le < l0
+
+
+def test_training_matches_the_reference_run(golden):
+    """tests/golden/train_tiny.npz = the UNMODIFIED reference's own losses (make_golden.py:train_case, dropout 0):
+    IRSNN eval loss, four sequential B = 1 Adam steps, eval loss again; Evaluator eval loss, three B = 4 steps, eval
+    loss.  Here the trunk runs on torch's GPU kernels and projection + cross entropy on the HIP engine."""
+    g = golden("train_tiny")
+    cfg = synth.make_config("tiny", dropout=0.0)
+    net = InfluentialNet(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.irn_state_dict(cfg, 1234).items()})
+    net.to(DEV)
+    irn = IRSNN(cfg, net, DEV)
+    seqs, users = torch.from_numpy(g["irn_seqs"]).to(DEV), torch.from_numpy(g["irn_users"]).to(DEV)
+    ev0 = [irn.get_loss_on_eval_data(seqs[i:i + 1], users[i:i + 1]) for i in range(4)]
+    tr = [irn.train_batch(seqs[i:i + 1], users[i:i + 1]) for i in range(4)]
+    ev1 = [irn.get_loss_on_eval_data(seqs[i:i + 1], users[i:i + 1]) for i in range(4)]
+    assert np.allclose(ev0, g["irn_eval_before"], rtol=2e-6, atol=0)
+    assert abs(tr[0] - g["irn_train"][0]) <= 2e-6 * abs(tr[0])
+    assert np.allclose(tr, g["irn_train"], rtol=2e-4, atol=0), (tr, g["irn_train"])  # after Adam steps on the previous rows
+    assert np.allclose(ev1, g["irn_eval_after"], rtol=5e-4, atol=0), (ev1, g["irn_eval_after"])
+    assert np.abs(net.project.bias.detach().cpu().numpy() - g["irn_bias_after"]).max() <= 0.35 * 4 * cfg.lr1  # 4 steps of <= lr
+    # the reference passes r_u through float(): the user tensors never receive a gradient
+    assert net.user_embedder.weight.grad is None and net.user_mask_layer.weight.grad is None
+
+    ecfg = synth.make_config("eval_tiny", dropout=0.0)
+    snet = SampleNet(ecfg)
+    snet.load_state_dict({k: torch.from_numpy(v) for k, v in synth.irn_state_dict(ecfg, 17, evaluator=True).items()})
+    snet.to(DEV)
+    ev = Evaluator(ecfg, snet, DEV)
+    t = torch.from_numpy(g["ev_target"]).to(DEV)
+    assert abs(ev.get_loss_on_eval_data(t) - g["ev_eval_before"][0]) <= 2e-6 * g["ev_eval_before"][0]
+    etr = [ev.train_batch(t) for _ in range(3)]
+    assert np.allclose(etr, g["ev_train"], rtol=2e-4, atol=0), (etr, g["ev_train"])
+    assert abs(ev.get_loss_on_eval_data(t) - g["ev_eval_after"][0]) <= 5e-4 * g["ev_eval_after"][0]

@@ -126,3 +126,19 @@ def test_torch_restatement_matches_numpy_oracle(oracle):
             nxt = oracle.select_next(ids0 + 1, vals, seqs[r][:hep + 1])
             got, new = irn.path_step_like_reference(torch.from_numpy(seqs[r]), r, hep)
             assert got == nxt and new[-2] == nxt and new[-1] == seqs[r][-1]
+
+
+def test_cpu_training_trunk_reproduces_the_reference_run(golden):
+    """The torch side of training (decoder trunk under autograd, as-called mask with r_u detached, Adam settings)
+    against tests/golden/train_tiny.npz = the unmodified reference's own losses.  A module left on the CPU uses the
+    reference's nn.Linear + CrossEntropyLoss formulation; the GPU test runs the same golden through the HIP engine."""
+    g = golden("train_tiny")
+    cfg = synth.make_config("tiny", dropout=0.0)
+    net = InfluentialNet(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.irn_state_dict(cfg, 1234).items()})
+    irn = IRSNN(cfg, net, "cpu")
+    seqs, users = torch.from_numpy(g["irn_seqs"]), torch.from_numpy(g["irn_users"])
+    tr = [irn.train_batch(seqs[i:i + 1], users[i:i + 1]) for i in range(4)]
+    assert np.allclose(tr, g["irn_train"], rtol=1e-5, atol=0), (tr, g["irn_train"])
+    assert np.abs(net.project.bias.detach().numpy() - g["irn_bias_after"]).max() < 1e-4
+    assert net.user_embedder.weight.grad is None  # the reference passes r_u through float(): no gradient

@@ -25,7 +25,7 @@ for sh in args.shapes:
         nh = d // 32
         cfg = synth.make_config("tiny", n_item=N, emb_dim=d, n_heads=nh, n_layers=1, max_len=4, ffn_dim=8, n_user=2)
         eng = Engine(n_item=N, n_user=2, d=d, max_len=4, n_heads=nh, ffn_dim=8, n_layers=1, u_dim=10, mask_mode=IRS_MASK_IRN,
-                     device=dev, max_rows=1024, max_seqs=1)
+                     device=dev, max_rows=max(1024, max(int(s.split(",")[2]) for s in args.shapes)), max_seqs=1)
         sd = {k: torch.from_numpy(v).to(dev) for k, v in synth.irn_state_dict(synth.make_config("tiny", n_item=8, emb_dim=d, n_heads=nh, n_layers=1, max_len=4, ffn_dim=8, n_user=2), 1).items()}
         g = torch.Generator(device=dev); g.manual_seed(1)
         sd["item_embedder.weight"] = torch.zeros((N + 1, d), device=dev)
