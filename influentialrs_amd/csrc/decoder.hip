@@ -561,26 +561,30 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : 2) k_linear(LinArgs a) {
 // Workgroup = 4 waves = 128 tokens; W (all N rows) and X slabs of 32 k stream through the same
 // swizzled double-buffered LDS image as k_linear.
 // FULL = N == 128, K a multiple of BK, every operand 16-byte aligned (host-checked): no guards anywhere.
-template <int BK, bool FULL, bool XF>
-__global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(LinArgs a) {
-    __shared__ __attribute__((aligned(16))) float sm[2 * 2 * LIN_BM * BK + 6 * LIN_BN];
-    float *vecs = sm + 2 * 2 * LIN_BM * BK; // bias, g1, b1, c, g2, b2 (zero padded to 128)
+// NT = 32-column tiles per token: 4 (N <= 128) or 8 (N <= 256: a lane then holds 128 of its token's values, the
+// W slab is two 128-row tiles; two waves per SIMD).  The fragment-major operands (Rf, Yf, Xf) exist for NT = 4 only.
+template <int BK, bool FULL, bool XF, int NT = 4>
+__global__ void __launch_bounds__(256, (BK == 16 && FULL && NT == 4) ? 3 : 2) k_linear_ln(LinArgs a) {
+    constexpr int NC = 32 * NT; // padded row width
+    static_assert(NT == 4 || (NT == 8 && !XF), "fragment-major X is a 128-column layout");
+    __shared__ __attribute__((aligned(16))) float sm[2 * (LIN_BM + NC) * BK + 6 * NC];
+    float *vecs = sm + 2 * (LIN_BM + NC) * BK; // bias, g1, b1, c, g2, b2 (zero padded to NC)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lk = lane >> 5;
     const int m0 = blockIdx.x * LIN_BM;
     const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M, N = a.N, K = a.K;
     if (m0 >= M) return;
-    auto Xs = [&](int st) { return sm + (st * 2 + 0) * LIN_BM * BK; };
-    auto Ws = [&](int st) { return sm + (st * 2 + 1) * LIN_BM * BK; };
-    if (tid < LIN_BN) {
+    auto Xs = [&](int st) { return sm + st * (LIN_BM + NC) * BK; };
+    auto Ws = [&](int st) { return sm + st * (LIN_BM + NC) * BK + LIN_BM * BK; };
+    if (tid < NC) {
         const bool in = tid < N;
-        vecs[0 * LIN_BN + tid] = (in && a.bias) ? a.bias[tid] : 0.f;
-        vecs[1 * LIN_BN + tid] = in ? a.g1[tid] : 0.f;
-        vecs[2 * LIN_BN + tid] = in ? a.b1[tid] : 0.f;
-        vecs[3 * LIN_BN + tid] = (in && a.c) ? a.c[tid] : 0.f;
-        vecs[4 * LIN_BN + tid] = (in && a.c) ? a.g2[tid] : 0.f;
-        vecs[5 * LIN_BN + tid] = (in && a.c) ? a.b2[tid] : 0.f;
+        vecs[0 * NC + tid] = (in && a.bias) ? a.bias[tid] : 0.f;
+        vecs[1 * NC + tid] = in ? a.g1[tid] : 0.f;
+        vecs[2 * NC + tid] = in ? a.b1[tid] : 0.f;
+        vecs[3 * NC + tid] = (in && a.c) ? a.c[tid] : 0.f;
+        vecs[4 * NC + tid] = (in && a.c) ? a.g2[tid] : 0.f;
+        vecs[5 * NC + tid] = (in && a.c) ? a.b2[tid] : 0.f;
     }
     const int mt = m0 + wave * 32 + li; // this lane's token
 
@@ -588,11 +592,11 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(L
     // column tn*32 + 8g + 4lk + e); bias is added in the epilogue from LDS.  A fragment-major residual
     // Rf[((token/32 * 4 + tn) * 4 + g) * 64 + lane] (float4) makes every wave load one contiguous KiB;
     // the row-major fallback reads 16-byte pieces of 64 different rows per instruction.
-    f32x16 acc[4];
+    f32x16 acc[NT];
     const int mtile = (m0 >> 5) + wave;
-    if (a.Rf) { // 16 unconditional, perfectly coalesced loads
+    if (NT == 4 && a.Rf) { // 16 unconditional, perfectly coalesced loads
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 t = reinterpret_cast<const float4 *>(a.Rf)[((size_t)(mtile * 4 + tn) * 4 + g) * 64 + lane];
@@ -604,7 +608,7 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(L
     } else if (FULL) { // full rows: unconditional loads from a clamped row (rows >= M are never stored)
         const float *rrow = a.R + (int64_t)min(mt, M - 1) * N;
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 t = *reinterpret_cast<const float4 *>(rrow + tn * 32 + 8 * g + 4 * lk);
@@ -615,7 +619,7 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(L
             }
     } else {
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = tn * 32 + 8 * g + 4 * lk;
@@ -634,13 +638,15 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(L
             }
     }
 
-    float4 xv[BK / 8], wv[BK / 8];
+    float4 xv[BK / 8], wv[BK / 8], wv2[BK / 8];
     if (XF) lin_load_tile_frag<BK>(a.Xf, m0, 0, tid, xv);
     else lin_load_tile<FULL, BK>(a.X, M, K, m0, 0, tid, xv);
     lin_load_tile<FULL, BK>(a.W, N, K, 0, 0, tid, wv);
+    if (NT == 8) lin_load_tile<FULL, BK>(a.W, N, K, LIN_BM, 0, tid, wv2);
     if (XF) lin_store_tile_frag<BK>(Xs(0), tid, xv);
     else lin_store_tile<BK>(Xs(0), tid, xv);
     lin_store_tile<BK>(Ws(0), tid, wv);
+    if (NT == 8) lin_store_tile<BK>(Ws(0) + LIN_BM * BK, tid, wv2);
     __syncthreads();
     const int nkt = (K + BK - 1) / BK;
     const int sw = lin_swz<BK>(li);
@@ -650,6 +656,7 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(L
             if (XF) lin_load_tile_frag<BK>(a.Xf, m0, (kt + 1) * BK, tid, xv);
             else lin_load_tile<FULL, BK>(a.X, M, K, m0, (kt + 1) * BK, tid, xv);
             lin_load_tile<FULL, BK>(a.W, N, K, 0, (kt + 1) * BK, tid, wv);
+            if (NT == 8) lin_load_tile<FULL, BK>(a.W, N, K, LIN_BM, (kt + 1) * BK, tid, wv2);
         }
         const float *xb = Xs(cur) + (wave * 32 + li) * BK;
         const float *wa = Ws(cur) + li * BK;
@@ -657,15 +664,12 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(L
         for (int q = 0; q < BK / 8; ++q) {
             const int off = ((2 * q + lk) ^ sw) << 2;
             const float4 x4 = *reinterpret_cast<const float4 *>(xb + off);
-            const float4 w0 = *reinterpret_cast<const float4 *>(wa + off);
-            const float4 w1 = *reinterpret_cast<const float4 *>(wa + 32 * BK + off);
-            const float4 w2 = *reinterpret_cast<const float4 *>(wa + 64 * BK + off);
-            const float4 w3 = *reinterpret_cast<const float4 *>(wa + 96 * BK + off);
-#define LN_STEP(E)                                                                   \
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.E, x4.E, acc[0], 0, 0, 0);      \
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.E, x4.E, acc[1], 0, 0, 0);      \
-    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2.E, x4.E, acc[2], 0, 0, 0);      \
-    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w3.E, x4.E, acc[3], 0, 0, 0);
+            float4 wq[NT];
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) wq[tn] = *reinterpret_cast<const float4 *>(wa + tn * 32 * BK + off);
+#define LN_STEP(E)                                                                                        \
+    _Pragma("unroll") for (int tn = 0; tn < NT; ++tn)                                                     \
+        acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[tn].E, x4.E, acc[tn], 0, 0, 0);
             LN_STEP(x) LN_STEP(y) LN_STEP(z) LN_STEP(w)
 #undef LN_STEP
         }
@@ -673,15 +677,16 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(L
             if (XF) lin_store_tile_frag<BK>(Xs(cur ^ 1), tid, xv);
             else lin_store_tile<BK>(Xs(cur ^ 1), tid, xv);
             lin_store_tile<BK>(Ws(cur ^ 1), tid, wv);
+            if (NT == 8) lin_store_tile<BK>(Ws(cur ^ 1) + LIN_BM * BK, tid, wv2);
         }
         __syncthreads();
         cur ^= 1;
     }
-    // ---- register-local LayerNorm of this lane's token (64 of its N values here, 64 in lane^32)
+    // ---- register-local LayerNorm of this lane's token (half of its N values here, half in lane^32)
     const float invn = 1.0f / (float)N;
     float sum = 0.f;
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
+    for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = tn * 32 + 8 * g + 4 * lk;
@@ -704,7 +709,7 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(L
         mu = (s1 + __shfl_xor(s1, 32, 64)) * invn;
         float q = 0.f;
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -718,13 +723,13 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(L
     const bool two = a.c != nullptr;
     sum = 0.f;
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
+    for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = tn * 32 + 8 * g + 4 * lk;
-            const float4 gg = *reinterpret_cast<const float4 *>(vecs + 1 * LIN_BN + n);
-            const float4 be = *reinterpret_cast<const float4 *>(vecs + 2 * LIN_BN + n);
-            const float4 cc = *reinterpret_cast<const float4 *>(vecs + 3 * LIN_BN + n);
+            const float4 gg = *reinterpret_cast<const float4 *>(vecs + 1 * NC + n);
+            const float4 be = *reinterpret_cast<const float4 *>(vecs + 2 * NC + n);
+            const float4 cc = *reinterpret_cast<const float4 *>(vecs + 3 * NC + n);
             float y0 = (acc[tn][4 * g + 0] - mu) * rstd * gg.x + be.x + cc.x;
             float y1 = (acc[tn][4 * g + 1] - mu) * rstd * gg.y + be.y + cc.y;
             float y2 = (acc[tn][4 * g + 2] - mu) * rstd * gg.z + be.z + cc.z;
@@ -742,21 +747,21 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(L
     if (two) {
         stats(sum, mu, rstd);
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = tn * 32 + 8 * g + 4 * lk;
-                const float4 gg = *reinterpret_cast<const float4 *>(vecs + 4 * LIN_BN + n);
-                const float4 be = *reinterpret_cast<const float4 *>(vecs + 5 * LIN_BN + n);
+                const float4 gg = *reinterpret_cast<const float4 *>(vecs + 4 * NC + n);
+                const float4 be = *reinterpret_cast<const float4 *>(vecs + 5 * NC + n);
                 acc[tn][4 * g + 0] = (acc[tn][4 * g + 0] - mu) * rstd * gg.x + be.x;
                 acc[tn][4 * g + 1] = (acc[tn][4 * g + 1] - mu) * rstd * gg.y + be.y;
                 acc[tn][4 * g + 2] = (acc[tn][4 * g + 2] - mu) * rstd * gg.z + be.z;
                 acc[tn][4 * g + 3] = (acc[tn][4 * g + 3] - mu) * rstd * gg.w + be.w;
             }
     }
-    if (a.Yf) { // fragment-major copy for the next LN-GEMM's residual (rows/cols beyond M/N are zeros)
+    if (NT == 4 && a.Yf) { // fragment-major copy for the next LN-GEMM's residual (rows/cols beyond M/N are zeros)
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 reinterpret_cast<float4 *>(a.Yf)[((size_t)(mtile * 4 + tn) * 4 + g) * 64 + lane] =
@@ -765,7 +770,7 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(L
     if (FULL && a.Y && mt < M) {
         float *Yr = a.Y + (int64_t)mt * N;
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<float4 *>(Yr + tn * 32 + 8 * g + 4 * lk) =
@@ -773,7 +778,7 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL) ? 3 : 2) k_linear_ln(L
     } else if (!FULL && a.Y && mt < M) {
         float *Yr = a.Y + (int64_t)mt * N;
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = tn * 32 + 8 * g + 4 * lk;
@@ -3240,6 +3245,15 @@ static int launch_linear(irs_ctx *ctx, const float *X, const float *W, const flo
     if (M <= 2048 && K <= 256) { // latency path: one wave per 32x32 tile, operands straight from L2
         if (g1 != nullptr) hipLaunchKernelGGL(k_linear_small<true>, dim3(1, (M + 31) / 32), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(k_linear_small<false>, dim3((N + 127) / 128, (M + 31) / 32), dim3(256), 0, s, a);
+    } else if (g1 != nullptr && N > LIN_BN) { // fused residual + LayerNorm, rows of up to 256 values (8 tiles per token)
+        if (N > 2 * LIN_BN || Xf || Rf || Yf) {
+            if (ctx) snprintf(ctx->err, sizeof(ctx->err), "launch_linear: LayerNorm epilogue needs N <= 256 (and row-major operands above 128)");
+            return IRS_E_INVALID;
+        }
+        dim3 grid((M + LIN_BM - 1) / LIN_BM);
+        const bool full = (N == 2 * LIN_BN) && (K % 16 == 0) && al16(X) && al16(W) && al16(R) && al16(Y);
+        if (full) hipLaunchKernelGGL((k_linear_ln<16, true, false, 8>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_linear_ln<16, false, false, 8>), grid, dim3(256), 0, s, a);
     } else if (g1 != nullptr) { // fused residual + LayerNorm: whole rows per wave (N <= 128)
         dim3 grid((M + LIN_BM - 1) / LIN_BM);
         const int bk = g_ln_bk;
@@ -3684,7 +3698,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             float *tswap = x; // the new x lives in the other buffer
             x = y;
             y = tswap;
-        } else if (d <= LIN_BN) {
+        } else if (d <= LIN_BN || (d <= 2 * LIN_BN && rows > 2048)) {
             // x <- LN2(LN1(x + ao W_o^T + b_o) + c_l), fused into the GEMM epilogue (y, not in place)
             if ((rc = launch_linear(ctx, ctx->act_ao, w.sa_out_w, w.sa_out_b, x, y, rows, d, d, false, s, w.n1_w, w.n1_b,
                                     cl, w.n2_w, w.n2_b, nullptr, nullptr, m_dev)))
