@@ -204,3 +204,30 @@ def test_training_matches_the_reference_run(golden):
     etr = [ev.train_batch(t) for _ in range(3)]
     assert np.allclose(etr, g["ev_train"], rtol=2e-4, atol=0), (etr, g["ev_train"])
     assert abs(ev.get_loss_on_eval_data(t) - g["ev_eval_after"][0]) <= 5e-4 * g["ev_eval_after"][0]
+
+
+def test_ce_entry_points_reject_item_shards_and_bad_buffers():
+    """irs_ce_* need the whole catalog on one device; ce_grad_logits checks its output buffer."""
+    from influentialrs_amd.engine import Engine, IrsError
+    from influentialrs_amd._lib import IRS_MASK_IRN
+    cfg = synth.make_config("tiny")
+    sd = {k: torch.from_numpy(v).to(DEV) for k, v in synth.irn_state_dict(cfg, 1234).items()}
+    x = torch.randn(8, cfg.emb_dim, device=DEV)
+    lab = torch.zeros(8, dtype=torch.int64, device=DEV)
+    shard = Engine(n_item=cfg.n_item, n_user=cfg.n_user, d=cfg.emb_dim, max_len=cfg.max_len, n_heads=cfg.n_heads,
+                   ffn_dim=cfg.ffn_dim, n_layers=cfg.n_layers, u_dim=cfg.u_emb_dim, mask_mode=IRS_MASK_IRN, device=torch.device(DEV),
+                   max_rows=8, max_seqs=8, rank=0, world=2)
+    shard.bind_state_dict(sd)
+    with pytest.raises(IrsError):
+        shard.ce_forward(x, lab)
+    full = Engine(n_item=cfg.n_item, n_user=cfg.n_user, d=cfg.emb_dim, max_len=cfg.max_len, n_heads=cfg.n_heads,
+                  ffn_dim=cfg.ffn_dim, n_layers=cfg.n_layers, u_dim=cfg.u_emb_dim, mask_mode=IRS_MASK_IRN, device=torch.device(DEV),
+                  max_rows=8, max_seqs=8)
+    full.bind_state_dict(sd)
+    lse, ls, tot = full.ce_forward(x, lab)
+    with pytest.raises(IrsError):
+        full.ce_grad_logits(x, lab, lse, 1.0, torch.empty((8, cfg.n_item - 1), device=DEV))  # too narrow
+    with pytest.raises(IrsError):
+        full.ce_forward(torch.randn(9, cfg.emb_dim, device=DEV), torch.zeros(9, dtype=torch.int64, device=DEV))  # M > max_rows
+    G = full.ce_grad_logits(x, lab, lse, 1.0, torch.empty((8, cfg.n_item), device=DEV))
+    assert abs(G.sum().item()) < 1e-3  # softmax minus one-hot sums to zero on every row
