@@ -16,18 +16,20 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, backend="gloo", own_gpu=False):
     import faulthandler
     import sys
     faulthandler.dump_traceback_later(170, exit=True)  # a stuck rank reports where, and dies
     sys.path.insert(0, REPO)
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if own_gpu:
+        torch.cuda.set_device(rank)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         from influentialrs_amd import synth
         from influentialrs_amd.model.influentialRS import IRSNN, InfluentialNet
-        dev = "cuda:0"
+        dev = f"cuda:{rank}" if own_gpu else "cuda:0"
         g = np.load(os.path.join(REPO, "tests", "golden", "irn_default.npz"))
         cfg = synth.make_config("default")
         net = InfluentialNet(cfg)
@@ -112,6 +114,30 @@ def test_sharded_handlers_world2():
             assert p.exitcode == 0, f"rank process exit code {p.exitcode} (None = still running after 200 s)"
     finally:
         for p in procs:  # never leave a rank behind: a live child keeps the whole test run from ending
+            if p.is_alive():
+                p.kill()
+                p.join(10)
+    assert sorted(ret.keys()) == [0, 1]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one rank per GPU over RCCL")
+def test_sharded_handlers_world2_rccl():
+    """The same checks with the production transport: backend nccl (= RCCL), one rank per GPU.  Skipped on the
+    one-GPU boxes the build loop has; it runs wherever `pytest -m gpu` finds two devices."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret, "nccl", True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0, f"rank process exit code {p.exitcode} (None = still running after 300 s)"
+    finally:
+        for p in procs:
             if p.is_alive():
                 p.kill()
                 p.join(10)
