@@ -2653,6 +2653,24 @@ __global__ void __launch_bounds__(256) k_attn_mfma(const float *__restrict__ qkv
 // both conflict-free for the four 16-lane groups ds_read_b128 is serviced in.  Keys in [L, 16 ceil(L/16)) of
 // the last tile carry p = 0; their K rows are zero-filled, their V^T columns are zero-filled up to S (a column
 // index >= S aliases the next row's first keys: finite values times 0).
+// Sum / maximum over the four lanes that share lane & 15 (l, l ^ 16, l ^ 32, l ^ 48), every lane getting the result:
+// gfx950's v_permlane16_swap / v_permlane32_swap (vector ALU) instead of two ds_bpermute round trips through the LDS
+// crossbar, each awaited at once.  With both operands the same register, the swap leaves {rows 0,0,2,2} and
+// {rows 1,1,3,3} (16-lane rows), resp. {low half twice} and {high half twice}: their sum is x[l] + x[l ^ 16], resp.
+// s[l] + s[l ^ 32], in every lane -- the same two additions as the shuffle form, so the bits are the same.
+__device__ __forceinline__ float quad16_sum(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float quad16_max(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 __device__ __forceinline__ int attn16_vstride(int Lmax) {
     int S = (Lmax + 7) & ~7;
     if ((S & 15) != 8) S += 8;
@@ -2898,12 +2916,9 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
             part = __fmaf_rn(qf[5], k1.y, part);
             part = __fmaf_rn(qf[6], k1.z, part);
             part = __fmaf_rn(qf[7], k1.w, part);
-            part += __shfl_xor(part, 16, 64);
-            part += __shfl_xor(part, 32, 64);
-            st = part + tgt_add;
+            st = quad16_sum(part) + tgt_add;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = quad16_max(mx);
         float m = fmaxf(mx, st);
         if (m == -INFINITY) m = 0.f; // nothing visible: every exp2(-inf - 0) is 0, l = 0 -> NaN row like torch
         // ---- pass 2: p = exp(s - m), O^T += V^T P^T on four accumulators (tile parity x column tile)
@@ -2950,8 +2965,7 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
         }
         }
         }
-        float lt = l + __shfl_xor(l, 16, 64);
-        lt += __shfl_xor(lt, 32, 64);
+        const float lt = quad16_sum(l);
         const float inv = 1.0f / lt; // 0 (fully masked) -> inf, 0 * inf = NaN like torch
         if (qi < L) {
             if (out_frag) { // fragment-major image (d = 128: column block tn = head): the fused block kernel's B operand
