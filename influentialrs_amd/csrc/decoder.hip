@@ -391,11 +391,44 @@ __device__ __forceinline__ void lin_store_tile_frag(float *S, int tid, const flo
     }
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+// ---- cross-lane all-reductions without the LDS crossbar.  hipcc lowers every __shfl_xor to ds_bpermute_b32 (an
+// LDS-pipe round trip, awaited at once when the next step depends on it); the latency kernels run chains of them.
+// Here: DPP for the steps inside a 16-lane row (quad_perm for xor 1 / 2, row_ror:8 for xor 8; row_half_mirror reaches
+// the other quad, so level 4 needs the quads to agree already -- true after levels 1 and 2, or when the data is
+// uniform per quad), gfx950's v_permlane16_swap / v_permlane32_swap for the steps across rows.  STEPS says which of
+// the six butterfly levels run (bit i = level 2^i).  Every lane of a reduced group ends with the same bits.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __uint_as_float((unsigned int)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
+struct OpSum {
+    __device__ __forceinline__ float operator()(float a, float b) const { return a + b; }
+};
+struct OpMax {
+    __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); }
+};
+template <int STEPS, typename OP>
+__device__ __forceinline__ float lanes_reduce(float v, OP op) {
+    if (STEPS & 1) v = op(v, dpp_f32<0xB1>(v));  // quad_perm [1,0,3,2]
+    if (STEPS & 2) v = op(v, dpp_f32<0x4E>(v));  // quad_perm [2,3,0,1]
+    if (STEPS & 4) v = op(v, dpp_f32<0x141>(v)); // row_half_mirror
+    if (STEPS & 8) v = op(v, dpp_f32<0x128>(v)); // row_ror:8 = lane ^ 8 inside the row, no agreement needed
+    if (STEPS & 16) {
+        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = op(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    }
+    if (STEPS & 32) {
+        const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = op(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    }
     return v;
 }
+template <int STEPS>
+__device__ __forceinline__ float lanes_sum(float v) { return lanes_reduce<STEPS>(v, OpSum()); }
+template <int STEPS>
+__device__ __forceinline__ float lanes_max(float v) { return lanes_reduce<STEPS>(v, OpMax()); }
+
+__device__ __forceinline__ float wave_sum(float v) { return lanes_sum<63>(v); }
 
 // One workgroup owns 128 rows and walks every 128-column block of the output: the (column block, k-slab)
 // steps form ONE software pipeline, so the global-load latency of a block's first slab and the store tail of
@@ -706,7 +739,7 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL && NT == 4) ? 3 : 2) k_
             sum += (z0 + z1) + (z2 + z3);
         }
     auto stats = [&](float s1, float &mu, float &rstd) {
-        mu = (s1 + __shfl_xor(s1, 32, 64)) * invn;
+        mu = lanes_sum<32>(s1) * invn;
         float q = 0.f;
 #pragma unroll
         for (int tn = 0; tn < NT; ++tn)
@@ -716,7 +749,7 @@ __global__ void __launch_bounds__(256, (BK == 16 && FULL && NT == 4) ? 3 : 2) k_
                 const float dlt = (n < N) ? acc[tn][r] - mu : 0.f;
                 q += dlt * dlt;
             }
-        rstd = 1.0f / sqrtf((q + __shfl_xor(q, 32, 64)) * invn + 1e-5f);
+        rstd = 1.0f / sqrtf(lanes_sum<32>(q) * invn + 1e-5f);
     };
     float mu, rstd;
     stats(sum, mu, rstd);
@@ -971,7 +1004,7 @@ __global__ void __launch_bounds__(256, 2) k_block(BlockArgs a) {
                     }
                     sum += (acc[tn][4 * g + 0] + acc[tn][4 * g + 1]) + (acc[tn][4 * g + 2] + acc[tn][4 * g + 3]);
                 }
-            const float mu = (sum + __shfl_xor(sum, 32, 64)) * invn;
+            const float mu = lanes_sum<32>(sum) * invn;
             float qs = 0.f;
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn)
@@ -980,7 +1013,7 @@ __global__ void __launch_bounds__(256, 2) k_block(BlockArgs a) {
                     const float dlt = acc[tn][r] - mu;
                     qs += dlt * dlt;
                 }
-            const float rstd = 1.0f / sqrtf((qs + __shfl_xor(qs, 32, 64)) * invn + 1e-5f);
+            const float rstd = 1.0f / sqrtf(lanes_sum<32>(qs) * invn + 1e-5f);
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
@@ -1108,7 +1141,7 @@ __global__ void __launch_bounds__(256, 2) k_block(BlockArgs a) {
             acc[tn][4 * g + 3] += bb.w;
             sum += (acc[tn][4 * g + 0] + acc[tn][4 * g + 1]) + (acc[tn][4 * g + 2] + acc[tn][4 * g + 3]);
         }
-    const float mu = (sum + __shfl_xor(sum, 32, 64)) * invn;
+    const float mu = lanes_sum<32>(sum) * invn;
     float qs = 0.f;
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn)
@@ -1117,7 +1150,7 @@ __global__ void __launch_bounds__(256, 2) k_block(BlockArgs a) {
             const float dlt = acc[tn][r] - mu;
             qs += dlt * dlt;
         }
-    const float rstd = 1.0f / sqrtf((qs + __shfl_xor(qs, 32, 64)) * invn + 1e-5f);
+    const float rstd = 1.0f / sqrtf(lanes_sum<32>(qs) * invn + 1e-5f);
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
@@ -1436,7 +1469,7 @@ __global__ void __launch_bounds__(256) k_linear_small(LinArgs a) {
         s1 += v;
     }
     auto row_total = [&](float v, int slot) { // sum over the 128 columns of each token (4 waves x 2 lane halves)
-        v += __shfl_xor(v, 32, 64);
+        v = lanes_sum<32>(v);
         if (lk == 0) part[slot][wave][li] = v;
         __syncthreads();
         float t = part[slot][0][li] + part[slot][1][li] + part[slot][2][li] + part[slot][3][li];
@@ -1742,12 +1775,9 @@ __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) 
             partv = __fmaf_rn(qf[5], aktg1.y, partv);
             partv = __fmaf_rn(qf[6], aktg1.z, partv);
             partv = __fmaf_rn(qf[7], aktg1.w, partv);
-            partv += __shfl_xor(partv, 16, 64);
-            partv += __shfl_xor(partv, 32, 64);
-            st = partv + tgt_add;
+            st = lanes_sum<48>(partv) + tgt_add;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = lanes_max<48>(mx);
         mx = fmaxf(mx, st);
         float *amax = bufH;                 // [4 heads][2 halves][16 queries]
         float *aobuf = bufH + 128;          // [4 heads][64 lanes][8]: the odd half's partial O^T
@@ -1779,8 +1809,7 @@ __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) 
                     for (int r = 0; r < 4; ++r) o[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(avf[i][ct][r], pa[r], o[ct], 0, 0, 0);
             }
         }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = lanes_sum<48>(l);
         if (ahalf == 1) {
             float *ob = aobuf + (ah * 64 + lane) * 8;
             *reinterpret_cast<float4 *>(ob) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
@@ -1803,8 +1832,7 @@ __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) 
     auto row_total = [&](float (&v)[MT], int slot) { // sums over the 128 columns of each token (SB_NW waves x 4 k-slot lanes)
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
-            v[u] += __shfl_xor(v[u], 16, 64);
-            v[u] += __shfl_xor(v[u], 32, 64);
+            v[u] = lanes_sum<48>(v[u]);
             if (gq == 0) part[slot][wave][16 * u + lq] = v[u];
         }
         __syncthreads();
@@ -2216,11 +2244,7 @@ __global__ void __launch_bounds__(256) k_block_small_any(SmallBlockArgs a, int d
     // LayerNorm of the 16 rows of bufZ in place (16 lanes per token: columns sub, sub + 16, ...)
     const int tk = tid >> 4, sub = tid & 15;
     auto group_sum = [&](float v) {
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 8, 64);
-        return v;
+        return lanes_sum<15>(v);
     };
     auto layer_norm = [&](const float *g, const float *b, const float *add) {
         float *zr = bufZ + tk * lda;
@@ -2552,7 +2576,7 @@ __global__ void __launch_bounds__(256) k_attn_mfma(const float *__restrict__ qkv
             float part = 0.f;
 #pragma unroll
             for (int s2 = 0; s2 < HH; ++s2) part = __fmaf_rn(qf[s2], Ks[(size_t)(L - 1) * KLD + kk * HH + s2], part);
-            float st = part + __shfl_xor(part, 32, 64) + 1.0f;
+            float st = lanes_sum<32>(part) + 1.0f;
             m = st;
             l = (kk == 0) ? 1.f : 0.f; // halves are summed at the end
 #pragma unroll
@@ -2588,7 +2612,7 @@ __global__ void __launch_bounds__(256) k_attn_mfma(const float *__restrict__ qkv
                     mx = fmaxf(mx, v);
                 }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = lanes_max<32>(mx);
             const float mn = fmaxf(m, mx);
             const bool dead = (mn == -INFINITY);
             const float alpha = dead ? 1.f : __expf(m - mn);
@@ -2613,7 +2637,7 @@ __global__ void __launch_bounds__(256) k_attn_mfma(const float *__restrict__ qkv
                                                                  o[ct], 0, 0, 0);
             }
         }
-        const float lt = l + __shfl_xor(l, 32, 64);
+        const float lt = lanes_sum<32>(l);
         const float inv = 1.0f / lt; // 0 (fully masked) -> inf, 0 * inf = NaN like torch
         if (qi < L) {
             float *orow = out + (base + qi) * d + h * hd;
@@ -3045,8 +3069,7 @@ __global__ void __launch_bounds__(64) k_attn_row(const float *__restrict__ qkv, 
         sc[t] = s;
         mx = fmaxf(mx, s);
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    mx = lanes_max<63>(mx);
     float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -3068,7 +3091,7 @@ __global__ void __launch_bounds__(64) k_attn_row(const float *__restrict__ qkv, 
                 const float *vcol = qkv + base * ld + 2 * d + h * hd + col;
                 for (int j = half; j < L; j += 2) o = __fmaf_rn(p_s[j], vcol[(int64_t)j * ld], o);
             }
-            o += __shfl_xor(o, 32, 64);
+            o = lanes_sum<32>(o);
             if (half == 0 && col < hd) out_rows[(int64_t)b * d + h * hd + col] = o / sum; // sum == 0 -> NaN like torch
         }
     }
@@ -3122,16 +3145,13 @@ __global__ void __launch_bounds__(256) k_attn_row32(const float *__restrict__ qk
         part = __fmaf_rn(q4.y, kv[it].y, part);
         part = __fmaf_rn(q4.z, kv[it].z, part);
         part = __fmaf_rn(q4.w, kv[it].w, part);
-        part += __shfl_xor(part, 1, 64);
-        part += __shfl_xor(part, 2, 64);
-        part += __shfl_xor(part, 4, 64);
+        part = lanes_sum<7>(part);
         const bool is_tgt = irn && has_tgt && (j == L - 1);
         const bool ok = (j < L) && (j != pq) && (is_tgt || j <= i);
         sc[it] = ok ? part + (is_tgt ? 1.0f : add_allowed) : -INFINITY;
         mx = fmaxf(mx, sc[it]);
     }
-#pragma unroll
-    for (int o = 8; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64)); // the 8 lanes of a key already agree
+    mx = lanes_max<56>(mx); // the 8 lanes of a key already agree
     if (lane == 0) red[wave][32] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0][32], red[1][32]), fmaxf(red[2][32], red[3][32]));
@@ -3146,14 +3166,12 @@ __global__ void __launch_bounds__(256) k_attn_row32(const float *__restrict__ qk
         o4.z = __fmaf_rn(pv, vv[it].z, o4.z);
         o4.w = __fmaf_rn(pv, vv[it].w, o4.w);
     }
-#pragma unroll
-    for (int o = 8; o < 64; o <<= 1) { // over the 8 key rows of the wave (lanes with the same chunk)
-        sum += __shfl_xor(sum, o, 64);
-        o4.x += __shfl_xor(o4.x, o, 64);
-        o4.y += __shfl_xor(o4.y, o, 64);
-        o4.z += __shfl_xor(o4.z, o, 64);
-        o4.w += __shfl_xor(o4.w, o, 64);
-    }
+    // over the 8 key rows of the wave (lanes with the same chunk): butterfly levels 8, 16, 32
+    sum = lanes_sum<56>(sum);
+    o4.x = lanes_sum<56>(o4.x);
+    o4.y = lanes_sum<56>(o4.y);
+    o4.z = lanes_sum<56>(o4.z);
+    o4.w = lanes_sum<56>(o4.w);
     if (lane < 8) {
         red[wave][4 * c4 + 0] = o4.x, red[wave][4 * c4 + 1] = o4.y, red[wave][4 * c4 + 2] = o4.z, red[wave][4 * c4 + 3] = o4.w;
         if (lane == 0) red[wave][33] = sum;
