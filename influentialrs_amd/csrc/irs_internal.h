@@ -337,4 +337,42 @@ __device__ __forceinline__ void irs_path_step_row(const irs_path_args &p_, int r
     }
 }
 
+// ---- cross-lane all-reductions without the LDS crossbar.  hipcc lowers every __shfl_xor to ds_bpermute_b32 (an
+// LDS-pipe round trip, awaited at once when the next step depends on it); the latency kernels run chains of them.
+// Here: DPP for the steps inside a 16-lane row (quad_perm for xor 1 / 2, row_ror:8 for xor 8; row_half_mirror reaches
+// the other quad, so level 4 needs the quads to agree already -- true after levels 1 and 2, or when the data is
+// uniform per quad), gfx950's v_permlane16_swap / v_permlane32_swap for the steps across rows.  STEPS says which of
+// the six butterfly levels run (bit i = level 2^i).  Every lane of a reduced group ends with the same bits.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __uint_as_float((unsigned int)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
+struct OpSum {
+    __device__ __forceinline__ float operator()(float a, float b) const { return a + b; }
+};
+struct OpMax {
+    __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); }
+};
+template <int STEPS, typename OP>
+__device__ __forceinline__ float lanes_reduce(float v, OP op) {
+    if (STEPS & 1) v = op(v, dpp_f32<0xB1>(v));  // quad_perm [1,0,3,2]
+    if (STEPS & 2) v = op(v, dpp_f32<0x4E>(v));  // quad_perm [2,3,0,1]
+    if (STEPS & 4) v = op(v, dpp_f32<0x141>(v)); // row_half_mirror
+    if (STEPS & 8) v = op(v, dpp_f32<0x128>(v)); // row_ror:8 = lane ^ 8 inside the row, no agreement needed
+    if (STEPS & 16) {
+        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = op(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    }
+    if (STEPS & 32) {
+        const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = op(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    }
+    return v;
+}
+template <int STEPS>
+__device__ __forceinline__ float lanes_sum(float v) { return lanes_reduce<STEPS>(v, OpSum()); }
+template <int STEPS>
+__device__ __forceinline__ float lanes_max(float v) { return lanes_reduce<STEPS>(v, OpMax()); }
+
+
 #endif

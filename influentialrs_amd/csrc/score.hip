@@ -1138,12 +1138,9 @@ __global__ void __launch_bounds__(256) k_prep_x(const float *__restrict__ x, int
         uint4 v = pack8_bf16(x + (size_t)row * d, 8 * lane, d, row < M, ss, ssr, ssd);
         xb[((size_t)ut * KS + (lane >> 1)) * 64 + (lane & 1) * 32 + r] = v;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        ss += __shfl_xor(ss, off, 64);
-        ssr += __shfl_xor(ssr, off, 64);
-        ssd += __shfl_xor(ssd, off, 64);
-    }
+    ss = lanes_sum<63>(ss);
+    ssr = lanes_sum<63>(ssr);
+    ssd = lanes_sum<63>(ssd);
     if (lane == 0) {
         const float nx = sqrtf(fmaxf(ss, ssr)), ndx = sqrtf(ssd);
         // 1.001: the float32 sums of squares / square roots above (relative error < d 2^-24 + 2^-23)
@@ -1170,12 +1167,9 @@ __global__ void __launch_bounds__(256) k_pack_w(const float *__restrict__ W, con
         uint4 v = pack8_bf16(W + (size_t)row * d, 8 * lane, d, row < n_local, ss, ssr, ssd);
         wp[((size_t)t * KS + (lane >> 1)) * 64 + (lane & 1) * 32 + r] = v;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        ss += __shfl_xor(ss, off, 64);
-        ssr += __shfl_xor(ssr, off, 64);
-        ssd += __shfl_xor(ssd, off, 64);
-    }
+    ss = lanes_sum<63>(ss);
+    ssr = lanes_sum<63>(ssr);
+    ssd = lanes_sum<63>(ssd);
     if (lane == 0) {
         bias_pad[row] = (row < n_local) ? b[row] : -INFINITY;
         if (row < n_local) { // non-negative floats order like their bit patterns
