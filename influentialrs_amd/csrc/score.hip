@@ -1409,6 +1409,17 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
     __shared__ unsigned int boff[IRS_CAND_BUCKETS + 1];
     __shared__ unsigned int s_prefix, s_k, s_nr, s_above, s_over;
     const int row = blockIdx.x, tid = threadIdx.x;
+    // Every slot of the row's candidate buckets is valid memory and the slot addresses do not depend on the bucket
+    // counts: the candidate loads, the row and the counts are all requested here, in one memory round trip (the
+    // first form waited for the counts and their scan before it asked for the candidates).
+    constexpr int PER = IRS_CAND_BUCKETS * IRS_CAND_SLOTS / 256;
+    unsigned long long cv[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int idx = tid + 256 * j;
+        cv[j] = cand[((size_t)row * IRS_CAND_BUCKETS + idx / IRS_CAND_SLOTS) * IRS_CAND_SLOTS + idx % IRS_CAND_SLOTS];
+    }
+    for (int i = tid; i < d; i += 256) xs[i] = x[(size_t)row * d + i];
     if (tid < IRS_CAND_BUCKETS) hist[tid] = cnt[(size_t)row * IRS_CAND_BUCKETS + tid];
     __syncthreads();
     if (tid < 64) { // exclusive scan of the (clamped) bucket counts by one wave (IRS_CAND_BUCKETS == 64)
@@ -1438,25 +1449,12 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
         return;
     }
     const unsigned int c = boff[IRS_CAND_BUCKETS];
-    {   // all of a thread's candidate loads are requested before the first is stored (one memory round trip instead of
-        // IRS_CAND_CAP / 256 dependent ones)
-        constexpr int PER = IRS_CAND_BUCKETS * IRS_CAND_SLOTS / 256;
-        unsigned long long v[PER];
-        unsigned int dst[PER];
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const int idx = tid + 256 * j;
-            const int b = idx / IRS_CAND_SLOTS, sl = idx % IRS_CAND_SLOTS;
-            const bool live = (unsigned int)sl < boff[b + 1] - boff[b];
-            dst[j] = live ? boff[b] + sl : 0xFFFFFFFFu;
-            v[j] = cand[((size_t)row * IRS_CAND_BUCKETS + b) * IRS_CAND_SLOTS + sl]; // every slot is valid memory: unconditional,
-                                                                                       // so the loads are not fenced one by one
-        }
-#pragma unroll
-        for (int j = 0; j < PER; ++j)
-            if (dst[j] != 0xFFFFFFFFu) ckeys[dst[j]] = v[j];
+    for (int j = 0; j < PER; ++j) { // compaction of the live slots into ckeys, bucket after bucket
+        const int idx = tid + 256 * j;
+        const int b = idx / IRS_CAND_SLOTS, sl = idx % IRS_CAND_SLOTS;
+        if ((unsigned int)sl < boff[b + 1] - boff[b]) ckeys[boff[b] + sl] = cv[j];
     }
-    for (int i = tid; i < d; i += 256) xs[i] = x[(size_t)row * d + i];
     __syncthreads();
     // validation of the (possibly speculative) emission threshold: at least k items must score >= traw,
     // otherwise items between the true k-th score and the threshold may be missing
