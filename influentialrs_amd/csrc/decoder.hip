@@ -3693,7 +3693,10 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             float *tswap = x; // the new x lives in the other buffer
             x = y;
             y = tswap;
-        } else if (d <= LIN_BN || (d <= 2 * LIN_BN && rows > 2048)) {
+        } else if (d <= LIN_BN || (d <= 2 * LIN_BN && rows >= 32768)) {
+            // (rows of 129..256 values: one workgroup per 128 tokens covers ALL columns, so below ~256 workgroups the
+            //  unfused form -- one workgroup per 128 x 128 output block, then a LayerNorm pass -- fills the chip better:
+            //  C5's 32 windows = 6400 rows ran 4 % slower fused)
             // x <- LN2(LN1(x + ao W_o^T + b_o) + c_l), fused into the GEMM epilogue (y, not in place)
             if ((rc = launch_linear(ctx, ctx->act_ao, w.sa_out_w, w.sa_out_b, x, y, rows, d, d, false, s, w.n1_w, w.n1_b,
                                     cl, w.n2_w, w.n2_b, nullptr, nullptr, m_dev)))

@@ -302,7 +302,8 @@ def test_sampled_paths_distribution():
 @pytest.mark.parametrize("cfgname,B,over", [("c2", 176, {}), ("c2", 24, {}), ("c2", 72, {}), ("default", 80, {}), ("c1", 72, {}),
                                              ("default", 1100, {}), ("c1", 1320, {}),
                                              ("c2", 136, {"max_len": 256}), ("c2", 24, {"ffn_dim": 128}),
-                                             ("c2", 16, {"emb_dim": 256, "n_heads": 8}), ("c2", 16, {"emb_dim": 192, "n_heads": 6, "ffn_dim": 200}),
+                                             ("c2", 16, {"emb_dim": 256, "n_heads": 8}), ("c2", 168, {"emb_dim": 256, "n_heads": 8}),
+                                             ("c2", 168, {"emb_dim": 192, "n_heads": 6, "ffn_dim": 200}),
                                              ("c2", 176, {"n_heads": 8}),
                                              ("c2", 24, {"n_heads": 8})])
 def test_throughput_shape_decode_matches_small_batches_and_oracle(oracle, cfgname, B, over):
@@ -315,7 +316,7 @@ def test_throughput_shape_decode_matches_small_batches_and_oracle(oracle, cfgnam
     kernel beyond the single-workgroup plan (24) and beyond the one-launch plan (72); default x 80 / c1 x 72 = the
     generic fused layer kernel (any d <= 96) at a few thousand rows; default x 1100 / c1 x 1320 (> 65536 rows) = the
     per-GEMM throughput kernels: default (d = 30) = row-major GEMMs; c1 (d = 64, head
-    dim 16) fragment-major GEMMs with the 32-query attention; L = 256 = the 16-tile limit of the 16-query attention; ffn 128 = fragment-major, unfused FFN; d = 256 (C4's decoder) = LayerNorm fused into the out-projection / FFN GEMMs with 8 accumulator tiles per token, d = 192 = the guarded form of the same; 8 heads at d = 128 (head dim 16) = 32-query
+    dim 16) fragment-major GEMMs with the 32-query attention; L = 256 = the 16-tile limit of the 16-query attention; ffn 128 = fragment-major, unfused FFN; d = 256 (C4's decoder) x 16 = separate LayerNorm kernels on packed rows, x 168 (>= 32768 rows) = LayerNorm fused into the out-projection / FFN GEMMs with 8 accumulator tiles per token, d = 192 = the guarded form of the same; 8 heads at d = 128 (head dim 16) = 32-query
     attention + LN-fused out-projection + the layer kernel without its out-projection phase."""
     cfg = synth.make_config(cfgname, **over)
     L = cfg.max_len
