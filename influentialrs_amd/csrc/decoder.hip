@@ -3237,7 +3237,8 @@ static int launch_linear(irs_ctx *ctx, const float *X, const float *W, const flo
     }
     if (ctx) irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
     auto al16 = [](const void *p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; };
-    if (M <= 2048 && K <= 256) { // latency path: one wave per 32x32 tile, operands straight from L2
+    if ((M <= 2048 || (M <= 8192 && g1 == nullptr && Xf == nullptr && N >= 256)) && K <= 256) { // latency path: one wave per 32x32 tile, operands straight from L2
+        // (wide outputs keep it up to 8192 rows: C5's 6400 rows x d = 256 give the 128 x 128 tiling 100-300 workgroups)
         if (g1 != nullptr) hipLaunchKernelGGL(k_linear_small<true>, dim3(1, (M + 31) / 32), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(k_linear_small<false>, dim3((N + 127) / 128, (M + 31) / 32), dim3(256), 0, s, a);
     } else if (g1 != nullptr && N > LIN_BN) { // fused residual + LayerNorm, rows of up to 256 values (8 tiles per token)
