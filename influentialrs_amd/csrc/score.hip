@@ -1074,14 +1074,19 @@ __global__ void __launch_bounds__(256, 1) k_lse_f32(SweepArgs a) {
                 }
             }
         };
-        float4 fa[QN], fb[QN], ba[4], bb[4];
+        // three fragment sets: two tiles (64 KB per wave, 256 KB per CU) are in flight behind the one being multiplied
+        float4 fa[QN], fb[QN], fc[QN], ba[4], bb[4], bc2[4];
         load(fa, ba, t0);
-        for (int t = t0; t < t1; t += 2 * ts) {
-            load(fb, bb, t + ts);
+        load(fb, bb, t0 + ts);
+        for (int t = t0; t < t1; t += 3 * ts) {
+            load(fc, bc2, t + 2 * ts);
             compute(fa, ba, t);
             if (t + ts >= t1) break;
-            load(fa, ba, t + 2 * ts);
+            load(fa, ba, t + 3 * ts);
             compute(fb, bb, t + ts);
+            if (t + 2 * ts >= t1) break;
+            load(fb, bb, t + 4 * ts);
+            compute(fc, bc2, t + 2 * ts);
         }
     }
     if (EMIT) emit_flush(a, eq, lane);

@@ -3,5 +3,5 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 900 python -m pytest tests -m gpu -q -x --durations=6 > gpurun_out/c5test.log 2>&1 || { tail -40 gpurun_out/c5test.log; exit 1; }; tail -12 gpurun_out/c5test.log
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_c5 -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-scoring --c4-steps 1 > gpurun_out/prof_c5.log 2>&1 || { tail -5 gpurun_out/prof_c5.log; exit 1; }
-tail -1 gpurun_out/prof_c5.log | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps(d['c4_item_sharded']))"
+grep -o "\"c5_beam32\": {[^}]*}" gpurun_out/prof_c5.log
 python3 tools/rocpd_kernels.py $(ls gpurun_out/prof_c5/*/*.db | head -1) > gpurun_out/c5_kernels.txt 2>&1; cat gpurun_out/c5_kernels.txt
