@@ -323,6 +323,43 @@ class Job:
         eng.path_step(self.seqs, self.hep, val, ids, 0, self.paths, self.status)
 
 
+def phase_times(job, steps=3):
+    """Rank-local time of each phase of a step (torch.cuda events on the current stream, which the engine and the
+    collectives both order against): where an N-GPU step goes -- reported beside the c4_item_sharded leg so that a
+    scaling run can be read without a profiler.  Not part of any timed region."""
+    import torch
+    names = ["decode", "gather_rows", "score_topk", "exchange_keys", "merge_and_path_step"]
+    acc = dict.fromkeys(names, 0.0)
+    eng = job.eng
+    for _ in range(steps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
+        ev[0].record()
+        _, xr, _ = eng.decode(job.seqs, job.users, want_x=False, pos=job.hep)
+        ev[1].record()
+        if job.sharded:
+            import torch.distributed as dist
+            job._collect(dist.all_gather_into_tensor, job.x_all, xr)
+            rows = job.x_all
+        else:
+            rows = xr
+        ev[2].record()
+        v, i, _ = eng.score_topk(rows, job.k, job.sweep)
+        keys = eng.pack_topk(v, i) if job.sharded else None
+        ev[3].record()
+        if job.sharded:
+            import torch.distributed as dist
+            job._collect(dist.all_to_all_single, job.k_recv, keys)
+        ev[4].record()
+        if job.sharded:
+            v, i = eng.merge_topk_keys(job.k_recv)
+        eng.path_step(job.seqs, job.hep, v, i, 0, job.paths, job.status)
+        ev[5].record()
+        torch.cuda.synchronize()
+        for n, a, b in zip(names, ev[:-1], ev[1:]):
+            acc[n] += a.elapsed_time(b)
+    return {n: round(t / steps, 4) for n, t in acc.items()}
+
+
 def timed(job, steps, world):
     import torch
     import torch.distributed as dist
@@ -582,6 +619,8 @@ def main():
               "parallelism": "single GPU holds the whole catalog" if world == 1 else
                              f"item shards of {j4.eng.n_local} rows x {world}; per step: all-gather of {u4} x {j4.cfg.emb_dim} f32 rows, "
                              f"one all_to_all of {u4} x 100 packed 64-bit keys per rank, merge"}
+        ph = phase_times(j4)  # every rank runs it (the collectives inside need all of them); rank 0 reports
+        c4["phase_ms_rank0"] = ph
         if world == 1 and rank == 0 and not args.no_latency:
             # BASELINE configs[4] (C5), D1 (ii): beam-width-32 persuasion-path search over the 10M-item catalog for one
             # user -- 32 windows decoded, scored (top-100 + exact log-sum-exp over the catalog) and re-ranked per step,
