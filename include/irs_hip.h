@@ -29,6 +29,10 @@
  *    0 is the pad id in sequences, which carry 1-based ids like the reference).
  *  - total order used by every selection: score descending, then id
  *    ascending (torch's own tie order is unspecified).
+ *  - indices are the caller's responsibility, as with any device gather: sequence entries in [0, n_item]
+ *    (0 = pad), user ids in [0, n_user), label / candidate ids0 in [0, n_item) or negative where documented;
+ *    nn.Embedding's IndexError has no device-side counterpart here.  Shapes and buffer sizes ARE checked
+ *    (IRS_E_INVALID).
  */
 #ifndef IRS_HIP_H
 #define IRS_HIP_H
