@@ -371,3 +371,40 @@ def test_topk_random_shapes_against_exhaustive(n_item, d, M, k):
     l0 = (m0.double() + e0.double().log()).cpu().numpy()
     l1 = (mx.double() + sm.double().log()).cpu().numpy()
     assert np.abs(l0 - l1).max() <= 4e-6 * max(1.0, np.abs(l0).max())
+
+
+@pytest.mark.parametrize("n_item,d,M,k", _random_shapes(int(os.environ.get("IRS_RANDOM_SHAPES", "16")),
+                                                        int(os.environ.get("IRS_RANDOM_SHAPES_SEED", "7"))))
+def test_rank_gather_dense_random_shapes_agree(n_item, d, M, k):
+    """The other scoring entry points on randomly drawn shapes, against each other (all of them evaluate the same
+    fixed-order float32 chain): gather == the dense logits at those ids, bit for bit; count_before == the rank
+    counted on the dense logits (score desc, id asc, excluded ids skipped); the top-k's values == dense at its ids;
+    max + log(sum exp) == the same over the dense logits."""
+    M = min(M, 48)
+    W, b = _weights(n_item, d, n_item + 3 * d)
+    x = _rows(M, d, M + 11 * k)
+    eng = scoring_only_engine(n_item, d, W, b, max_rows=M, max_k=k)
+    xt = torch.from_numpy(x).cuda()
+    dense = eng.score_dense(xt)                                   # [M, n_item]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(n_item + M)
+    ids = torch.randint(0, n_item, (M, 7), generator=g, device="cuda")
+    got = eng.score_gather(xt, ids)
+    assert torch.equal(got.view(torch.int32), dense.gather(1, ids).view(torch.int32))
+    ref_id = ids[:, 0].contiguous()
+    ref = got[:, 0].contiguous()
+    excl = torch.randint(0, n_item, (M, 5), generator=g, device="cuda")
+    excl[:, 0] = torch.argmax(dense, dim=1)                       # an item that certainly ranks before most references
+    cnt = eng.score_count_before(xt, ref, ref_id, excl)
+    ar = torch.arange(n_item, device="cuda")[None, :]
+    before = (dense > ref[:, None]) | ((dense == ref[:, None]) & (ar < ref_id[:, None]))
+    mask = torch.zeros_like(before)
+    mask.scatter_(1, excl, True)
+    want = (before & ~mask).sum(1)
+    assert torch.equal(cnt, want)
+    val, tid, st = eng.score_topk(xt, k, IRS_SWEEP_BF16)
+    live = tid >= 0
+    assert torch.equal(val[live].view(torch.int32), dense.gather(1, tid.clamp(min=0))[live].view(torch.int32))
+    mx, sm = eng.score_lse(xt)
+    want_lse = torch.logsumexp(dense.double(), dim=1)
+    assert ((mx.double() + sm.double().log()) - want_lse).abs().max().item() <= 4e-6 * max(1.0, want_lse.abs().max().item())
