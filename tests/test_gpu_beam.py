@@ -81,3 +81,45 @@ def test_beam_frontend_kwarg():
     assert allp.shape == (3, 4, 6) and np.array_equal(allp[:, 0], pb4)
     # the best beam's cumulative log-probability is at least the greedy path's
     assert pb4.shape == p1.shape and len(hist) == 3
+
+
+def _random_beam_cases(n, seed):
+    g = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        hd = int(g.choice([8, 16, 32]))
+        H = int(g.integers(1, 5))
+        out.append(dict(emb_dim=hd * H, n_heads=H, ffn_dim=int(g.choice([32, 64, 100])), max_len=int(g.choice([10, 24, 40])),
+                        n_layers=int(g.integers(1, 3)), n_item=int(g.choice([150, 900, 5000])), n_user=9,
+                        B=int(g.integers(1, 5)), beam=int(g.integers(1, 9)), P=int(g.integers(2, 8)), graph=bool(g.integers(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_beam_cases(int(__import__("os").environ.get("IRS_RANDOM_SHAPES", "10")),
+                                                    int(__import__("os").environ.get("IRS_RANDOM_SHAPES_SEED", "5"))))
+def test_beam_random_cases_match_cpu_restatement(oracle, case):
+    """Randomly drawn model shapes, beam widths, path lengths and batch sizes (stream launches and the captured graph)
+    against oracle_np.beam_search: scores within the float32 log-sum-exp noise, paths id for id wherever the beams
+    are separated by more than that noise."""
+    c = dict(case)
+    B, beam, P, graph = c.pop("B"), c.pop("beam"), c.pop("P"), c.pop("graph")
+    cfg = synth.make_config("tiny", **c)
+    sd = synth.irn_state_dict(cfg, 77)
+    hists = synth.user_histories(8, cfg.n_item, seed=7)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=11)[:B]
+    raws, seqs, users, targets, labels = synth.collate_eval_irs(rows, cfg.max_len, gap_len=0)
+    L = cfg.max_len
+    eng = make_engine(cfg, sd, max_rows=B * beam, max_seqs=B * beam)
+    hep = torch.full((B,), L - 2, dtype=torch.int32, device="cuda")
+    paths, scores, st = eng.beam_search(torch.from_numpy(seqs).cuda(), torch.from_numpy(users).cuda(), hep, P, beam,
+                                        sweep=IRS_SWEEP_BF16, use_graph=graph)
+    paths, scores = paths.cpu().numpy(), scores.cpu().numpy()
+    op, osc = oracle.beam_search(sd, cfg, seqs, users, max_path_len=P, gap_len=0, beam=beam)
+    fin = np.isfinite(osc)
+    assert np.array_equal(fin, np.isfinite(scores))
+    assert np.allclose(scores[fin], osc[fin], rtol=0, atol=2e-4), (scores, osc)
+    for b in range(B):
+        nb = int(fin[b].sum())
+        gaps = np.abs(np.diff(osc[b, :nb]))
+        n_safe = nb if len(gaps) == 0 or gaps.min() > 1e-4 else int(np.argmax(gaps <= 1e-4)) + 1
+        assert np.array_equal(paths[b, :n_safe], op[b, :n_safe]), (b, paths[b], op[b])
