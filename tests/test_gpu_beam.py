@@ -58,6 +58,12 @@ def test_beam_matches_cpu_restatement(oracle, cfgname, beam, P, use_graph):
         gaps = np.abs(np.diff(osc[b]))
         n_safe = beam if len(gaps) == 0 or gaps.min() > 1e-4 else int(np.argmax(gaps <= 1e-4)) + 1
         assert np.array_equal(paths[b, :n_safe], op[b, :n_safe]), (b, paths[b], op[b])
+    if beam == 1:  # the greedy entry point (irs_generate_paths) walks the same paths
+        seq2 = torch.from_numpy(seqs).cuda()
+        hep2 = torch.full((B,), L - 2, dtype=torch.int32, device="cuda")
+        gp = eng.generate_paths(seq2, torch.from_numpy(users).cuda(), hep2, P, use_graph=not graph)
+        gp = (gp[0] if isinstance(gp, tuple) else gp).cpu().numpy()
+        assert np.array_equal(gp, paths[:, 0])
     # scores are sorted, windows end with the path
     assert (np.diff(scores, axis=1) <= 0).all()
     w = fin.cpu().numpy()
@@ -123,3 +129,9 @@ def test_beam_random_cases_match_cpu_restatement(oracle, case):
         gaps = np.abs(np.diff(osc[b, :nb]))
         n_safe = nb if len(gaps) == 0 or gaps.min() > 1e-4 else int(np.argmax(gaps <= 1e-4)) + 1
         assert np.array_equal(paths[b, :n_safe], op[b, :n_safe]), (b, paths[b], op[b])
+    if beam == 1:  # the greedy entry point (irs_generate_paths) walks the same paths
+        seq2 = torch.from_numpy(seqs).cuda()
+        hep2 = torch.full((B,), L - 2, dtype=torch.int32, device="cuda")
+        gp = eng.generate_paths(seq2, torch.from_numpy(users).cuda(), hep2, P, use_graph=not graph)
+        gp = (gp[0] if isinstance(gp, tuple) else gp).cpu().numpy()
+        assert np.array_equal(gp, paths[:, 0])
