@@ -38,6 +38,26 @@ for (N, d) in ((1_000_000, 128), (1_250_000, 256)):
     print(f"N={N} d={d}: {nb} batches ok, fallback rows {fb}", flush=True)
     del eng
 
+# near-duplicate items (clusters of ~1000 items a few 1e-3 apart: the bf16 filter cannot tell them apart, the
+# candidate buffers fill, rows fall back to the exhaustive path) -- results must stay exact
+N, d = 400_000, 128
+centers = torch.randn((400, d), generator=g, device=dev) * d ** -0.5
+W = (centers[torch.randint(0, 400, (N,), generator=g, device=dev)] + torch.randn((N, d), generator=g, device=dev) * 2e-3).cpu().numpy()
+b = (torch.randn(N, generator=g, device=dev) * 0.01).cpu().numpy()
+eng = scoring_only_engine(N, d, W, b, max_rows=256)
+fb = 0
+for it in range(max(nb // 4, 4)):
+    M = int(torch.randint(1, 257, (1,), generator=g, device=dev).item())
+    x = torch.randn((M, d), generator=g, device=dev)
+    v, i, st = eng.score_topk(x, 100, IRS_SWEEP_BF16)
+    rows = torch.randint(0, M, (min(M, 3),), generator=g, device=dev)
+    ev, ei, _ = eng.score_topk(x[rows].contiguous(), 100, IRS_SWEEP_EXHAUSTIVE)
+    torch.cuda.synchronize()
+    assert torch.equal(i[rows], ei) and torch.equal(v[rows].view(torch.int32), ev.view(torch.int32)), ("clustered", it)
+    fb += int((st & 1).sum().item())
+print(f"clustered catalog N={N}: {max(nb // 4, 4)} batches ok, fallback rows {fb}", flush=True)
+del eng
+
 cfg = synth.make_config("c2")
 sd = synth.irn_state_dict(cfg, 1234)
 B = 512
