@@ -426,6 +426,17 @@ def scoring_legs(device, reps=10):
                 leg.update(bound="hbm", w_stream_floor_us=wbytes / PEAK_HBM_GBS / 1e3,
                            emit_sweep_frac_hbm=wbytes / sweep_us / 1e3 / PEAK_HBM_GBS,
                            score_topk_frac_hbm=wbytes / total_us / 1e3 / PEAK_HBM_GBS)
+            if M == 32:  # a beam-search step's scoring: candidates AND log-sum-exp out of one pass over the fp32 catalog
+                for _ in range(2):
+                    eng.score_topk_lse(x, 100, IRS_SWEEP_BF16)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    eng.score_topk_lse(x, 100, IRS_SWEEP_BF16)
+                torch.cuda.synchronize()
+                fused_us = (time.perf_counter() - t0) / reps * 1e6
+                leg.update(score_topk_lse_us=fused_us, fp32_stream_floor_us=N * d * 4.0 / PEAK_HBM_GBS / 1e3,
+                           score_topk_lse_frac_hbm=N * d * 4.0 / fused_us / 1e3 / PEAK_HBM_GBS)
             legs[f"M={M}"] = leg
         out[name] = legs
         del eng, sd
