@@ -1408,7 +1408,10 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
                                                 int64_t item_lo, int64_t n_local, float *__restrict__ val,
                                                 int64_t *__restrict__ ids, int32_t *__restrict__ status) {
     __shared__ __attribute__((aligned(16))) unsigned long long ckeys[IRS_CAND_CAP + 2];
-    __shared__ __attribute__((aligned(16))) unsigned long long rkeys[IRS_REFINE_CAP + 2];
+    // the survivors are compacted into the candidates' own array (every thread holds its candidates in registers
+    // across the barrier in between): up to IRS_CAND_CAP survivors fit, no second buffer, and a row with thousands
+    // of near-equal scores around its k-th is re-scored here instead of being redone exhaustively
+    unsigned long long *rkeys = ckeys;
     __shared__ unsigned int hist[256];
     __shared__ float xs[256];
     __shared__ unsigned int boff[IRS_CAND_BUCKETS + 1];
@@ -1505,27 +1508,32 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
         thr2 = irs_unkey(s_prefix) - 2.0f * eps[row];
     }
     // survivors
-    for (int i = tid; i < (int)c; i += 256) {
-        float a = irs_unkey((unsigned int)(ckeys[i] >> 32));
-        if (a >= thr2) {
-            unsigned int slot = atomicAdd(&s_nr, 1u);
-            if (slot < IRS_REFINE_CAP) rkeys[slot] = ckeys[i] & 0xFFFFFFFFull;
+    {
+        constexpr int PERC = IRS_CAND_CAP / 256;
+        unsigned int keep[PERC];
+#pragma unroll
+        for (int j = 0; j < PERC; ++j) {
+            const int i = tid + 256 * j;
+            keep[j] = 0xFFFFFFFFu;
+            if (i < (int)c) {
+                const unsigned long long key = ckeys[i];
+                if (irs_unkey((unsigned int)(key >> 32)) >= thr2) keep[j] = (unsigned int)key; // low word = the item's local index (< 2^32 - 1)
+            }
         }
+        __syncthreads(); // every candidate has been read: the array is free for the compacted survivors
+#pragma unroll
+        for (int j = 0; j < PERC; ++j)
+            if (keep[j] != 0xFFFFFFFFu) rkeys[atomicAdd(&s_nr, 1u)] = (unsigned long long)keep[j];
     }
     __syncthreads();
     const unsigned int nr = s_nr;
-    if (nr > IRS_REFINE_CAP) {
-        if (tid == 0) status[row] |= IRS_ROW_FALLBACK;
-        exhaustive_row(x, d, W, bias, n_local, item_lo, k, row, val, ids, status, ckeys, xs, false);
-        return;
-    }
     // exact re-score
     for (int i = tid; i < (int)nr; i += 256) {
         unsigned int j = (unsigned int)rkeys[i];
         float e = irs_chain(xs, W + (size_t)j * d, bias[j], d);
         rkeys[i] = ((unsigned long long)irs_fkey(e) << 32) | (0xFFFFFFFFu - j);
     }
-    if ((nr & 1) && tid == 0) rkeys[nr] = 0ull; // rkeys has IRS_REFINE_CAP + 2 slots
+    if ((nr & 1) && tid == 0) rkeys[nr] = 0ull; // (the array has IRS_CAND_CAP + 2 slots)
     __syncthreads();
     // final order by rank counting as well (keys distinct): winners go straight to their slots
     {

@@ -64,7 +64,7 @@ def test_topk_ties_and_fallback(oracle):
     """Massive exact ties (duplicate item rows, constant bias) overflow the
     candidate buffers: the exhaustive kernel must take over and still return
     the (score desc, id asc) order."""
-    n_item, d, M, k = 20_000, 32, 4, 100
+    n_item, d, M, k = 60_000, 32, 4, 100  # 8571 copies of each distinct row: more exact ties than a row's buffers hold
     W, b = _weights(n_item, d, 3)
     W[:] = W[:7][np.arange(n_item) % 7]  # only 7 distinct rows
     b[:] = 0.25
@@ -79,6 +79,25 @@ def test_topk_ties_and_fallback(oracle):
             ov, oi = oracle.topk(s, k)
             assert np.array_equal(ids[m].cpu().numpy(), oi)
             assert np.array_equal(val[m].cpu().numpy().view(np.uint32), ov.view(np.uint32))
+
+
+def test_topk_thousands_of_ties_without_fallback(oracle):
+    """2857 copies of each distinct item row: every row's k-th score is tied thousands of times -- more survivors than
+    the 1024 the first refine kept, fewer than the candidate buffers hold.  They are re-scored and ordered in place
+    (score desc, id asc); rows that still overflow fall back, all stay exact."""
+    n_item, d, M, k = 20_000, 32, 6, 100
+    W, b = _weights(n_item, d, 3)
+    W[:] = W[:7][np.arange(n_item) % 7]
+    b[:] = 0.25
+    x = _rows(M, d, 4)
+    eng = scoring_only_engine(n_item, d, W, b, max_rows=M)
+    val, ids, st = eng.score_topk(torch.from_numpy(x).cuda(), k, IRS_SWEEP_BF16)
+    torch.cuda.synchronize()
+    assert not (st.cpu().numpy() & 1).all(), "some rows should be handled without the exhaustive fallback"
+    for m in range(M):
+        ov, oi = oracle.topk(oracle.score_chain(x[m], W, b), k)
+        assert np.array_equal(ids[m].cpu().numpy(), oi)
+        assert np.array_equal(val[m].cpu().numpy().view(np.uint32), ov.view(np.uint32))
 
 
 DIRECT_CASES = [  # the small-shard path (n_item <= 4096, k <= 256): one launch up to 32 rows, two up to 1024
@@ -318,7 +337,7 @@ def test_topk_many_rows_ring_kernel(oracle, n_item, d, M, k):
 def test_topk_many_rows_ties_and_dense_hits(oracle):
     """The ring kernel's dense-hit path (more than 8 lanes of a tile above the threshold: duplicate item rows make whole
     tiles tie) and the overflow fallback behind it, at 256+ rows."""
-    n_item, d, M, k = 20_000, 32, 288, 100
+    n_item, d, M, k = 40_000, 32, 288, 100
     W, b = _weights(n_item, d, 3)
     W[:] = W[:7][np.arange(n_item) % 7]  # only 7 distinct rows
     b[:] = 0.25
