@@ -123,11 +123,25 @@ struct EmitQ {
 
 // candidate lists are bucketed by item tile (bucket = tile mod 64): 64 counters per row keep the
 // same-address atomic chains short, and interleaving tiles spreads any id-locality of the scores.
+// A full bucket hands the candidate to ONE second choice, the opposite bucket (the buckets only spread the atomics; a
+// row's candidates are one unordered set): a row overflows when two buckets are full, not when 65 candidates share a
+// tile class -- then bit 31 of its first counter is set and k_refine redoes the row exhaustively.  (A probe loop over
+// all buckets, inline or as a call, cost the d = 128 emission sweep 10-35 %.)  Counters of full buckets keep counting
+// the attempts; readers clamp them to IRS_CAND_SLOTS.
+#define IRS_CAND_OVERFLOW 0x80000000u
 __device__ __forceinline__ void emit_append_global(const SweepArgs &a, unsigned int user, unsigned long long key) {
     const unsigned int bucket = (((unsigned int)key) >> 5) & (IRS_CAND_BUCKETS - 1);
-    const size_t cell = (size_t)user * IRS_CAND_BUCKETS + bucket;
-    unsigned int slot = atomicAdd(&a.cnt[cell], 1u);
-    if (slot < IRS_CAND_SLOTS) a.cand[cell * IRS_CAND_SLOTS + slot] = key;
+    size_t cell = (size_t)user * IRS_CAND_BUCKETS + bucket;
+    unsigned int slot = atomicAdd(&a.cnt[cell], 1u) & ~IRS_CAND_OVERFLOW;
+    if (slot >= IRS_CAND_SLOTS) { // full: one second choice (the opposite bucket), then the row counts as overflowed
+        cell ^= IRS_CAND_BUCKETS / 2;
+        slot = atomicAdd(&a.cnt[cell], 1u) & ~IRS_CAND_OVERFLOW;
+        if (slot >= IRS_CAND_SLOTS) {
+            atomicOr(&a.cnt[(size_t)user * IRS_CAND_BUCKETS], IRS_CAND_OVERFLOW);
+            return;
+        }
+    }
+    a.cand[cell * IRS_CAND_SLOTS + slot] = key;
 }
 
 __device__ __forceinline__ void emit_flush(const SweepArgs &a, EmitQ &q, int lane) {
@@ -1431,7 +1445,7 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
     if (tid < IRS_CAND_BUCKETS) hist[tid] = cnt[(size_t)row * IRS_CAND_BUCKETS + tid];
     __syncthreads();
     if (tid < 64) { // exclusive scan of the (clamped) bucket counts by one wave (IRS_CAND_BUCKETS == 64)
-        const unsigned int cb = hist[tid];
+        const unsigned int cb = hist[tid] & ~IRS_CAND_OVERFLOW;
         const unsigned int cl = cb > IRS_CAND_SLOTS ? IRS_CAND_SLOTS : cb;
         unsigned int incl = cl;
 #pragma unroll
@@ -1441,7 +1455,7 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
         }
         boff[tid] = incl - cl;
         if (tid == 63) boff[IRS_CAND_BUCKETS] = incl;
-        const unsigned long long ov = __ballot(cb > IRS_CAND_SLOTS);
+        const unsigned long long ov = __ballot((hist[tid] & IRS_CAND_OVERFLOW) != 0u); // (set on the row's first counter)
         if (tid == 0) {
             s_over = ov ? 1u : 0u;
             s_prefix = 0;
