@@ -200,9 +200,13 @@ int irs_score_topk_lse(irs_ctx *ctx, const float *dev_xrows, int32_t M, int32_t 
  * get_loss_on_eval_data (influentialRS.py:252-310) and Evaluator.train_batch (evaluator.py:53-92) WITHOUT the
  * [M, n_item] logits the reference materialises.  One device holds the whole catalog.  project.weight / bias are
  * read where they were bound: an optimizer step that updates them in place needs no re-finalisation for these two.
+ * They do mark the context's derived catalog (bf16 copy, filter norms) as possibly stale: the entry points that
+ * filter through it (irs_score_topk / _topk_lse with IRS_SWEEP_BF16, irs_generate_paths, irs_beam_search) return
+ * IRS_E_STATE until irs_finalize_weights has run again.
  *  irs_ce_forward:  dev_labels0 int64 [M] 0-based, -1 = row ignored (a pad target);
  *                   dev_lse float [M] = log sum_j exp(logit_mj); dev_label_score float [M];
- *                   dev_loss double [2] = { sum over valid rows of (lse - label score), number of valid rows }.
+ *                   dev_loss double [3] = { sum over valid rows of (lse - label score), number of valid rows,
+ *                   number of labels >= n_item (nn.CrossEntropyLoss raises on those; they count in neither sum) }.
  *  irs_ce_grad_logits: dL/dlogits of rows [0, M) (a chunk the caller sizes: M x ld floats), written ONCE by the
  *                   fp32-MFMA sweep's epilogue: scale * (exp(logit - lse) - [item == label]); ignored rows 0.
  *                   The caller finishes with two plain GEMMs (dX = G W, dW = G^T X) and a column sum (db). */

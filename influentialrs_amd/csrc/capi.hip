@@ -205,6 +205,7 @@ extern "C" int irs_finalize_weights(irs_ctx *ctx, void *arena, size_t bytes, voi
     if ((rc = irs_launch_cross_const(ctx, s))) return rc;
     if ((rc = irs_launch_pack_small(ctx, s))) return rc;
     ctx->finalized = true;
+    ctx->proj_stale = false;
     if (ctx->graph_exec) {
         hipGraphExecDestroy(ctx->graph_exec);
         ctx->graph_exec = nullptr;
@@ -347,6 +348,17 @@ static int ready(irs_ctx *ctx) {
     return IRS_OK;
 }
 
+// entry points that filter through the bf16 catalog copy and its norms: a training entry point since the last
+// irs_finalize_weights means project.* may have moved under them (the filter's |approx - exact| <= eps would not hold)
+static int ready_filter(irs_ctx *ctx, int sweep) {
+    int rc = ready(ctx);
+    if (rc) return rc;
+    if (ctx->proj_stale && sweep == IRS_SWEEP_BF16)
+        IRS_FAIL(ctx, IRS_E_STATE, "project.* may have changed since irs_finalize_weights (irs_ce_forward / irs_ce_grad_logits "
+                                   "ran): call irs_finalize_weights before filtering through the bf16 catalog");
+    return IRS_OK;
+}
+
 // ------------------------------------------------------------------ entry points
 extern "C" int irs_pif(irs_ctx *ctx, const int64_t *user, int32_t B, float *r_u, void *stream) {
     int rc = ready(ctx);
@@ -375,7 +387,7 @@ static int check_rows(irs_ctx *ctx, const char *fn, const void *xrows, int M) {
 
 extern "C" int irs_score_topk(irs_ctx *ctx, const float *xrows, int32_t M, int32_t k, int32_t sweep, float *val,
                               int64_t *ids0, int32_t *status, void *stream) {
-    int rc = ready(ctx);
+    int rc = ready_filter(ctx, sweep);
     if (rc) return rc;
     if ((rc = check_rows(ctx, "irs_score_topk", xrows, M))) return rc;
     if (k < 1 || k > ctx->dims.max_k || !val || !ids0 || !status) IRS_FAIL(ctx, IRS_E_INVALID, "irs_score_topk: bad k / outputs");
@@ -421,7 +433,7 @@ extern "C" int irs_score_lse(irs_ctx *ctx, const float *xrows, int32_t M, float 
 
 extern "C" int irs_score_topk_lse(irs_ctx *ctx, const float *xrows, int32_t M, int32_t k, int32_t sweep, float *val,
                                   int64_t *ids0, int32_t *status, float *omax, float *osum, void *stream) {
-    int rc = ready(ctx);
+    int rc = ready_filter(ctx, sweep);
     if (rc) return rc;
     if ((rc = check_rows(ctx, "irs_score_topk_lse", xrows, M))) return rc;
     if (k < 1 || k > ctx->dims.max_k || !val || !ids0 || !status || !omax || !osum)
@@ -439,6 +451,7 @@ extern "C" int irs_ce_forward(irs_ctx *ctx, const float *xrows, const int64_t *l
     if (!labels0 || !lse || !label_score || !loss) IRS_FAIL(ctx, IRS_E_INVALID, "irs_ce_forward: null arguments");
     if (ctx->shard.world != 1) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "irs_ce_forward needs the whole catalog on one device");
     hipStream_t s = (hipStream_t)stream;
+    ctx->proj_stale = true;
     if ((rc = irs_launch_refresh_bias(ctx, s))) return rc;
     if ((rc = irs_launch_lse(ctx, xrows, M, ctx->lse_max, ctx->lse_sum, s))) return rc;
     if ((rc = irs_launch_lse_combine(ctx, ctx->lse_max, ctx->lse_sum, lse, M, s))) return rc;
@@ -454,6 +467,7 @@ extern "C" int irs_ce_grad_logits(irs_ctx *ctx, const float *xrows, const int64_
     if (!labels0 || !lse || !out || ld < ctx->n_local) IRS_FAIL(ctx, IRS_E_INVALID, "irs_ce_grad_logits: bad arguments");
     if (ctx->shard.world != 1) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "irs_ce_grad_logits needs the whole catalog on one device");
     hipStream_t s = (hipStream_t)stream;
+    ctx->proj_stale = true;
     if ((rc = irs_launch_refresh_bias(ctx, s))) return rc;
     return irs_launch_ce_grad(ctx, xrows, labels0, lse, M, scale, out, ld, s);
 }
@@ -531,7 +545,7 @@ static int enqueue_step(irs_ctx *ctx, int64_t *seq, const int64_t *user, int32_t
 extern "C" int irs_generate_paths(irs_ctx *ctx, int64_t *seq, const int64_t *user, int32_t *hep, int32_t B,
                                   int32_t max_path_len, int32_t k, int32_t sweep, int32_t sample, int32_t sample_k,
                                   uint64_t seed, int32_t use_graph, float *paths, int32_t *status, void *stream) {
-    int rc = ready(ctx);
+    int rc = ready_filter(ctx, sweep);
     if (rc) return rc;
     if (ctx->shard.world != 1) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "irs_generate_paths needs the whole catalog on one device");
     if (!seq || !hep || !paths || !status || B < 1 || max_path_len < 1) IRS_FAIL(ctx, IRS_E_INVALID, "irs_generate_paths: bad arguments");
@@ -635,7 +649,7 @@ static int enqueue_beam_step(irs_ctx *ctx, int in, int B, int W, int k, int swee
 extern "C" int irs_beam_search(irs_ctx *ctx, const int64_t *seq0, const int64_t *user, const int32_t *hep0, int32_t B,
                                int32_t W, int32_t P, int32_t k, int32_t sweep, int32_t use_graph, float *paths,
                                double *scores, int64_t *seq_final, int32_t *status, void *stream) {
-    int rc = ready(ctx);
+    int rc = ready_filter(ctx, sweep);
     if (rc) return rc;
     if (ctx->shard.world != 1) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "irs_beam_search needs the whole catalog on one device");
     if (!seq0 || !hep0 || !paths || !scores || !status || B < 1) IRS_FAIL(ctx, IRS_E_INVALID, "irs_beam_search: bad arguments");

@@ -50,6 +50,7 @@ struct irs_ctx {
     float *wnorm_max; // [3] max_j max(||W_j||, ||bf16(W_j)||), max_j ||W_j - bf16(W_j)||, max_j |b_j| (k_prep_x)
     float *w_frag16;  // fragment-packed layer weights of the 16-token latency kernel (d = 128, F = 256), or null
     bool finalized;
+    bool proj_stale;  // a training entry point ran since irs_finalize_weights: wp / wnorm_max may lag project.*
 
     // workspace (device, caller-owned)
     char *ws;

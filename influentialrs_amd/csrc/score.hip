@@ -2313,32 +2313,40 @@ int irs_launch_refresh_bias(irs_ctx *ctx, hipStream_t s) {
 // labels0 global 0-based (-1: row ignored) -> local; ignored rows get the sentinel the sweep tests for
 __global__ void k_ce_localize(const int64_t *__restrict__ labels0, int64_t item_lo, int64_t *__restrict__ out, int M) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < M) out[i] = labels0[i] < 0 ? INT64_MIN : labels0[i] - item_lo;
+    if (i < M) out[i] = labels0[i] < 0 ? INT64_MIN : labels0[i] - item_lo; // labels >= n_item match no column (reported by irs_ce_forward)
 }
 
-// loss[0] = sum over valid rows of (lse - label score), loss[1] = number of valid rows (one workgroup; M is a batch)
+// loss[0] = sum over valid rows of (lse - label score), loss[1] = number of valid rows, loss[2] = number of labels
+// >= n_item (nn.CrossEntropyLoss raises on those; such a row is left out of [0] and [1]) (one workgroup; M is a batch)
 __global__ void __launch_bounds__(256) k_ce_reduce(const float *__restrict__ lse, const float *__restrict__ lab_score,
-                                                   const int64_t *__restrict__ labels0, int M, double *__restrict__ out) {
-    __shared__ double ssum[4], scnt[4];
-    double acc = 0.0, cnt = 0.0;
-    for (int i = threadIdx.x; i < M; i += 256)
-        if (labels0[i] >= 0) {
+                                                   const int64_t *__restrict__ labels0, int M, int64_t n_item,
+                                                   double *__restrict__ out) {
+    __shared__ double ssum[4], scnt[4], sbad[4];
+    double acc = 0.0, cnt = 0.0, bad = 0.0;
+    for (int i = threadIdx.x; i < M; i += 256) {
+        const int64_t l = labels0[i];
+        if (l >= n_item) bad += 1.0;
+        else if (l >= 0) {
             acc += (double)lse[i] - (double)lab_score[i];
             cnt += 1.0;
         }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         acc += __shfl_xor(acc, off, 64);
         cnt += __shfl_xor(cnt, off, 64);
+        bad += __shfl_xor(bad, off, 64);
     }
     if ((threadIdx.x & 63) == 0) {
         ssum[threadIdx.x >> 6] = acc;
         scnt[threadIdx.x >> 6] = cnt;
+        sbad[threadIdx.x >> 6] = bad;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         out[0] = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
         out[1] = (scnt[0] + scnt[1]) + (scnt[2] + scnt[3]);
+        out[2] = (sbad[0] + sbad[1]) + (sbad[2] + sbad[3]);
     }
 }
 
@@ -2355,7 +2363,7 @@ int irs_launch_lse_combine(irs_ctx *ctx, const float *mx, const float *sm, float
 
 int irs_launch_ce_reduce(irs_ctx *ctx, const float *lse, const float *lab_score, const int64_t *labels0, int M, double *out,
                          hipStream_t s) {
-    hipLaunchKernelGGL(k_ce_reduce, dim3(1), dim3(256), 0, s, lse, lab_score, labels0, M, out);
+    hipLaunchKernelGGL(k_ce_reduce, dim3(1), dim3(256), 0, s, lse, lab_score, labels0, M, ctx->dims.n_item, out);
     IRS_CHECK_HIP(ctx, hipGetLastError());
     return IRS_OK;
 }

@@ -34,8 +34,12 @@ class ShardGroup:
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         # gloo (the CPU rehearsal backend) is only dependable on host tensors: with device tensors and several
         # ranks sharing one GPU its collectives were seen to hang now and then.  Its payloads go through the host.
-        self._via_host = self.world > 1 and dist.get_backend(group) == "gloo"
-        self._a2a = None  # None: all_to_all untried; True / False: supported or not by the backend
+        backend = dist.get_backend(group) if self.world > 1 else ""
+        self._via_host = backend == "gloo"
+        # all_to_all: nccl (= RCCL) and gloo both implement it.  Decided ONCE from the backend's name, never by
+        # catching an exception from a collective: a rank-local failure there must surface as an error, not send
+        # this rank into a different collective than its peers sit in.
+        self._a2a = backend in ("nccl", "gloo")
 
     # -- plumbing ---------------------------------------------------------
     def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
@@ -73,16 +77,10 @@ class ShardGroup:
         """[world, ...] -> [world, ...]: slice j goes to rank j; slice i of the result came from rank i."""
         t = t.contiguous()
         src = t.cpu() if (self._via_host and t.is_cuda) else t
-        out = torch.empty_like(src)
-        if self._a2a is not False:
-            try:
-                dist.all_to_all_single(out.view(-1), src.view(-1), group=self.group)
-                self._a2a = True
-            except (RuntimeError, NotImplementedError):
-                if self._a2a is True:
-                    raise
-                self._a2a = False  # backend without all_to_all: all-gather, keep the own column
-        if self._a2a is False:
+        if self._a2a:
+            out = torch.empty_like(src)
+            dist.all_to_all_single(out.view(-1), src.view(-1), group=self.group)
+        else:  # a backend without all_to_all (neither nccl nor gloo): all-gather, keep the own column
             allt = torch.empty((self.world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
             dist.all_gather_into_tensor(allt.view(-1), src.view(-1), group=self.group)
             out = allt[:, self.rank].contiguous()

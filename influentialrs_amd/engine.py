@@ -219,14 +219,14 @@ class Engine:
 
     # ---- projection + cross entropy without the logits (training side)
     def ce_forward(self, xrows: torch.Tensor, labels0: torch.Tensor):
-        """(lse[M] float32, label_score[M] float32, loss[2] float64 = {sum over valid rows of lse - label score,
-        number of valid rows}); labels0 int64 0-based, -1 = row ignored."""
+        """(lse[M] float32, label_score[M] float32, loss[3] float64 = {sum over valid rows of lse - label score,
+        number of valid rows, number of labels >= n_item}); labels0 int64 0-based, -1 = row ignored."""
         xrows = self._dev(xrows, torch.float32)
         labels0 = self._dev(labels0, torch.int64)
         M = xrows.shape[0]
         lse = torch.empty(M, dtype=torch.float32, device=self.device)
         ls = torch.empty(M, dtype=torch.float32, device=self.device)
-        loss = torch.empty(2, dtype=torch.float64, device=self.device)
+        loss = torch.empty(3, dtype=torch.float64, device=self.device)
         self._call(self.lib.irs_ce_forward, _ptr(xrows), _ptr(labels0), M, _ptr(lse), _ptr(ls), _ptr(loss))
         return lse, ls, loss
 

@@ -24,6 +24,7 @@ class HipBackend:
         self.group: Optional[ShardGroup] = None
         self.sweep = IRS_SWEEP_BF16
         self.rank, self.world = 0, 1
+        self._stale = False  # a training entry point ran since the derived weights were built
 
     def __deepcopy__(self, memo):
         """copy.deepcopy(net): the copy gets its own backend and builds its own engine on first use (an engine is a
@@ -33,7 +34,7 @@ class HipBackend:
         memo[id(self)] = new
         new.net = copy.deepcopy(self.net, memo)
         new.mask_mode, new.sweep = self.mask_mode, self.sweep
-        new.engine, new._fp, new.group = None, None, None
+        new.engine, new._fp, new.group, new._stale = None, None, None, False
         new.rank, new.world = self.rank, self.world
         return new
 
@@ -49,8 +50,12 @@ class HipBackend:
             from ..engine import shard_bounds
             lo, hi = shard_bounds(self.net.n_item, world, rank)
             with torch.no_grad():
-                proj.weight = nn.Parameter(proj.weight[lo:hi].detach().clone(), requires_grad=proj.weight.requires_grad)
-                proj.bias = nn.Parameter(proj.bias[lo:hi].detach().clone(), requires_grad=proj.bias.requires_grad)
+                # shrink the SAME Parameter objects: optimizers built earlier (InfluentialNet.__init__, IRSNN, Evaluator)
+                # keep pointing at live tensors, and no reference to the full [n_item, d] storage survives
+                for p_ in (proj.weight, proj.bias):
+                    p_.data = p_.data[lo:hi].clone()
+                    p_.grad = None
+                proj.out_features = hi - lo
             self._fp = None
 
     def _fingerprint(self):
@@ -78,11 +83,16 @@ class HipBackend:
             self.group = ShardGroup(self.engine) if self.world > 1 else None
         fp = self._fingerprint()
         if for_training and self._fp is not None and [a for a, _ in fp] == [a for a, _ in self._fp]:
-            return self.engine  # same storage: the CE entry points read project.* in place, nothing derived is used
-        if fp != self._fp:
+            # same storage: the CE entry points read project.* in place, nothing derived is used -- but whatever the
+            # caller does with the gradients (an optimizer step, also through .data, which bumps no version counter)
+            # leaves the bf16 catalog and the filter's norms behind: the next inference get() re-finalises
+            self._stale = True
+            return self.engine
+        if fp != self._fp or self._stale:
             sd = {k: v.detach() for k, v in net.state_dict(keep_vars=True).items() if v.dtype == torch.float32}
             self.engine.bind_state_dict(sd)
             self._fp = fp
+            self._stale = for_training
         return self.engine
 
     # ---- row-level helpers (single shard or sharded group) ---------------
@@ -117,14 +127,21 @@ class _ProjectCE(torch.autograd.Function):
         eng = backend.get(1, min(M, _ProjectCE.ROWS), for_training=True)
         xd = x.detach().contiguous()
         lse = torch.empty(M, dtype=torch.float32, device=x.device)
-        tot = torch.zeros(2, dtype=torch.float64, device=x.device)
+        tot = torch.zeros(3, dtype=torch.float64, device=x.device)
         for c0 in range(0, M, _ProjectCE.ROWS):
             c1 = min(M, c0 + _ProjectCE.ROWS)
             l, _, t = eng.ce_forward(xd[c0:c1], labels0[c0:c1])
             lse[c0:c1] = l
             tot += t
+        _, n_valid, n_bad = tot.tolist()  # one host read per loss, as nn.CrossEntropyLoss's own target check costs
+        if n_bad > 0:
+            raise IndexError(f"Target out of bounds: {int(n_bad)} label(s) >= n_item {weight.shape[0]} (nn.CrossEntropyLoss "
+                             "raises here, reference influentialRS.py:270,301)")
         ctx.save_for_backward(xd, weight, labels0, lse, tot)
         ctx.backend = backend
+        ctx.n_valid = n_valid
+        if n_valid == 0:  # every target is a pad: the reference's mean over an empty selection is nan, its gradient zero
+            return torch.full((), float("nan"), dtype=torch.float32, device=x.device)
         return (tot[0] / tot[1]).to(torch.float32)
 
     @staticmethod
@@ -132,6 +149,8 @@ class _ProjectCE(torch.autograd.Function):
         xd, weight, labels0, lse, tot = ctx.saved_tensors
         M, d = xd.shape
         N = weight.shape[0]
+        if ctx.n_valid == 0:
+            return torch.zeros_like(xd), torch.zeros_like(weight), torch.zeros(N, dtype=torch.float32, device=xd.device), None, None
         eng = ctx.backend.get(1, min(M, _ProjectCE.ROWS), for_training=True)
         mc = max(32, min(_ProjectCE.ROWS, M, (_ProjectCE.CHUNK_BYTES // (4 * N)) // 32 * 32))
         G = torch.empty((mc, N), dtype=torch.float32, device=xd.device)

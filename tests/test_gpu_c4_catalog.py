@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from influentialrs_amd import synth
-from influentialrs_amd._lib import IRS_SWEEP_BF16, IRS_SWEEP_F32
+from influentialrs_amd._lib import IRS_SWEEP_BF16, IRS_SWEEP_EXHAUSTIVE, IRS_SWEEP_F32
 from influentialrs_amd.engine import Engine
 from influentialrs_amd._lib import IRS_MASK_IRN
 
@@ -58,7 +58,7 @@ def _embedding(dev):
     return _EMB["emb"]
 
 
-def _scoring_engine(catalog, rank=0, world=1):
+def _scoring_engine(catalog, rank=0, world=1, max_rows=8):
     """Engine over the GPU-resident catalog with a 1-layer dummy decoder: only project.* matters to the scoring
     entry points.  item_embedder.weight must be bound with its full element count: the module's shared table."""
     W, b = catalog[0], catalog[1]
@@ -67,7 +67,7 @@ def _scoring_engine(catalog, rank=0, world=1):
     small = synth.irn_state_dict(synth.make_config("tiny", n_item=8, emb_dim=D, n_heads=8, n_layers=1, max_len=4,
                                                    ffn_dim=8, n_user=2), seed=1)
     eng = Engine(n_item=N_ITEM, n_user=cfg.n_user, d=D, max_len=cfg.max_len, n_heads=cfg.n_heads, ffn_dim=cfg.ffn_dim,
-                 n_layers=1, u_dim=cfg.u_emb_dim, mask_mode=IRS_MASK_IRN, device=dev, max_rows=8, max_seqs=1, max_k=K,
+                 n_layers=1, u_dim=cfg.u_emb_dim, mask_mode=IRS_MASK_IRN, device=dev, max_rows=max_rows, max_seqs=1, max_k=K,
                  rank=rank, world=world)
     sd = {k_: torch.from_numpy(v).to(dev) for k_, v in small.items()
           if k_ not in ("project.weight", "project.bias", "item_embedder.weight")}
@@ -147,6 +147,70 @@ def test_c4_eight_shards_merge_equals_unsharded(oracle, catalog, oracle_rows):
         ov, oi = oracle.topk(oracle_rows[m], K)
         assert np.array_equal(mi[m], oi) and np.array_equal(mv[m].view(np.uint32), ov.view(np.uint32)), f"row {m}"
         assert cnt[m] + 1 == oracle.rank_of(oracle_rows[m], int(lab[m]), np.zeros(0, dtype=np.int64)), f"row {m}"
+
+
+M_RING = 512  # >= 256 rows: irs_score_topk takes the compute-bound LDS-DMA ring sweep (k_sweep_ring), the kernel every
+              # catalog-scale bench leg and every N = 8 shard runs
+
+
+def _ring_rows(catalog):
+    """512 rows; the first three are rows the oracle has scored over the whole catalog."""
+    x = catalog[2]
+    g = torch.Generator(device=x.device)
+    g.manual_seed(4242)
+    xs = torch.randn((M_RING, D), generator=g, device=x.device, dtype=torch.float32)
+    xs[:3] = x[:3]
+    return xs
+
+
+def test_c4_ring_kernel_512_rows_single_shard(oracle, catalog, oracle_rows):
+    """The ring kernel (PRE + EMIT) at the FULL 10M x 256 catalog with 512 rows -- the 5 GB bf16 fragment image (byte
+    offsets past 2^32), several rounds of workgroups, strips 30x longer than any other ring test: every row equal
+    to the float32 sweep (another kernel family: k_sweep_f32) bit for bit, 16 sampled rows equal to the
+    exhaustive exact kernel, 3 rows equal to the CPU oracle.  Reference: influentialRS.py:418-421."""
+    eng = _scoring_engine(catalog, max_rows=M_RING)
+    xs = _ring_rows(catalog)
+    for rep in range(2):  # the second call runs on a warm workspace (stale candidate counts would show here)
+        val, ids, st = eng.score_topk(xs, K, IRS_SWEEP_BF16)
+    vf, idf, stf = eng.score_topk(xs, K, IRS_SWEEP_F32)
+    torch.cuda.synchronize()
+    assert not (st & 1).any() and not (stf & 1).any(), "no row may need the exhaustive fallback on benign data"
+    assert torch.equal(ids, idf), "bf16 ring sweep and float32 sweep disagree on ids"
+    assert torch.equal(val.view(torch.int32), vf.view(torch.int32)), "bf16 ring sweep and float32 sweep disagree on values"
+    sel = torch.tensor([0, 1, 2, 31, 32, 63, 64, 127, 128, 255, 256, 300, 383, 384, 480, 511], device=xs.device)
+    ev, ei, _ = eng.score_topk(xs[sel].contiguous(), K, IRS_SWEEP_EXHAUSTIVE)
+    torch.cuda.synchronize()
+    assert torch.equal(ids[sel], ei) and torch.equal(val[sel].view(torch.int32), ev.view(torch.int32))
+    val, ids = val.cpu().numpy(), ids.cpu().numpy()
+    for m in range(3):
+        ov, oi = oracle.topk(oracle_rows[m], K)
+        assert np.array_equal(ids[m], oi) and np.array_equal(val[m].view(np.uint32), ov.view(np.uint32)), f"row {m}"
+
+
+def test_c4_ring_kernel_512_rows_eight_shards(oracle, catalog, oracle_rows):
+    """The same 512 rows through BASELINE config 4's partition: 8 shard engines (1.25M x 256 each, ring kernel),
+    packed keys, merge -- equal to the unsharded float32 sweep on every row and to the oracle on its three rows."""
+    xs = _ring_rows(catalog)
+    full = _scoring_engine(catalog, max_rows=M_RING)
+    vf, idf, _ = full.score_topk(xs, K, IRS_SWEEP_F32)
+    torch.cuda.synchronize()
+    del full
+    keys = []
+    eng = None
+    for r in range(8):
+        del eng
+        eng = _scoring_engine(catalog, rank=r, world=8, max_rows=M_RING)
+        v, i, st = eng.score_topk(xs, K, IRS_SWEEP_BF16)
+        assert not (st & 1).any()
+        keys.append(eng.pack_topk(v, i))
+        torch.cuda.synchronize()
+    mv, mi = eng.merge_topk_keys(torch.stack(keys))
+    torch.cuda.synchronize()
+    assert torch.equal(mi, idf) and torch.equal(mv.view(torch.int32), vf.view(torch.int32))
+    mv, mi = mv.cpu().numpy(), mi.cpu().numpy()
+    for m in range(3):
+        ov, oi = oracle.topk(oracle_rows[m], K)
+        assert np.array_equal(mi[m], oi) and np.array_equal(mv[m].view(np.uint32), ov.view(np.uint32)), f"row {m}"
 
 
 def test_c5_beam32_full_catalog(oracle, catalog):

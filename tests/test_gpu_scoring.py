@@ -315,6 +315,35 @@ RING_CASES = [  # >= 256 rows: the compute-bound LDS-DMA ring sweep (PRE and EMI
 ]
 
 
+def test_ring_kernel_c3_bench_shape(oracle):
+    """BASELINE configs[2]'s scoring shape exactly as bench.py's C3 leg and `scoring` object run it: 1,000,000 x 128,
+    1024 rows through the ring kernel -- every row equal to the float32 sweep bit for bit, 16 sampled rows equal to the
+    exhaustive exact kernel, 3 rows equal to the CPU oracle's chain + top-k."""
+    n_item, d, M, k = 1_000_000, 128, 1024, 100
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    Wt = (torch.rand((n_item, d), generator=g, device=dev, dtype=torch.float32) * 2 - 1) * d ** -0.5
+    bt = torch.randn((n_item,), generator=g, device=dev, dtype=torch.float32) * 0.1
+    xt = torch.randn((M, d), generator=g, device=dev, dtype=torch.float32)
+    W, b = Wt.cpu().numpy(), bt.cpu().numpy()
+    eng = scoring_only_engine(n_item, d, W, b, max_rows=M, max_k=k)
+    for rep in range(2):
+        val, ids, st = eng.score_topk(xt, k, IRS_SWEEP_BF16)
+    vf, idf, stf = eng.score_topk(xt, k, IRS_SWEEP_F32)
+    sel = torch.arange(0, M, 64, device=dev)
+    ev, ei, _ = eng.score_topk(xt[sel].contiguous(), k, IRS_SWEEP_EXHAUSTIVE)
+    torch.cuda.synchronize()
+    assert not (st & 1).any() and not (stf & 1).any()
+    assert torch.equal(ids, idf) and torch.equal(val.view(torch.int32), vf.view(torch.int32))
+    assert torch.equal(ids[sel], ei) and torch.equal(val[sel].view(torch.int32), ev.view(torch.int32))
+    x = xt.cpu().numpy()
+    val, ids = val.cpu().numpy(), ids.cpu().numpy()
+    for m in (0, 511, 1023):
+        ov, oi = oracle.topk(oracle.score_chain(x[m], W, b), k)
+        assert np.array_equal(ids[m], oi) and np.array_equal(val[m].view(np.uint32), ov.view(np.uint32)), f"row {m}"
+
+
 @pytest.mark.parametrize("n_item,d,M,k", RING_CASES)
 def test_topk_many_rows_ring_kernel(oracle, n_item, d, M, k):
     """The ring kernel against the exhaustive exact kernel (every row, bit for bit) and the CPU oracle (a few rows)."""

@@ -231,3 +231,97 @@ def test_ce_entry_points_reject_item_shards_and_bad_buffers():
         full.ce_forward(torch.randn(9, cfg.emb_dim, device=DEV), torch.zeros(9, dtype=torch.int64, device=DEV))  # M > max_rows
     G = full.ce_grad_logits(x, lab, lse, 1.0, torch.empty((8, cfg.n_item), device=DEV))
     assert abs(G.sum().item()) < 1e-3  # softmax minus one-hot sums to zero on every row
+
+
+def test_ce_marks_the_bf16_catalog_stale_until_refinalised():
+    """irs_ce_forward / irs_ce_grad_logits read project.* in place; the bf16 catalog copy and the filter's norms are
+    then possibly behind the weights, and every entry point that filters through them refuses (IRS_E_STATE) until
+    irs_finalize_weights ran -- a stale filter could silently drop true top-k items."""
+    from influentialrs_amd.engine import Engine, IrsError
+    from influentialrs_amd._lib import IRS_MASK_IRN, IRS_SWEEP_BF16, IRS_SWEEP_F32
+    cfg = synth.make_config("tiny")
+    sd = {k: torch.from_numpy(v).to(DEV) for k, v in synth.irn_state_dict(cfg, 1234).items()}
+    eng = Engine(n_item=cfg.n_item, n_user=cfg.n_user, d=cfg.emb_dim, max_len=cfg.max_len, n_heads=cfg.n_heads,
+                 ffn_dim=cfg.ffn_dim, n_layers=cfg.n_layers, u_dim=cfg.u_emb_dim, mask_mode=IRS_MASK_IRN, device=torch.device(DEV),
+                 max_rows=8, max_seqs=8)
+    eng.bind_state_dict(sd)
+    x = torch.randn(8, cfg.emb_dim, device=DEV)
+    lab = torch.arange(8, dtype=torch.int64, device=DEV)
+    v0, i0, _ = eng.score_topk(x, 10, IRS_SWEEP_BF16)
+    eng.ce_forward(x, lab)
+    with pytest.raises(IrsError, match="irs_finalize_weights"):
+        eng.score_topk(x, 10, IRS_SWEEP_BF16)
+    with pytest.raises(IrsError):
+        eng.score_topk_lse(x, 10, IRS_SWEEP_BF16)
+    eng.score_topk(x, 10, IRS_SWEEP_F32)  # the float32 sweep reads project.* in place: allowed
+    # an in-place update of the catalog "behind the back" of every version counter, then re-finalisation
+    with torch.no_grad():
+        sd["project.weight"].data.mul_(-1.0)
+    eng.finalize()
+    v1, i1, _ = eng.score_topk(x, 10, IRS_SWEEP_BF16)
+    vf, i_f, _ = eng.score_topk(x, 10, IRS_SWEEP_F32)
+    torch.cuda.synchronize()
+    assert torch.equal(i1, i_f) and torch.equal(v1.view(torch.int32), vf.view(torch.int32)) and not torch.equal(i0, i1)
+
+
+def test_frontend_refinalises_after_a_training_call_even_without_version_bumps():
+    """HipBackend: after a for_training get() the next inference get() rebuilds the derived weights, also when the
+    optimizer wrote through .data (no _version bump): top-k after the update equals the float32 chain's."""
+    from influentialrs_amd._lib import IRS_SWEEP_F32
+    cfg = synth.make_config("tiny", dropout=0.0)
+    net = InfluentialNet(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.irn_state_dict(cfg, 1234).items()})
+    net.to(DEV).eval()
+    x = torch.randn(16, cfg.emb_dim, device=DEV)
+    eng = net._hip.get(4, 16)
+    net._hip.topk(x, 10)
+    lab = torch.arange(16, dtype=torch.int64, device=DEV)
+    _backend.project_ce(x.clone().requires_grad_(True), net.project, lab, net._hip).backward()
+    with torch.no_grad():
+        net.project.weight.data.add_(torch.randn_like(net.project.weight) * 0.5)  # no version bump
+    eng = net._hip.get(4, 16)
+    v1, i1, _ = net._hip.topk(x, 10)
+    vf, i_f, _ = eng.score_topk(x, 10, IRS_SWEEP_F32)
+    torch.cuda.synchronize()
+    assert torch.equal(i1, i_f) and torch.equal(v1.view(torch.int32), vf.view(torch.int32))
+
+
+def test_project_ce_rejects_labels_beyond_the_catalog_and_handles_all_pad_batches():
+    """nn.CrossEntropyLoss raises on a target >= n_item (reference influentialRS.py:270,301); a batch whose targets are
+    all pads gives the reference's nan loss with zero gradients instead of inf * 0."""
+    cfg = synth.make_config("tiny", dropout=0.0)
+    net = InfluentialNet(cfg).to(DEV)
+    x = torch.randn(12, cfg.emb_dim, device=DEV, requires_grad=True)
+    lab = torch.randint(0, cfg.n_item, (12,), device=DEV)
+    bad = lab.clone()
+    bad[5] = cfg.n_item
+    with pytest.raises(IndexError):
+        _backend.project_ce(x, net.project, bad, net._hip)
+    loss = _backend.project_ce(x, net.project, torch.full((12,), -1, dtype=torch.int64, device=DEV), net._hip)
+    assert torch.isnan(loss)
+    loss.backward()
+    assert x.grad.abs().max().item() == 0 and net.project.weight.grad.abs().max().item() == 0
+    ok = _backend.project_ce(x, net.project, lab, net._hip)
+    assert torch.isfinite(ok)
+
+
+def test_shard_items_frees_the_full_catalog_and_keeps_the_optimizers_bound():
+    """net.shard_items(rank, world) after net.to(dev): the full [n_item, d] projection is released (the module's own
+    Adam and any handler's optimizer keep pointing at the SAME, now shard-sized, Parameter objects)."""
+    cfg = synth.make_config("tiny", n_item=400_000, emb_dim=64, n_heads=2, n_layers=1, max_len=8, ffn_dim=16, n_user=4)
+    net = InfluentialNet(cfg).to(DEV)
+    irs = IRSNN(cfg, net, DEV)
+    w_id, b_id = id(net.project.weight), id(net.project.bias)
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    net.shard_items(1, 4)
+    torch.cuda.synchronize()
+    after = torch.cuda.memory_allocated()
+    full_bytes = cfg.n_item * cfg.emb_dim * 4
+    assert before - after >= 0.7 * full_bytes, (before, after, full_bytes)
+    assert id(net.project.weight) == w_id and id(net.project.bias) == b_id
+    assert net.project.weight.shape[0] == 100_000
+    for opt in (net.optimizer, irs.optimizer):
+        held = {id(p) for gp in opt.param_groups for p in gp["params"]}
+        assert w_id in held and b_id in held
+        assert all(p.shape[0] == 100_000 for gp in opt.param_groups for p in gp["params"] if id(p) in (w_id, b_id))
