@@ -294,33 +294,25 @@ class Job:
         self.hep = torch.full((self.B,), cfg.max_len - 2, dtype=torch.int32, device=device)
         self.paths = torch.zeros((self.B, 1), dtype=torch.float32, device=device)
         self.status = torch.zeros(self.B, dtype=torch.int32, device=device)
+        self.comm = None
         if self.sharded:
+            from influentialrs_amd.engine import Comm
+            self.comm = Comm(device)  # RCCL (backend nccl) or, for the one-GPU rehearsal, gloo through the host
             self.x_all = torch.empty((rows, cfg.emb_dim), dtype=torch.float32, device=device)
             self.k_recv = torch.empty((world, self.B, self.k), dtype=torch.int64, device=device)
 
-    def _collect(self, fn, out, inp):
-        """RCCL works on device tensors; the gloo rehearsal backend (several ranks on ONE GPU) goes through the host."""
-        import torch.distributed as dist
-        if dist.get_backend() == "gloo":
-            o, i = out.cpu(), inp.cpu()
-            fn(o.view(-1), i.view(-1))
-            out.copy_(o)
-        else:
-            fn(out.view(-1), inp.view(-1))
-
     def step(self):
         eng = self.eng
-        _, xr, _ = eng.decode(self.seqs, self.users, want_x=False, pos=self.hep)
         if not self.sharded:
+            _, xr, _ = eng.decode(self.seqs, self.users, want_x=False, pos=self.hep)
             val, ids, _ = eng.score_topk(xr, self.k, self.sweep)
+            eng.path_step(self.seqs, self.hep, val, ids, 0, self.paths, self.status)
         else:
-            import torch.distributed as dist
-            self._collect(dist.all_gather_into_tensor, self.x_all, xr)
-            v, i, _ = eng.score_topk(self.x_all, self.k, self.sweep)    # all rows x this rank's item shard
-            keys = eng.pack_topk(v, i)                                   # one 64-bit key per entry (irs_hip.h)
-            self._collect(dist.all_to_all_single, self.k_recv, keys)     # the world's lists of THIS rank's rows
-            val, ids = eng.merge_topk_keys(self.k_recv)
-        eng.path_step(self.seqs, self.hep, val, ids, 0, self.paths, self.status)
+            # one search step below the C ABI (irs_generate_paths_sharded): decode -> row all-gather -> sweep of this rank's
+            # item shard for all rows -> pack -> ONE all-to-all of 64-bit keys -> merge -> path step, one stream-ordered
+            # sequence over workspace buffers, replayed from a hipGraph when the communicator is RCCL
+            eng.generate_paths_sharded(self.comm, self.seqs, self.users, self.hep, 1, k=self.k, sweep=self.sweep,
+                                       use_graph=self.comm.is_rccl, paths=self.paths, status=self.status)
 
 
 def verify_job(job, n=4):
@@ -334,9 +326,7 @@ def verify_job(job, n=4):
     _, xr, _ = eng.decode(job.seqs, job.users, want_x=False, pos=job.hep)
     rows = xr
     if job.sharded:
-        import torch.distributed as dist
-        job._collect(dist.all_gather_into_tensor, job.x_all, xr)
-        rows = job.x_all
+        rows = eng.allgather_rows(job.comm, xr, job.x_all)
     v, i, st = eng.score_topk(rows, job.k, job.sweep)
     sel = torch.linspace(0, rows.shape[0] - 1, n, device=rows.device).long()
     vf, i_f, _ = eng.score_topk(rows[sel].contiguous(), job.k, IRS_SWEEP_F32)
@@ -368,19 +358,13 @@ def phase_times(job, steps=3):
         ev[0].record()
         _, xr, _ = eng.decode(job.seqs, job.users, want_x=False, pos=job.hep)
         ev[1].record()
-        if job.sharded:
-            import torch.distributed as dist
-            job._collect(dist.all_gather_into_tensor, job.x_all, xr)
-            rows = job.x_all
-        else:
-            rows = xr
+        rows = eng.allgather_rows(job.comm, xr, job.x_all) if job.sharded else xr   # irs_allgather_rows
         ev[2].record()
         v, i, _ = eng.score_topk(rows, job.k, job.sweep)
-        keys = eng.pack_topk(v, i) if job.sharded else None
+        keys = eng.pack_topk(v, i).view(job.world, job.B, job.k) if job.sharded else None
         ev[3].record()
         if job.sharded:
-            import torch.distributed as dist
-            job._collect(dist.all_to_all_single, job.k_recv, keys)
+            eng.exchange_topk(job.comm, keys, job.k_recv)                           # irs_exchange_topk
         ev[4].record()
         if job.sharded:
             v, i = eng.merge_topk_keys(job.k_recv)
@@ -522,12 +506,12 @@ def main():
         cpu = cpu_baseline(args.workload if args.workload in ("c1", "c2", "default", "tiny") else "c2")
 
     import torch
+    import torch.distributed as dist
     from influentialrs_amd._lib import (IRS_PROF_ATTN, IRS_PROF_LINEAR, IRS_PROF_NONE, IRS_PROF_REFINE, IRS_PROF_SWEEP,
                                         IRS_SWEEP_BF16)
     device = torch.device("cuda", 0 if args.same_device else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
-        import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -549,6 +533,10 @@ def main():
         return
     for _ in range(args.warmup):
         job.step()
+    # the windows as the timed region finds them: every instrumented pass below restarts from this state, so that it
+    # executes exactly the timed region's work (a window gains a token per step until it is full: 20 steps later the
+    # decoder would run ~10 % more packed rows)
+    snap = (job.seqs.clone(), job.hep.clone())
     dt = timed(job, args.steps, world)
     users_total = job.B * world
     value = users_total * cfg.n_item * args.steps / dt
@@ -556,6 +544,8 @@ def main():
     # second, instrumented pass: HIP events around every launch of each kernel family
     fam = {}
     for name, f in (("linear", IRS_PROF_LINEAR), ("attn", IRS_PROF_ATTN), ("sweep", IRS_PROF_SWEEP), ("refine", IRS_PROF_REFINE)):
+        job.seqs.copy_(snap[0])
+        job.hep.copy_(snap[1])
         job.eng.prof_enable(f)
         f0 = packed_fraction(job)
         for _ in range(args.steps):
@@ -622,8 +612,9 @@ def main():
             except Exception as e:  # a malformed profile file must not cost the bench line
                 roof["traffic_source"] = f"profiles/r03/c2_b4096_pmc.json unreadable: {e}"
         roof["flops_counted"] = "executed (dense-shape flops x packed non-pad row fraction %.3f)" % fam[dom].get("packed_fraction", 1.0)
-        roof["time_basis"] = ("HIP events around every launch of the family (second pass of the same K steps), scaled by %.4f so "
-                              "that the four families sum to no more than the un-instrumented ms_per_step" % fscale)
+        roof["time_basis"] = ("HIP events around every launch of the family (a second pass over the SAME K steps: the windows are "
+                              "reset to their state at the start of the timed region), scaled by %.4f so that the four families "
+                              "sum to no more than the un-instrumented ms_per_step" % fscale)
         roof["avg_launch_ms"] = per_launch_ms
         roof["launches_per_step"] = f["launches"] / args.steps
         roof["family_ms_per_step"] = {k: v["ms"] / args.steps for k, v in fam.items()}
@@ -674,7 +665,8 @@ def main():
                "packed_row_fraction": fam["linear"]["packed_fraction"],
                "sweep": args.sweep + (" filter + exact f32 re-score" if args.sweep == "bf16" else ""),
                "parallelism": "single GPU" if world == 1 else (
-                   f"rows data-parallel + item-sharded x{world}: RCCL all-gather of rows, one all_to_all of packed 64-bit top-100 keys"
+                   f"rows data-parallel + item-sharded x{world}: RCCL all-gather of rows, one all_to_all of packed 64-bit top-100 keys "
+                   f"(irs_generate_paths_sharded: collectives below the C ABI, captured step)"
                    if job.sharded else
                    f"users partitioned over {world} GPUs, catalog replicated ({cfg.n_item} items): no data-path collective")}
     del job
@@ -725,27 +717,52 @@ def main():
         c4["fallback_rows"] = fb4
         ph = phase_times(j4)  # every rank runs it (the collectives inside need all of them); rank 0 reports
         c4["phase_ms_rank0"] = ph
-        if world == 1 and rank == 0 and not args.no_latency:
-            # BASELINE configs[4] (C5), D1 (ii): beam-width-32 persuasion-path search over the 10M-item catalog for one
+        if not args.no_latency and 32 % world == 0:
+            # BASELINE configs[4] (C5), D1 (ii): beam-width-32 persuasion-path search over the 10M-item catalog for ONE
             # user -- 32 windows decoded, scored (top-100 + exact log-sum-exp over the catalog) and re-ranked per step,
-            # 20 steps; p50 over 10 repetitions after 2 warm-ups, stream launches and the captured two-step hipGraph
+            # 20 steps; p50 over 10 repetitions after 2 warm-ups, stream launches and the captured two-step hipGraph.
+            # N > 1: the SAME user on every rank (seeded windows), the 32 beam windows' decode split 32 / N per rank, rows
+            # all-gathered, every rank sweeps its item shard for all 32 rows, packed lists all-gathered and merged,
+            # log-sum-exp all-reduced, beam step replicated (irs_beam_search_sharded, split_decode); max over ranks.
             fresh = gpu_windows(4, j4.cfg.max_len, j4.cfg.n_item, device, seed=7)
-            b_seq, b_usr, b_hep = fresh[:1].contiguous(), j4.users[:1].contiguous(), j4.hep[:1].contiguous()
-            c5 = {"workload": "c5: beam 32 x 20 steps, 1 user, n_item=10000000, d=256 (one GPU holds the whole catalog)"}
+            g5 = torch.Generator(device=device)
+            g5.manual_seed(5)
+            b_seq, b_hep = fresh[:1].contiguous(), j4.hep[:1].contiguous()
+            b_usr = torch.randint(0, j4.cfg.n_user, (1,), generator=g5, device=device, dtype=torch.int64)
+            c5 = {"workload": "c5: beam 32 x 20 steps, 1 user, n_item=10000000, d=256 (" +
+                              ("one GPU holds the whole catalog)" if world == 1 else
+                               f"{world} item shards of {j4.eng.n_local} rows; beam windows decoded {32 // world} per rank)"),
+                  "n_gpus": world}
             for label, graph in (("stream", False), ("hipgraph", True)):
                 ts = []
                 for it in range(12):
+                    if world > 1:
+                        dist.barrier()
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    j4.eng.beam_search(b_seq, b_usr, b_hep, 20, 32, k=100, sweep=j4.sweep, use_graph=graph)
+                    if world == 1:
+                        j4.eng.beam_search(b_seq, b_usr, b_hep, 20, 32, k=100, sweep=j4.sweep, use_graph=graph)
+                    else:
+                        j4.eng.beam_search_sharded(j4.comm, b_seq, b_usr, b_hep, 20, 32, k=100, sweep=j4.sweep, split_decode=True,
+                                                   use_graph=graph)
                     torch.cuda.synchronize()
+                    dt5 = time.perf_counter() - t0
+                    if world > 1:
+                        t5 = torch.tensor([dt5], dtype=torch.float64, device=device)
+                        if dist.get_backend() == "gloo":
+                            h5 = t5.cpu()
+                            dist.all_reduce(h5, op=dist.ReduceOp.MAX)
+                            dt5 = float(h5.item())
+                        else:
+                            dist.all_reduce(t5, op=dist.ReduceOp.MAX)
+                            dt5 = float(t5.item())
                     if it >= 2:
-                        ts.append((time.perf_counter() - t0) * 1e3)
+                        ts.append(dt5 * 1e3)
                 c5[f"search_p50_ms_{label}"] = float(np.median(ts))
                 c5[f"step_p50_ms_{label}"] = float(np.median(ts)) / 20
-            # HBM floor of a step: the fp32 catalog once (candidates + exact log-sum-exp out of one pass) + the 1/8 sample
-            # of the bf16 catalog the threshold comes from
-            c5["step_hbm_floor_ms"] = (j4.cfg.n_item * j4.cfg.emb_dim * (4.0 + 2.0 / 8)) / (PEAK_HBM_GBS * 1e9) * 1e3
+            # HBM floor of a step per GPU: its share of the fp32 catalog once (candidates + exact log-sum-exp out of one
+            # pass) + the 1/8 sample of the bf16 catalog the threshold comes from
+            c5["step_hbm_floor_ms"] = (j4.eng.n_local * j4.cfg.emb_dim * (4.0 + 2.0 / 8)) / (PEAK_HBM_GBS * 1e9) * 1e3
             c4["c5_beam32"] = c5
         del j4
         torch.cuda.empty_cache()
@@ -777,7 +794,6 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if world > 1:
-        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 

@@ -297,6 +297,61 @@ int irs_beam_search(irs_ctx *ctx, const int64_t *dev_seq0, const int64_t *dev_us
                     int32_t W, int32_t P, int32_t k, int32_t sweep, int32_t use_graph, float *dev_paths,
                     double *dev_scores, int64_t *dev_seq_final, int32_t *dev_status, void *stream);
 
+/* ---- multi-GPU: the exchange steps and the sharded search loops below the ABI (section 8 row B2's
+ *      `allgather_merge(ctx, comm, ...)`).  One process per GPU; rank r holds item rows [item_lo, item_hi) (irs_shard).
+ * A communicator is either RCCL (librccl.so is dlopen()ed on first use: ncclCommInitRank over a 128-byte unique id the
+ * caller distributes, e.g. with its torch.distributed store) or a set of caller-supplied collectives (the CPU
+ * rehearsal tests run gloo through it).  Every collective is enqueued on the caller's stream: decode -> row
+ * all-gather -> shard sweep -> pack -> key exchange -> merge -> path / beam step is ONE stream-ordered sequence over
+ * buffers of the context's workspace, nothing is allocated per call, and with RCCL the whole step can be captured
+ * into a hipGraph (use_graph).  The reference has no counterpart (nn.DataParallel only, pipeline.py:43-44). */
+typedef struct irs_comm irs_comm;
+#define IRS_COMM_ID_BYTES 128
+#define IRS_REDUCE_SUM 0
+#define IRS_REDUCE_MAX 1
+/* all-gather: every rank contributes bytes_per_rank bytes, receives world * bytes_per_rank (rank-major);
+ * all-to-all: slice j of send (bytes_per_rank bytes) goes to rank j, slice i of recv came from rank i;
+ * all-reduce: in place over `count` float32.  Device pointers; ordered against `stream`; return 0 on success. */
+typedef int (*irs_allgather_fn)(void *user, const void *dev_send, void *dev_recv, size_t bytes_per_rank, void *stream);
+typedef int (*irs_alltoall_fn)(void *user, const void *dev_send, void *dev_recv, size_t bytes_per_rank, void *stream);
+typedef int (*irs_allreduce_f32_fn)(void *user, float *dev_buf, size_t count, int op, void *stream);
+
+int irs_comm_unique_id(void *out_id128);                        /* RCCL: ncclGetUniqueId (call on one rank) */
+int irs_comm_init_rccl(irs_comm **out, const void *id128, int32_t rank, int32_t world); /* ncclCommInitRank on the CURRENT device */
+int irs_comm_init_callbacks(irs_comm **out, int32_t rank, int32_t world, void *user, irs_allgather_fn allgather,
+                            irs_alltoall_fn alltoall, irs_allreduce_f32_fn allreduce);
+void irs_comm_destroy(irs_comm *comm);
+const char *irs_comm_last_error(void);
+int irs_comm_is_rccl(const irs_comm *comm);
+
+/* rows decoded data-parallel -> all rows on every rank, rank-major: dev_rows_all float [world * B, d]. */
+int irs_allgather_rows(irs_ctx *ctx, irs_comm *comm, const float *dev_rows_local, int32_t B, float *dev_rows_all, void *stream);
+/* packed per-shard lists of ALL rows (dev_keys_send uint64 [world, B, k], rank-major rows: what irs_pack_topk makes of
+ * this rank's irs_score_topk over the gathered rows) -> the world's lists of THIS rank's B rows (dev_keys_recv
+ * uint64 [world, B, k], shard-major): one all-to-all of M * k * 8 bytes per rank (SURVEY 8e's budget). */
+int irs_exchange_topk(irs_ctx *ctx, irs_comm *comm, const uint64_t *dev_keys_send, uint64_t *dev_keys_recv, int32_t B,
+                      int32_t k, void *stream);
+
+/* irs_generate_paths over an item-sharded catalog (replaces the loop of IRSNN.get_seq_in_batch, influentialRS.py:412-450):
+ * this rank's B users, per step { decode, row all-gather, sweep of the local shard for all world * B rows, pack,
+ * all-to-all of keys, merge, path step }.  Needs max_rows >= world * B, max_seqs >= B; every rank calls it with the
+ * same B / max_path_len / k / sweep.  Results equal the single-device irs_generate_paths bit for bit. */
+int irs_generate_paths_sharded(irs_ctx *ctx, irs_comm *comm, int64_t *dev_seq, const int64_t *dev_user, int32_t *dev_hep,
+                               int32_t B, int32_t max_path_len, int32_t k, int32_t sweep, int32_t sample, int32_t sample_k,
+                               uint64_t seed, int32_t use_graph, float *dev_paths, int32_t *dev_status, void *stream);
+
+/* irs_beam_search over an item-sharded catalog.  split_decode == 0: this rank's OWN B users (rows = B * W per rank;
+ * all-gather of rows, all-to-all of keys, all-reduce of the rows' (max, sum exp)); needs max_rows >= world * B * W.
+ * split_decode != 0 (BASELINE configs[4]: ONE user's beams spread over the node): every rank passes the SAME B users
+ * and keeps the same beam state; per step rank r decodes rows [r R/world, (r+1) R/world) of the R = B * W beam windows
+ * (R a multiple of world), the rows are all-gathered, every rank sweeps its shard for all R rows, the packed lists are
+ * all-gathered and merged on every rank, and the (deterministic) beam step runs replicated; needs max_rows >= R,
+ * max_k * world <= 2048.  Outputs as irs_beam_search (identical on every rank when split_decode). */
+int irs_beam_search_sharded(irs_ctx *ctx, irs_comm *comm, const int64_t *dev_seq0, const int64_t *dev_user,
+                            const int32_t *dev_hep0, int32_t B, int32_t W, int32_t P, int32_t k, int32_t sweep,
+                            int32_t split_decode, int32_t use_graph, float *dev_paths, double *dev_scores,
+                            int64_t *dev_seq_final, int32_t *dev_status, void *stream);
+
 /* ---- measurement hooks (bench.py only) ---------------------------------
  * While enabled, every launch of the named kernel family is bracketed by HIP
  * events on the launch stream; irs_prof_read() synchronises those events and

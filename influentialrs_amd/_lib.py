@@ -65,9 +65,27 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     "irs_beam_search": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                   c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "irs_comm_unique_id": (c_int32, [c_void_p]),
+    "irs_comm_init_rccl": (c_int32, [POINTER(c_void_p), c_void_p, c_int32, c_int32]),
+    "irs_comm_init_callbacks": (c_int32, [POINTER(c_void_p), c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "irs_comm_destroy": (None, [c_void_p]),
+    "irs_comm_last_error": (c_char_p, []),
+    "irs_comm_is_rccl": (c_int32, [c_void_p]),
+    "irs_allgather_rows": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "irs_exchange_topk": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "irs_generate_paths_sharded": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                             c_int32, c_int32, c_uint64, c_int32, c_void_p, c_void_p, c_void_p]),
+    "irs_beam_search_sharded": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                          c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "irs_prof_enable": (c_int32, [c_void_p, c_int32]),
     "irs_prof_read": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
 }
+
+# collective callbacks of irs_comm_init_callbacks (include/irs_hip.h): (user, send, recv, bytes_per_rank, stream) -> int
+ALLGATHER_FN = ctypes.CFUNCTYPE(c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p)
+ALLTOALL_FN = ctypes.CFUNCTYPE(c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p)
+ALLREDUCE_F32_FN = ctypes.CFUNCTYPE(c_int32, c_void_p, c_void_p, c_size_t, c_int32, c_void_p)
+IRS_COMM_ID_BYTES = 128
 
 _LIB = None
 

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libirs_hip.so")
-SOURCES = ["capi.hip", "decoder.hip", "score.hip", "path.hip"]
+SOURCES = ["capi.hip", "decoder.hip", "score.hip", "path.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "irs_internal.h"), os.path.join(os.path.dirname(HERE), "include", "irs_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
@@ -46,7 +46,7 @@ def build_lib(force: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
     if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

@@ -76,6 +76,7 @@ extern "C" void irs_destroy(irs_ctx *ctx) {
     if (!ctx) return;
     if (ctx->graph_exec) hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->beam_graph) hipGraphExecDestroy(ctx->beam_graph);
+    if (ctx->sh_graph) hipGraphExecDestroy(ctx->sh_graph);
     if (ctx->prof_ev) {
         for (int i = 0; i < ctx->prof_cap; ++i) {
             hipEventDestroy(ctx->prof_ev[i].a);
@@ -206,6 +207,10 @@ extern "C" int irs_finalize_weights(irs_ctx *ctx, void *arena, size_t bytes, voi
     if ((rc = irs_launch_pack_small(ctx, s))) return rc;
     ctx->finalized = true;
     ctx->proj_stale = false;
+    if (ctx->sh_graph) {
+        hipGraphExecDestroy(ctx->sh_graph);
+        ctx->sh_graph = nullptr;
+    }
     if (ctx->graph_exec) {
         hipGraphExecDestroy(ctx->graph_exec);
         ctx->graph_exec = nullptr;
@@ -220,7 +225,7 @@ extern "C" int irs_finalize_weights(irs_ctx *ctx, void *arena, size_t bytes, voi
 // ------------------------------------------------------------------ workspace
 struct ws_plan {
     size_t x, y, xf, yf, qkv, qkv_b1, ao, h, ru, xb, eps, thr, gm, cnt, cand, lse, ref, xrows, tval, tids, status, step, pos;
-    size_t bseq[2], bhep[2], bcum[2], bpaths[2], buser, lmax, lsum, tokrow, scnt, soff, sqrow, spadq, mdev, total;
+    size_t bseq[2], bhep[2], bcum[2], bpaths[2], buser, lmax, lsum, tokrow, scnt, soff, sqrow, spadq, mdev, xlocal, ksend, krecv, gmax, total;
 };
 
 static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
@@ -272,6 +277,10 @@ static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
     p->sqrow = take((size_t)ctx->max_seqs * 4);
     p->spadq = take((size_t)ctx->max_seqs * 4);
     p->mdev = take(256);
+    p->xlocal = take((size_t)ctx->max_seqs * D.d * 4);
+    p->ksend = take((size_t)ctx->max_rows * D.max_k * 8); // exchange buffers of the item-sharded loops (comm.hip)
+    p->krecv = take((size_t)ctx->max_rows * D.max_k * 8);
+    p->gmax = take((size_t)ctx->max_rows * 4);
     p->total = off;
 }
 
@@ -330,6 +339,14 @@ extern "C" int irs_bind_workspace(irs_ctx *ctx, void *ws, size_t bytes) {
     ctx->seq_qrow = (int32_t *)(b + p.sqrow);
     ctx->seq_padq = (int32_t *)(b + p.spadq);
     ctx->m_dev = (int32_t *)(b + p.mdev);
+    ctx->x_local = (float *)(b + p.xlocal);
+    ctx->keys_send = (uint64_t *)(b + p.ksend);
+    ctx->keys_recv = (uint64_t *)(b + p.krecv);
+    ctx->lse_gmax = (float *)(b + p.gmax);
+    if (ctx->sh_graph) {
+        hipGraphExecDestroy(ctx->sh_graph);
+        ctx->sh_graph = nullptr;
+    }
     if (ctx->beam_graph) {
         hipGraphExecDestroy(ctx->beam_graph);
         ctx->beam_graph = nullptr;

@@ -90,6 +90,14 @@ struct irs_ctx {
     float *bm_paths[2];  // [max_seqs][IRS_MAX_PATH]
     int64_t *bm_user;    // [max_seqs]
     float *lse_max, *lse_sum; // [max_rows]
+    // item-sharded loops (comm.hip)
+    float *x_local;           // [max_seqs][d] this rank's decoded rows (the all-gather's send buffer)
+    uint64_t *keys_send, *keys_recv; // [max_rows][max_k] packed per-shard lists
+    float *lse_gmax;          // [max_rows] all-reduced row maxima
+    hipGraphExec_t sh_graph;  // captured sharded step (greedy: one step; beam: two)
+    int sh_kind, sh_B, sh_W, sh_P, sh_k, sh_sweep, sh_sample, sh_sample_k, sh_nograph;
+    uint64_t sh_seed;
+    void *sh_comm, *sh_ptr[5];
     hipGraphExec_t beam_graph;
     int beam_B, beam_W, beam_k, beam_sweep, beam_P;
     void *beam_status; // the status buffer baked into the captured beam steps

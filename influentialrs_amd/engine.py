@@ -366,6 +366,74 @@ class Engine:
                                              int(use_graph), _ptr(paths), _ptr(scores), _ptr(fin), _ptr(status))
         return (paths, scores, status, fin) if want_windows else (paths, scores, status)
 
+    # ------------------------------------------------------------------ item-sharded loops below the ABI (comm.hip)
+    def allgather_rows(self, comm: "Comm", rows_local: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        rows_local = self._dev(rows_local, torch.float32)
+        B = rows_local.shape[0]
+        if out is None:
+            out = torch.empty((comm.world * B, self.d), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.irs_allgather_rows(self.h, comm.h, _ptr(rows_local), B, _ptr(out), self._stream()))
+        return out
+
+    def exchange_topk(self, comm: "Comm", keys_send: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[world, B, k] packed lists of all rows (this shard) -> [world, B, k] the world's lists of this rank's rows."""
+        keys_send = self._dev(keys_send, torch.int64)
+        W, B, k = keys_send.shape
+        if W != comm.world:
+            raise IrsError("exchange_topk: keys must be [world, B, k]")
+        if out is None:
+            out = torch.empty_like(keys_send)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.irs_exchange_topk(self.h, comm.h, _ptr(keys_send), _ptr(out), B, k, self._stream()))
+        return out
+
+    def generate_paths_sharded(self, comm: "Comm", seqs: torch.Tensor, users: Optional[torch.Tensor], hep: torch.Tensor,
+                               max_path_len: int, k: int = 100, sweep: int = IRS_SWEEP_BF16, sample=False, sample_k=3, seed=0,
+                               use_graph: bool = False, paths: Optional[torch.Tensor] = None,
+                               status: Optional[torch.Tensor] = None):
+        """generate_paths over the item-sharded catalog: this rank's B users; every rank calls it together."""
+        seqs = self._inplace(seqs, torch.int64, "generate_paths_sharded: seqs")
+        hep = self._inplace(hep, torch.int32, "generate_paths_sharded: hep")
+        if users is not None:
+            users = self._dev(users, torch.int64)
+        B = seqs.shape[0]
+        if seqs.shape[1] != self.L or hep.shape[0] != B or (users is not None and users.shape[0] != B):
+            raise IrsError("generate_paths_sharded: inconsistent shapes")
+        if paths is None:
+            paths = torch.zeros((B, max_path_len), dtype=torch.float32, device=self.device)
+        if status is None:
+            status = torch.zeros(B, dtype=torch.int32, device=self.device)
+        paths = self._inplace(paths, torch.float32, "generate_paths_sharded: paths")
+        status = self._inplace(status, torch.int32, "generate_paths_sharded: status")
+        if paths.shape != (B, max_path_len):
+            raise IrsError("generate_paths_sharded: paths must be [B, max_path_len]")
+        with torch.cuda.device(self.device):
+            self._check(self.lib.irs_generate_paths_sharded(self.h, comm.h, _ptr(seqs), _ptr(users), _ptr(hep), B, max_path_len, k,
+                                                            sweep, int(sample), sample_k, seed, int(use_graph), _ptr(paths),
+                                                            _ptr(status), self._stream()))
+        return paths, status
+
+    def beam_search_sharded(self, comm: "Comm", seqs: torch.Tensor, users: Optional[torch.Tensor], hep: torch.Tensor,
+                            max_path_len: int, beam: int, k: int = 100, sweep: int = IRS_SWEEP_BF16, split_decode: bool = False,
+                            use_graph: bool = False, want_windows: bool = False):
+        """beam_search over the item-sharded catalog.  split_decode=False: this rank's own B users; True: the SAME users on
+        every rank, their B * beam windows decoded 1/world each (one user's beams spread over the node)."""
+        seqs = self._dev(seqs, torch.int64)
+        hep = self._dev(hep, torch.int32)
+        if users is not None:
+            users = self._dev(users, torch.int64)
+        B = seqs.shape[0]
+        paths = torch.zeros((B, beam, max_path_len), dtype=torch.float32, device=self.device)
+        scores = torch.zeros((B, beam), dtype=torch.float64, device=self.device)
+        status = torch.zeros(B, dtype=torch.int32, device=self.device)
+        fin = torch.empty((B, beam, self.L), dtype=torch.int64, device=self.device) if want_windows else None
+        with torch.cuda.device(self.device):
+            self._check(self.lib.irs_beam_search_sharded(self.h, comm.h, _ptr(seqs), _ptr(users), _ptr(hep), B, beam, max_path_len, k,
+                                                         sweep, int(split_decode), int(use_graph), _ptr(paths), _ptr(scores),
+                                                         _ptr(fin), _ptr(status), self._stream()))
+        return (paths, scores, status, fin) if want_windows else (paths, scores, status)
+
     # ------------------------------------------------------------------ measurement
     def prof_enable(self, family: int):
         with torch.cuda.device(self.device):
@@ -377,3 +445,113 @@ class Engine:
         with torch.cuda.device(self.device):
             self._check(self.lib.irs_prof_read(self.h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
         return n.value, ms.value, fl.value, by.value
+
+
+class Comm:
+    """irs_comm handle (include/irs_hip.h, multi-GPU section): the collectives of the item-sharded loops, enqueued on the
+    engine's stream BELOW the C ABI.  With torch.distributed's "nccl" backend it is an RCCL communicator of its own
+    (ncclCommInitRank over a unique id that rank 0 draws and the process group broadcasts); with "gloo" (the CPU
+    rehearsal backend: several ranks, possibly on ONE GPU) the library calls back into gloo through the host.  world == 1
+    without a process group gives a one-rank RCCL communicator (the single-GPU anchor runs the same code path)."""
+
+    def __init__(self, device: torch.device, group=None, backend: Optional[str] = None):
+        import torch.distributed as dist
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.group = group
+        inited = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if inited else 1
+        self.rank = dist.get_rank(group) if inited else 0
+        if backend is None:
+            backend = dist.get_backend(group) if inited else "nccl"
+        self.backend = backend
+        h = ctypes.c_void_p()
+        if backend == "nccl":
+            buf = ctypes.create_string_buffer(_lib.IRS_COMM_ID_BYTES)
+            if self.rank == 0:
+                if self.lib.irs_comm_unique_id(buf) != 0:
+                    raise IrsError(f"irs_comm_unique_id: {self.lib.irs_comm_last_error().decode()}")
+            if self.world > 1:
+                box = [bytes(buf.raw)]
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                buf = ctypes.create_string_buffer(box[0], _lib.IRS_COMM_ID_BYTES)
+            with torch.cuda.device(self.device):
+                rc = self.lib.irs_comm_init_rccl(ctypes.byref(h), buf, self.rank, self.world)
+            if rc != 0:
+                raise IrsError(f"irs_comm_init_rccl: {self.lib.irs_comm_last_error().decode()}")
+        else:
+            self._make_callbacks()
+            rc = self.lib.irs_comm_init_callbacks(ctypes.byref(h), self.rank, self.world, None,
+                                                  ctypes.cast(self._cb[0], ctypes.c_void_p), ctypes.cast(self._cb[1], ctypes.c_void_p),
+                                                  ctypes.cast(self._cb[2], ctypes.c_void_p))
+            if rc != 0:
+                raise IrsError(f"irs_comm_init_callbacks: {self.lib.irs_comm_last_error().decode()}")
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.irs_comm_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    @property
+    def is_rccl(self) -> bool:
+        return bool(self.lib.irs_comm_is_rccl(self.h))
+
+    def _make_callbacks(self):
+        """gloo through the host: wait for the stream, stage the payload in host memory, run the collective, copy back.
+        (Not capturable, not fast: it exists so that the N > 1 code path runs where no second GPU does.)"""
+        import numpy as np
+        import torch.distributed as dist
+        hip = ctypes.CDLL("libamdhip64.so")  # the copy torch has already loaded
+        hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        D2H, H2D = 2, 1
+        world, group, dev = self.world, self.group, self.device
+
+        def fetch(ptr, n, stream):
+            with torch.cuda.device(dev):
+                if hip.hipStreamSynchronize(stream) != 0:
+                    raise RuntimeError("hipStreamSynchronize")
+                h = np.empty(n, dtype=np.uint8)
+                if hip.hipMemcpy(h.ctypes.data, ptr, n, D2H) != 0:
+                    raise RuntimeError("hipMemcpy D2H")
+            return torch.from_numpy(h)
+
+        def store(ptr, t):
+            with torch.cuda.device(dev):
+                if hip.hipMemcpy(ptr, t.data_ptr(), t.numel() * t.element_size(), H2D) != 0:
+                    raise RuntimeError("hipMemcpy H2D")
+
+        def allgather(user, send, recv, nbytes, stream):
+            try:
+                h = fetch(send, nbytes, stream)
+                out = torch.empty(world * nbytes, dtype=torch.uint8)
+                dist.all_gather_into_tensor(out, h, group=group)
+                store(recv, out)
+                return 0
+            except Exception:  # noqa: BLE001 -- reported through the C return code
+                return 1
+
+        def alltoall(user, send, recv, nbytes, stream):
+            try:
+                h = fetch(send, world * nbytes, stream)
+                out = torch.empty_like(h)
+                dist.all_to_all_single(out, h, group=group)
+                store(recv, out)
+                return 0
+            except Exception:  # noqa: BLE001
+                return 1
+
+        def allreduce(user, buf, count, op, stream):
+            try:
+                h = fetch(buf, 4 * count, stream).view(torch.float32)
+                dist.all_reduce(h, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM, group=group)
+                store(buf, h)
+                return 0
+            except Exception:  # noqa: BLE001
+                return 1
+
+        self._cb = (_lib.ALLGATHER_FN(allgather), _lib.ALLTOALL_FN(alltoall), _lib.ALLREDUCE_F32_FN(allreduce))  # kept alive

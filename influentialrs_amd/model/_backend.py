@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from .._lib import IRS_MASK_CAUSAL, IRS_MASK_IRN, IRS_SWEEP_BF16
 from ..dist import ShardGroup
-from ..engine import Engine, IrsError
+from ..engine import Comm, Engine, IrsError
 
 
 class HipBackend:
@@ -25,6 +25,7 @@ class HipBackend:
         self.sweep = IRS_SWEEP_BF16
         self.rank, self.world = 0, 1
         self._stale = False  # a training entry point ran since the derived weights were built
+        self.comm: Optional[Comm] = None  # collectives below the C ABI (item-sharded search loops)
 
     def __deepcopy__(self, memo):
         """copy.deepcopy(net): the copy gets its own backend and builds its own engine on first use (an engine is a
@@ -34,7 +35,7 @@ class HipBackend:
         memo[id(self)] = new
         new.net = copy.deepcopy(self.net, memo)
         new.mask_mode, new.sweep = self.mask_mode, self.sweep
-        new.engine, new._fp, new.group, new._stale = None, None, None, False
+        new.engine, new._fp, new.group, new._stale, new.comm = None, None, None, False, None
         new.rank, new.world = self.rank, self.world
         return new
 
@@ -81,6 +82,8 @@ class HipBackend:
                 max_seqs=max(n_seqs, prev_s, 8), max_k=100, rank=self.rank, world=self.world)
             self._fp = None
             self.group = ShardGroup(self.engine) if self.world > 1 else None
+            if self.world > 1 and (self.comm is None or self.comm.device != dev):
+                self.comm = Comm(dev)  # RCCL under torch.distributed's nccl backend, gloo callbacks otherwise
         fp = self._fingerprint()
         if for_training and self._fp is not None and [a for a, _ in fp] == [a for a, _ in self._fp]:
             # same storage: the CE entry points read project.* in place, nothing derived is used -- but whatever the

@@ -244,34 +244,11 @@ class IRSNN(nn.Module):
         if hip.world == 1:
             eng = hip.get(B * W, B * W)
             paths, scores, status = eng.beam_search(seqs.contiguous(), users, hep, max_path_len, W, k=100, sweep=hip.sweep)
-        else:
+        else:  # item-sharded: the whole loop runs below the C ABI (irs_beam_search_sharded: row all-gather, packed top-100
+            # all-to-all, log-sum-exp all-reduce per step, one stream-ordered sequence; captured into a hipGraph over RCCL)
             eng = hip.get(B * W, B * W * hip.world)
-            g = hip.group
-
-            def mk():
-                return (torch.empty((B, W, L), dtype=torch.int64, device=dev), torch.empty((B, W), dtype=torch.int32, device=dev),
-                        torch.empty((B, W), dtype=torch.float64, device=dev),
-                        torch.zeros((B, W, max_path_len), dtype=torch.float32, device=dev))
-            st = [mk(), mk()]
-            st[0][0].copy_(seqs.unsqueeze(1).expand(B, W, L))
-            st[0][1].copy_(hep.unsqueeze(1).expand(B, W))
-            st[0][2].fill_(float("-inf"))
-            st[0][2][:, 0] = 0.0
-            urep = users.repeat_interleave(W).contiguous()
-            status = torch.zeros(B, dtype=torch.int32, device=dev)
-            sl = g.my_slice(B * W)
-            for i in range(max_path_len):
-                cur, nxt = st[i & 1], st[(i & 1) ^ 1]
-                _, xr, _ = eng.decode(cur[0].view(B * W, L), urep, want_x=False, pos=cur[1].view(-1))
-                allrows = g.gather_rows(xr)
-                lse = None
-                if W > 1:  # candidates and the log-softmax normaliser out of one sweep of the shard
-                    val, ids, _, m, sm = g.topk_own_lse(allrows, 100, hip.sweep)
-                    lse = (m[sl].contiguous(), sm[sl].contiguous())
-                else:
-                    val, ids, _ = g.topk_own(allrows, 100, hip.sweep)
-                eng.beam_step(cur, val, ids, lse, i, nxt, status)
-            paths, scores = st[max_path_len & 1][3], st[max_path_len & 1][2]
+            paths, scores, status = eng.beam_search_sharded(hip.comm, seqs.contiguous(), users, hep, max_path_len, W, k=100,
+                                                            sweep=hip.sweep, split_decode=False, use_graph=hip.comm.is_rccl)
         self.last_beams = (paths.detach().cpu().numpy(), scores.detach().cpu().numpy())
         return paths[:, 0].contiguous(), status
 
@@ -295,16 +272,11 @@ class IRSNN(nn.Module):
             eng = hip.get(B, B)
             paths_t, status = eng.generate_paths(work, users, hep, max_path_len, k=100, sweep=hip.sweep,
                                                  sample=sample, sample_k=sample_k, seed=seed, use_graph=False)
-        else:
+        else:  # item-sharded: irs_generate_paths_sharded (decode, row all-gather, shard sweep, key all-to-all, merge, path
+            # step per search step, below the C ABI on one stream)
             eng = hip.get(B, B * hip.world)
-            paths_t = torch.zeros((B, max_path_len), dtype=torch.float32, device=dev)
-            status = torch.zeros(B, dtype=torch.int32, device=dev)
-            sl = hip.group.my_slice(B)
-            for i in range(max_path_len):
-                _, xr, _ = eng.decode(work, users, want_x=False, pos=hep)
-                allrows = hip.group.gather_rows(xr)
-                val, ids, _ = hip.group.topk_own(allrows, 100, hip.sweep)
-                eng.path_step(work, hep, val, ids, i, paths_t, status, sample, sample_k, seed)
+            paths_t, status = eng.generate_paths_sharded(hip.comm, work, users, hep, max_path_len, k=100, sweep=hip.sweep,
+                                                         sample=sample, sample_k=sample_k, seed=seed, use_graph=False)
         if int((status & IRS_ROW_NO_CANDIDATE).sum().item()) > 0:
             raise IndexError("index 0 is out of bounds: every top-100 candidate is already in the window "
                              "(same condition as reference influentialRS.py:429)")

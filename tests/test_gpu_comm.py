@@ -1,0 +1,82 @@
+"""-m gpu: the communicator and the item-sharded search loops below the C ABI (include/irs_hip.h, multi-GPU section)
+on the production transport -- RCCL, loaded with dlopen -- with a ONE-rank communicator: what a single-GPU box can
+run of that path (library load and symbol resolution, ncclCommInitRank, the collectives on the engine's stream, the
+captured step with the collectives inside).  The N > 1 behaviour of the same entry points runs over gloo callbacks in
+tests/test_gpu_multirank.py (two ranks on one GPU) and over RCCL wherever two devices exist."""
+import numpy as np
+import pytest
+import torch
+
+from influentialrs_amd import synth
+from influentialrs_amd._lib import IRS_SWEEP_BF16
+from influentialrs_amd.engine import Comm, IrsError
+from gpu_util import make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def comm():
+    return Comm(torch.device("cuda:0"), backend="nccl")  # no process group: one rank
+
+
+def _windows(cfg, n, seed):
+    g = np.random.default_rng(seed)
+    L = cfg.max_len
+    seqs = np.zeros((n, L), dtype=np.int64)
+    for i in range(n):
+        h = int(g.integers(3, L - 1))
+        seqs[i, L - 1 - h:] = g.integers(1, cfg.n_item + 1, size=h + 1)
+    return torch.from_numpy(seqs).cuda(), torch.from_numpy(g.integers(0, cfg.n_user, size=n)).cuda()
+
+
+def test_rccl_one_rank_collectives(comm):
+    assert comm.is_rccl and comm.world == 1
+    cfg = synth.make_config("tiny")
+    eng = make_engine(cfg, synth.irn_state_dict(cfg, 1234), max_rows=16, max_seqs=16)
+    x = torch.randn((7, cfg.emb_dim), device="cuda")
+    assert torch.equal(eng.allgather_rows(comm, x), x)
+    k = torch.randint(0, 2 ** 62, (1, 7, 9), device="cuda", dtype=torch.int64)
+    assert torch.equal(eng.exchange_topk(comm, k), k)
+
+
+@pytest.mark.parametrize("cfgname", ["tiny", "c1"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_sharded_greedy_equals_single_device_loop(comm, cfgname, use_graph):
+    """irs_generate_paths_sharded on a one-shard 'world' = irs_generate_paths id for id (the same kernels around two
+    RCCL calls per step); with use_graph the step, collectives included, is captured and replayed."""
+    cfg = synth.make_config(cfgname)
+    eng = make_engine(cfg, synth.irn_state_dict(cfg, 1234), max_rows=16, max_seqs=16)
+    seqs, users = _windows(cfg, 9, 5)
+    hep = torch.full((9,), cfg.max_len - 2, dtype=torch.int32, device="cuda")
+    for rep in range(2):  # the second call reuses the captured graph
+        p1, s1 = eng.generate_paths(seqs.clone(), users, hep.clone(), 6, k=100, sweep=IRS_SWEEP_BF16)
+        p2, s2 = eng.generate_paths_sharded(comm, seqs.clone(), users, hep.clone(), 6, k=100, sweep=IRS_SWEEP_BF16, use_graph=use_graph)
+        torch.cuda.synchronize()
+        assert torch.equal(p1, p2) and torch.equal(s1, s2)
+
+
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_sharded_beam_equals_single_device_loop(comm, split, use_graph):
+    cfg = synth.make_config("tiny")
+    eng = make_engine(cfg, synth.irn_state_dict(cfg, 1234), max_rows=32, max_seqs=32)
+    seqs, users = _windows(cfg, 3, 8)
+    hep = torch.full((3,), cfg.max_len - 2, dtype=torch.int32, device="cuda")
+    p1, c1, s1 = eng.beam_search(seqs, users, hep, 5, 4, k=100)
+    for rep in range(2):
+        p2, c2, s2 = eng.beam_search_sharded(comm, seqs, users, hep, 5, 4, k=100, split_decode=split, use_graph=use_graph)
+        torch.cuda.synchronize()
+        assert torch.equal(p1, p2) and torch.equal(c1, c2) and torch.equal(s1, s2)
+
+
+def test_sharded_entry_points_validate(comm):
+    cfg = synth.make_config("tiny")
+    eng = make_engine(cfg, synth.irn_state_dict(cfg, 1234), max_rows=8, max_seqs=8)
+    seqs, users = _windows(cfg, 9, 5)
+    hep = torch.full((9,), cfg.max_len - 2, dtype=torch.int32, device="cuda")
+    with pytest.raises(IrsError):  # B > max_seqs
+        eng.generate_paths_sharded(comm, seqs.clone(), users, hep.clone(), 3)
+    shard = make_engine(cfg, synth.irn_state_dict(cfg, 1234), max_rows=32, max_seqs=8, rank=0, world=2)
+    with pytest.raises(IrsError, match="communicator is rank"):  # a one-rank communicator on a two-shard context
+        shard.generate_paths_sharded(comm, seqs[:4].clone(), users[:4], hep[:4].clone(), 3)

@@ -73,6 +73,37 @@ def _worker(rank, world, port, ret, backend="gloo", own_gpu=False):
             n_safe = Wb if gaps.min() > 1e-4 else int(np.argmax(gaps <= 1e-4)) + 1
             assert np.array_equal(sp[b_, :n_safe], fp[b_, :n_safe]), (b_, sp[b_], fp[b_])
         assert np.array_equal(pb, sp[:, 0])
+        # ---- the same search with ONE set of users on every rank and their beam windows' decode split over the ranks
+        #      (irs_beam_search_sharded, split_decode: BASELINE configs[4]'s "one user's beams spread over the node"):
+        #      every rank ends with the same beams, equal to the single-device search
+        eng = net._hip.get(nb * 4, nb * 4 * world)
+        comm = net._hip.comm
+        assert comm is not None and comm.world == world and comm.is_rccl == (backend == "nccl")
+        hep4 = torch.full((nb,), cfg.max_len - 2, dtype=torch.int32, device=dev)
+        seq_all = torch.from_numpy(g["seqs"][:nb]).to(dev)  # rank 0's first users, on BOTH ranks
+        u_all = torch.from_numpy(g["users"][:nb]).to(dev)
+        with torch.no_grad():
+            p_s, s_s, st_s = eng.beam_search_sharded(comm, seq_all, u_all, hep4, Pb, 4, k=100, split_decode=True)
+            e1 = full._hip.get(nb * 4, nb * 4)
+            p_1, s_1, st_1 = e1.beam_search(seq_all, u_all, hep4, Pb, 4, k=100)
+        torch.cuda.synchronize()
+        assert np.allclose(s_s.cpu().numpy(), s_1.cpu().numpy(), rtol=0, atol=2e-4)
+        for b_ in range(nb):
+            f1 = s_1[b_].cpu().numpy()
+            gaps = np.abs(np.diff(f1))
+            n_safe = 4 if gaps.min() > 1e-4 else int(np.argmax(gaps <= 1e-4)) + 1
+            assert np.array_equal(p_s[b_, :n_safe].cpu().numpy(), p_1[b_, :n_safe].cpu().numpy()), (b_, rank)
+        # ---- the two exchange steps on their own (irs_allgather_rows / irs_exchange_topk) against torch.distributed
+        xl = torch.randn((5, cfg.emb_dim), device=dev) + rank
+        xa = eng.allgather_rows(comm, xl)
+        ref = [torch.empty_like(xl).cpu() for _ in range(world)]
+        dist.all_gather(ref, xl.cpu())
+        assert torch.equal(xa.cpu(), torch.cat(ref))
+        ks = torch.randint(0, 2 ** 62, (world, 5, 7), device=dev, dtype=torch.int64) + rank
+        kr = eng.exchange_topk(comm, ks)
+        ref = torch.empty_like(ks).cpu()
+        dist.all_to_all_single(ref.view(-1), ks.cpu().view(-1))
+        assert torch.equal(kr.cpu(), ref)
         # ---- evaluator handlers with an item-sharded SampleNet: every rank feeds the SAME batch, the shards'
         #      counts / maxima / exp-sums / label scores are all-reduced; results equal the reference goldens
         from influentialrs_amd.model.evaluator import Evaluator

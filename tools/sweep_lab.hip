@@ -98,6 +98,65 @@ static void check_pre(irs_ctx *ctx, SweepArgs a, int nt, int stride, int tpw, hi
     }
 }
 
+// 16x16x32 ring instantiations with explicit parameters
+template <int KS, int RT16, int NW, int NSLOT, int MODE>
+static void launch_ring16_lab(SweepArgs a, int nt, int rounds_x10, hipStream_t s) {
+    a.n_ublocks = (a.UT + NW * (RT16 / 2) - 1) / (NW * (RT16 / 2));
+    const size_t lds = ring16_lds_bytes(KS, RT16, NW, NSLOT);
+    auto kern = k_sweep_ring16<KS, RT16, NW, NSLOT, MODE>;
+    static int slots = 0;
+    if (!slots) {
+        if (lds > 65536) CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        slots = resident_workgroups(kern, NW * 64, lds);
+        printf("   [%d resident workgroups]\n", slots);
+    }
+    int strips = (int)((long long)rounds_x10 * slots / 10 / a.n_ublocks) & ~7;
+    if (strips < 8) strips = 8;
+    a.tile_begin = 0, a.tile_end = nt, a.tile_stride = 1;
+    if (MODE == MODE_PRE) {
+        a.tiles_per_wg = 0;
+        a.tiles_per_wave = ((nt + strips - 1) / strips + 3) / 4;
+        a.n_strips = (nt + 4 * a.tiles_per_wave - 1) / (4 * a.tiles_per_wave);
+        if (8 * a.n_strips > IRS_MAX_GROUPS) {
+            printf("   (PRE variant skipped: %d groups > %d)\n", 8 * a.n_strips, IRS_MAX_GROUPS);
+            return;
+        }
+        a.n_groups = 8 * a.n_strips;
+    } else {
+        a.tiles_per_wg = (nt + strips - 1) / strips;
+        a.n_strips = (nt + a.tiles_per_wg - 1) / a.tiles_per_wg;
+    }
+    dim3 grid(((a.n_strips + 7) / 8) * 8 * a.n_ublocks);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
+}
+
+// in-kernel stamps of the 16x16x32 ring (DBG = 1 build): where a wave's cycles go
+template <int KS, int RT16, int NW, int NSLOT>
+static void stamps_ring16(irs_ctx *ctx, SweepArgs a, int nt, hipStream_t s) {
+    a.n_ublocks = (a.UT + NW * (RT16 / 2) - 1) / (NW * (RT16 / 2));
+    const size_t lds = ring16_lds_bytes(KS, RT16, NW, NSLOT);
+    auto kern = k_sweep_ring16<KS, RT16, NW, NSLOT, MODE_EMIT, 1>;
+    if (lds > 65536) CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int slots = resident_workgroups(kern, NW * 64, lds);
+    a.tile_begin = 0, a.tile_end = nt;
+    ring_emit_grid(a, slots);
+    const unsigned grid = ((a.n_strips + 7) / 8) * 8 * a.n_ublocks;
+    CK(hipMemsetAsync(ctx->cand_cnt, 0, (size_t)a.M_pad * IRS_CAND_BUCKETS * 4, s));
+    CK(hipMemsetAsync(ctx->gm, 0, (size_t)grid * NW * 64, s));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, a);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h((size_t)grid * NW * 8);
+    CK(hipMemcpy(h.data(), ctx->gm, h.size() * 8, hipMemcpyDeviceToHost));
+    double tot = 0, tv = 0, tb = 0, th = 0, nh = 0, ns = 0, n = 0;
+    for (size_t i = 0; i < h.size(); i += 8) {
+        if (!h[i + 5]) continue;
+        tot += h[i], tv += h[i + 1], tb += h[i + 2], th += h[i + 3], nh += h[i + 4], ns += h[i + 5], n += 1;
+    }
+    printf("  stamps ring16<KS=%d,RT16=%d>: %0.f waves, %.1f steps each; per STEP: total %.0f cycles, DMA wait %.0f, barrier %.0f, "
+           "hit handling %.0f (%.2f handled sub-tiles with hits per step, %.0f cycles each incl. ~80 of stamps)\n",
+           KS, RT16, n, ns / n, tot / ns, tv / ns, tb / ns, th / ns, nh / ns, nh > 0 ? th / nh : 0.0);
+}
+
 static float median(std::vector<float> v) {
     std::sort(v.begin(), v.end());
     return v[v.size() / 2];
@@ -198,11 +257,11 @@ int main(int argc, char **argv) {
     {   // thresholds of the production pipeline per 128-row slice, against the previous kernels' (same sampled tiles)
         std::vector<float> t0(mp), t1(mp);
         CK(hipMemcpy(t0.data(), ctx->thr, mp * 4, hipMemcpyDeviceToHost));
-        ctx->sweep_variant = 1;
+        ctx->sweep_variant = 4;
         if (irs_launch_topk(ctx, x, M, k, IRS_SWEEP_BF16, val, ids, status, s)) { printf("topk: %s\n", ctx->err); return 1; }
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(t1.data(), ctx->thr, mp * 4, hipMemcpyDeviceToHost));
-        ctx->sweep_variant = 2;
+        ctx->sweep_variant = 1;
         std::vector<float> t2(mp);
         if (irs_launch_topk(ctx, x, M, k, IRS_SWEEP_BF16, val, ids, status, s)) { printf("topk: %s\n", ctx->err); return 1; }
         CK(hipDeviceSynchronize());
@@ -210,7 +269,7 @@ int main(int argc, char **argv) {
         ctx->sweep_variant = 0;
         int bad = 0, bad2 = 0;
         for (int i = 0; i < M; ++i) bad += t0[i] != t1[i], bad2 += t2[i] != t1[i];
-        printf("  thresholds differing from the previous kernels': %d of %d rows (without the stagger: %d)\n", bad, M, bad2);
+        printf("  thresholds differing from the 32x32x16 ring's: %d of %d rows (32x32x16 ring vs the round-1 kernels: %d)\n", bad, M, bad2);
         if (bad)
             for (int q = 0; q < M; q += 128) {
                 int b = 0;
@@ -255,11 +314,30 @@ int main(int argc, char **argv) {
         const int nub = (a.UT + UBh - 1) / UBh;
         SweepArgs e = a;
         sweep_decompose(e, 0, nt, nub, 0);
+        for (int rep = 0; rep < 3; ++rep) {
+            ctx->sweep_variant = 0;
+            time_it("production EMIT (ring, 16x16x32)", [&]() { SweepArgs e2 = e; launch_sweep_bf16<MODE_EMIT>(ctx, e2, s); }, true);
+            ctx->sweep_variant = 4;
+            time_it("round-2 EMIT (ring, 32x32x16)", [&]() { SweepArgs e2 = e; launch_sweep_bf16<MODE_EMIT>(ctx, e2, s); }, true);
+        }
         ctx->sweep_variant = 0;
-        time_it("production EMIT (ring)", [&]() { SweepArgs e2 = e; launch_sweep_bf16<MODE_EMIT>(ctx, e2, s); }, true);
-        ctx->sweep_variant = 1;
-        time_it("previous EMIT (rs / streaming)", [&]() { SweepArgs e2 = e; launch_sweep_bf16<MODE_EMIT>(ctx, e2, s); }, true);
-        ctx->sweep_variant = 0;
+    }
+    if (ctx->KS == 8) stamps_ring16<8, 8, 4, 4>(ctx, a, nt, s);
+    if (ctx->KS == 16) stamps_ring16<16, 4, 4, 4>(ctx, a, nt, s);
+#define RING16(KS_, RT16_, NW_, NSLOT_, MODE_, R10_, EM_)                                                              \
+    time_it((EM_) ? "ring16 RT16=" #RT16_ " NW=" #NW_ " slots=" #NSLOT_ " rounds/10=" #R10_ " EMIT"                   \
+                  : "ring16 RT16=" #RT16_ " NW=" #NW_ " slots=" #NSLOT_ " rounds/10=" #R10_ " PRE",                   \
+            [&]() { launch_ring16_lab<KS_, RT16_, NW_, NSLOT_, MODE_>(a, nt, R10_, s); }, EM_)
+    for (int rep = 0; rep < 2; ++rep) {
+        if (ctx->KS == 8) {
+            RING16(8, 8, 4, 4, MODE_EMIT, 40, true);
+            RING16(8, 4, 4, 4, MODE_EMIT, 40, true);
+            RING16(8, 8, 4, 4, MODE_PRE, 10, false);
+        } else if (ctx->KS == 16) {
+            RING16(16, 4, 4, 3, MODE_EMIT, 40, true);
+            RING16(16, 4, 4, 4, MODE_EMIT, 40, true);
+            RING16(16, 4, 4, 4, MODE_PRE, 10, false);
+        }
     }
 #define RING(KS_, RT_, TPS_, NW_, WPS_, NSLOT_, MODE_, R10_, EM_)                                                          \
     time_it((EM_) ? "ring RT=" #RT_ " TPS=" #TPS_ " NW=" #NW_ " wps=" #WPS_ " slots=" #NSLOT_ " rounds/10=" #R10_ " EMIT" \
@@ -267,21 +345,10 @@ int main(int argc, char **argv) {
             [&]() { launch_ring_lab<KS_, RT_, TPS_, NW_, WPS_, NSLOT_, MODE_>(a, nt, R10_, s); }, EM_)
     for (int rep = 0; rep < 2; ++rep) { // twice, interleaved: the box's clocks drift within a process
     if (ctx->KS == 8) {
-        RING(8, 4, 1, 4, 2, 4, MODE_EMIT, 30, true);
-        RING(8, 4, 1, 4, 2, 4, MODE_EMIT, 20, true);
         RING(8, 4, 1, 4, 2, 4, MODE_EMIT, 40, true);
-        RING(8, 2, 1, 4, 3, 4, MODE_EMIT, 30, true);
-        RING(8, 2, 1, 4, 3, 4, MODE_EMIT, 45, true);
-        RING(8, 2, 1, 4, 3, 5, MODE_EMIT, 30, true);
-        RING(8, 2, 2, 4, 2, 4, MODE_EMIT, 30, true);
         RING(8, 4, 1, 4, 2, 4, MODE_PRE, 10, false);
-        RING(8, 2, 1, 4, 3, 4, MODE_PRE, 10, false);
     } else if (ctx->KS == 16) {
-        RING(16, 2, 1, 4, 2, 4, MODE_EMIT, 30, true);
-        RING(16, 2, 1, 4, 2, 4, MODE_EMIT, 20, true);
         RING(16, 2, 1, 4, 2, 4, MODE_EMIT, 40, true);
-        RING(16, 2, 1, 4, 2, 3, MODE_EMIT, 30, true);
-        RING(16, 2, 1, 8, 2, 4, MODE_EMIT, 30, true);
         RING(16, 2, 1, 4, 2, 4, MODE_PRE, 10, false);
     }
     }
