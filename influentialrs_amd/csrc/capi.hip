@@ -225,7 +225,7 @@ extern "C" int irs_finalize_weights(irs_ctx *ctx, void *arena, size_t bytes, voi
 // ------------------------------------------------------------------ workspace
 struct ws_plan {
     size_t x, y, xf, yf, qkv, qkv_b1, ao, h, ru, xb, eps, thr, gm, cnt, cand, lse, ref, xrows, tval, tids, status, step, pos;
-    size_t bseq[2], bhep[2], bcum[2], bpaths[2], buser, lmax, lsum, tokrow, scnt, soff, sqrow, spadq, mdev, xlocal, ksend, krecv, gmax, total;
+    size_t bseq[2], bhep[2], bcum[2], bpaths[2], buser, lmax, lsum, tokrow, scnt, soff, sqrow, spadq, mdev, xlocal, ksend, krecv, gmax, fbcount, fblist, exhkeys, total;
 };
 
 static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
@@ -281,6 +281,9 @@ static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
     p->ksend = take((size_t)ctx->max_rows * D.max_k * 8); // exchange buffers of the item-sharded loops (comm.hip)
     p->krecv = take((size_t)ctx->max_rows * D.max_k * 8);
     p->gmax = take((size_t)ctx->max_rows * 4);
+    p->fbcount = take(256);
+    p->fblist = take((size_t)ctx->max_rows * 4);
+    p->exhkeys = ctx->n_local >= IRS_COOP_FALLBACK_MIN_ITEMS ? take((size_t)IRS_EXH_SCRATCH_KEYS * 8) : 0;
     p->total = off;
 }
 
@@ -343,6 +346,9 @@ extern "C" int irs_bind_workspace(irs_ctx *ctx, void *ws, size_t bytes) {
     ctx->keys_send = (uint64_t *)(b + p.ksend);
     ctx->keys_recv = (uint64_t *)(b + p.krecv);
     ctx->lse_gmax = (float *)(b + p.gmax);
+    ctx->fb_count = (unsigned int *)(b + p.fbcount);
+    ctx->fb_list = (int32_t *)(b + p.fblist);
+    ctx->exh_keys = ctx->n_local >= IRS_COOP_FALLBACK_MIN_ITEMS ? (unsigned long long *)(b + p.exhkeys) : nullptr;
     if (ctx->sh_graph) {
         hipGraphExecDestroy(ctx->sh_graph);
         ctx->sh_graph = nullptr;

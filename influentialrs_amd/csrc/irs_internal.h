@@ -16,6 +16,8 @@
 #define IRS_REFINE_CAP 1024 // candidates exactly re-scored per row
 #define IRS_MAX_GROUPS 2048 // pre-pass group maxima per row (upper bound: the pre-pass is decomposed to stay below it)
 #define IRS_MAX_PATH 64     // beam-search path length bound
+#define IRS_COOP_FALLBACK_MIN_ITEMS 262144 // shards from this size up redo flagged rows cooperatively (score.hip: k_exh_strips)
+#define IRS_EXH_SCRATCH_KEYS (64 * 32768)  // EXH_FB_MAX x EXH_KEYS_PER_ROW keys of scratch for it
 
 struct irs_layer_w {
     const float *sa_in_w, *sa_in_b, *sa_out_w, *sa_out_b;
@@ -74,6 +76,9 @@ struct irs_ctx {
     float *lse_part;    // [lse_slots][m_pad][2]
     int lse_slots;
     float *ref_tmp;     // [m_pad]
+    unsigned int *fb_count;        // [1] rows recorded for the cooperative exhaustive fallback
+    int32_t *fb_list;              // [max_rows]
+    unsigned long long *exh_keys;  // [EXH_FB_MAX][strips][k] per-strip lists (null on small shards)
     // path generation scratch
     float *xrows;       // [max_rows][d]
     float *top_val;     // [max_rows][max_k]

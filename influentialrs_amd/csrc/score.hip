@@ -1789,6 +1789,87 @@ __device__ void exhaustive_row(const float *__restrict__ x, int d, const float *
     if (tid == 0 && (int)n < k) status[row] |= IRS_ROW_FEWER_THAN_K;
 }
 
+// ---- cooperative exhaustive fallback (big shards).  A row k_refine cannot finish from its candidate lists (a bucket
+// overflowed, or the speculative threshold failed its check: thousands of items within the filter's error of the
+// row's k-th score -- near-duplicate catalogs) used to be redone by ONE workgroup walking the whole shard: 25 ms per
+// row at 10M x 256.  Now k_refine only records such a row; k_exh_strips spreads the exact scoring of the recorded rows
+// over EXH_STRIPS item strips (every workgroup keeps its strip's best k keys per row), k_exh_merge selects each row's
+// top k out of the strips' lists with the same streaming selection.  Bound: one pass over the float32 shard for ALL
+// flagged rows together (10 GB at 10M x 256: ~2 ms) instead of 25 ms per row.  Both launches return at once when no
+// row was recorded (~2 us each).  Rows beyond EXH_FB_MAX recorded rows are redone the old way by k_exh_merge.
+#define EXH_FB_MAX 64
+#define EXH_STRIPS 256
+#define EXH_KEYS_PER_ROW 32768 // strips x k <= this: the strip count shrinks for k > 128
+
+// streaming top-k of keys keyfn(j), j in [j0, j1), 0 = no key: leaves the best min(n, k) keys sorted descending in
+// buf[0 ..) and returns their number.  (exhaustive_row's loop, generalised over where the keys come from.)
+template <typename KeyFn>
+__device__ __forceinline__ unsigned int exh_select(KeyFn &&keyfn, int64_t j0, int64_t j1, int k, unsigned long long *buf) {
+    __shared__ unsigned int s_n;
+    __shared__ unsigned long long s_thr;
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if (tid == 0) {
+        s_n = 0;
+        s_thr = 0ull;
+    }
+    __syncthreads();
+    for (int64_t base = j0; base < j1; base += 256) {
+        const int64_t j = base + tid;
+        if (j < j1) {
+            const unsigned long long key = keyfn(j);
+            if (key > s_thr) {
+                const unsigned int slot = atomicAdd(&s_n, 1u);
+                buf[slot] = key;
+            }
+        }
+        __syncthreads();
+        if (s_n > EXH_BUF - 256) {
+            const unsigned int n = s_n;
+            for (int i = n + tid; i < EXH_BUF; i += 256) buf[i] = 0ull;
+            bitonic_desc(buf, EXH_BUF);
+            if (tid == 0) {
+                s_n = (n < (unsigned int)k) ? n : k;
+                if (n >= (unsigned int)k) s_thr = buf[k - 1];
+            }
+            __syncthreads();
+        }
+    }
+    const unsigned int n = s_n;
+    for (int i = n + tid; i < EXH_BUF; i += 256) buf[i] = 0ull;
+    bitonic_desc(buf, EXH_BUF);
+    __syncthreads();
+    return n < (unsigned int)k ? n : (unsigned int)k;
+}
+
+__global__ void __launch_bounds__(256) k_exh_strips(const float *__restrict__ x, int d, const float *__restrict__ W,
+                                                    const float *__restrict__ bias, int64_t n_local, int k, int n_strips,
+                                                    const unsigned int *__restrict__ fb_count, const int32_t *__restrict__ fb_list,
+                                                    unsigned long long *__restrict__ exh_keys) {
+    __shared__ unsigned long long buf[EXH_BUF];
+    __shared__ float xs[256];
+    unsigned int nfb = *fb_count;
+    if (nfb == 0u) return;
+    if (nfb > EXH_FB_MAX) nfb = EXH_FB_MAX;
+    const int strip = blockIdx.x;
+    const int64_t per = (n_local + n_strips - 1) / n_strips;
+    const int64_t j0 = (int64_t)strip * per, j1 = (j0 + per < n_local) ? j0 + per : n_local;
+    for (unsigned int fi = blockIdx.y; fi < nfb; fi += gridDim.y) {
+        const int row = fb_list[fi];
+        __syncthreads();
+        for (int i = threadIdx.x; i < d; i += 256) xs[i] = x[(size_t)row * d + i];
+        __syncthreads();
+        const unsigned int n = exh_select(
+            [&](int64_t j) -> unsigned long long {
+                const float e = irs_chain(xs, W + (size_t)j * d, bias[j], d);
+                return ((unsigned long long)irs_fkey(e) << 32) | (0xFFFFFFFFu - (unsigned int)j);
+            },
+            j0, j1, k, buf);
+        unsigned long long *o = exh_keys + ((size_t)fi * n_strips + strip) * k;
+        for (int i = threadIdx.x; i < k; i += 256) o[i] = i < (int)n ? buf[i] : 0ull;
+    }
+}
+
 // One workgroup per row: gather the row's bucketed candidates, validate the emission threshold,
 // refine, re-score exactly, sort, write top-k.
 __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int d, const float *__restrict__ W,
@@ -1796,7 +1877,8 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
                                                 const unsigned long long *__restrict__ cand,
                                                 const float *__restrict__ eps, const float *__restrict__ traw, int k,
                                                 int64_t item_lo, int64_t n_local, float *__restrict__ val,
-                                                int64_t *__restrict__ ids, int32_t *__restrict__ status) {
+                                                int64_t *__restrict__ ids, int32_t *__restrict__ status,
+                                                unsigned int *__restrict__ fb_count, int32_t *__restrict__ fb_list) {
     __shared__ __attribute__((aligned(16))) unsigned long long ckeys[IRS_CAND_CAP + 2];
     // the survivors are compacted into the candidates' own array (every thread holds its candidates in registers
     // across the barrier in between): up to IRS_CAND_CAP survivors fit, no second buffer, and a row with thousands
@@ -1841,8 +1923,12 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
         }
     }
     __syncthreads();
-    if (s_over) { // a bucket overflowed -> the row is redone exhaustively, here
+    if (s_over) { // a bucket overflowed -> the row is redone exhaustively: recorded for the cooperative kernels, or here
         if (tid == 0) status[row] |= IRS_ROW_FALLBACK;
+        if (fb_count) {
+            if (tid == 0) fb_list[atomicAdd(fb_count, 1u)] = row;
+            return;
+        }
         exhaustive_row(x, d, W, bias, n_local, item_lo, k, row, val, ids, status, ckeys, xs, true);
         return;
     }
@@ -1864,6 +1950,10 @@ __global__ void __launch_bounds__(256) k_refine(const float *__restrict__ x, int
         __syncthreads();
         if (s_above < (unsigned int)k) {
             if (tid == 0) status[row] |= IRS_ROW_FALLBACK;
+            if (fb_count) {
+                if (tid == 0) fb_list[atomicAdd(fb_count, 1u)] = row;
+                return;
+            }
             exhaustive_row(x, d, W, bias, n_local, item_lo, k, row, val, ids, status, ckeys, xs, false);
             return;
         }
@@ -2200,6 +2290,40 @@ __global__ void __launch_bounds__(256) k_exhaustive(const float *__restrict__ x,
     const int row = blockIdx.x;
     if (only_flagged && !(status[row] & IRS_ROW_FALLBACK)) return;
     exhaustive_row(x, d, W, bias, n_local, item_lo, k, row, val, ids, status, buf, xs, true);
+}
+
+// top k of every recorded row out of its strips' lists (k_exh_strips); recorded rows beyond EXH_FB_MAX are redone by
+// one workgroup each over the whole shard (exhaustive_row)
+__global__ void __launch_bounds__(256) k_exh_merge(const float *__restrict__ x, int d, const float *__restrict__ W,
+                                                   const float *__restrict__ bias, int64_t n_local, int64_t item_lo, int k,
+                                                   int n_strips, const unsigned int *__restrict__ fb_count,
+                                                   const int32_t *__restrict__ fb_list, const unsigned long long *__restrict__ exh_keys,
+                                                   float *__restrict__ val, int64_t *__restrict__ ids, int32_t *__restrict__ status) {
+    __shared__ unsigned long long buf[EXH_BUF];
+    __shared__ float xs[256];
+    const unsigned int nfb = *fb_count;
+    if (nfb == 0u) return;
+    for (unsigned int fi = blockIdx.x; fi < nfb; fi += gridDim.x) {
+        const int row = fb_list[fi];
+        if (fi >= EXH_FB_MAX) {
+            exhaustive_row(x, d, W, bias, n_local, item_lo, k, row, val, ids, status, buf, xs, true);
+            continue;
+        }
+        const unsigned long long *src = exh_keys + (size_t)fi * n_strips * k;
+        const unsigned int n = exh_select([&](int64_t j) -> unsigned long long { return src[j]; }, 0, (int64_t)n_strips * k, k, buf);
+        for (int i = threadIdx.x; i < k; i += 256) {
+            if (i < (int)n) {
+                const unsigned long long kk = buf[i];
+                val[(size_t)row * k + i] = irs_unkey((unsigned int)(kk >> 32));
+                ids[(size_t)row * k + i] = item_lo + (int64_t)(0xFFFFFFFFu - (unsigned int)kk);
+            } else {
+                val[(size_t)row * k + i] = -INFINITY;
+                ids[(size_t)row * k + i] = -1;
+            }
+        }
+        if (threadIdx.x == 0 && (int)n < k) status[row] |= IRS_ROW_FEWER_THAN_K;
+        __syncthreads();
+    }
 }
 
 // exact scores at chosen items; -inf outside the shard
@@ -2650,9 +2774,22 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
     }
 
     irs_prof_begin(ctx, IRS_PROF_REFINE, s);
+    // big shards: rows that need the exhaustive path are recorded by k_refine and redone cooperatively (see k_exh_strips);
+    // on small shards one workgroup walks the shard faster than two more launches cost
+    const bool coop = ctx->n_local >= IRS_COOP_FALLBACK_MIN_ITEMS && ctx->exh_keys != nullptr;
+    if (coop) IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->fb_count, 0, sizeof(unsigned int), s));
     hipLaunchKernelGGL(k_refine, dim3(M), dim3(256), 0, s, xrows, d, ctx->proj_w, ctx->proj_b, ctx->cand_cnt, ctx->cand,
-                       ctx->eps, ctx->ref_tmp, k, ctx->shard.item_lo, ctx->n_local, val, ids0, status);
-    irs_prof_end(ctx, IRS_PROF_REFINE, s, 0.0, 0.0); // (rows flagged IRS_ROW_FALLBACK were redone exhaustively inside k_refine)
+                       ctx->eps, ctx->ref_tmp, k, ctx->shard.item_lo, ctx->n_local, val, ids0, status,
+                       coop ? ctx->fb_count : nullptr, ctx->fb_list);
+    if (coop) {
+        int ns = EXH_STRIPS;
+        while (ns > 1 && (long long)ns * k > EXH_KEYS_PER_ROW) ns >>= 1;
+        hipLaunchKernelGGL(k_exh_strips, dim3(ns, 4), dim3(256), 0, s, xrows, d, ctx->proj_w, ctx->proj_b, ctx->n_local, k, ns,
+                           ctx->fb_count, ctx->fb_list, ctx->exh_keys);
+        hipLaunchKernelGGL(k_exh_merge, dim3(EXH_FB_MAX), dim3(256), 0, s, xrows, d, ctx->proj_w, ctx->proj_b, ctx->n_local,
+                           ctx->shard.item_lo, k, ns, ctx->fb_count, ctx->fb_list, ctx->exh_keys, val, ids0, status);
+    }
+    irs_prof_end(ctx, IRS_PROF_REFINE, s, 0.0, 0.0); // (rows flagged IRS_ROW_FALLBACK were redone exhaustively: inside k_refine or by the two kernels behind it)
     IRS_CHECK_HIP(ctx, hipGetLastError());
     if (lse_max && !fused_lse) return irs_launch_lse(ctx, xrows, M, lse_max, lse_sum, s);
     return IRS_OK;
