@@ -39,6 +39,10 @@ sys.path.insert(0, REPO)
 PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (exact f32) dense peak
 PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0           # HBM3E spec
+# Multi-rank legs: the sharded step runs below the C ABI either way; replaying it from a captured hipGraph (RCCL calls
+# inside) is covered by the one-rank RCCL tests but has never run on more than one device, so the first real multi-GPU
+# bench keeps to plain stream launches unless asked (a 12 ms C4 step gains nothing from it; C5's sub-millisecond steps would).
+SHARDED_GRAPH = os.environ.get("IRS_BENCH_SHARDED_GRAPH", "0") == "1"
 
 
 # ---------------------------------------------------------------------------------------------------- CPU baselines
@@ -310,9 +314,9 @@ class Job:
         else:
             # one search step below the C ABI (irs_generate_paths_sharded): decode -> row all-gather -> sweep of this rank's
             # item shard for all rows -> pack -> ONE all-to-all of 64-bit keys -> merge -> path step, one stream-ordered
-            # sequence over workspace buffers, replayed from a hipGraph when the communicator is RCCL
+            # sequence over workspace buffers (IRS_BENCH_SHARDED_GRAPH=1: replayed from a hipGraph over RCCL)
             eng.generate_paths_sharded(self.comm, self.seqs, self.users, self.hep, 1, k=self.k, sweep=self.sweep,
-                                       use_graph=self.comm.is_rccl, paths=self.paths, status=self.status)
+                                       use_graph=SHARDED_GRAPH and self.comm.is_rccl, paths=self.paths, status=self.status)
 
 
 def verify_job(job, n=4):
@@ -734,6 +738,8 @@ def main():
                                f"{world} item shards of {j4.eng.n_local} rows; beam windows decoded {32 // world} per rank)"),
                   "n_gpus": world}
             for label, graph in (("stream", False), ("hipgraph", True)):
+                if graph and world > 1 and not SHARDED_GRAPH:
+                    continue
                 ts = []
                 for it in range(12):
                     if world > 1:

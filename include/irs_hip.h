@@ -352,6 +352,10 @@ int irs_beam_search_sharded(irs_ctx *ctx, irs_comm *comm, const int64_t *dev_seq
                             int32_t split_decode, int32_t use_graph, float *dev_paths, double *dev_scores,
                             int64_t *dev_seq_final, int32_t *dev_status, void *stream);
 
+/* State of the sharded loops' step capture (tests / diagnostics): bit 0 = a captured step is held, bit 1 = capture was
+ * attempted and refused by the collective library (plain stream launches from then on). */
+int irs_sharded_graph_state(const irs_ctx *ctx);
+
 /* ---- measurement hooks (bench.py only) ---------------------------------
  * While enabled, every launch of the named kernel family is bracketed by HIP
  * events on the launch stream; irs_prof_read() synchronises those events and

@@ -77,6 +77,7 @@ SIGNATURES = {
                                              c_int32, c_int32, c_uint64, c_int32, c_void_p, c_void_p, c_void_p]),
     "irs_beam_search_sharded": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                           c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "irs_sharded_graph_state": (c_int32, [c_void_p]),
     "irs_prof_enable": (c_int32, [c_void_p, c_int32]),
     "irs_prof_read": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
 }

@@ -241,6 +241,10 @@ extern "C" int irs_exchange_topk(irs_ctx *ctx, irs_comm *comm, const uint64_t *k
     return comm_alltoall(ctx, comm, keys_send, keys_recv, (size_t)B * k * sizeof(uint64_t), (hipStream_t)stream);
 }
 
+extern "C" int irs_sharded_graph_state(const irs_ctx *ctx) {
+    return ctx ? ((ctx->sh_graph ? 1 : 0) | (ctx->sh_nograph ? 2 : 0)) : 0;
+}
+
 // ---- small kernels of the sharded loops
 // global (max, sum exp) of a row from the per-shard pairs: gm = all-reduced max (already in gmax); the local sum is
 // rescaled to it before the sum all-reduce.  A shard whose maximum is -inf (no items) contributes 0.

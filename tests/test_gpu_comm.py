@@ -54,6 +54,8 @@ def test_sharded_greedy_equals_single_device_loop(comm, cfgname, use_graph):
         p2, s2 = eng.generate_paths_sharded(comm, seqs.clone(), users, hep.clone(), 6, k=100, sweep=IRS_SWEEP_BF16, use_graph=use_graph)
         torch.cuda.synchronize()
         assert torch.equal(p1, p2) and torch.equal(s1, s2)
+    # the step -- RCCL calls included -- really was captured and replayed (bit 0), not silently run as plain launches (bit 1)
+    assert eng.lib.irs_sharded_graph_state(eng.h) == (1 if use_graph else 0)
 
 
 @pytest.mark.parametrize("split", [False, True])
