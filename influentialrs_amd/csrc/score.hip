@@ -487,6 +487,15 @@ template <int N>
 __device__ __forceinline__ void lds_wait(u32x4 &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
 template <int N>
 __device__ __forceinline__ void lds_wait(u32x4 &a, u32x4 &b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_read8(unsigned int addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait8(u32x2 &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
 
 // one candidate into the wave's LDS queue; the stores are inline asm for the same reason as the reads (a
 // compiler-visible LDS store behind an LDS-DMA issue gets an s_waitcnt vmcnt(0) in front)
@@ -1387,8 +1396,14 @@ __global__ void __launch_bounds__(256, 2) k_sweep_f32(SweepArgs a) {
 // bf16 pre-pass) -- a search that needs both the top-k and the log-sum-exp (beam search) then reads the float32
 // catalog once and the bf16 one not at all.  The scores here differ from the chain's by < eps[row] (a different
 // float32 summation order is within the accumulation term of eps), so k_refine's validity test holds unchanged.
-template <int KS, int UB, bool EMIT>
+// XREG (one row tile per workgroup, i.e. at most 32 rows -- a beam search's rows): the rows' fragments live in REGISTERS
+// (QN float4 per lane) and two fragment sets of W are in flight instead of three.  The LDS form's inner loop came out as
+// "ds_read_b128; s_waitcnt lgkmcnt(0); 4 MFMAs": with one wave per SIMD the LDS round trip (~120 cycles) stood in
+// front of every 256 cycles of matrix work (MFMA busy ~50 %), and the register file (506 of 512) had no room for a read
+// ahead -- every attempt spilled and put a vmcnt(0) in front of each read.
+template <int KS, int UB, bool EMIT, bool XREG = false>
 __global__ void __launch_bounds__(256, 1) k_lse_f32(SweepArgs a) {
+    static_assert(!XREG || UB == 1, "rows in registers: one row tile per workgroup");
     constexpr int QN = 2 * KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *xs4 = reinterpret_cast<float4 *>(smem); // [UB][QN][64]
@@ -1400,14 +1415,22 @@ __global__ void __launch_bounds__(256, 1) k_lse_f32(SweepArgs a) {
     const int ut0 = ublock * UB;
     const int ubc = min(UB, a.UT - ut0);
     EmitQ eq = emit_queue(smem + (size_t)UB * KS * 2048, wave);
-    for (int i = tid; i < ubc * QN * 64; i += 256) {
-        const int ln = i & 63, q = (i >> 6) % QN, u = (i >> 6) / QN;
-        const int row = (ut0 + u) * 32 + (ln & 31);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < a.M) v = *reinterpret_cast<const float4 *>(a.x32 + (size_t)row * a.d + 8 * q + 4 * (ln >> 5));
-        xs4[i] = v;
+    float4 xr4[XREG ? QN : 1];
+    if (XREG) {
+        const int row = ut0 * 32 + r;
+#pragma unroll
+        for (int q = 0; q < QN; ++q)
+            xr4[q] = row < a.M ? *reinterpret_cast<const float4 *>(a.x32 + (size_t)row * a.d + 8 * q + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        for (int i = tid; i < ubc * QN * 64; i += 256) {
+            const int ln = i & 63, q = (i >> 6) % QN, u = (i >> 6) / QN;
+            const int row = (ut0 + u) * 32 + (ln & 31);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < a.M) v = *reinterpret_cast<const float4 *>(a.x32 + (size_t)row * a.d + 8 * q + 4 * (ln >> 5));
+            xs4[i] = v;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const int gw = strip * 4 + wave;
     const int ts = a.tile_stride;
     const int t0 = a.tile_begin + gw * a.tiles_per_wave * ts;
@@ -1446,7 +1469,7 @@ __global__ void __launch_bounds__(256, 1) k_lse_f32(SweepArgs a) {
                     }
 #pragma unroll
                     for (int q = 0; q < QN; ++q) {
-                        const float4 bv = xs4[(u * QN + q) * 64 + lane];
+                        const float4 bv = XREG ? xr4[q] : xs4[(u * QN + q) * 64 + lane];
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].x, bv.x, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].y, bv.y, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].z, bv.z, acc, 0, 0, 0);
@@ -1465,18 +1488,30 @@ __global__ void __launch_bounds__(256, 1) k_lse_f32(SweepArgs a) {
             }
         };
         // three fragment sets: two tiles (64 KB per wave, 256 KB per CU) are in flight behind the one being multiplied
-        float4 fa[QN], fb[QN], fc[QN], ba[4], bb[4], bc2[4];
-        load(fa, ba, t0);
-        load(fb, bb, t0 + ts);
-        for (int t = t0; t < t1; t += 3 * ts) {
-            load(fc, bc2, t + 2 * ts);
-            compute(fa, ba, t);
-            if (t + ts >= t1) break;
-            load(fa, ba, t + 3 * ts);
-            compute(fb, bb, t + ts);
-            if (t + 2 * ts >= t1) break;
-            load(fb, bb, t + 4 * ts);
-            compute(fc, bc2, t + 2 * ts);
+        if constexpr (XREG) { // two sets: one tile (32 KB per wave, 128 KB per CU) in flight behind the one being multiplied
+            float4 fa[QN], fb[QN], ba[4], bb[4];
+            load(fa, ba, t0);
+            for (int t = t0; t < t1; t += 2 * ts) {
+                load(fb, bb, t + ts);
+                compute(fa, ba, t);
+                if (t + ts >= t1) break;
+                load(fa, ba, t + 2 * ts);
+                compute(fb, bb, t + ts);
+            }
+        } else {
+            float4 fa[QN], fb[QN], fc[QN], ba[4], bb[4], bc2[4];
+            load(fa, ba, t0);
+            load(fb, bb, t0 + ts);
+            for (int t = t0; t < t1; t += 3 * ts) {
+                load(fc, bc2, t + 2 * ts);
+                compute(fa, ba, t);
+                if (t + ts >= t1) break;
+                load(fa, ba, t + 3 * ts);
+                compute(fb, bb, t + ts);
+                if (t + 2 * ts >= t1) break;
+                load(fb, bb, t + 4 * ts);
+                compute(fc, bc2, t + 2 * ts);
+            }
         }
     }
     if (EMIT) emit_flush(a, eq, lane);
@@ -2623,25 +2658,29 @@ static bool lse_fast_ok(const irs_ctx *ctx, const SweepArgs &a) {
 
 template <bool EMIT>
 static int launch_lse_f32(irs_ctx *ctx, SweepArgs &a, hipStream_t s) {
-    const int KS = ctx->KS, UB = ub_f32(KS);
+    const int KS = ctx->KS;
+    // at most 32 rows at d_pad = 256: the rows' fragments in registers (k_lse_f32<.., XREG>): 2.5M x 256 x 32 rows 686 -> 644 us.
+    // (At d_pad = 128 the same form, with only 16 KB per wave in flight behind the tile being multiplied, was slower: 181 vs 151 us at 1M x 128.)
+    const bool xreg = a.UT == 1 && KS == 16;
+    const int UB = xreg ? 1 : ub_f32(KS);
     a.n_ublocks = (a.UT + UB - 1) / UB;
     dim3 grid(((a.n_strips + 7) / 8) * 8 * a.n_ublocks);
     const size_t lds = (size_t)UB * KS * 2048 + EMIT_Q_BYTES;
-#define L_(KS_, UB_)                                                                                                      \
+#define L_(KS_, UB_, XR_)                                                                                                 \
     do {                                                                                                                  \
         static bool attr = false;                                                                                         \
         if (!attr) {                                                                                                      \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lse_f32<KS_, UB_, EMIT>),                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lse_f32<KS_, UB_, EMIT, XR_>),                     \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             attr = true;                                                                                                  \
         }                                                                                                                 \
-        hipLaunchKernelGGL((k_lse_f32<KS_, UB_, EMIT>), grid, dim3(256), lds, s, a);                                      \
+        hipLaunchKernelGGL((k_lse_f32<KS_, UB_, EMIT, XR_>), grid, dim3(256), lds, s, a);                                 \
     } while (0)
     switch (KS) {
-    case 2: L_(2, 8); break;
-    case 4: L_(4, 8); break;
-    case 8: L_(8, 4); break;
-    case 16: L_(16, 2); break;
+    case 2: L_(2, 8, false); break;
+    case 4: L_(4, 8, false); break;
+    case 8: L_(8, 4, false); break;
+    case 16: if (xreg) L_(16, 1, true); else L_(16, 2, false); break;
     default: IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "unsupported d_pad %d", ctx->d_pad);
     }
 #undef L_
