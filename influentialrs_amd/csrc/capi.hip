@@ -68,6 +68,10 @@ extern "C" int irs_create(irs_ctx **out, const irs_dims *dims, const irs_shard *
     c->max_seqs = D.max_seqs > 0 ? D.max_seqs : D.max_rows;
     c->m_pad_max = (c->max_rows + 31) & ~31;
     c->lse_slots = 2048;
+    {   // decoder GEMMs of the throughput path: split-bf16 MFMAs (k_block_x6) or float32 MFMAs (k_block)
+        const char *e = getenv("IRS_DECODER_GEMM");
+        c->use_x6 = e ? (strcmp(e, "x6") == 0) : 0;
+    }
     *out = c;
     return IRS_OK;
 }
@@ -167,7 +171,7 @@ static int check_bound(irs_ctx *ctx) {
     return IRS_OK;
 }
 
-static size_t derived_plan(const irs_ctx *ctx, size_t *o_wp, size_t *o_bias, size_t *o_cl, size_t *o_wn, size_t *o_wf) {
+static size_t derived_plan(const irs_ctx *ctx, size_t *o_wp, size_t *o_bias, size_t *o_cl, size_t *o_wn, size_t *o_wf, size_t *o_x6 = nullptr) {
     size_t off = 0;
     *o_wp = off;
     off = align_up(off + (size_t)ctx->n_tiles * ctx->KS * 1024, 256);
@@ -179,6 +183,8 @@ static size_t derived_plan(const irs_ctx *ctx, size_t *o_wp, size_t *o_bias, siz
     off = align_up(off + 256, 256);
     *o_wf = off;
     off = align_up(off + irs_small_frag_floats(ctx) * sizeof(float), 256);
+    if (o_x6) *o_x6 = off;
+    off = align_up(off + irs_x6_bytes(ctx), 256);
     return off;
 }
 
@@ -191,8 +197,8 @@ extern "C" int irs_finalize_weights(irs_ctx *ctx, void *arena, size_t bytes, voi
     if (!ctx || !arena) return IRS_E_INVALID;
     int rc = check_bound(ctx);
     if (rc) return rc;
-    size_t o_wp, o_bias, o_cl, o_wn, o_wf;
-    size_t need = derived_plan(ctx, &o_wp, &o_bias, &o_cl, &o_wn, &o_wf);
+    size_t o_wp, o_bias, o_cl, o_wn, o_wf, o_x6;
+    size_t need = derived_plan(ctx, &o_wp, &o_bias, &o_cl, &o_wn, &o_wf, &o_x6);
     if (bytes < need) IRS_FAIL(ctx, IRS_E_INVALID, "derived arena too small: %zu < %zu", bytes, need);
     if (((uintptr_t)arena) & 255) IRS_FAIL(ctx, IRS_E_INVALID, "derived arena must be 256-byte aligned");
     char *base = (char *)arena;
@@ -201,10 +207,12 @@ extern "C" int irs_finalize_weights(irs_ctx *ctx, void *arena, size_t bytes, voi
     ctx->c_l = (float *)(base + o_cl);
     ctx->wnorm_max = (float *)(base + o_wn);
     ctx->w_frag16 = irs_small_frag_floats(ctx) ? (float *)(base + o_wf) : nullptr;
+    ctx->w_x6 = irs_x6_bytes(ctx) ? (uint4 *)(base + o_x6) : nullptr;
     hipStream_t s = (hipStream_t)stream;
     if ((rc = irs_launch_pack_w(ctx, s))) return rc;
     if ((rc = irs_launch_cross_const(ctx, s))) return rc;
     if ((rc = irs_launch_pack_small(ctx, s))) return rc;
+    if ((rc = irs_launch_pack_x6(ctx, s))) return rc;
     ctx->finalized = true;
     ctx->proj_stale = false;
     if (ctx->sh_graph) {

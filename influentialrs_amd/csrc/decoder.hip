@@ -1177,6 +1177,441 @@ __global__ void __launch_bounds__(256, 2) k_block(BlockArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ fused post-attention block on split-bf16 MFMAs
+// k_block<true, true> with every GEMM on v_mfma_f32_32x32x16_bf16: a float32 value is the exact sum of three bf16
+// values (hi + mid + lo: 8 + 8 + 8 significant bits), so the six products hh, hm, mh, hl, lh, mm reproduce a float32
+// product to ~2^-24 relative (the three dropped ones are below 2^-32) at 6/16 of the fp32-MFMA cost.  Round 2 tried
+// this on k_linear's tile and pipeline and found it no faster (a 16-k slab is 768 MFMA cycles: one slab of register
+// prefetch and a barrier per slab no longer cover the load latency) -- this kernel is built around it instead:
+//   * the weights are split ONCE at finalisation (k_pack_x6) into the exact A-fragment order the kernel consumes, one
+//     24 KiB block per pipeline step (4 output tiles x 2 k-steps of 16 x 3 planes x 1 KiB), so a step's weights are 24
+//     contiguous KiB pieces that go HBM/L2 -> LDS by LDS-DMA (no VGPR staging, no ds_write) into a ring of 3 slots
+//     with ONE raw s_barrier per step placed in the middle of the step's MFMAs (the sweep kernels' protocol);
+//   * a pipeline step is 32 k (one accumulator tile of the producing GEMM) x 128 output rows = 48 MFMAs = 1536 cycles;
+//     32 steps per 128-token workgroup: out-projection 4, feed-forward 16 (per hidden tile of 32 units one FFN-1 step
+//     over the whole K and one FFN-2 step), the next layer's QKV 12 (three passes of 128 columns; a k | v-only tail skips the first);
+//   * activations still chain through registers in the transposed orientation (a lane owns a token): an accumulator
+//     tile IS a B operand -- registers 8s .. 8s+7 of a tile, converted pairwise to bf16, are the B fragment of k-step s,
+//     the k order inside a step being 16s + 8(j>>2) + 4h + (j&3) (cdna_hip_programming.md section 3), which is the
+//     order k_pack_x6 packs the weights in; the split of a tile into its three planes costs ~5.5 vector instructions
+//     per value, once per tile and pipeline step (1.8 per MFMA);
+//   * fragment reads are inline-asm ds_read_b128 three fragments ahead through a ring of four registers sets with
+//     hand-counted lgkmcnt (a compiler-visible LDS read behind an LDS-DMA issue gets a vmcnt(0) in front).
+// Accuracy: the bf16 matrix pipe accumulates without round-to-nearest; round 2 measured the decoder rows' error at
+// ~1.5-3x the fp32-MFMA kernels' (still 1e-5-scale against the 1e-3 relative bar of the north star).
+typedef __attribute__((ext_vector_type(8))) __bf16 x6_bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int x6_u32x4;
+#define X6_STEP_B 24576
+#define X6_NSTEP 32
+#define X6_LAYER_BYTES (X6_NSTEP * X6_STEP_B)
+
+// one layer's weights -> the kernel's step stream.  Thread = one 16-byte fragment piece (8 bf16 of one lane).
+__global__ void __launch_bounds__(256) k_pack_x6(const float *__restrict__ Wo, const float *__restrict__ W1,
+                                                 const float *__restrict__ W2, const float *__restrict__ Win,
+                                                 uint4 *__restrict__ out) {
+    const int gid = blockIdx.x * 256 + threadIdx.x; // < 32 steps * 24 pieces * 64 lanes
+    if (gid >= X6_NSTEP * 24 * 64) return;
+    const int lane = gid & 63, piece = (gid >> 6) % 24, step = gid / (24 * 64);
+    // piece = 3 g + plane in the kernel's consumption order.  "Four-tile" steps (out-projection, FFN-2, QKV): group g =
+    // (k-step s = g >> 2, output tile nt = g & 3) of one 32-wide k tile; "one-tile" steps (FFN-1): ONE output tile over
+    // the whole K = 128, group g = (k tile g >> 1, k-step s = g & 1).
+    const int p = piece % 3, g = piece / 3;
+    const int r = lane & 31, hh = lane >> 5;
+    const float *W;
+    int ld, n, kb, s;
+    if (step < 4) W = Wo, ld = 128, s = g >> 2, n = 32 * (g & 3) + r, kb = 32 * step;
+    else if (step < 20) {
+        const int ft = (step - 4) >> 1;
+        if (((step - 4) & 1) == 0) W = W1, ld = 128, s = g & 1, n = 32 * ft + r, kb = 32 * (g >> 1); // FFN-1, hidden tile ft
+        else W = W2, ld = 256, s = g >> 2, n = 32 * (g & 3) + r, kb = 32 * ft;                       // FFN-2, k tile ft
+    } else W = Win, ld = 128, s = g >> 2, n = 32 * (4 * ((step - 20) >> 2) + (g & 3)) + r, kb = 32 * ((step - 20) & 3);
+    unsigned int hw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = kb + 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
+        float v = W ? W[(size_t)n * ld + k] : 0.f;
+        unsigned int bits = 0;
+#pragma unroll
+        for (int q = 0; q <= p; ++q) { // plane q = bf16(v - the planes before it), round to nearest even
+            unsigned int u = __float_as_uint(v);
+            u += 0x7FFFu + ((u >> 16) & 1u);
+            bits = u >> 16;
+            v -= __uint_as_float(bits << 16);
+        }
+        hw[j] = bits;
+    }
+    out[gid] = make_uint4(hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16));
+}
+
+struct BlockX6Args {
+    const float *Af, *Rf;  // attention output and residual x, fragment-major
+    const uint4 *Wx;       // this layer's step stream (k_pack_x6)
+    const float *bo, *g1, *b1n, *c, *g2, *b2n, *b1, *b2, *g, *b, *bin;
+    float *Xf;             // fragment-major x' (may be null)
+    float *QKV;            // row-major [M][384]
+    int M;
+    const int32_t *m_dev;
+    int qkv_pass0;         // (documentation only: the kernel's QP0 template parameter decides)
+#ifdef X6_DUMP
+    uint4 *dbg;            // (lab) the fragments workgroup 0 / wave 0 consumed, [step][fragment][lane]
+#endif
+};
+
+// float32 accumulator tile -> the three bf16 planes of its k-step s (registers 8s .. 8s+7) as B fragments
+__device__ __forceinline__ void x6_split(const f32x16 &t, int s, x6_bf16x8 (&X)[3]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = t[8 * s + j];
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        X[0][j] = h;
+        X[1][j] = m;
+        X[2][j] = (__bf16)r2;
+    }
+}
+
+template <int B_, int E_, class Fn>
+__device__ __forceinline__ void x6_static_for(Fn &&fn) {
+    if constexpr (B_ < E_) {
+        fn(std::integral_constant<int, B_>{});
+        x6_static_for<B_ + 1, E_>(fn);
+    }
+}
+// (asm: a compiler-visible LDS read behind an LDS-DMA issue gets a vmcnt(0) in front; the offset is an immediate so that
+// the 72 fragment addresses of the ring cost three base registers, not one register each)
+template <int OFF>
+__device__ __forceinline__ x6_u32x4 x6_rd(unsigned int base) {
+    x6_u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base), "i"(OFF));
+    return v;
+}
+
+// QP0 = 0: the tail computes q | k | v; 1: k | v only (feeding the rows-only last layer)
+template <int QP0>
+__global__ void __launch_bounds__(256, 2) k_block_x6(BlockX6Args a) {
+    constexpr int D = 128, F = 256, NSLOT = 3, PPW = 6;
+    constexpr int V_B1 = 0, V_B2 = F, V_G = F + D, V_B = F + 2 * D, V_BIN = F + 3 * D, V_O = F + 3 * D + 3 * D;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *vecs = reinterpret_cast<float *>(smem + NSLOT * X6_STEP_B); // b1[256], b2, g, b, b_in[384], b_o, g1, b1n, c, g2, b2n
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    const int m0 = blockIdx.x * 128;
+    const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M;
+    if (m0 >= M) return;
+    vecs[V_B1 + tid] = a.b1[tid];
+    vecs[V_BIN + tid] = a.bin[tid];
+    if (tid < D) {
+        vecs[V_B2 + tid] = a.b2[tid];
+        vecs[V_G + tid] = a.g[tid];
+        vecs[V_B + tid] = a.b[tid];
+        vecs[V_BIN + 256 + tid] = a.bin[256 + tid];
+        vecs[V_O + 0 * D + tid] = a.bo ? a.bo[tid] : 0.f;
+        vecs[V_O + 1 * D + tid] = a.g1[tid];
+        vecs[V_O + 2 * D + tid] = a.b1n[tid];
+        vecs[V_O + 3 * D + tid] = a.c ? a.c[tid] : 0.f;
+        vecs[V_O + 4 * D + tid] = a.c ? a.g2[tid] : 0.f;
+        vecs[V_O + 5 * D + tid] = a.c ? a.b2n[tid] : 0.f;
+    }
+    const int mtile = (m0 >> 5) + wave;
+    const int mt = m0 + wave * 32 + li;
+    const size_t fbase = (size_t)mtile * 16 * 64 + lane;
+    const unsigned int lds0 = (unsigned int)(size_t)(__attribute__((address_space(3))) char *)smem;
+    const unsigned int fr_addr = lds0 + lane * 16; // + slot * X6_STEP_B + piece * 1024
+    const unsigned int vecs_addr = lds0 + NSLOT * X6_STEP_B + 16 * lk; // this lane's float4 of a 32-value tile's group g: + 32 g bytes
+    constexpr int nsteps = X6_NSTEP - 4 * QP0;  // executed steps; step i of the sequence is stream block i (+ 4 past the FFN when QP0)
+    constexpr int qoff = 4 * QP0;
+    auto issue = [&](int i) __attribute__((always_inline)) { // DMA of sequence step i into slot i % NSLOT
+        const int blk = i < 20 ? i : i + qoff;
+        const uint4 *src = a.Wx + (size_t)blk * (X6_STEP_B / 16) + lane;
+        char *dst = smem + (i % NSLOT) * X6_STEP_B;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int p = wave + 4 * j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64),
+                                             (__attribute__((address_space(3))) void *)(dst + p * 1024), 16, 0, 0);
+        }
+    };
+    // accumulators start from the residual x; the attention output tile 0 is requested with it
+    f32x16 acc[4];
+    const float4 *rfrag = reinterpret_cast<const float4 *>(a.Rf) + fbase;
+    const float4 *afrag = reinterpret_cast<const float4 *>(a.Af) + fbase;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 t4 = rfrag[(tn * 4 + g) * 64];
+            acc[tn][4 * g + 0] = t4.x, acc[tn][4 * g + 1] = t4.y, acc[tn][4 * g + 2] = t4.z, acc[tn][4 * g + 3] = t4.w;
+        }
+    f32x16 at; // attention output tile (B operand source of the out-projection), one tile ahead
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 t4 = afrag[g * 64];
+        at[4 * g + 0] = t4.x, at[4 * g + 1] = t4.y, at[4 * g + 2] = t4.z, at[4 * g + 3] = t4.w;
+    }
+    issue(0);
+    // everything older than this point has landed (the compiler is free to order the plain loads above around the DMA
+    // issue, so no counted wait here), the vecs stores too; step 1 goes out behind the barrier
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(1);
+
+    // fragment reads: the stream of a step is 8 groups x (plane 0, 1, 2) = 24 reads in consumption order (k_pack_x6); a
+    // ring of four register sets, three reads ahead
+    x6_u32x4 af[4];
+    auto landed_all = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[q]));
+    };
+    af[0] = x6_rd<0>(fr_addr);
+    af[1] = x6_rd<1024>(fr_addr);
+    af[2] = x6_rd<2048>(fr_addr);
+    af[3] = x6_rd<2048>(fr_addr); // (its own read: a register copy of af[2] would be taken before the data has landed)
+    landed_all();
+
+    const float invn = 1.0f / (float)D;
+    x6_bf16x8 X[3];
+    // one pipeline step: 8 groups x 6 MFMAs onto T[0..3]; the mid-step barrier publishes step i + 1 and frees the slot
+    // of step i - 1 for the DMA of step i + 2
+#ifdef X6_NO_MFMA
+#define X6_MFMA(Wreg, Xp, T_) asm volatile("" :: "v"(Wreg), "v"(X[Xp]))
+#else
+#define X6_MFMA(Wreg, Xp, T_) T_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x6_bf16x8, Wreg), X[Xp], T_, 0, 0, 0)
+#endif
+#ifdef X6_DUMP
+#define X6_DUMP_FRAG(I_, f_) if (blockIdx.x == 0 && wave == 0) a.dbg[((I_) * 24 + (f_)) * 64 + lane] = __builtin_bit_cast(uint4, af[(f_) & 3]);
+#else
+#define X6_DUMP_FRAG(I_, f_)
+#endif
+#define X6_READ_AHEAD(f_)                                                                                                \
+    if constexpr ((f_) + 3 < 24) af[((f_) + 3) & 3] = x6_rd<((f_) + 3) * 1024>(sb_);                                     \
+    else af[((f_) + 3) & 3] = x6_rd<((f_) + 3 - 24) * 1024>(sn_); /* next step's head (behind this step's barrier) */    \
+    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(af[(f_) & 3]));                                                           \
+    X6_DUMP_FRAG(step_, f_)
+#define X6_PUBLISH(I_)                                                                                                   \
+    if ((I_) + 1 < nsteps) {                                                                                             \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                 \
+        __builtin_amdgcn_s_barrier();                                                                                    \
+        if ((I_) + 2 < nsteps) issue((I_) + 2);                                                                          \
+    }
+#define X6_STEP(I_, SRC, T0, T1, T2, T3)                                                                                \
+    {                                                                                                                    \
+        const int step_ = (I_);                                                                                          \
+        const unsigned int sb_ = fr_addr + (unsigned int)((step_ % NSLOT) * X6_STEP_B);                                  \
+        const unsigned int sn_ = fr_addr + (unsigned int)(((step_ + 1) % NSLOT) * X6_STEP_B);                            \
+        x6_static_for<0, 24>([&](auto fc_) __attribute__((always_inline)) {                                              \
+            constexpr int f_ = decltype(fc_)::value, g_ = f_ / 3, pl_ = f_ % 3;                                          \
+            if constexpr (f_ == 0) x6_split(SRC, 0, X);                                                                  \
+            if constexpr (f_ == 12) {                                                                                    \
+                X6_PUBLISH(step_)                                                                                        \
+                x6_split(SRC, 1, X);                                                                                     \
+            }                                                                                                            \
+            X6_READ_AHEAD(f_)                                                                                            \
+            f32x16 &T_ = (g_ & 3) == 0 ? T0 : (g_ & 3) == 1 ? T1 : (g_ & 3) == 2 ? T2 : T3;                              \
+            if constexpr (pl_ == 0) {                                                                                    \
+                X6_MFMA(af[f_ & 3], 2, T_);                                                                              \
+                X6_MFMA(af[f_ & 3], 1, T_);                                                                              \
+                X6_MFMA(af[f_ & 3], 0, T_);                                                                              \
+            } else if constexpr (pl_ == 1) {                                                                             \
+                X6_MFMA(af[f_ & 3], 1, T_);                                                                              \
+                X6_MFMA(af[f_ & 3], 0, T_);                                                                              \
+            } else                                                                                                       \
+                X6_MFMA(af[f_ & 3], 0, T_);                                                                              \
+        });                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    }
+    // (reads past the last step of the sequence fetch a stale slot and are never multiplied: the counted waits assume
+    // every read of the schedule is in flight)
+
+    // ---- out-projection: acc += W_o . ao^T, k tile tn = step
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const f32x16 cur = at;
+        if (t + 1 < 4) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t4 = afrag[((t + 1) * 4 + g) * 64];
+                at[4 * g + 0] = t4.x, at[4 * g + 1] = t4.y, at[4 * g + 2] = t4.z, at[4 * g + 3] = t4.w;
+            }
+        }
+        X6_STEP(t, cur, acc[0], acc[1], acc[2], acc[3])
+    }
+    // ---- + b_o, LN1, + c, LN2: register-local (64 of the 128 values here, 64 in lane ^ 32)
+    auto layer_norm = [&](int vb, int vg, int vbeta, int vadd) __attribute__((always_inline)) {
+        float sum = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (vb >= 0) {
+                    const float4 bb = *reinterpret_cast<const float4 *>(vecs + vb + tn * 32 + 8 * g + 4 * lk);
+                    acc[tn][4 * g + 0] += bb.x, acc[tn][4 * g + 1] += bb.y, acc[tn][4 * g + 2] += bb.z, acc[tn][4 * g + 3] += bb.w;
+                }
+                sum += (acc[tn][4 * g + 0] + acc[tn][4 * g + 1]) + (acc[tn][4 * g + 2] + acc[tn][4 * g + 3]);
+                __builtin_amdgcn_sched_barrier(0); // (the scheduler otherwise hoists every parameter read of the phase: ~480 registers)
+            }
+        const float mu = lanes_sum<32>(sum) * invn;
+        float qs = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float dlt = acc[tn][r] - mu;
+                qs += dlt * dlt;
+            }
+        const float rstd = 1.0f / sqrtf(lanes_sum<32>(qs) * invn + 1e-5f);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = tn * 32 + 8 * g + 4 * lk;
+                const float4 gg = *reinterpret_cast<const float4 *>(vecs + vg + n);
+                const float4 be = *reinterpret_cast<const float4 *>(vecs + vbeta + n);
+                float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (vadd >= 0) ad = *reinterpret_cast<const float4 *>(vecs + vadd + n);
+                acc[tn][4 * g + 0] = (acc[tn][4 * g + 0] - mu) * rstd * gg.x + be.x + ad.x;
+                acc[tn][4 * g + 1] = (acc[tn][4 * g + 1] - mu) * rstd * gg.y + be.y + ad.y;
+                acc[tn][4 * g + 2] = (acc[tn][4 * g + 2] - mu) * rstd * gg.z + be.z + ad.z;
+                acc[tn][4 * g + 3] = (acc[tn][4 * g + 3] - mu) * rstd * gg.w + be.w + ad.w;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+    layer_norm(V_O + 0 * D, V_O + 1 * D, V_O + 2 * D, V_O + 3 * D);
+    if (a.c) layer_norm(-1, V_O + 4 * D, V_O + 5 * D, -1);
+
+    // ---- feed-forward, one hidden tile (32 units) at a time: FFN-1 step h_ft = W1[32 ft ..] y^T over the whole K = 128
+    //      (B operand: y's bf16 planes, split ONCE and kept -- 96 registers -- while acc itself goes on as the residual
+    //      accumulator), bias + relu on the 16 values, FFN-2 step acc += W2[:, 32 ft ..] h_ft^T.  (The round-2 order --
+    //      all eight hidden tiles, then FFN-2 -- keeps 128 registers of h beside the 64 of y: with the split's
+    //      temporaries that is ~265 of the 256 registers two waves per SIMD have: 173 spilled.)
+    x6_bf16x8 Yp[4][2][3];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            x6_split(acc[tn], s2, Yp[tn][s2]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#define X6_STEP1(I_, T_)                                                                                                 \
+    {                                                                                                                    \
+        const int step_ = (I_);                                                                                          \
+        const unsigned int sb_ = fr_addr + (unsigned int)((step_ % NSLOT) * X6_STEP_B);                                  \
+        const unsigned int sn_ = fr_addr + (unsigned int)(((step_ + 1) % NSLOT) * X6_STEP_B);                            \
+        x6_static_for<0, 24>([&](auto fc_) __attribute__((always_inline)) {                                              \
+            constexpr int f_ = decltype(fc_)::value, g_ = f_ / 3, pl_ = f_ % 3;                                          \
+            if constexpr (f_ == 12) { X6_PUBLISH(step_) }                                                                \
+            X6_READ_AHEAD(f_)                                                                                            \
+            const x6_bf16x8 w_ = __builtin_bit_cast(x6_bf16x8, af[f_ & 3]);                                              \
+            if constexpr (pl_ == 0) {                                                                                    \
+                T_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, Yp[g_ >> 1][g_ & 1][2], T_, 0, 0, 0);                   \
+                T_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, Yp[g_ >> 1][g_ & 1][1], T_, 0, 0, 0);                   \
+                T_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, Yp[g_ >> 1][g_ & 1][0], T_, 0, 0, 0);                   \
+            } else if constexpr (pl_ == 1) {                                                                             \
+                T_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, Yp[g_ >> 1][g_ & 1][1], T_, 0, 0, 0);                   \
+                T_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, Yp[g_ >> 1][g_ & 1][0], T_, 0, 0, 0);                   \
+            } else                                                                                                       \
+                T_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, Yp[g_ >> 1][g_ & 1][0], T_, 0, 0, 0);                   \
+        });                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    }
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft) {
+        f32x16 hft;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hft[r] = 0.f;
+        X6_STEP1(4 + 2 * ft, hft)
+        // b1 of this hidden tile: asm reads too (a compiler-visible LDS read here waits for the DMA issued half a step
+        // ago); the wait drains the fragment read-aheads with it, which only makes the next step's counted waits pass early
+        x6_u32x4 bq[4];
+        {
+            const unsigned int ba_ = vecs_addr + (unsigned int)((V_B1 + ft * 32) * 4);
+            bq[0] = x6_rd<0>(ba_), bq[1] = x6_rd<32>(ba_), bq[2] = x6_rd<64>(ba_), bq[3] = x6_rd<96>(ba_);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]));
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bb = __builtin_bit_cast(float4, bq[g]);
+            hft[4 * g + 0] = fmaxf(hft[4 * g + 0] + bb.x, 0.f);
+            hft[4 * g + 1] = fmaxf(hft[4 * g + 1] + bb.y, 0.f);
+            hft[4 * g + 2] = fmaxf(hft[4 * g + 2] + bb.z, 0.f);
+            hft[4 * g + 3] = fmaxf(hft[4 * g + 3] + bb.w, 0.f);
+        }
+        X6_STEP(5 + 2 * ft, hft, acc[0], acc[1], acc[2], acc[3])
+    }
+#undef X6_STEP1
+    // ---- + b2, LN3 -> x' (fragment-major store), kept in acc as the QKV tail's B operand
+    {
+        float sum = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bb = *reinterpret_cast<const float4 *>(vecs + V_B2 + tn * 32 + 8 * g + 4 * lk);
+                acc[tn][4 * g + 0] += bb.x, acc[tn][4 * g + 1] += bb.y, acc[tn][4 * g + 2] += bb.z, acc[tn][4 * g + 3] += bb.w;
+                sum += (acc[tn][4 * g + 0] + acc[tn][4 * g + 1]) + (acc[tn][4 * g + 2] + acc[tn][4 * g + 3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        const float mu = lanes_sum<32>(sum) * invn;
+        float qs = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float dlt = acc[tn][r] - mu;
+                qs += dlt * dlt;
+            }
+        const float rstd = 1.0f / sqrtf(lanes_sum<32>(qs) * invn + 1e-5f);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = tn * 32 + 8 * g + 4 * lk;
+                const float4 gg = *reinterpret_cast<const float4 *>(vecs + V_G + n);
+                const float4 be = *reinterpret_cast<const float4 *>(vecs + V_B + n);
+                const float4 o = make_float4((acc[tn][4 * g + 0] - mu) * rstd * gg.x + be.x, (acc[tn][4 * g + 1] - mu) * rstd * gg.y + be.y,
+                                             (acc[tn][4 * g + 2] - mu) * rstd * gg.z + be.z, (acc[tn][4 * g + 3] - mu) * rstd * gg.w + be.w);
+                if (a.Xf) reinterpret_cast<float4 *>(a.Xf)[((size_t)(mtile * 4 + tn) * 4 + g) * 64 + lane] = o;
+                acc[tn][4 * g + 0] = o.x, acc[tn][4 * g + 1] = o.y, acc[tn][4 * g + 2] = o.z, acc[tn][4 * g + 3] = o.w;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+    // ---- the next layer's QKV: passes of 128 output columns (4 tiles), k tile tn; sequence steps 20 ..
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) {
+        if (pp >= 3 - QP0) break;
+        f32x16 qa[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qa[i][r] = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            X6_STEP(20 + 4 * pp + tn, acc[tn], qa[0], qa[1], qa[2], qa[3])
+        }
+        landed_all(); // (control flow ahead: no fragment register may still be awaiting its LDS return)
+        if (mt < M) {
+            const int c0 = 128 * (pp + QP0);
+            float *qrow = a.QKV + (int64_t)mt * (3 * D) + c0 + 4 * lk;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bb = *reinterpret_cast<const float4 *>(vecs + V_BIN + c0 + i * 32 + 8 * g + 4 * lk);
+                    *reinterpret_cast<float4 *>(qrow + i * 32 + 8 * g) =
+                        make_float4(qa[i][4 * g + 0] + bb.x, qa[i][4 * g + 1] + bb.y, qa[i][4 * g + 2] + bb.z, qa[i][4 * g + 3] + bb.w);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+    }
+    landed_all(); // the reads issued past the last step
+#undef X6_STEP
+#undef X6_PUBLISH
+#undef X6_READ_AHEAD
+#undef X6_MFMA
+}
+
 // ------------------------------------------------------------------ embed + layer 0's QKV (d = 128, throughput shapes)
 // x = item_emb[seq] * sqrt(d) + pe[pos] is computed straight into the transposed accumulator layout (lane = token),
 // written once to the fragment-major image (layer 0's residual) and used as the B operand of the QKV projection,
@@ -3378,6 +3813,23 @@ int irs_launch_cross_const(irs_ctx *ctx, hipStream_t s) {
 }
 
 // fragment-packed weight copies for k_block_small16: [n_layers][Wo | W1 | W2] then [n_layers][Win]
+// split-bf16 fused layer kernel (k_block_x6): one 768 KB step stream per layer that has a successor (d = 128, F = 256,
+// head dim 32: the shapes k_block<true, true> serves)
+static bool x6_shape(const irs_ctx *ctx) {
+    return ctx->dims.d == 128 && ctx->dims.ffn_dim == 256 && ctx->dims.d / ctx->dims.n_heads == 32 && ctx->dims.n_layers >= 2;
+}
+size_t irs_x6_bytes(const irs_ctx *ctx) { return x6_shape(ctx) ? (size_t)(ctx->dims.n_layers - 1) * X6_LAYER_BYTES : 0; }
+int irs_launch_pack_x6(irs_ctx *ctx, hipStream_t s) {
+    if (!ctx->w_x6) return IRS_OK;
+    for (int l = 0; l + 1 < ctx->dims.n_layers; ++l) {
+        const irs_layer_w &w = ctx->layer[l];
+        hipLaunchKernelGGL(k_pack_x6, dim3(X6_NSTEP * 24 * 64 / 256), dim3(256), 0, s, w.sa_out_w, w.l1_w, w.l2_w,
+                           ctx->layer[l + 1].sa_in_w, ctx->w_x6 + (size_t)l * (X6_LAYER_BYTES / 16));
+    }
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}
+
 size_t irs_small_frag_floats(const irs_ctx *ctx) {
     const int d = ctx->dims.d, F = ctx->dims.ffn_dim;
     if (small_any_shape(d, F)) return (size_t)ctx->dims.n_layers * small_any_layer_floats(d, F);
@@ -3620,7 +4072,19 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                 ba.Af = yf, ba.Rf = xf, ba.Wo = w.sa_out_w, ba.bo = w.sa_out_b;
                 ba.g1 = w.n1_w, ba.b1n = w.n1_b, ba.c = cl, ba.g2 = w.n2_w, ba.b2n = w.n2_b;
                 irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
-                if (tail) hipLaunchKernelGGL((k_block<true, true>), dim3((rows + 127) / 128), dim3(256), 0, s, ba);
+                if (tail && ctx->use_x6 && ctx->w_x6) { // the same layer tail on split-bf16 MFMAs
+                    BlockX6Args xa{yf, xf, ctx->w_x6 + (size_t)l * (X6_LAYER_BYTES / 16), w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b,
+                                   w.l1_b, w.l2_b, w.n3_w, w.n3_b, ctx->layer[l + 1].sa_in_b, xf, ctx->act_qkv, rows, m_dev, kv_only ? 1 : 0};
+                    constexpr int x6_lds = 3 * X6_STEP_B + 1792 * 4;
+                    static bool attr = false;
+                    if (!attr) {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<1>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds);
+                        attr = true;
+                    }
+                    if (kv_only) hipLaunchKernelGGL(k_block_x6<1>, dim3((rows + 127) / 128), dim3(256), x6_lds, s, xa);
+                    else hipLaunchKernelGGL(k_block_x6<0>, dim3((rows + 127) / 128), dim3(256), x6_lds, s, xa);
+                } else if (tail) hipLaunchKernelGGL((k_block<true, true>), dim3((rows + 127) / 128), dim3(256), 0, s, ba);
                 else hipLaunchKernelGGL((k_block<true, false>), dim3((rows + 127) / 128), dim3(256), 0, s, ba);
                 irs_prof_end(ctx, IRS_PROF_LINEAR, s, ffn_flops + 2.0 * rows * (double)d * d, (8.0 + 4.0 + (tail ? 12.0 : 0.0)) * rows * (double)d);
                 qkv_done = tail;

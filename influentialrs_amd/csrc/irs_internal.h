@@ -51,6 +51,8 @@ struct irs_ctx {
     float *c_l;       // [n_layers][d] cross-attention constants
     float *wnorm_max; // [3] max_j max(||W_j||, ||bf16(W_j)||), max_j ||W_j - bf16(W_j)||, max_j |b_j| (k_prep_x)
     float *w_frag16;  // fragment-packed layer weights of the 16-token latency kernel (d = 128, F = 256), or null
+    uint4 *w_x6;      // split-bf16 step streams of the fused layer kernel k_block_x6 ([n_layers - 1] x 768 KB), or null
+    int use_x6;       // decoder GEMMs of the throughput path on split-bf16 MFMAs (IRS_DECODER_GEMM=x6|f32)
     bool finalized;
     bool proj_stale;  // a training entry point ran since irs_finalize_weights: wp / wnorm_max may lag project.*
 
@@ -151,6 +153,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
 int irs_launch_cross_const(irs_ctx *ctx, hipStream_t s);
 size_t irs_small_frag_floats(const irs_ctx *ctx);
 int irs_launch_pack_small(irs_ctx *ctx, hipStream_t s);
+size_t irs_x6_bytes(const irs_ctx *ctx);
+int irs_launch_pack_x6(irs_ctx *ctx, hipStream_t s);
 
 // ---- score.hip ----
 int irs_launch_pack_w(irs_ctx *ctx, hipStream_t s);
