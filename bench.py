@@ -511,8 +511,8 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from influentialrs_amd._lib import (IRS_PROF_ATTN, IRS_PROF_LINEAR, IRS_PROF_NONE, IRS_PROF_REFINE, IRS_PROF_SWEEP,
-                                        IRS_SWEEP_BF16)
+    from influentialrs_amd._lib import (IRS_GEMM_X6, IRS_PROF_ATTN, IRS_PROF_LAYER, IRS_PROF_LINEAR, IRS_PROF_NONE, IRS_PROF_REFINE,
+                                        IRS_PROF_SWEEP, IRS_SWEEP_BF16)
     device = torch.device("cuda", 0 if args.same_device else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
@@ -547,7 +547,9 @@ def main():
 
     # second, instrumented pass: HIP events around every launch of each kernel family
     fam = {}
-    for name, f in (("linear", IRS_PROF_LINEAR), ("attn", IRS_PROF_ATTN), ("sweep", IRS_PROF_SWEEP), ("refine", IRS_PROF_REFINE)):
+    # ("layer" is the fused layer kernel alone, a subset of "linear": the kernel the decoder roofline is quoted on)
+    for name, f in (("linear", IRS_PROF_LINEAR), ("attn", IRS_PROF_ATTN), ("sweep", IRS_PROF_SWEEP), ("refine", IRS_PROF_REFINE),
+                    ("layer", IRS_PROF_LAYER)):
         job.seqs.copy_(snap[0])
         job.hep.copy_(snap[1])
         job.eng.prof_enable(f)
@@ -558,9 +560,11 @@ def main():
         f1 = packed_fraction(job)
         n, ms, fl, by = job.eng.prof_read()
         # decoder kernels run on the packed (non-pad) rows: executed flops = dense-shape flops x packed fraction
-        scale = 0.5 * (f0 + f1) if name in ("linear", "attn") else 1.0
+        scale = 0.5 * (f0 + f1) if name in ("linear", "attn", "layer") else 1.0
         fam[name] = dict(launches=n, ms=ms, flops=fl * scale, bytes=by, packed_fraction=scale)
     job.eng.prof_enable(IRS_PROF_NONE)
+    layer = fam.pop("layer")
+    x6 = job.eng.decoder_gemm == IRS_GEMM_X6
 
     roof = None
     if rank == 0:
@@ -579,7 +583,24 @@ def main():
         dom = max(fam, key=lambda k: fam[k]["ms"])
         f = fam[dom]
         per_launch_ms = f["ms"] / max(f["launches"], 1)
-        if dom in ("linear", "attn"):
+        if dom == "linear" and layer["launches"] > 0:
+            # the family's dominant KERNEL: the fused layer kernel (5 of the 8 launches of a C2 step, ~80 % of the
+            # family's time).  Flops are the algorithmic ones (2 per float32 multiply-add of the dense shapes, x the packed
+            # row fraction).  IRS_GEMM_X6 executes SIX bf16 MFMA products per float32 product, so the peak that bounds it
+            # is the dense bf16 peak / 6; IRS_GEMM_F32 is bounded by the float32-MFMA peak.
+            layer["ms_instrumented"] = layer["ms"]
+            layer["ms"] = layer["ms"] * fscale
+            f = layer
+            per_launch_ms = f["ms"] / max(f["launches"], 1)
+            ach = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
+            peak = PEAK_BF16_TFLOPS / 6.0 if x6 else PEAK_F32_MATRIX_TFLOPS
+            roof = {"kernel": ("k_block_x6 (fused decoder layer: out-projection, layer norms, feed-forward, next q|k|v; split-bf16 "
+                               "MFMA, 6 bf16 products per float32 product)" if x6 else
+                               "k_block (fused decoder layer: out-projection, layer norms, feed-forward, next q|k|v; float32 MFMA)"),
+                    "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                    "peak_basis": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 products" if x6 else "float32 MFMA dense peak"),
+                    "executed_mfma_tflops": ach * (6.0 if x6 else 1.0)}
+        elif dom in ("linear", "attn"):
             ach = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
             roof = {"kernel": {"linear": "k_block + k_linear (decoder fp32 MFMA GEMM family: fused layer kernel, layer-0 QKV)",
                                "attn": "k_attn16 / k_attn_mfma (decoder self-attention, fp32 MFMA)"}[dom],
@@ -603,13 +624,13 @@ def main():
             try:
                 with open(pmc_file) as fh:
                     pm = json.load(fh)
-                kb = pm["kernels"]["k_block"]
+                kb = pm["kernels"]["k_block_x6" if x6 and "k_block_x6" in pm["kernels"] else "k_block"]
                 roof["traffic"] = float(kb["hbm_bytes_per_launch"])
                 roof["traffic_measured_at_packed_rows"] = float(pm["packed_rows_mean"])
                 roof["traffic_source"] = ("profiles/r03/c2_b4096_pmc.json (tools/r03_measure.sh: this round's binary, `bench.py "
                                           "--pmc-run` under rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in separate passes, "
-                                          "2 x FETCH_SIZE + WRITE_SIZE per the gfx950 note): k_block (5 of the family's 6 launches "
-                                          "per step), at that run's own mean packed row count")
+                                          "2 x FETCH_SIZE + WRITE_SIZE per the gfx950 note): the fused layer kernel, at "
+                                          "that run's own mean packed row count")
                 roof["algorithmic_bytes_per_launch"] = float(kb["algorithmic_bytes_per_launch"])
                 roof["mfma_busy_pmc"] = kb.get("mfma_busy")
                 roof["packed_rows_this_run"] = fam[dom]["packed_fraction"] * job.B * cfg.max_len

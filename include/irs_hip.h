@@ -356,16 +356,33 @@ int irs_beam_search_sharded(irs_ctx *ctx, irs_comm *comm, const int64_t *dev_seq
  * attempted and refused by the collective library (plain stream launches from then on). */
 int irs_sharded_graph_state(const irs_ctx *ctx);
 
+/* ---- decoder GEMM arithmetic -------------------------------------------
+ * The throughput path's fused layer kernel (d = 128, ffn = 256: out-projection, both layer norms, feed-forward, the
+ * next layer's q | k | v) multiplies in one of two ways; both accumulate in float32 and agree to ~1e-6 relative on the
+ * decoder rows (tests/test_gpu_decoder_path.py holds the bound):
+ *   IRS_GEMM_X6  (default) every float32 operand is split exactly into three bf16 planes (h + m + l) and the six
+ *                leading products hh, hm, mh, hl, lh, mm are summed on v_mfma_f32_32x32x16_bf16: float32-grade products
+ *                at 6/16 of the float32-MFMA instruction time;
+ *   IRS_GEMM_F32 v_mfma_f32_32x32x2f32.
+ * The initial mode is IRS_GEMM_X6 unless the environment holds IRS_DECODER_GEMM=f32 when the context is created.
+ * Changing the mode drops the context's captured steps (they are re-captured on the next graph call). */
+#define IRS_GEMM_F32 0
+#define IRS_GEMM_X6 1
+int irs_set_decoder_gemm(irs_ctx *ctx, int32_t mode);
+int irs_get_decoder_gemm(const irs_ctx *ctx);
+
 /* ---- measurement hooks (bench.py only) ---------------------------------
  * While enabled, every launch of the named kernel family is bracketed by HIP
  * events on the launch stream; irs_prof_read() synchronises those events and
  * returns launches and total milliseconds since the last reset. */
 #define IRS_PROF_NONE 0
-#define IRS_PROF_LINEAR 1  /* decoder fp32 MFMA GEMM */
+#define IRS_PROF_LINEAR 1  /* decoder GEMM family (fused layer kernel, layer-0 QKV) */
 #define IRS_PROF_ATTN 2    /* decoder attention */
 #define IRS_PROF_SWEEP 3   /* catalog sweep (pre-pass + emit) */
 #define IRS_PROF_REFINE 4  /* candidate refine / exact re-score / sort */
 #define IRS_PROF_SWEEP_EMIT 5 /* the emission sweep of irs_score_topk alone (the kernel the bf16 MFMA roofline is quoted on) */
+#define IRS_PROF_LAYER 6   /* the fused layer kernel with the next layer's q | k | v (k_block_x6 / k_block) alone: the
+                            * launches the decoder roofline is quoted on; flops are the algorithmic (float32-product) ones */
 int irs_prof_enable(irs_ctx *ctx, int32_t family);
 int irs_prof_read(irs_ctx *ctx, int32_t *launches, double *total_ms, double *total_flops, double *total_bytes);
 

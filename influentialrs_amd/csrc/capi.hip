@@ -68,9 +68,10 @@ extern "C" int irs_create(irs_ctx **out, const irs_dims *dims, const irs_shard *
     c->max_seqs = D.max_seqs > 0 ? D.max_seqs : D.max_rows;
     c->m_pad_max = (c->max_rows + 31) & ~31;
     c->lse_slots = 2048;
-    {   // decoder GEMMs of the throughput path: split-bf16 MFMAs (k_block_x6) or float32 MFMAs (k_block)
+    {   // decoder GEMMs of the throughput path: split-bf16 MFMAs (k_block_x6, the default) or float32 MFMAs (k_block);
+        // the environment variable sets the initial mode, irs_set_decoder_gemm() changes it on a live context
         const char *e = getenv("IRS_DECODER_GEMM");
-        c->use_x6 = e ? (strcmp(e, "x6") == 0) : 0;
+        c->use_x6 = e ? (strcmp(e, "f32") != 0) : 1;
     }
     *out = c;
     return IRS_OK;
@@ -371,6 +372,33 @@ extern "C" int irs_bind_workspace(irs_ctx *ctx, void *ws, size_t bytes) {
     }
     return IRS_OK;
 }
+
+static void drop_graphs(irs_ctx *ctx) { // captured steps hold kernel choices and buffer addresses
+    if (ctx->sh_graph) {
+        hipGraphExecDestroy(ctx->sh_graph);
+        ctx->sh_graph = nullptr;
+    }
+    if (ctx->beam_graph) {
+        hipGraphExecDestroy(ctx->beam_graph);
+        ctx->beam_graph = nullptr;
+    }
+    if (ctx->graph_exec) {
+        hipGraphExecDestroy(ctx->graph_exec);
+        ctx->graph_exec = nullptr;
+    }
+}
+
+extern "C" int irs_set_decoder_gemm(irs_ctx *ctx, int32_t mode) {
+    if (!ctx) return IRS_E_INVALID;
+    if (mode != IRS_GEMM_F32 && mode != IRS_GEMM_X6) IRS_FAIL(ctx, IRS_E_INVALID, "decoder GEMM mode %d (IRS_GEMM_F32 or IRS_GEMM_X6)", mode);
+    if (ctx->use_x6 != mode) {
+        ctx->use_x6 = mode;
+        drop_graphs(ctx);
+    }
+    return IRS_OK;
+}
+
+extern "C" int irs_get_decoder_gemm(const irs_ctx *ctx) { return ctx ? ctx->use_x6 : IRS_E_INVALID; }
 
 static int ready(irs_ctx *ctx) {
     if (!ctx) return IRS_E_INVALID;

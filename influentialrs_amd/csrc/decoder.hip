@@ -1204,6 +1204,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned int x6_u32x4;
 #define X6_STEP_B 24576
 #define X6_NSTEP 32
 #define X6_LAYER_BYTES (X6_NSTEP * X6_STEP_B)
+#ifndef X6_NW
+#define X6_NW 4 // waves per workgroup of k_block_x6 (tools/x6_lab measures both)
+#endif
 
 // one layer's weights -> the kernel's step stream.  Thread = one 16-byte fragment piece (8 bf16 of one lane).
 __global__ void __launch_bounds__(256) k_pack_x6(const float *__restrict__ Wo, const float *__restrict__ W1,
@@ -1255,10 +1258,18 @@ struct BlockX6Args {
 #ifdef X6_DUMP
     uint4 *dbg;            // (lab) the fragments workgroup 0 / wave 0 consumed, [step][fragment][lane]
 #endif
+#ifdef X6_STAMP
+    unsigned long long *stamps; // (lab) per wave: total, DMA wait, barrier, DMA issue, steps (cycles of s_memtime)
+#endif
 };
 
 // float32 accumulator tile -> the three bf16 planes of its k-step s (registers 8s .. 8s+7) as B fragments
 __device__ __forceinline__ void x6_split(const f32x16 &t, int s, x6_bf16x8 (&X)[3]) {
+#ifdef X6_NO_SPLIT
+#pragma unroll
+    for (int p = 0; p < 3; ++p) X[p] = __builtin_bit_cast(x6_bf16x8, make_float4(t[8 * s + p], t[8 * s + p + 1], t[8 * s + p + 2], t[8 * s + p + 3]));
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float v = t[8 * s + j];
@@ -1289,20 +1300,30 @@ __device__ __forceinline__ x6_u32x4 x6_rd(unsigned int base) {
 }
 
 // QP0 = 0: the tail computes q | k | v; 1: k | v only (feeding the rows-only last layer)
-template <int QP0>
-__global__ void __launch_bounds__(256, 2) k_block_x6(BlockX6Args a) {
-    constexpr int D = 128, F = 256, NSLOT = 3, PPW = 6;
+#ifdef X6_STAMP
+#define X6_T(v_) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); v_ = t_; }
+#else
+#define X6_T(v_)
+#endif
+// NW = waves per workgroup (4 or 8), each on its own 32 tokens; the 24 1-KB pieces of a step are fetched 24 / NW per wave
+template <int QP0, int NW>
+__global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
+    constexpr int D = 128, F = 256, NSLOT = 3, PPW = 24 / NW;
     constexpr int V_B1 = 0, V_B2 = F, V_G = F + D, V_B = F + 2 * D, V_BIN = F + 3 * D, V_O = F + 3 * D + 3 * D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *vecs = reinterpret_cast<float *>(smem + NSLOT * X6_STEP_B); // b1[256], b2, g, b, b_in[384], b_o, g1, b1n, c, g2, b2n
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lk = lane >> 5;
-    const int m0 = blockIdx.x * 128;
+    unsigned long long st_p[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // (lab) phase boundaries
+    X6_T(st_p[0])
+    const int m0 = blockIdx.x * (32 * NW);
     const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M;
     if (m0 >= M) return;
-    vecs[V_B1 + tid] = a.b1[tid];
-    vecs[V_BIN + tid] = a.bin[tid];
+    if (tid < 256) {
+        vecs[V_B1 + tid] = a.b1[tid];
+        vecs[V_BIN + tid] = a.bin[tid];
+    }
     if (tid < D) {
         vecs[V_B2 + tid] = a.b2[tid];
         vecs[V_G + tid] = a.g[tid];
@@ -1315,6 +1336,10 @@ __global__ void __launch_bounds__(256, 2) k_block_x6(BlockX6Args a) {
         vecs[V_O + 4 * D + tid] = a.c ? a.g2[tid] : 0.f;
         vecs[V_O + 5 * D + tid] = a.c ? a.b2n[tid] : 0.f;
     }
+#ifdef X6_STAGGER
+    if (blockIdx.x >= 256 && blockIdx.x < 512)
+        for (int i = 0; i < X6_STAGGER; ++i) __builtin_amdgcn_s_sleep(127); // (lab) second resident workgroup of a CU starts ~4 us x N late
+#endif
     const int mtile = (m0 >> 5) + wave;
     const int mt = m0 + wave * 32 + li;
     const size_t fbase = (size_t)mtile * 16 * 64 + lane;
@@ -1323,16 +1348,20 @@ __global__ void __launch_bounds__(256, 2) k_block_x6(BlockX6Args a) {
     const unsigned int vecs_addr = lds0 + NSLOT * X6_STEP_B + 16 * lk; // this lane's float4 of a 32-value tile's group g: + 32 g bytes
     constexpr int nsteps = X6_NSTEP - 4 * QP0;  // executed steps; step i of the sequence is stream block i (+ 4 past the FFN when QP0)
     constexpr int qoff = 4 * QP0;
-    auto issue = [&](int i) __attribute__((always_inline)) { // DMA of sequence step i into slot i % NSLOT
+    // DMA of sequence step i into slot i % NSLOT: this wave's pieces PPW wave .. PPW wave + PPW - 1.  The slot holds the
+    // step's block in stream order, and the instruction's immediate offset moves the global source AND the LDS destination
+    // (tools/dma_probe.hip), so the pieces share one address register pair and one M0: base = the middle piece, offsets
+    // -(PPW / 2) .. PPW / 2 - 1 KB (13-bit signed immediates).
+    const uint4 *dma_src = a.Wx + (PPW * wave + PPW / 2) * 64 + lane;
+    auto issue = [&](int i) __attribute__((always_inline)) {
         const int blk = i < 20 ? i : i + qoff;
-        const uint4 *src = a.Wx + (size_t)blk * (X6_STEP_B / 16) + lane;
-        char *dst = smem + (i % NSLOT) * X6_STEP_B;
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            const int p = wave + 4 * j;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64),
-                                             (__attribute__((address_space(3))) void *)(dst + p * 1024), 16, 0, 0);
-        }
+        const uint4 *src = dma_src + (size_t)blk * (X6_STEP_B / 16);
+        char *dst = smem + (i % NSLOT) * X6_STEP_B + (PPW * wave + PPW / 2) * 1024;
+        x6_static_for<0, PPW>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int off = (decltype(jc)::value - PPW / 2) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)dst, 16, off, 0);
+        });
     };
     // accumulators start from the residual x; the attention output tile 0 is requested with it
     f32x16 acc[4];
@@ -1345,12 +1374,15 @@ __global__ void __launch_bounds__(256, 2) k_block_x6(BlockX6Args a) {
             const float4 t4 = rfrag[(tn * 4 + g) * 64];
             acc[tn][4 * g + 0] = t4.x, acc[tn][4 * g + 1] = t4.y, acc[tn][4 * g + 2] = t4.z, acc[tn][4 * g + 3] = t4.w;
         }
-    f32x16 at; // attention output tile (B operand source of the out-projection), one tile ahead
+    f32x16 at[4]; // attention output tiles (B operand source of the out-projection): all four requested here, so that
+                  // the steps carry no plain global load (its wait would be a vmcnt(0) behind the DMA pieces)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const float4 t4 = afrag[g * 64];
-        at[4 * g + 0] = t4.x, at[4 * g + 1] = t4.y, at[4 * g + 2] = t4.z, at[4 * g + 3] = t4.w;
-    }
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 t4 = afrag[(tn * 4 + g) * 64];
+            at[tn][4 * g + 0] = t4.x, at[tn][4 * g + 1] = t4.y, at[tn][4 * g + 2] = t4.z, at[tn][4 * g + 3] = t4.w;
+        }
     issue(0);
     // everything older than this point has landed (the compiler is free to order the plain loads above around the DMA
     // issue, so no counted wait here), the vecs stores too; step 1 goes out behind the barrier
@@ -1373,32 +1405,57 @@ __global__ void __launch_bounds__(256, 2) k_block_x6(BlockX6Args a) {
 
     const float invn = 1.0f / (float)D;
     x6_bf16x8 X[3];
+    unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_wait = 0, st_bar = 0, st_iss = 0, st_0 = 0, st_1 = 0, st_steps = 0;
+    X6_T(st_0)
     // one pipeline step: 8 groups x 6 MFMAs onto T[0..3]; the mid-step barrier publishes step i + 1 and frees the slot
     // of step i - 1 for the DMA of step i + 2
+    // (lab switches, tools/x6_lab.hip: X6_NO_MFMA drops the matrix instructions, X6_NO_DMA the ring refills past the first
+    // three steps, X6_NO_SPLIT the plane split arithmetic -- timing experiments, results are then wrong)
 #ifdef X6_NO_MFMA
-#define X6_MFMA(Wreg, Xp, T_) asm volatile("" :: "v"(Wreg), "v"(X[Xp]))
+#define X6_MM(W_, X_, T_) asm volatile("" :: "v"(W_), "v"(X_))
 #else
-#define X6_MFMA(Wreg, Xp, T_) T_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x6_bf16x8, Wreg), X[Xp], T_, 0, 0, 0)
+#define X6_MM(W_, X_, T_) T_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W_, X_, T_, 0, 0, 0)
 #endif
+#define X6_MFMA(Wreg, Xp, T_) X6_MM(__builtin_bit_cast(x6_bf16x8, Wreg), X[Xp], T_)
 #ifdef X6_DUMP
 #define X6_DUMP_FRAG(I_, f_) if (blockIdx.x == 0 && wave == 0) a.dbg[((I_) * 24 + (f_)) * 64 + lane] = __builtin_bit_cast(uint4, af[(f_) & 3]);
 #else
 #define X6_DUMP_FRAG(I_, f_)
 #endif
+#ifdef X6_NO_READS
+#define X6_READ_AHEAD(f_) asm volatile("" : "+v"(af[(f_) & 3]));
+#else
 #define X6_READ_AHEAD(f_)                                                                                                \
     if constexpr ((f_) + 3 < 24) af[((f_) + 3) & 3] = x6_rd<((f_) + 3) * 1024>(sb_);                                     \
     else af[((f_) + 3) & 3] = x6_rd<((f_) + 3 - 24) * 1024>(sn_); /* next step's head (behind this step's barrier) */    \
     asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(af[(f_) & 3]));                                                           \
     X6_DUMP_FRAG(step_, f_)
+#endif
+#ifdef X6_NO_DMA
+#define X6_ISSUE(i_)
+#else
+#define X6_ISSUE(i_) issue(i_)
+#endif
+#ifdef X6_NO_BARRIER
+#define X6_PUBLISH(I_) if ((I_) + 2 < nsteps) X6_ISSUE((I_) + 2);
+#else
 #define X6_PUBLISH(I_)                                                                                                   \
     if ((I_) + 1 < nsteps) {                                                                                             \
+        X6_T(st_a)                                                                                                       \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                 \
+        X6_T(st_b)                                                                                                       \
         __builtin_amdgcn_s_barrier();                                                                                    \
-        if ((I_) + 2 < nsteps) issue((I_) + 2);                                                                          \
+        X6_T(st_c)                                                                                                       \
+        if ((I_) + 2 < nsteps) X6_ISSUE((I_) + 2);                                                                       \
+        X6_T(st_d)                                                                                                       \
+        st_wait += st_b - st_a, st_bar += st_c - st_b, st_iss += st_d - st_c;                                            \
     }
+#endif
 #define X6_STEP(I_, SRC, T0, T1, T2, T3)                                                                                \
     {                                                                                                                    \
         const int step_ = (I_);                                                                                          \
+        unsigned long long sq_0 = 0, sq_1 = 0;                                                                           \
+        X6_T(sq_0)                                                                                                       \
         const unsigned int sb_ = fr_addr + (unsigned int)((step_ % NSLOT) * X6_STEP_B);                                  \
         const unsigned int sn_ = fr_addr + (unsigned int)(((step_ + 1) % NSLOT) * X6_STEP_B);                            \
         x6_static_for<0, 24>([&](auto fc_) __attribute__((always_inline)) {                                              \
@@ -1420,6 +1477,8 @@ __global__ void __launch_bounds__(256, 2) k_block_x6(BlockX6Args a) {
             } else                                                                                                       \
                 X6_MFMA(af[f_ & 3], 0, T_);                                                                              \
         });                                                                                                              \
+        X6_T(sq_1)                                                                                                       \
+        st_steps += sq_1 - sq_0;                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }
     // (reads past the last step of the sequence fetch a stale slot and are never multiplied: the counted waits assume
@@ -1428,15 +1487,7 @@ __global__ void __launch_bounds__(256, 2) k_block_x6(BlockX6Args a) {
     // ---- out-projection: acc += W_o . ao^T, k tile tn = step
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const f32x16 cur = at;
-        if (t + 1 < 4) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 t4 = afrag[((t + 1) * 4 + g) * 64];
-                at[4 * g + 0] = t4.x, at[4 * g + 1] = t4.y, at[4 * g + 2] = t4.z, at[4 * g + 3] = t4.w;
-            }
-        }
-        X6_STEP(t, cur, acc[0], acc[1], acc[2], acc[3])
+        X6_STEP(t, at[t], acc[0], acc[1], acc[2], acc[3])
     }
     // ---- + b_o, LN1, + c, LN2: register-local (64 of the 128 values here, 64 in lane ^ 32)
     auto layer_norm = [&](int vb, int vg, int vbeta, int vadd) __attribute__((always_inline)) {
@@ -1478,8 +1529,10 @@ __global__ void __launch_bounds__(256, 2) k_block_x6(BlockX6Args a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
+    X6_T(st_p[1])
     layer_norm(V_O + 0 * D, V_O + 1 * D, V_O + 2 * D, V_O + 3 * D);
     if (a.c) layer_norm(-1, V_O + 4 * D, V_O + 5 * D, -1);
+    X6_T(st_p[2])
 
     // ---- feed-forward, one hidden tile (32 units) at a time: FFN-1 step h_ft = W1[32 ft ..] y^T over the whole K = 128
     //      (B operand: y's bf16 planes, split ONCE and kept -- 96 registers -- while acc itself goes on as the residual
@@ -1494,9 +1547,25 @@ __global__ void __launch_bounds__(256, 2) k_block_x6(BlockX6Args a) {
             x6_split(acc[tn], s2, Yp[tn][s2]);
             __builtin_amdgcn_sched_barrier(0);
         }
+    // a 32-value bias tile (vecs offset vo) into an accumulator tile: asm reads (a compiler-visible LDS read here would wait
+    // for the DMA issued half a step ago); the wait drains the fragment read-aheads with it, which only makes the next
+    // step's counted waits pass early
+    auto bias_tile = [&](f32x16 &t, int vo) __attribute__((always_inline)) {
+        x6_u32x4 bq[4];
+        const unsigned int ba_ = vecs_addr + (unsigned int)(vo * 4);
+        bq[0] = x6_rd<0>(ba_), bq[1] = x6_rd<32>(ba_), bq[2] = x6_rd<64>(ba_), bq[3] = x6_rd<96>(ba_);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bb = __builtin_bit_cast(float4, bq[g]);
+            t[4 * g + 0] = bb.x, t[4 * g + 1] = bb.y, t[4 * g + 2] = bb.z, t[4 * g + 3] = bb.w;
+        }
+    };
 #define X6_STEP1(I_, T_)                                                                                                 \
     {                                                                                                                    \
         const int step_ = (I_);                                                                                          \
+        unsigned long long sq_0 = 0, sq_1 = 0;                                                                           \
+        X6_T(sq_0)                                                                                                       \
         const unsigned int sb_ = fr_addr + (unsigned int)((step_ % NSLOT) * X6_STEP_B);                                  \
         const unsigned int sn_ = fr_addr + (unsigned int)(((step_ + 1) % NSLOT) * X6_STEP_B);                            \
         x6_static_for<0, 24>([&](auto fc_) __attribute__((always_inline)) {                                              \
@@ -1505,43 +1574,59 @@ __global__ void __launch_bounds__(256, 2) k_block_x6(BlockX6Args a) {
             X6_READ_AHEAD(f_)                                                                                            \
             const x6_bf16x8 w_ = __builtin_bit_cast(x6_bf16x8, af[f_ & 3]);                                              \
             if constexpr (pl_ == 0) {                                                                                    \
-                T_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, Yp[g_ >> 1][g_ & 1][2], T_, 0, 0, 0);                   \
-                T_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, Yp[g_ >> 1][g_ & 1][1], T_, 0, 0, 0);                   \
-                T_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, Yp[g_ >> 1][g_ & 1][0], T_, 0, 0, 0);                   \
+                X6_MM(w_, Yp[g_ >> 1][g_ & 1][2], T_);                   \
+                X6_MM(w_, Yp[g_ >> 1][g_ & 1][1], T_);                   \
+                X6_MM(w_, Yp[g_ >> 1][g_ & 1][0], T_);                   \
             } else if constexpr (pl_ == 1) {                                                                             \
-                T_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, Yp[g_ >> 1][g_ & 1][1], T_, 0, 0, 0);                   \
-                T_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, Yp[g_ >> 1][g_ & 1][0], T_, 0, 0, 0);                   \
+                X6_MM(w_, Yp[g_ >> 1][g_ & 1][1], T_);                   \
+                X6_MM(w_, Yp[g_ >> 1][g_ & 1][0], T_);                   \
             } else                                                                                                       \
-                T_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, Yp[g_ >> 1][g_ & 1][0], T_, 0, 0, 0);                   \
+                X6_MM(w_, Yp[g_ >> 1][g_ & 1][0], T_);                   \
         });                                                                                                              \
+        X6_T(sq_1)                                                                                                       \
+        st_steps += sq_1 - sq_0;                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    }
+    // four-tile step on CACHED planes XC_[s][plane] of the k tile (the QKV passes: x' is split once, not once per pass)
+#define X6_STEPC(I_, XC_, T0, T1, T2, T3)                                                                                \
+    {                                                                                                                    \
+        const int step_ = (I_);                                                                                          \
+        unsigned long long sq_0 = 0, sq_1 = 0;                                                                           \
+        X6_T(sq_0)                                                                                                       \
+        const unsigned int sb_ = fr_addr + (unsigned int)((step_ % NSLOT) * X6_STEP_B);                                  \
+        const unsigned int sn_ = fr_addr + (unsigned int)(((step_ + 1) % NSLOT) * X6_STEP_B);                            \
+        x6_static_for<0, 24>([&](auto fc_) __attribute__((always_inline)) {                                              \
+            constexpr int f_ = decltype(fc_)::value, g_ = f_ / 3, pl_ = f_ % 3;                                          \
+            if constexpr (f_ == 12) { X6_PUBLISH(step_) }                                                                \
+            X6_READ_AHEAD(f_)                                                                                            \
+            const x6_bf16x8 w_ = __builtin_bit_cast(x6_bf16x8, af[f_ & 3]);                                              \
+            f32x16 &T_ = (g_ & 3) == 0 ? T0 : (g_ & 3) == 1 ? T1 : (g_ & 3) == 2 ? T2 : T3;                              \
+            if constexpr (pl_ == 0) {                                                                                    \
+                X6_MM(w_, XC_[g_ >> 2][2], T_);                          \
+                X6_MM(w_, XC_[g_ >> 2][1], T_);                          \
+                X6_MM(w_, XC_[g_ >> 2][0], T_);                          \
+            } else if constexpr (pl_ == 1) {                                                                             \
+                X6_MM(w_, XC_[g_ >> 2][1], T_);                          \
+                X6_MM(w_, XC_[g_ >> 2][0], T_);                          \
+            } else                                                                                                       \
+                X6_MM(w_, XC_[g_ >> 2][0], T_);                          \
+        });                                                                                                              \
+        X6_T(sq_1)                                                                                                       \
+        st_steps += sq_1 - sq_0;                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }
 #pragma unroll
     for (int ft = 0; ft < 8; ++ft) {
         f32x16 hft;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hft[r] = 0.f;
+        bias_tile(hft, V_B1 + ft * 32); // the accumulator starts from b1 of this hidden tile
         X6_STEP1(4 + 2 * ft, hft)
-        // b1 of this hidden tile: asm reads too (a compiler-visible LDS read here waits for the DMA issued half a step
-        // ago); the wait drains the fragment read-aheads with it, which only makes the next step's counted waits pass early
-        x6_u32x4 bq[4];
-        {
-            const unsigned int ba_ = vecs_addr + (unsigned int)((V_B1 + ft * 32) * 4);
-            bq[0] = x6_rd<0>(ba_), bq[1] = x6_rd<32>(ba_), bq[2] = x6_rd<64>(ba_), bq[3] = x6_rd<96>(ba_);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]));
-        }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 bb = __builtin_bit_cast(float4, bq[g]);
-            hft[4 * g + 0] = fmaxf(hft[4 * g + 0] + bb.x, 0.f);
-            hft[4 * g + 1] = fmaxf(hft[4 * g + 1] + bb.y, 0.f);
-            hft[4 * g + 2] = fmaxf(hft[4 * g + 2] + bb.z, 0.f);
-            hft[4 * g + 3] = fmaxf(hft[4 * g + 3] + bb.w, 0.f);
-        }
+        for (int r = 0; r < 16; ++r) hft[r] = fmaxf(hft[r], 0.f);
         X6_STEP(5 + 2 * ft, hft, acc[0], acc[1], acc[2], acc[3])
     }
 #undef X6_STEP1
-    // ---- + b2, LN3 -> x' (fragment-major store), kept in acc as the QKV tail's B operand
+    X6_T(st_p[3])
+    // ---- + b2, LN3 -> x' (fragment-major store), then split ONCE into the plane registers as the QKV tail's B operand
     {
         float sum = 0.f;
 #pragma unroll
@@ -1577,39 +1662,60 @@ __global__ void __launch_bounds__(256, 2) k_block_x6(BlockX6Args a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
     }
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            x6_split(acc[tn], s2, Yp[tn][s2]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    X6_T(st_p[4])
+    unsigned long long st_q0 = 0, st_q1 = 0, st_qst = 0;
     // ---- the next layer's QKV: passes of 128 output columns (4 tiles), k tile tn; sequence steps 20 ..
 #pragma unroll
     for (int pp = 0; pp < 3; ++pp) {
         if (pp >= 3 - QP0) break;
+        const int c0 = 128 * (pp + QP0);
         f32x16 qa[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) qa[i][r] = 0.f;
+        for (int i = 0; i < 4; ++i) bias_tile(qa[i], V_BIN + c0 + i * 32); // the accumulators start from b_in
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) {
-            X6_STEP(20 + 4 * pp + tn, acc[tn], qa[0], qa[1], qa[2], qa[3])
+            X6_STEPC(20 + 4 * pp + tn, Yp[tn], qa[0], qa[1], qa[2], qa[3])
         }
         landed_all(); // (control flow ahead: no fragment register may still be awaiting its LDS return)
+        X6_T(st_q0)
         if (mt < M) {
-            const int c0 = 128 * (pp + QP0);
             float *qrow = a.QKV + (int64_t)mt * (3 * D) + c0 + 4 * lk;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 bb = *reinterpret_cast<const float4 *>(vecs + V_BIN + c0 + i * 32 + 8 * g + 4 * lk);
-                    *reinterpret_cast<float4 *>(qrow + i * 32 + 8 * g) =
-                        make_float4(qa[i][4 * g + 0] + bb.x, qa[i][4 * g + 1] + bb.y, qa[i][4 * g + 2] + bb.z, qa[i][4 * g + 3] + bb.w);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4 *>(qrow + i * 32 + 8 * g) = make_float4(qa[i][4 * g + 0], qa[i][4 * g + 1], qa[i][4 * g + 2], qa[i][4 * g + 3]);
         }
+        X6_T(st_q1)
+        st_qst += st_q1 - st_q0;
     }
     landed_all(); // the reads issued past the last step
+#ifdef X6_STAMP
+    X6_T(st_1)
+    if (lane == 0) {
+        unsigned long long *o = a.stamps + (size_t)(blockIdx.x * NW + wave) * 8;
+        o[0] = st_1 - st_p[0], o[1] = st_wait, o[2] = st_bar, o[3] = st_iss, o[4] = st_steps;
+        o[5] = st_0 - st_p[0];                                   // prologue
+        o[6] = (st_p[2] - st_p[1]) + (st_p[4] - st_p[3]);         // layer norms + plane splits
+        o[7] = st_qst;                                            // q | k | v stores
+    }
+#endif
+    (void)st_p, (void)st_q0, (void)st_q1, (void)st_qst;
+    (void)st_a, (void)st_b, (void)st_c, (void)st_d, (void)st_wait, (void)st_bar, (void)st_iss, (void)st_0, (void)st_1, (void)st_steps;
 #undef X6_STEP
+#undef X6_STEPC
 #undef X6_PUBLISH
+#undef X6_ISSUE
 #undef X6_READ_AHEAD
 #undef X6_MFMA
+#undef X6_MM
 }
 
 // ------------------------------------------------------------------ embed + layer 0's QKV (d = 128, throughput shapes)
@@ -4072,21 +4178,24 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                 ba.Af = yf, ba.Rf = xf, ba.Wo = w.sa_out_w, ba.bo = w.sa_out_b;
                 ba.g1 = w.n1_w, ba.b1n = w.n1_b, ba.c = cl, ba.g2 = w.n2_w, ba.b2n = w.n2_b;
                 irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
+                if (tail) irs_prof_begin(ctx, IRS_PROF_LAYER, s); // (one family is enabled at a time)
                 if (tail && ctx->use_x6 && ctx->w_x6) { // the same layer tail on split-bf16 MFMAs
                     BlockX6Args xa{yf, xf, ctx->w_x6 + (size_t)l * (X6_LAYER_BYTES / 16), w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b,
                                    w.l1_b, w.l2_b, w.n3_w, w.n3_b, ctx->layer[l + 1].sa_in_b, xf, ctx->act_qkv, rows, m_dev, kv_only ? 1 : 0};
                     constexpr int x6_lds = 3 * X6_STEP_B + 1792 * 4;
                     static bool attr = false;
                     if (!attr) {
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds);
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<1>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, X6_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<1, X6_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds);
                         attr = true;
                     }
-                    if (kv_only) hipLaunchKernelGGL(k_block_x6<1>, dim3((rows + 127) / 128), dim3(256), x6_lds, s, xa);
-                    else hipLaunchKernelGGL(k_block_x6<0>, dim3((rows + 127) / 128), dim3(256), x6_lds, s, xa);
+                    const dim3 x6_grid((rows + 32 * X6_NW - 1) / (32 * X6_NW));
+                    if (kv_only) hipLaunchKernelGGL((k_block_x6<1, X6_NW>), x6_grid, dim3(64 * X6_NW), x6_lds, s, xa);
+                    else hipLaunchKernelGGL((k_block_x6<0, X6_NW>), x6_grid, dim3(64 * X6_NW), x6_lds, s, xa);
                 } else if (tail) hipLaunchKernelGGL((k_block<true, true>), dim3((rows + 127) / 128), dim3(256), 0, s, ba);
                 else hipLaunchKernelGGL((k_block<true, false>), dim3((rows + 127) / 128), dim3(256), 0, s, ba);
                 irs_prof_end(ctx, IRS_PROF_LINEAR, s, ffn_flops + 2.0 * rows * (double)d * d, (8.0 + 4.0 + (tail ? 12.0 : 0.0)) * rows * (double)d);
+                if (tail) irs_prof_end(ctx, IRS_PROF_LAYER, s, ffn_flops + 2.0 * rows * (double)d * d, (8.0 + 4.0 + 12.0) * rows * (double)d);
                 qkv_done = tail;
                 IRS_CHECK_HIP(ctx, hipGetLastError());
                 continue;

@@ -434,6 +434,16 @@ class Engine:
                                                          _ptr(fin), _ptr(status), self._stream()))
         return (paths, scores, status, fin) if want_windows else (paths, scores, status)
 
+    # ------------------------------------------------------------------ decoder GEMM arithmetic
+    @property
+    def decoder_gemm(self) -> int:
+        """IRS_GEMM_X6 (split-bf16 MFMAs, the default) or IRS_GEMM_F32 (float32 MFMAs): include/irs_hip.h."""
+        return int(self.lib.irs_get_decoder_gemm(self.h))
+
+    @decoder_gemm.setter
+    def decoder_gemm(self, mode: int):
+        self._check(self.lib.irs_set_decoder_gemm(self.h, int(mode)))
+
     # ------------------------------------------------------------------ measurement
     def prof_enable(self, family: int):
         with torch.cuda.device(self.device):

@@ -486,3 +486,66 @@ def test_decoder_random_shapes_against_oracle(oracle, d, H, F, L, B, nl):
         m = np.isfinite(ref) & np.isfinite(got)
         assert np.array_equal(np.isnan(ref), np.isnan(got))
         assert np.abs(ref - got)[m].max() < tol, (b, np.abs(ref - got)[m].max())
+
+
+@pytest.mark.parametrize("B,kv_only", [(176, False), (2048, True)])
+def test_split_bf16_layer_kernel_equals_float32_mfma_kernel(oracle, B, kv_only):
+    """irs_set_decoder_gemm: the fused layer kernel on split-bf16 MFMAs (IRS_GEMM_X6, the default: three bf16 planes per
+    float32 operand, the six leading products) against the same kernel on float32 MFMAs (IRS_GEMM_F32) on the same
+    batch: rows agree to float32 accumulation noise (both accumulate in float32; after six layers the two differ by up to
+    ~1e-5 on O(1) values, the same size as either one's distance to the numpy oracle: the bound is the decoder tolerance), top-100 ids agree wherever the float32 scores are separated by more than that noise, and both
+    agree with the numpy oracle.  B = 176 decodes every row (q | k | v tail everywhere), B = 2048 with rows-only output
+    packs the rows and feeds the last layer its k | v only (the kernel's second instantiation).  A mode change drops
+    the captured path-search step: the graph call after it must follow the new mode."""
+    from influentialrs_amd._lib import IRS_GEMM_F32, IRS_GEMM_X6
+    cfg = synth.make_config("c2")
+    L = cfg.max_len
+    sd = synth.irn_state_dict(cfg, 777)
+    eng = make_engine(cfg, sd, max_rows=B, max_seqs=B)
+    assert eng.decoder_gemm == (IRS_GEMM_F32 if os.environ.get("IRS_DECODER_GEMM") == "f32" else IRS_GEMM_X6)
+    hists = synth.user_histories(B, cfg.n_item, seed=41)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=43)
+    _, seqs, users, _, _ = synth.collate_eval_irs(rows, L, gap_len=1)
+    seq, u = torch.from_numpy(seqs).cuda(), torch.from_numpy(users).cuda()
+    pos = torch.full((B,), L - 2, dtype=torch.int32, device="cuda")
+    out = {}
+    for mode in (IRS_GEMM_X6, IRS_GEMM_F32):
+        eng.decoder_gemm = mode
+        assert eng.decoder_gemm == mode
+        x, xr, _ = eng.decode(seq, u, want_x=not kv_only, pos=pos)
+        val, ids, st = eng.score_topk(xr, 100, IRS_SWEEP_F32)
+        out[mode] = (None if kv_only else x.clone(), xr.clone(), val.clone(), ids.clone())
+    xa, ra, va, ia = out[IRS_GEMM_X6]
+    xb, rb, vb, ib = out[IRS_GEMM_F32]
+    assert not torch.equal(ra, rb), "the two modes must not be the same code path"
+    assert (ra - rb).abs().max().item() < X_TOL
+    if not kv_only:
+        ok = torch.isfinite(xa) & torch.isfinite(xb)
+        assert torch.equal(torch.isnan(xa), torch.isnan(xb)) and (xa - xb)[ok].abs().max().item() < X_TOL
+    assert (va - vb).abs().max().item() < TAU
+    vbn, ian, ibn = vb.cpu().numpy(), ia.cpu().numpy(), ib.cpu().numpy()
+    for b in range(B):  # ids equal up to swaps inside near-ties of the float32-mode scores
+        diff = np.nonzero(ian[b] != ibn[b])[0]
+        for j in diff:
+            near = np.abs(vbn[b] - vbn[b, j]) < TAU
+            assert near.sum() > 1 or j == 99, (b, j)
+    for b in (0, 7):
+        ref = oracle.decode(sd, cfg, seqs[b], int(users[b]))[0][L - 2]
+        for r in (ra, rb):
+            assert np.abs(ref - r[b].cpu().numpy()).max() < X_TOL
+    # captured steps follow the mode (B = 176: 35200 token rows, the throughput kernels)
+    if kv_only:
+        return
+    nb = B
+    hep = torch.full((nb,), L - 2, dtype=torch.int32, device="cuda")
+    paths = {}
+    for mode in (IRS_GEMM_F32, IRS_GEMM_X6, IRS_GEMM_F32):
+        eng.decoder_gemm = mode
+        p, _ = eng.generate_paths(seq[:nb].clone(), u[:nb], hep.clone(), 6, use_graph=True)[:2]  # (windows are advanced in place)
+        pe, _ = eng.generate_paths(seq[:nb].clone(), u[:nb], hep.clone(), 6, use_graph=False)[:2]
+        assert torch.equal(p, pe)
+        paths.setdefault(mode, p.clone())
+        assert torch.equal(paths[mode], p)
+    with pytest.raises(Exception):
+        eng.decoder_gemm = 7
+    eng.decoder_gemm = IRS_GEMM_X6

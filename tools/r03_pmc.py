@@ -13,7 +13,8 @@ import os
 import sys
 
 KERNELS = {  # name prefix -> algorithmic HBM bytes per packed row of one launch (d = 128, float32)
-    "k_block": 4 * 128 * (2 + 1 + 3),      # in: attention output + residual x; out: x' and the next layer's q | k | v
+    "k_block_x6": 4 * 128 * (2 + 1 + 3),   # in: attention output + residual x; out: x' and the next layer's q | k | v
+    "k_block": 4 * 128 * (2 + 1 + 3),      # (IRS_GEMM_F32: the same kernel on float32 MFMAs; with IRS_GEMM_X6 only the last layer's, whose outputs differ)
     "k_attn16": 4 * 128 * (3 + 1),         # in: q | k | v; out: attention output (fragment-major)
     "k_embed_qkv": 4 * 128 * (1 + 1 + 3),  # in: embedding row; out: x and layer 0's q | k | v
 }

@@ -50,12 +50,17 @@ int main(int argc, char **argv) {
     ba.W1 = W1, ba.b1 = b1, ba.W2 = W2, ba.b2 = b2, ba.g = g3, ba.b = b3, ba.Xf = Xf[0], ba.Y = nullptr, ba.M = M, ba.m_dev = nullptr;
     ba.Win = Win, ba.bin = bin, ba.QKV = QKV[0], ba.qkv_n0 = 0, ba.qkv_nt1 = 6;
     BlockX6Args xa{Af, Rf, Wx, bo, g1, b1n, c, g2, b2n, b1, b2, g3, b3, bin, Xf[1], QKV[1], M, nullptr, 0};
+#ifdef X6_STAMP
+    const size_t nwave = (size_t)((M + 32 * X6_NW - 1) / (32 * X6_NW)) * X6_NW;
+    CK(hipMalloc(&xa.stamps, nwave * 64));
+    CK(hipMemset(xa.stamps, 0, nwave * 64));
+#endif
 #ifdef X6_DUMP
     CK(hipMalloc(&xa.dbg, X6_LAYER_BYTES));
     CK(hipMemset(xa.dbg, 0xEE, X6_LAYER_BYTES));
 #endif
     constexpr int x6_lds = 3 * X6_STEP_B + 1792 * 4;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, X6_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -69,7 +74,7 @@ int main(int argc, char **argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         printf("k_block<f32>  %8.1f us\n", ms * 1e3);
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k_block_x6<0>, dim3((M + 127) / 128), dim3(256), x6_lds, 0, xa);
+        hipLaunchKernelGGL((k_block_x6<0, X6_NW>), dim3((M + 32 * X6_NW - 1) / (32 * X6_NW)), dim3(64 * X6_NW), x6_lds, 0, xa);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         CK(hipGetLastError());
@@ -105,6 +110,18 @@ int main(int argc, char **argv) {
             }
             printf("\n");
         }
+    }
+#endif
+#ifdef X6_STAMP
+    {
+        std::vector<unsigned long long> hs(nwave * 8);
+        CK(hipMemcpy(hs.data(), xa.stamps, nwave * 64, hipMemcpyDeviceToHost));
+        double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t w = 0; w < nwave; ++w)
+            for (int k = 0; k < 8; ++k) t[k] += (double)hs[w * 8 + k] / nwave;
+        printf("stamps (s_memtime ticks per wave, mean over %zu waves): kernel %.0f = prologue %.0f + layer norms and splits %.0f + q|k|v stores %.0f + "
+               "steps %.0f (%.1f per step; of which DMA wait %.0f, barrier %.0f, DMA issue %.0f) + rest %.0f\n", nwave, t[0], t[5], t[6], t[7], t[4],
+               t[4] / 32, t[1], t[2], t[3], t[0] - t[5] - t[6] - t[7] - t[4]);
     }
 #endif
     cmp("x' (fragment-major)", Xf[0], Xf[1], (size_t)M * D);
