@@ -1215,8 +1215,8 @@ __global__ void __launch_bounds__(256) k_pack_x6(const float *__restrict__ Wo, c
     const int gid = blockIdx.x * 256 + threadIdx.x; // < 32 steps * 24 pieces * 64 lanes
     if (gid >= X6_NSTEP * 24 * 64) return;
     const int lane = gid & 63, piece = (gid >> 6) % 24, step = gid / (24 * 64);
-    // piece = 3 g + plane in the kernel's consumption order.  "Four-tile" steps (out-projection, FFN-2, QKV): group g =
-    // (k-step s = g >> 2, output tile nt = g & 3) of one 32-wide k tile; "one-tile" steps (FFN-1): ONE output tile over
+    // piece = 3 g + plane in the kernel's consumption order.  "Four-tile" steps (out-projection, FFN-2): group g =
+    // (k-step s = g >> 2, output tile nt = g & 3) of one 32-wide k tile; "one-tile" steps (FFN-1, QKV): ONE output tile over
     // the whole K = 128, group g = (k tile g >> 1, k-step s = g & 1).
     const int p = piece % 3, g = piece / 3;
     const int r = lane & 31, hh = lane >> 5;
@@ -1227,7 +1227,7 @@ __global__ void __launch_bounds__(256) k_pack_x6(const float *__restrict__ Wo, c
         const int ft = (step - 4) >> 1;
         if (((step - 4) & 1) == 0) W = W1, ld = 128, s = g & 1, n = 32 * ft + r, kb = 32 * (g >> 1); // FFN-1, hidden tile ft
         else W = W2, ld = 256, s = g >> 2, n = 32 * (g & 3) + r, kb = 32 * ft;                       // FFN-2, k tile ft
-    } else W = Win, ld = 128, s = g >> 2, n = 32 * (4 * ((step - 20) >> 2) + (g & 3)) + r, kb = 32 * ((step - 20) & 3);
+    } else W = Win, ld = 128, s = g & 1, n = 32 * (step - 20) + r, kb = 32 * (g >> 1); // q | k | v output tile step - 20 (one-tile)
     unsigned int hw[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1255,6 +1255,13 @@ struct BlockX6Args {
     int M;
     const int32_t *m_dev;
     int qkv_pass0;         // (documentation only: the kernel's QP0 template parameter decides)
+    // EMBED instantiation (layer 0's input: x = item_emb[seq] * sqrt(d) + pe[pos], then layer 0's q | k | v)
+    const int64_t *seq;
+    const float *E, *pe;
+    const int32_t *tok_row;
+    int L;
+    float sqrtd;
+    int64_t n_item;
 #ifdef X6_DUMP
     uint4 *dbg;            // (lab) the fragments workgroup 0 / wave 0 consumed, [step][fragment][lane]
 #endif
@@ -1306,9 +1313,13 @@ __device__ __forceinline__ x6_u32x4 x6_rd(unsigned int base) {
 #define X6_T(v_)
 #endif
 // NW = waves per workgroup (4 or 8), each on its own 32 tokens; the 24 1-KB pieces of a step are fetched 24 / NW per wave
-template <int QP0, int NW>
+// EMBED: the kernel in front of layer 0 -- the accumulator tiles are filled with the embedded tokens (k_embed_frag's
+// arithmetic) instead of a layer's result, written to Xf, and only the q | k | v steps (20 .. 31 of a stream whose other
+// blocks are unused) run: the same ring, the same step code.
+template <int QP0, int NW, bool EMBED>
 __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
     constexpr int D = 128, F = 256, NSLOT = 3, PPW = 24 / NW;
+    constexpr int S0 = EMBED ? 20 : 0; // first step of the sequence
     constexpr int V_B1 = 0, V_B2 = F, V_G = F + D, V_B = F + 2 * D, V_BIN = F + 3 * D, V_O = F + 3 * D + 3 * D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *vecs = reinterpret_cast<float *>(smem + NSLOT * X6_STEP_B); // b1[256], b2, g, b, b_in[384], b_o, g1, b1n, c, g2, b2n
@@ -1321,10 +1332,12 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
     const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M;
     if (m0 >= M) return;
     if (tid < 256) {
-        vecs[V_B1 + tid] = a.b1[tid];
+        if (!EMBED) vecs[V_B1 + tid] = a.b1[tid];
         vecs[V_BIN + tid] = a.bin[tid];
     }
-    if (tid < D) {
+    if (EMBED) {
+        if (tid < D) vecs[V_BIN + 256 + tid] = a.bin[256 + tid];
+    } else if (tid < D) {
         vecs[V_B2 + tid] = a.b2[tid];
         vecs[V_G + tid] = a.g[tid];
         vecs[V_B + tid] = a.b[tid];
@@ -1365,30 +1378,55 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
     };
     // accumulators start from the residual x; the attention output tile 0 is requested with it
     f32x16 acc[4];
-    const float4 *rfrag = reinterpret_cast<const float4 *>(a.Rf) + fbase;
-    const float4 *afrag = reinterpret_cast<const float4 *>(a.Af) + fbase;
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 t4 = rfrag[(tn * 4 + g) * 64];
-            acc[tn][4 * g + 0] = t4.x, acc[tn][4 * g + 1] = t4.y, acc[tn][4 * g + 2] = t4.z, acc[tn][4 * g + 3] = t4.w;
-        }
     f32x16 at[4]; // attention output tiles (B operand source of the out-projection): all four requested here, so that
                   // the steps carry no plain global load (its wait would be a vmcnt(0) behind the DMA pieces)
+    if constexpr (!EMBED) {
+        const float4 *rfrag = reinterpret_cast<const float4 *>(a.Rf) + fbase;
+        const float4 *afrag = reinterpret_cast<const float4 *>(a.Af) + fbase;
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 t4 = afrag[(tn * 4 + g) * 64];
-            at[tn][4 * g + 0] = t4.x, at[tn][4 * g + 1] = t4.y, at[tn][4 * g + 2] = t4.z, at[tn][4 * g + 3] = t4.w;
-        }
-    issue(0);
+            for (int g = 0; g < 4; ++g) {
+                const float4 t4 = rfrag[(tn * 4 + g) * 64];
+                acc[tn][4 * g + 0] = t4.x, acc[tn][4 * g + 1] = t4.y, acc[tn][4 * g + 2] = t4.z, acc[tn][4 * g + 3] = t4.w;
+            }
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t4 = afrag[(tn * 4 + g) * 64];
+                at[tn][4 * g + 0] = t4.x, at[tn][4 * g + 1] = t4.y, at[tn][4 * g + 2] = t4.z, at[tn][4 * g + 3] = t4.w;
+            }
+    } else { // this lane's token, columns 32 tn + 8 g + 4 lk + e (k_embed_frag's arithmetic: the bits k_embed_qkv writes)
+        const bool live = mt < M;
+        const int orig = live ? (a.tok_row ? a.tok_row[mt] : mt) : 0;
+        int64_t id = live ? a.seq[orig] : 0;
+        if (id < 0) id = 0;
+        if (id > a.n_item) id = a.n_item;
+        const float *e = a.E + id * (int64_t)D;
+        const float *pp_ = a.pe + (int64_t)(orig % a.L) * D;
+        float4 *xo = reinterpret_cast<float4 *>(a.Xf) + fbase;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = tn * 32 + 8 * g + 4 * lk;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live) {
+                    const float4 ev = *reinterpret_cast<const float4 *>(e + n), pv = *reinterpret_cast<const float4 *>(pp_ + n);
+                    v = make_float4(__fadd_rn(__fmul_rn(ev.x, a.sqrtd), pv.x), __fadd_rn(__fmul_rn(ev.y, a.sqrtd), pv.y),
+                                    __fadd_rn(__fmul_rn(ev.z, a.sqrtd), pv.z), __fadd_rn(__fmul_rn(ev.w, a.sqrtd), pv.w));
+                }
+                xo[(tn * 4 + g) * 64] = v;
+                acc[tn][4 * g + 0] = v.x, acc[tn][4 * g + 1] = v.y, acc[tn][4 * g + 2] = v.z, acc[tn][4 * g + 3] = v.w;
+            }
+    }
+    issue(S0);
     // everything older than this point has landed (the compiler is free to order the plain loads above around the DMA
-    // issue, so no counted wait here), the vecs stores too; step 1 goes out behind the barrier
+    // issue, so no counted wait here), the vecs stores too; the second step goes out behind the barrier
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    issue(1);
+    issue(S0 + 1);
 
     // fragment reads: the stream of a step is 8 groups x (plane 0, 1, 2) = 24 reads in consumption order (k_pack_x6); a
     // ring of four register sets, three reads ahead
@@ -1397,10 +1435,10 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[q]));
     };
-    af[0] = x6_rd<0>(fr_addr);
-    af[1] = x6_rd<1024>(fr_addr);
-    af[2] = x6_rd<2048>(fr_addr);
-    af[3] = x6_rd<2048>(fr_addr); // (its own read: a register copy of af[2] would be taken before the data has landed)
+    af[0] = x6_rd<(S0 % NSLOT) * X6_STEP_B>(fr_addr);
+    af[1] = x6_rd<(S0 % NSLOT) * X6_STEP_B + 1024>(fr_addr);
+    af[2] = x6_rd<(S0 % NSLOT) * X6_STEP_B + 2048>(fr_addr);
+    af[3] = x6_rd<(S0 % NSLOT) * X6_STEP_B + 2048>(fr_addr); // (its own read: a register copy of af[2] would be taken before the data has landed)
     landed_all();
 
     const float invn = 1.0f / (float)D;
@@ -1485,9 +1523,11 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
     // every read of the schedule is in flight)
 
     // ---- out-projection: acc += W_o . ao^T, k tile tn = step
+    if constexpr (!EMBED) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        X6_STEP(t, at[t], acc[0], acc[1], acc[2], acc[3])
+        for (int t = 0; t < 4; ++t) {
+            X6_STEP(t, at[t], acc[0], acc[1], acc[2], acc[3])
+        }
     }
     // ---- + b_o, LN1, + c, LN2: register-local (64 of the 128 values here, 64 in lane ^ 32)
     auto layer_norm = [&](int vb, int vg, int vbeta, int vadd) __attribute__((always_inline)) {
@@ -1530,8 +1570,10 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
             }
     };
     X6_T(st_p[1])
-    layer_norm(V_O + 0 * D, V_O + 1 * D, V_O + 2 * D, V_O + 3 * D);
-    if (a.c) layer_norm(-1, V_O + 4 * D, V_O + 5 * D, -1);
+    if constexpr (!EMBED) {
+        layer_norm(V_O + 0 * D, V_O + 1 * D, V_O + 2 * D, V_O + 3 * D);
+        if (a.c) layer_norm(-1, V_O + 4 * D, V_O + 5 * D, -1);
+    }
     X6_T(st_p[2])
 
     // ---- feed-forward, one hidden tile (32 units) at a time: FFN-1 step h_ft = W1[32 ft ..] y^T over the whole K = 128
@@ -1540,13 +1582,15 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
     //      all eight hidden tiles, then FFN-2 -- keeps 128 registers of h beside the 64 of y: with the split's
     //      temporaries that is ~265 of the 256 registers two waves per SIMD have: 173 spilled.)
     x6_bf16x8 Yp[4][2][3];
+    if constexpr (!EMBED) {
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            x6_split(acc[tn], s2, Yp[tn][s2]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+            for (int s2 = 0; s2 < 2; ++s2) {
+                x6_split(acc[tn], s2, Yp[tn][s2]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
     // a 32-value bias tile (vecs offset vo) into an accumulator tile: asm reads (a compiler-visible LDS read here would wait
     // for the DMA issued half a step ago); the wait drains the fragment read-aheads with it, which only makes the next
     // step's counted waits pass early
@@ -1561,73 +1605,71 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
             t[4 * g + 0] = bb.x, t[4 * g + 1] = bb.y, t[4 * g + 2] = bb.z, t[4 * g + 3] = bb.w;
         }
     };
-#define X6_STEP1(I_, T_)                                                                                                 \
+    // One-tile step (FFN-1, QKV): ONE 32-row output tile over the whole K = 128, B operand = the cached planes
+    // XP_[k tile][k-step][plane].  The bf16 matrix pipe adds into its float32 accumulator by truncation, so every MFMA on an
+    // accumulator of full magnitude costs up to one ulp of it; here the 40 small products (h.m, h.l, m.m, m.h, l.h) go FIRST
+    // into the zero-started accumulator, where they and their truncation are 2^-8 of the result, and the 8 h.h products
+    // last: 8 full-size truncations per output instead of 48 (the W_h fragments are read from the slot a second time: the
+    // step's virtual read sequence is its 24 fragments, then fragments 0, 3, .., 21 again).
+#ifdef X6_NO_READS
+#define X6_RD_V(v_)
+#define X6_WAIT_V(v_) asm volatile("" : "+v"(af[(v_) & 3]));
+#else
+#define X6_RD_V(v_)                                                                                                      \
+    if constexpr ((v_) < 24) af[(v_) & 3] = x6_rd<(v_) * 1024>(sb_);                                                     \
+    else if constexpr ((v_) < 32) af[(v_) & 3] = x6_rd<3 * ((v_) - 24) * 1024>(sb_);                                     \
+    else af[(v_) & 3] = x6_rd<((v_) - 32) * 1024>(sn_); /* next step's head (behind this step's barrier) */
+#define X6_WAIT_V(v_) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(af[(v_) & 3]));
+#endif
+#define X6_STEP1(I_, XP_, T_)                                                                                            \
     {                                                                                                                    \
         const int step_ = (I_);                                                                                          \
         unsigned long long sq_0 = 0, sq_1 = 0;                                                                           \
         X6_T(sq_0)                                                                                                       \
         const unsigned int sb_ = fr_addr + (unsigned int)((step_ % NSLOT) * X6_STEP_B);                                  \
         const unsigned int sn_ = fr_addr + (unsigned int)(((step_ + 1) % NSLOT) * X6_STEP_B);                            \
-        x6_static_for<0, 24>([&](auto fc_) __attribute__((always_inline)) {                                              \
-            constexpr int f_ = decltype(fc_)::value, g_ = f_ / 3, pl_ = f_ % 3;                                          \
-            if constexpr (f_ == 12) { X6_PUBLISH(step_) }                                                                \
-            X6_READ_AHEAD(f_)                                                                                            \
-            const x6_bf16x8 w_ = __builtin_bit_cast(x6_bf16x8, af[f_ & 3]);                                              \
-            if constexpr (pl_ == 0) {                                                                                    \
-                X6_MM(w_, Yp[g_ >> 1][g_ & 1][2], T_);                   \
-                X6_MM(w_, Yp[g_ >> 1][g_ & 1][1], T_);                   \
-                X6_MM(w_, Yp[g_ >> 1][g_ & 1][0], T_);                   \
-            } else if constexpr (pl_ == 1) {                                                                             \
-                X6_MM(w_, Yp[g_ >> 1][g_ & 1][1], T_);                   \
-                X6_MM(w_, Yp[g_ >> 1][g_ & 1][0], T_);                   \
-            } else                                                                                                       \
-                X6_MM(w_, Yp[g_ >> 1][g_ & 1][0], T_);                   \
+        x6_static_for<0, 32>([&](auto vc_) __attribute__((always_inline)) {                                              \
+            constexpr int v_ = decltype(vc_)::value;                                                                     \
+            if constexpr (v_ == 16) { X6_PUBLISH(step_) }                                                                \
+            X6_RD_V(v_ + 3)                                                                                              \
+            X6_WAIT_V(v_)                                                                                                \
+            const x6_bf16x8 w_ = __builtin_bit_cast(x6_bf16x8, af[v_ & 3]);                                              \
+            if constexpr (v_ < 24) {                                                                                     \
+                constexpr int g_ = v_ / 3, pl_ = v_ % 3;                                                                 \
+                X6_DUMP_FRAG(step_, v_)                                                                                  \
+                if constexpr (pl_ == 0) {                                                                                \
+                    X6_MM(w_, XP_[g_ >> 1][g_ & 1][2], T_);                                                              \
+                    X6_MM(w_, XP_[g_ >> 1][g_ & 1][1], T_);                                                              \
+                } else if constexpr (pl_ == 1) {                                                                         \
+                    X6_MM(w_, XP_[g_ >> 1][g_ & 1][1], T_);                                                              \
+                    X6_MM(w_, XP_[g_ >> 1][g_ & 1][0], T_);                                                              \
+                } else                                                                                                   \
+                    X6_MM(w_, XP_[g_ >> 1][g_ & 1][0], T_);                                                              \
+            } else {                                                                                                     \
+                constexpr int g_ = v_ - 24;                                                                              \
+                X6_MM(w_, XP_[g_ >> 1][g_ & 1][0], T_);                                                                  \
+            }                                                                                                            \
         });                                                                                                              \
         X6_T(sq_1)                                                                                                       \
         st_steps += sq_1 - sq_0;                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }
-    // four-tile step on CACHED planes XC_[s][plane] of the k tile (the QKV passes: x' is split once, not once per pass)
-#define X6_STEPC(I_, XC_, T0, T1, T2, T3)                                                                                \
-    {                                                                                                                    \
-        const int step_ = (I_);                                                                                          \
-        unsigned long long sq_0 = 0, sq_1 = 0;                                                                           \
-        X6_T(sq_0)                                                                                                       \
-        const unsigned int sb_ = fr_addr + (unsigned int)((step_ % NSLOT) * X6_STEP_B);                                  \
-        const unsigned int sn_ = fr_addr + (unsigned int)(((step_ + 1) % NSLOT) * X6_STEP_B);                            \
-        x6_static_for<0, 24>([&](auto fc_) __attribute__((always_inline)) {                                              \
-            constexpr int f_ = decltype(fc_)::value, g_ = f_ / 3, pl_ = f_ % 3;                                          \
-            if constexpr (f_ == 12) { X6_PUBLISH(step_) }                                                                \
-            X6_READ_AHEAD(f_)                                                                                            \
-            const x6_bf16x8 w_ = __builtin_bit_cast(x6_bf16x8, af[f_ & 3]);                                              \
-            f32x16 &T_ = (g_ & 3) == 0 ? T0 : (g_ & 3) == 1 ? T1 : (g_ & 3) == 2 ? T2 : T3;                              \
-            if constexpr (pl_ == 0) {                                                                                    \
-                X6_MM(w_, XC_[g_ >> 2][2], T_);                          \
-                X6_MM(w_, XC_[g_ >> 2][1], T_);                          \
-                X6_MM(w_, XC_[g_ >> 2][0], T_);                          \
-            } else if constexpr (pl_ == 1) {                                                                             \
-                X6_MM(w_, XC_[g_ >> 2][1], T_);                          \
-                X6_MM(w_, XC_[g_ >> 2][0], T_);                          \
-            } else                                                                                                       \
-                X6_MM(w_, XC_[g_ >> 2][0], T_);                          \
-        });                                                                                                              \
-        X6_T(sq_1)                                                                                                       \
-        st_steps += sq_1 - sq_0;                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
-    }
+    if constexpr (!EMBED) {
 #pragma unroll
-    for (int ft = 0; ft < 8; ++ft) {
-        f32x16 hft;
-        bias_tile(hft, V_B1 + ft * 32); // the accumulator starts from b1 of this hidden tile
-        X6_STEP1(4 + 2 * ft, hft)
+        for (int ft = 0; ft < 8; ++ft) {
+            f32x16 hft, bt;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hft[r] = fmaxf(hft[r], 0.f);
-        X6_STEP(5 + 2 * ft, hft, acc[0], acc[1], acc[2], acc[3])
+            for (int r = 0; r < 16; ++r) hft[r] = 0.f;
+            X6_STEP1(4 + 2 * ft, Yp, hft)
+            bias_tile(bt, V_B1 + ft * 32);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hft[r] = fmaxf(hft[r] + bt[r], 0.f);
+            X6_STEP(5 + 2 * ft, hft, acc[0], acc[1], acc[2], acc[3])
+        }
     }
-#undef X6_STEP1
     X6_T(st_p[3])
     // ---- + b2, LN3 -> x' (fragment-major store), then split ONCE into the plane registers as the QKV tail's B operand
-    {
+    if constexpr (!EMBED) {
         float sum = 0.f;
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
@@ -1676,25 +1718,24 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
     for (int pp = 0; pp < 3; ++pp) {
         if (pp >= 3 - QP0) break;
         const int c0 = 128 * (pp + QP0);
-        f32x16 qa[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bias_tile(qa[i], V_BIN + c0 + i * 32); // the accumulators start from b_in
+        for (int i = 0; i < 4; ++i) { // output tile 4 pp + i: columns c0 + 32 i ..
+            f32x16 qt, bt;
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            X6_STEPC(20 + 4 * pp + tn, Yp[tn], qa[0], qa[1], qa[2], qa[3])
-        }
-        landed_all(); // (control flow ahead: no fragment register may still be awaiting its LDS return)
-        X6_T(st_q0)
-        if (mt < M) {
-            float *qrow = a.QKV + (int64_t)mt * (3 * D) + c0 + 4 * lk;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int r = 0; r < 16; ++r) qt[r] = 0.f;
+            X6_STEP1(20 + 4 * pp + i, Yp, qt)
+            bias_tile(bt, V_BIN + c0 + i * 32); // (its wait lands every fragment register too: control flow ahead)
+            X6_T(st_q0)
+            if (mt < M) {
+                float *qrow = a.QKV + (int64_t)mt * (3 * D) + c0 + i * 32 + 4 * lk;
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4 *>(qrow + i * 32 + 8 * g) = make_float4(qa[i][4 * g + 0], qa[i][4 * g + 1], qa[i][4 * g + 2], qa[i][4 * g + 3]);
+                    *reinterpret_cast<float4 *>(qrow + 8 * g) = make_float4(qt[4 * g + 0] + bt[4 * g + 0], qt[4 * g + 1] + bt[4 * g + 1],
+                                                                            qt[4 * g + 2] + bt[4 * g + 2], qt[4 * g + 3] + bt[4 * g + 3]);
+            }
+            X6_T(st_q1)
+            st_qst += st_q1 - st_q0;
         }
-        X6_T(st_q1)
-        st_qst += st_q1 - st_q0;
     }
     landed_all(); // the reads issued past the last step
 #ifdef X6_STAMP
@@ -1710,7 +1751,9 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
     (void)st_p, (void)st_q0, (void)st_q1, (void)st_qst;
     (void)st_a, (void)st_b, (void)st_c, (void)st_d, (void)st_wait, (void)st_bar, (void)st_iss, (void)st_0, (void)st_1, (void)st_steps;
 #undef X6_STEP
-#undef X6_STEPC
+#undef X6_STEP1
+#undef X6_RD_V
+#undef X6_WAIT_V
 #undef X6_PUBLISH
 #undef X6_ISSUE
 #undef X6_READ_AHEAD
@@ -3924,16 +3967,30 @@ int irs_launch_cross_const(irs_ctx *ctx, hipStream_t s) {
 static bool x6_shape(const irs_ctx *ctx) {
     return ctx->dims.d == 128 && ctx->dims.ffn_dim == 256 && ctx->dims.d / ctx->dims.n_heads == 32 && ctx->dims.n_layers >= 2;
 }
-size_t irs_x6_bytes(const irs_ctx *ctx) { return x6_shape(ctx) ? (size_t)(ctx->dims.n_layers - 1) * X6_LAYER_BYTES : 0; }
+// streams 0 .. n_layers - 2: layer l's out-projection / FFN and layer l + 1's q | k | v; stream n_layers - 1: layer 0's
+// q | k | v alone (the embed kernel's; its other blocks are zero and never fetched)
+size_t irs_x6_bytes(const irs_ctx *ctx) { return x6_shape(ctx) ? (size_t)ctx->dims.n_layers * X6_LAYER_BYTES : 0; }
 int irs_launch_pack_x6(irs_ctx *ctx, hipStream_t s) {
     if (!ctx->w_x6) return IRS_OK;
-    for (int l = 0; l + 1 < ctx->dims.n_layers; ++l) {
+    const int nl = ctx->dims.n_layers;
+    for (int l = 0; l + 1 < nl; ++l) {
         const irs_layer_w &w = ctx->layer[l];
         hipLaunchKernelGGL(k_pack_x6, dim3(X6_NSTEP * 24 * 64 / 256), dim3(256), 0, s, w.sa_out_w, w.l1_w, w.l2_w,
                            ctx->layer[l + 1].sa_in_w, ctx->w_x6 + (size_t)l * (X6_LAYER_BYTES / 16));
     }
+    hipLaunchKernelGGL(k_pack_x6, dim3(X6_NSTEP * 24 * 64 / 256), dim3(256), 0, s, (const float *)nullptr, (const float *)nullptr,
+                       (const float *)nullptr, ctx->layer[0].sa_in_w, ctx->w_x6 + (size_t)(nl - 1) * (X6_LAYER_BYTES / 16));
     IRS_CHECK_HIP(ctx, hipGetLastError());
     return IRS_OK;
+}
+static constexpr int X6_LDS_BYTES = 3 * X6_STEP_B + 1792 * 4;
+static void x6_attr_once() { // (the kernels' dynamic LDS exceeds the default 64 KB limit)
+    static bool done = false;
+    if (done) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, X6_NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<1, X6_NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, X6_NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES);
+    done = true;
 }
 
 size_t irs_small_frag_floats(const irs_ctx *ctx) {
@@ -4033,6 +4090,14 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         EmbedQkvArgs ea{seq, ctx->item_emb, ctx->pe, tok, m_dev, rows, L, sqrtf((float)d), ctx->dims.n_item, xf,
                         ctx->layer[0].sa_in_w, ctx->layer[0].sa_in_b, ctx->act_qkv};
         irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
+        if (ctx->use_x6 && ctx->w_x6) { // the same kernel on split-bf16 MFMAs: k_block_x6's q | k | v steps behind an embed prologue
+            BlockX6Args xa{};
+            xa.Wx = ctx->w_x6 + (size_t)(ctx->dims.n_layers - 1) * (X6_LAYER_BYTES / 16);
+            xa.bin = ctx->layer[0].sa_in_b, xa.Xf = xf, xa.QKV = ctx->act_qkv, xa.M = rows, xa.m_dev = m_dev;
+            xa.seq = seq, xa.E = ctx->item_emb, xa.pe = ctx->pe, xa.tok_row = tok, xa.L = L, xa.sqrtd = sqrtf((float)d), xa.n_item = ctx->dims.n_item;
+            x6_attr_once();
+            hipLaunchKernelGGL((k_block_x6<0, X6_NW, true>), dim3((rows + 32 * X6_NW - 1) / (32 * X6_NW)), dim3(64 * X6_NW), X6_LDS_BYTES, s, xa);
+        } else
         hipLaunchKernelGGL(k_embed_qkv, dim3((rows + 127) / 128), dim3(256), 0, s, ea);
         irs_prof_end(ctx, IRS_PROF_LINEAR, s, 6.0 * rows * (double)d * d, 4.0 * 4.0 * rows * (double)d);
         qkv0_done = true;
@@ -4182,16 +4247,10 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                 if (tail && ctx->use_x6 && ctx->w_x6) { // the same layer tail on split-bf16 MFMAs
                     BlockX6Args xa{yf, xf, ctx->w_x6 + (size_t)l * (X6_LAYER_BYTES / 16), w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b,
                                    w.l1_b, w.l2_b, w.n3_w, w.n3_b, ctx->layer[l + 1].sa_in_b, xf, ctx->act_qkv, rows, m_dev, kv_only ? 1 : 0};
-                    constexpr int x6_lds = 3 * X6_STEP_B + 1792 * 4;
-                    static bool attr = false;
-                    if (!attr) {
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, X6_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds);
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<1, X6_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds);
-                        attr = true;
-                    }
+                    x6_attr_once();
                     const dim3 x6_grid((rows + 32 * X6_NW - 1) / (32 * X6_NW));
-                    if (kv_only) hipLaunchKernelGGL((k_block_x6<1, X6_NW>), x6_grid, dim3(64 * X6_NW), x6_lds, s, xa);
-                    else hipLaunchKernelGGL((k_block_x6<0, X6_NW>), x6_grid, dim3(64 * X6_NW), x6_lds, s, xa);
+                    if (kv_only) hipLaunchKernelGGL((k_block_x6<1, X6_NW, false>), x6_grid, dim3(64 * X6_NW), X6_LDS_BYTES, s, xa);
+                    else hipLaunchKernelGGL((k_block_x6<0, X6_NW, false>), x6_grid, dim3(64 * X6_NW), X6_LDS_BYTES, s, xa);
                 } else if (tail) hipLaunchKernelGGL((k_block<true, true>), dim3((rows + 127) / 128), dim3(256), 0, s, ba);
                 else hipLaunchKernelGGL((k_block<true, false>), dim3((rows + 127) / 128), dim3(256), 0, s, ba);
                 irs_prof_end(ctx, IRS_PROF_LINEAR, s, ffn_flops + 2.0 * rows * (double)d * d, (8.0 + 4.0 + (tail ? 12.0 : 0.0)) * rows * (double)d);

@@ -49,7 +49,9 @@ int main(int argc, char **argv) {
     ba.Af = Af, ba.Rf = Rf, ba.Wo = Wo, ba.bo = bo, ba.g1 = g1, ba.b1n = b1n, ba.c = c, ba.g2 = g2, ba.b2n = b2n;
     ba.W1 = W1, ba.b1 = b1, ba.W2 = W2, ba.b2 = b2, ba.g = g3, ba.b = b3, ba.Xf = Xf[0], ba.Y = nullptr, ba.M = M, ba.m_dev = nullptr;
     ba.Win = Win, ba.bin = bin, ba.QKV = QKV[0], ba.qkv_n0 = 0, ba.qkv_nt1 = 6;
-    BlockX6Args xa{Af, Rf, Wx, bo, g1, b1n, c, g2, b2n, b1, b2, g3, b3, bin, Xf[1], QKV[1], M, nullptr, 0};
+    BlockX6Args xa{};
+    xa.Af = Af, xa.Rf = Rf, xa.Wx = Wx, xa.bo = bo, xa.g1 = g1, xa.b1n = b1n, xa.c = c, xa.g2 = g2, xa.b2n = b2n, xa.b1 = b1, xa.b2 = b2;
+    xa.g = g3, xa.b = b3, xa.bin = bin, xa.Xf = Xf[1], xa.QKV = QKV[1], xa.M = M;
 #ifdef X6_STAMP
     const size_t nwave = (size_t)((M + 32 * X6_NW - 1) / (32 * X6_NW)) * X6_NW;
     CK(hipMalloc(&xa.stamps, nwave * 64));
@@ -60,7 +62,7 @@ int main(int argc, char **argv) {
     CK(hipMemset(xa.dbg, 0xEE, X6_LAYER_BYTES));
 #endif
     constexpr int x6_lds = 3 * X6_STEP_B + 1792 * 4;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, X6_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, X6_NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -74,7 +76,7 @@ int main(int argc, char **argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         printf("k_block<f32>  %8.1f us\n", ms * 1e3);
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((k_block_x6<0, X6_NW>), dim3((M + 32 * X6_NW - 1) / (32 * X6_NW)), dim3(64 * X6_NW), x6_lds, 0, xa);
+        hipLaunchKernelGGL((k_block_x6<0, X6_NW, false>), dim3((M + 32 * X6_NW - 1) / (32 * X6_NW)), dim3(64 * X6_NW), x6_lds, 0, xa);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         CK(hipGetLastError());
