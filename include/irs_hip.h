@@ -365,7 +365,9 @@ int irs_sharded_graph_state(const irs_ctx *ctx);
  *                at 6/16 of the float32-MFMA instruction time;
  *   IRS_GEMM_F32 v_mfma_f32_32x32x2f32.
  * The initial mode is IRS_GEMM_X6 unless the environment holds IRS_DECODER_GEMM=f32 when the context is created.
- * Changing the mode drops the context's captured steps (they are re-captured on the next graph call). */
+ * Changing the mode drops the context's captured steps (they are re-captured on the next graph call).
+ * (IRS_ATTN_GEMM=x6 in the environment at creation additionally moves the head-dim-32 attention of the throughput
+ * path to split-bf16 MFMAs; it measured slower than the float32-MFMA attention and is off by default.) */
 #define IRS_GEMM_F32 0
 #define IRS_GEMM_X6 1
 int irs_set_decoder_gemm(irs_ctx *ctx, int32_t mode);

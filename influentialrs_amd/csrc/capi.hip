@@ -72,6 +72,10 @@ extern "C" int irs_create(irs_ctx **out, const irs_dims *dims, const irs_shard *
         // the environment variable sets the initial mode, irs_set_decoder_gemm() changes it on a live context
         const char *e = getenv("IRS_DECODER_GEMM");
         c->use_x6 = e ? (strcmp(e, "f32") != 0) : 1;
+        const char *ea = getenv("IRS_ATTN_GEMM");
+        c->use_attn_x6 = ea ? (strcmp(ea, "x6") == 0) : 0;
+        const char *er = getenv("IRS_LSE_RING");
+        c->lse_no_ring = er ? (strcmp(er, "0") == 0) : 0;
     }
     *out = c;
     return IRS_OK;
@@ -263,7 +267,10 @@ static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
     p->gm = take((size_t)IRS_MAX_GROUPS * mp * 4);
     p->cnt = take(mp * (size_t)IRS_CAND_BUCKETS * 4);
     p->cand = take(mp * (size_t)IRS_CAND_CAP * 8);
-    p->lse = take((size_t)ctx->lse_slots * mp * 8);
+    {
+        size_t lse_b = (size_t)ctx->lse_slots * mp * 8, ring_b = (size_t)IRS_LSE_SLOTS_RING * 32 * 8; // (the ring form: <= 32 rows, more slots)
+        p->lse = take(lse_b > ring_b ? lse_b : ring_b);
+    }
     p->ref = take(mp * 4);
     p->xrows = take((size_t)ctx->max_rows * D.d * 4);
     p->tval = take((size_t)ctx->max_rows * D.max_k * 4);

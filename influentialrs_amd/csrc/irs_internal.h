@@ -16,6 +16,7 @@
 #define IRS_REFINE_CAP 1024 // candidates exactly re-scored per row
 #define IRS_MAX_GROUPS 2048 // pre-pass group maxima per row (upper bound: the pre-pass is decomposed to stay below it)
 #define IRS_MAX_PATH 64     // beam-search path length bound
+#define IRS_LSE_SLOTS_RING 4096 // (max, sum) partial slots of the <= 32-row ring log-sum-exp sweep: 2048 waves x 2 lane halves
 #define IRS_COOP_FALLBACK_MIN_ITEMS 262144 // shards from this size up redo flagged rows cooperatively (score.hip: k_exh_strips)
 #define IRS_EXH_SCRATCH_KEYS (64 * 32768)  // EXH_FB_MAX x EXH_KEYS_PER_ROW keys of scratch for it
 
@@ -53,6 +54,8 @@ struct irs_ctx {
     float *w_frag16;  // fragment-packed layer weights of the 16-token latency kernel (d = 128, F = 256), or null
     uint4 *w_x6;      // split-bf16 step streams of the fused layer kernel k_block_x6 ([n_layers - 1] x 768 KB), or null
     int use_x6;       // decoder GEMMs of the throughput path on split-bf16 MFMAs (IRS_DECODER_GEMM=x6|f32)
+    int use_attn_x6;  // head-dim-32 attention of the throughput path on split-bf16 MFMAs (IRS_ATTN_GEMM=x6; default off: slower)
+    int lse_no_ring;  // IRS_LSE_RING=0: the register-fragment log-sum-exp kernel at <= 32 rows too (A/B measurements, tests)
     bool finalized;
     bool proj_stale;  // a training entry point ran since irs_finalize_weights: wp / wnorm_max may lag project.*
 

@@ -1524,6 +1524,176 @@ __global__ void __launch_bounds__(256, 1) k_lse_f32(SweepArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ log-sum-exp (+ emission), at most 32 rows: ring form
+// k_lse_f32<.., XREG> with the float32 catalog staged through LDS by LDS-DMA instead of loaded into fragment registers.
+// There a lane's 16-byte loads walk 32 different item rows per instruction (32-byte pieces: every 128-byte line is
+// requested by four instructions of the wave, and a tile's 32 KB does not stay in the 32 KB L1 between them) and only one
+// tile per wave fits in registers behind the one being multiplied: 3.8 TB/s on 10M x 256 (beam search, C5) with the
+// float32 MFMAs at ~47 %.  Here
+//   * a STEP is one CK-wide k chunk of a 32-item tile (CK = 32: 4 KB, four DMA instructions of 1 KB = eight items' 128-byte
+//     segments each; the tile's 32 biases ride with its first chunk as one 4-byte-per-lane DMA); each wave owns a ring of
+//     four slots (three steps in flight behind the one being multiplied, counted vmcnt -- no barrier, the waves share
+//     nothing); eight waves per CU, two per SIMD, so that one wave's DMA issue (~100 cycles per instruction) and epilogue
+//     run under the other's MFMAs (four waves with 8-KB steps: 2.65 ms per C5 step against 3.10 of the register form);
+//   * the 16-byte chunk p of item i's segment sits at chunk position p ^ key(i), key(i) = (i / items per 256 bytes) mod
+//     chunks per segment (the XOR is applied to the global source address, the DMA itself is lane-linear), so the fragment
+//     reads -- lane (item r, half h) takes chunks 2 q + h -- are conflict-free in each 16-lane group of ds_read_b128;
+//   * fragment reads are inline asm, one chunk ahead inside a tile (counted lgkmcnt); across the tile boundary nothing is
+//     in flight, because the epilogue (emission queue, exp) is compiler code that must not find pending asm returns;
+//   * the rows' fragments live in registers as in XREG; one wave per SIMD.
+// Pad items read row 0 and carry bias -inf.  Summation order per score: that of k_lse_f32 (bias first, then k ascending in
+// the MFMA pairing), so the emitted candidates and the (max, sum) partials are those of the register form bit for bit.
+template <int B_, int E_, class Fn>
+__device__ __forceinline__ void irs_static_for(Fn &&fn) {
+    if constexpr (B_ < E_) {
+        fn(std::integral_constant<int, B_>{});
+        irs_static_for<B_ + 1, E_>(fn);
+    }
+}
+#define LSE_RING_NSLOT 4
+#define LSE_RING_NW 8   // waves per workgroup = per CU (two per SIMD: one wave's DMA issue and epilogue under the other's MFMAs)
+#define LSE_RING_CK 32  // k values per step
+#define LSE_RING_WAVE_B (LSE_RING_NSLOT * (LSE_RING_CK * 128 + 256))
+template <int KS, bool EMIT, int NW, int CK>
+__global__ void __launch_bounds__(64 * NW, NW / 4) k_lse_ring(SweepArgs a) {
+    constexpr int NC = 16 * KS / CK, QN = 2 * KS, NSLOT = LSE_RING_NSLOT, SB = CK * 128, QS = CK / 8;
+    constexpr int CH = CK / 4;          // 16-byte chunks of an item's segment
+    constexpr int IPB = 16 / CH;        // items per 256 bytes (the bank period)
+    static_assert(IPB * 4 * CK == 256 && (1024 / (4 * CK)) / IPB == 4, "key(item) = (4 i + (lane >> 4)) % CH below");
+    constexpr int NI = SB / 1024;       // 1-KB DMA instructions per step
+    constexpr int NPAT = CH / 4;        // distinct source-chunk patterns over the instructions of a step
+    static_assert((NC % NSLOT == 0) || (NSLOT % NC == 0), "slots must stay compile-time constants");
+    constexpr int TPI = NC >= NSLOT ? 1 : NSLOT / NC; // tiles per loop iteration
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // a workgroup covers NW / 4 strips of four waves (the sweeps' decomposition unit), XCD-interleaved like sweep_map
+    const int strip = ((int)(blockIdx.x >> 3) * 8 + (int)(blockIdx.x & 7)) * (NW / 4) + (wave >> 2);
+    if (strip >= a.n_strips) return; // (no barrier in this kernel: a half workgroup may leave)
+    const int r = lane & 31, h = lane >> 5;
+    EmitQ eq = emit_queue(smem + NW * LSE_RING_WAVE_B, wave);
+    float4 xr4[QN];
+#pragma unroll
+    for (int q = 0; q < QN; ++q)
+        xr4[q] = r < a.M ? *reinterpret_cast<const float4 *>(a.x32 + (size_t)r * a.d + 8 * q + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int gw = strip * 4 + (wave & 3);
+    const int ts = a.tile_stride;
+    const int t0 = a.tile_begin + gw * a.tiles_per_wave * ts;
+    const int t1 = min(t0 + a.tiles_per_wave * ts, a.tile_end);
+    float mx = -INFINITY, sm = 0.f;
+    const float thr = EMIT ? fmaxf(a.thr[r], -3.0e38f) : INFINITY;
+    if (t0 < t1) {
+        const int ntile = (t1 - 1 - t0) / ts + 1;
+        char *ring = smem + wave * LSE_RING_WAVE_B;            // [NSLOT][SB], then [NSLOT][256 B] biases
+        const unsigned int ring_a = (unsigned int)(size_t)(__attribute__((address_space(3))) char *)ring;
+        // DMA: instruction i of a step brings items i (1024 / (4 CK)) + lane / CH; lane chunk position p = lane % CH holds the
+        // item's source chunk p ^ key(item), key(item) = (item / IPB) % CH = (4 i + (lane >> 4)) % CH
+        const int jl = lane >> 4, p = lane & (CH - 1), it_l = lane / CH;
+        int goff[NPAT]; // float offset inside the item row (without the chunk's CK c), per i % NPAT
+#pragma unroll
+        for (int i = 0; i < NPAT; ++i) goff[i] = (p ^ ((4 * i + jl) & (CH - 1))) * 4;
+        // fragment read addresses: item r, chunks (2 q + h) ^ key(r)
+        unsigned int fra[QS];
+#pragma unroll
+        for (int q = 0; q < QS; ++q) fra[q] = ring_a + (unsigned int)(r * (CK * 4) + (((2 * q + h) ^ ((r / IPB) & (CH - 1))) << 4));
+        const unsigned int ba = ring_a + NSLOT * SB + 16 * h; // bias float4 q: + 32 q (+ 256 slot)
+        auto issue = [&](int tix, auto cc, auto sc) __attribute__((always_inline)) { // step (tile index tix, chunk C) -> slot S
+            constexpr int C = decltype(cc)::value, S = decltype(sc)::value;
+            const int t = t0 + min(tix, ntile - 1) * ts; // (a request past the strip re-reads its last tile: counts stay fixed)
+            irs_static_for<0, NI>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                const int64_t item = (int64_t)t * 32 + i * (1024 / (4 * CK)) + it_l;
+                const float *src = a.w32 + (size_t)(item < a.n_local ? item : 0) * a.d + CK * C + goff[i % NPAT];
+                __builtin_amdgcn_global_load_lds((irs_glb_void *)src, (irs_lds_void *)(ring + S * SB + i * 1024), 16, 0, 0);
+            });
+            if constexpr (C == 0) // the tile's 32 biases ride with its first chunk
+                __builtin_amdgcn_global_load_lds((irs_glb_void *)(a.bias + (size_t)t * 32 + (lane & 31)),
+                                                 (irs_lds_void *)(ring + NSLOT * SB + S * 256), 4, 0, 0);
+        };
+// DMA instructions of the two steps behind step (chunk C_): the count a wait for step C_'s slot leaves in flight
+#define LSE_RING_YOUNGER(C_) (2 * NI + ((((C_) + 1) % NC) == 0 ? 1 : 0) + ((((C_) + 2) % NC) == 0 ? 1 : 0))
+        // prologue: steps 0, 1, 2
+        issue(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        issue(1 / NC, std::integral_constant<int, 1 % NC>{}, std::integral_constant<int, 1>{});
+        issue(2 / NC, std::integral_constant<int, 2 % NC>{}, std::integral_constant<int, 2>{});
+        u32x4 fa[2][QS];
+        for (int tb = 0; tb < ntile; tb += TPI) {
+            irs_static_for<0, TPI>([&](auto tic) __attribute__((always_inline)) {
+                constexpr int TI = decltype(tic)::value;
+                const int tix = tb + TI;
+                if (tix < ntile) { // wave-uniform
+                    constexpr int S0 = (TI * NC) % NSLOT; // slot of this tile's chunk 0
+                    const int t = t0 + tix * ts;
+                    f32x16 acc;
+                    irs_static_for<0, NC>([&](auto cc) __attribute__((always_inline)) {
+                        constexpr int C = decltype(cc)::value, S = (S0 + C) % NSLOT, SET = C & 1;
+                        if constexpr (C == 0) {
+                            // this step's slot has landed once only the two younger steps are in flight; slot + 3 is free
+                            // (read out a step ago)
+                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LSE_RING_YOUNGER(0)) : "memory");
+                            issue(tix + (C + 3) / NC, std::integral_constant<int, (C + 3) % NC>{}, std::integral_constant<int, (S + 3) % NSLOT>{});
+                            irs_static_for<0, QS>([&](auto qc) __attribute__((always_inline)) {
+                                constexpr int q = decltype(qc)::value;
+                                fa[SET][q] = lds_read16<S * SB>(fra[q]);
+                            });
+                            u32x4 bq[4];
+                            bq[0] = lds_read16<S * 256>(ba), bq[1] = lds_read16<S * 256 + 32>(ba), bq[2] = lds_read16<S * 256 + 64>(ba),
+                            bq[3] = lds_read16<S * 256 + 96>(ba);
+                            if constexpr (QS == 8)
+                                asm volatile("s_waitcnt lgkmcnt(0)"
+                                             : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(fa[SET][0]), "+v"(fa[SET][1]), "+v"(fa[SET][2]),
+                                               "+v"(fa[SET][3]), "+v"(fa[SET][4]), "+v"(fa[SET][5]), "+v"(fa[SET][6]), "+v"(fa[SET][QS - 1]));
+                            else
+                                asm volatile("s_waitcnt lgkmcnt(0)"
+                                             : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(fa[SET][0]), "+v"(fa[SET][1]), "+v"(fa[SET][2]),
+                                               "+v"(fa[SET][QS - 1]));
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float4 b4 = __builtin_bit_cast(float4, bq[q]);
+                                acc[4 * q + 0] = b4.x, acc[4 * q + 1] = b4.y, acc[4 * q + 2] = b4.z, acc[4 * q + 3] = b4.w;
+                            }
+                        }
+                        if constexpr (C + 1 < NC) // the next chunk's slot has landed (read ahead below)
+                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LSE_RING_YOUNGER(C + 1)) : "memory");
+                        irs_static_for<0, QS>([&](auto qc) __attribute__((always_inline)) {
+                            constexpr int q = decltype(qc)::value;
+                            if constexpr (C + 1 < NC) {
+                                fa[SET ^ 1][q] = lds_read16<((S + 1) % NSLOT) * SB>(fra[q]);
+                                lds_wait<QS>(fa[SET][q]);
+                            } else
+                                lds_wait<QS - 1 - q>(fa[SET][q]);
+                            const float4 af = __builtin_bit_cast(float4, fa[SET][q]);
+                            const float4 bv = xr4[QS * C + q];
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bv.x, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bv.y, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bv.z, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bv.w, acc, 0, 0, 0);
+                        });
+                        // this chunk's slot is read out (its last read returned before the last MFMA group): refill it
+                        if constexpr (C + 1 < NC)
+                            issue(tix + (C + 4) / NC, std::integral_constant<int, (C + 4) % NC>{}, std::integral_constant<int, S>{});
+                    });
+                    if (EMIT) emit_candidates(a, acc, thr, r, t, h, eq, lane);
+                    const float m = fmaxf(mx, max16(acc));
+                    if (m > -INFINITY) {
+                        float sacc = sm * __expf(mx - m);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) sacc += __expf(acc[i] - m);
+                        mx = m;
+                        sm = sacc;
+                    }
+                }
+            });
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the requests past the strip
+#undef LSE_RING_YOUNGER
+    }
+    if (EMIT) emit_flush(a, eq, lane);
+    float *pp = a.lse_part + ((size_t)(gw * 2 + h) * a.M_pad + r) * 2;
+    pp[0] = mx;
+    pp[1] = sm;
+}
+
 // =============================== small kernels ===============================
 // 8 consecutive k of one row -> one 16-byte bf16 fragment piece (RNE, finite inputs).  Accumulates the squared
 // norms the error bound is made of: ss of the values, ssr of the rounded values, ssd of the rounding errors
@@ -2656,11 +2826,36 @@ static bool lse_fast_ok(const irs_ctx *ctx, const SweepArgs &a) {
     return ctx->KS >= 2 && a.d == ctx->KS * 16 && ((((uintptr_t)a.w32) & 15) == 0) && ((((uintptr_t)a.x32) & 15) == 0);
 }
 
+static bool lse_ring_ok(const irs_ctx *ctx, const SweepArgs &a) {
+    return a.UT == 1 && (ctx->KS == 16 || ctx->KS == 8) && !ctx->lse_no_ring && lse_fast_ok(ctx, a);
+}
+// waves (= pairs of (max, sum) partial slots) a log-sum-exp sweep may use: the ring form runs 8 waves on every CU
+static int lse_wave_budget(const irs_ctx *ctx, const SweepArgs &a) {
+    return lse_ring_ok(ctx, a) ? IRS_LSE_SLOTS_RING / 2 : ctx->lse_slots / 2;
+}
+
 template <bool EMIT>
 static int launch_lse_f32(irs_ctx *ctx, SweepArgs &a, hipStream_t s) {
     const int KS = ctx->KS;
     // at most 32 rows at d_pad = 256: the rows' fragments in registers (k_lse_f32<.., XREG>): 2.5M x 256 x 32 rows 686 -> 644 us.
     // (At d_pad = 128 the same form, with only 16 KB per wave in flight behind the tile being multiplied, was slower: 181 vs 151 us at 1M x 128.)
+    if (lse_ring_ok(ctx, a)) { // at most 32 rows (a beam search's): the LDS-ring form
+        a.n_ublocks = 1;
+        constexpr int SPW = LSE_RING_NW / 4; // strips per workgroup
+        const int nwg = (a.n_strips + SPW - 1) / SPW;
+        dim3 grid(((nwg + 7) / 8) * 8);
+        const size_t lds = (size_t)LSE_RING_NW * LSE_RING_WAVE_B + (size_t)LSE_RING_NW * (EMIT_Q * 12 + 16);
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lse_ring<16, EMIT, LSE_RING_NW, LSE_RING_CK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lse_ring<8, EMIT, LSE_RING_NW, LSE_RING_CK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        if (KS == 16) hipLaunchKernelGGL((k_lse_ring<16, EMIT, LSE_RING_NW, LSE_RING_CK>), grid, dim3(64 * LSE_RING_NW), lds, s, a);
+        else hipLaunchKernelGGL((k_lse_ring<8, EMIT, LSE_RING_NW, LSE_RING_CK>), grid, dim3(64 * LSE_RING_NW), lds, s, a);
+        IRS_CHECK_HIP(ctx, hipGetLastError());
+        return IRS_OK;
+    }
     const bool xreg = a.UT == 1 && KS == 16;
     const int UB = xreg ? 1 : ub_f32(KS);
     a.n_ublocks = (a.UT + UB - 1) / UB;
@@ -2789,12 +2984,12 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
     a.cand = ctx->cand;
     int lse_slots = 0;
     if (fused_lse) { // bounded number of (max, sum) partials: tiles per wave from the slot budget, like irs_launch_lse
-        const int max_waves = ctx->lse_slots / 2;
+        const int max_waves = lse_wave_budget(ctx, a);
         int tpw = (nt + max_waves - 1) / max_waves;
         if (tpw < 1) tpw = 1;
         sweep_decompose(a, 0, nt, 1, tpw);
         lse_slots = a.n_strips * 4 * 2;
-        if (lse_slots > ctx->lse_slots) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "lse slots %d > %d", lse_slots, ctx->lse_slots);
+        if (lse_slots > 2 * max_waves) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "lse slots %d > %d", lse_slots, 2 * max_waves);
         a.lse_part = ctx->lse_part;
     } else
         sweep_decompose(a, 0, nt, nub, 0);
@@ -2990,12 +3185,12 @@ int irs_launch_lse(irs_ctx *ctx, const float *xrows, int M, float *out_max, floa
     sweep_common(ctx, a, xrows, M);
     const int nub = (a.UT + ub_f32(ctx->KS) - 1) / ub_f32(ctx->KS);
     // bounded number of partial slots: tiles per wave from the slot budget
-    int max_waves = ctx->lse_slots / 2;
+    int max_waves = lse_wave_budget(ctx, a);
     int tpw = (ctx->n_tiles + max_waves - 1) / max_waves;
     if (tpw < 1) tpw = 1;
     sweep_decompose(a, 0, ctx->n_tiles, nub, tpw);
     int slots = a.n_strips * 4 * 2;
-    if (slots > ctx->lse_slots) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "lse slots %d > %d", slots, ctx->lse_slots);
+    if (slots > 2 * max_waves) IRS_FAIL(ctx, IRS_E_UNSUPPORTED, "lse slots %d > %d", slots, 2 * max_waves);
     a.lse_part = ctx->lse_part;
     irs_prof_begin(ctx, IRS_PROF_SWEEP, s);
     int rc = IRS_OK;

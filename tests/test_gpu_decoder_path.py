@@ -556,3 +556,36 @@ def test_split_bf16_layer_kernel_equals_float32_mfma_kernel(oracle, B, kv_only):
     with pytest.raises(Exception):
         eng.decoder_gemm = 7
     eng.decoder_gemm = IRS_GEMM_X6
+
+
+def test_split_bf16_attention_kernel_on_request(oracle, monkeypatch):
+    """IRS_ATTN_GEMM=x6 (read when a context is created) runs the head-dim-32 attention of the throughput path on
+    split-bf16 MFMAs (k_attn16x: K / V / p as three bf16 planes, six plane products, V^T through the transposing LDS
+    read).  It is off by default because it measured slower than the float32-MFMA kernel (profiles/r03/README.md); its
+    rows must agree with the default kernel's and with the oracle like every other pair of decoder kernels."""
+    cfg = synth.make_config("c2")
+    L, B = cfg.max_len, 176
+    sd = synth.irn_state_dict(cfg, 778)
+    hists = synth.user_histories(B, cfg.n_item, seed=45)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=47)
+    _, seqs, users, _, _ = synth.collate_eval_irs(rows, L, gap_len=1)
+    seqs[1, :] = 0
+    seqs[1, -1] = 5              # an all-pad window with a target
+    seqs[2, seqs[2] == 0] = 3    # a full window
+    seq, u = torch.from_numpy(seqs).cuda(), torch.from_numpy(users).cuda()
+    pos = torch.full((B,), L - 2, dtype=torch.int32, device="cuda")
+    base = make_engine(cfg, sd, max_rows=B, max_seqs=B)
+    xa, ra, _ = base.decode(seq, u, want_x=True, pos=pos)
+    _, rpa, _ = base.decode(seq, u, want_x=False, pos=pos)  # packed rows: the FAST instantiation
+    monkeypatch.setenv("IRS_ATTN_GEMM", "x6")
+    eng = make_engine(cfg, sd, max_rows=B, max_seqs=B)
+    monkeypatch.delenv("IRS_ATTN_GEMM")
+    xb, rb, _ = eng.decode(seq, u, want_x=True, pos=pos)
+    _, rpb, _ = eng.decode(seq, u, want_x=False, pos=pos)
+    assert not torch.equal(ra, rb), "the request must change the code path"
+    ok = torch.isfinite(xa) & torch.isfinite(xb)
+    assert torch.equal(torch.isnan(xa), torch.isnan(xb)) and (xa - xb)[ok].abs().max().item() < X_TOL_X6
+    assert (rpa - rpb).abs().max().item() < X_TOL_X6
+    for b in (0, 2, 9):
+        ref = oracle.decode(sd, cfg, seqs[b], int(users[b]))[0][L - 2]
+        assert np.abs(ref - rpb[b].cpu().numpy()).max() < X_TOL_X6
