@@ -689,6 +689,9 @@ def main():
                           "(packed rows), results identical",
                "packed_row_fraction": fam["linear"]["packed_fraction"],
                "sweep": args.sweep + (" filter + exact f32 re-score" if args.sweep == "bf16" else ""),
+               "decoder_gemm": ("x6: float32 operands split exactly into three bf16 planes, six plane products per float32 product on "
+                                "v_mfma_f32_32x32x16_bf16, float32 accumulation (fused layer kernel and embed + layer-0 q|k|v); attention "
+                                "and the last layer's rows on float32 MFMAs" if x6 else "float32 MFMAs"),
                "parallelism": "single GPU" if world == 1 else (
                    f"rows data-parallel + item-sharded x{world}: RCCL all-gather of rows, one all_to_all of packed 64-bit top-100 keys "
                    f"(irs_generate_paths_sharded: collectives below the C ABI, captured step)"

@@ -1534,7 +1534,10 @@ __global__ void __launch_bounds__(256, 1) k_lse_f32(SweepArgs a) {
 //     segments each; the tile's 32 biases ride with its first chunk as one 4-byte-per-lane DMA); each wave owns a ring of
 //     four slots (three steps in flight behind the one being multiplied, counted vmcnt -- no barrier, the waves share
 //     nothing); eight waves per CU, two per SIMD, so that one wave's DMA issue (~100 cycles per instruction) and epilogue
-//     run under the other's MFMAs (four waves with 8-KB steps: 2.65 ms per C5 step against 3.10 of the register form);
+//     run under the other's MFMAs (four waves with 8-KB steps: 2.65 ms per C5 step against 3.10 of the register form;
+//     this form 2.61.  What bounds it now is the data in flight: ~96 KB per CU is all the LDS holds, i.e. ~4.6 TB/s at the
+//     loaded HBM latency; a timing experiment with every step reading 4 KB of CONTIGUOUS memory changed nothing, so a
+//     tile-major copy of the float32 catalog would not help);
 //   * the 16-byte chunk p of item i's segment sits at chunk position p ^ key(i), key(i) = (i / items per 256 bytes) mod
 //     chunks per segment (the XOR is applied to the global source address, the DMA itself is lane-linear), so the fragment
 //     reads -- lane (item r, half h) takes chunks 2 q + h -- are conflict-free in each 16-lane group of ds_read_b128;
