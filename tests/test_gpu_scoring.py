@@ -520,3 +520,36 @@ def test_rank_gather_dense_random_shapes_agree(n_item, d, M, k):
     mx, sm = eng.score_lse(xt)
     want_lse = torch.logsumexp(dense.double(), dim=1)
     assert ((mx.double() + sm.double().log()) - want_lse).abs().max().item() <= 4e-6 * max(1.0, want_lse.abs().max().item())
+
+
+@pytest.mark.parametrize("n_item,d,M", [(300_017, 128, 32), (150_001, 256, 32), (150_001, 256, 9), (40_000, 128, 1)])
+def test_lse_ring_equals_register_form(oracle, monkeypatch, n_item, d, M):
+    """At most 32 rows at d = 128 / 256 (a beam search's rows) the log-sum-exp pass over the float32 catalog -- alone
+    (irs_score_lse) and fused with the emission (irs_score_topk_lse) -- runs through per-wave LDS-DMA rings (k_lse_ring).
+    IRS_LSE_RING=0 at context creation keeps the register-fragment kernel (k_lse_f32) for those shapes too.  Both sum a
+    score in the same order, so the top-k (ids, value bits, status) must be identical and the (max, sum) pairs equal to
+    the partial sums' regrouping (the ring form runs 2048 waves, the register form 1024: different partials); one row
+    also against the oracle."""
+    W, b = _weights(n_item, d, 31)
+    x = _rows(M, d, 32)
+    xt = torch.from_numpy(x).cuda()
+    res = {}
+    for ring in ("1", "0"):
+        monkeypatch.setenv("IRS_LSE_RING", ring)
+        eng = scoring_only_engine(n_item, d, W, b, max_rows=32)
+        monkeypatch.delenv("IRS_LSE_RING")
+        v, i, s, m, e = eng.score_topk_lse(xt, 100, IRS_SWEEP_BF16)
+        m2, e2 = eng.score_lse(xt)
+        torch.cuda.synchronize()
+        res[ring] = (v.clone(), i.clone(), s.clone(), (m.double() + e.double().log()).cpu().numpy(), (m2.double() + e2.double().log()).cpu().numpy(),
+                     m.clone())
+        del eng
+    a, c = res["1"], res["0"]
+    assert torch.equal(a[1], c[1]) and torch.equal(a[0].view(torch.int32), c[0].view(torch.int32)) and torch.equal(a[2], c[2])
+    assert torch.equal(a[5], c[5]), "the rows' maxima are exact in both forms"
+    assert np.abs(a[3] - c[3]).max() <= 2e-6 * max(1.0, np.abs(c[3]).max()) and np.abs(a[4] - c[4]).max() <= 2e-6 * max(1.0, np.abs(c[4]).max())
+    s0 = oracle.score_chain(x[0], W, b)
+    ov, oi = oracle.topk(s0, 100)
+    assert np.array_equal(a[1][0].cpu().numpy(), oi) and np.array_equal(a[0][0].cpu().numpy().view(np.uint32), ov.view(np.uint32))
+    om, osum = oracle.max_sumexp(s0)
+    assert abs(a[3][0] - (om + np.log(osum))) <= 4e-6 * max(1.0, abs(om))
