@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import threading
 import os
 import sys
 import time
@@ -477,6 +478,8 @@ def main():
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-scoring", action="store_true", help="skip the catalog-scale scoring legs")
     ap.add_argument("--no-c4", action="store_true", help="skip the 10M-item item-sharded leg")
+    ap.add_argument("--extras-timeout", type=int, default=420, help="seconds the legs behind the headline may take before the "
+                    "line is printed without them")
     ap.add_argument("--no-c3", action="store_true", help="skip the 1M-item (BASELINE configs[2]) leg")
     ap.add_argument("--c3-batch", type=int, default=1024, help="users per rank per step of the c3 leg")
     ap.add_argument("--c3-steps", type=int, default=10)
@@ -700,104 +703,14 @@ def main():
     del job
     torch.cuda.empty_cache()
 
-    scoring = None
-    if rank == 0 and world == 1 and not args.no_scoring:
-        scoring = scoring_legs(device)
+    # ---- the extra legs (scoring, C3, C4, C5).  The headline above is complete at this point: whatever happens below -- an
+    #      exception on some rank, a collective that never returns on a node this build has not seen -- the line is still
+    #      printed, with "extras_error" saying which leg did not finish.
+    X = {"scoring": None, "c3": None, "c4": None, "stage": None, "err": None}
 
-    # ---- BASELINE configs[2]: the 1M-item / d = 128 catalog (item-sharded when N > 1), 1024 users per rank per step
-    c3 = None
-    if not args.no_c3:
-        j3 = Job("c3", args.c3_batch, rank, world, device, "items", args.sweep)
-        for _ in range(2):
-            j3.step()
-        dt3 = timed(j3, args.c3_steps, world)
-        u3 = j3.B * world
-        ok3, fb3 = verify_job(j3)
-        c3 = {"metric": "scored user-item pairs/sec (whole node)", "value": u3 * j3.cfg.n_item * args.c3_steps / dt3,
-              "unit": "pairs/s", "n_gpus": world, "steps": args.c3_steps, "ms_per_step": dt3 / args.c3_steps * 1e3,
-              "scaling": "weak", "users_per_gpu": j3.B, "items_per_gpu": j3.eng.n_local,
-              "workload": f"c3: n_item={j3.cfg.n_item}, d={j3.cfg.emb_dim}, L={j3.cfg.max_len}, H={j3.cfg.n_heads}; one greedy "
-                          f"path-search step, top-100",
-              "verified": ok3, "verified_how": "4 rows of the last step: ring-sweep top-100 == float32-sweep top-100 (ids and value bits)",
-              "fallback_rows": fb3, "phase_ms_rank0": phase_times(j3)}
-        del j3
-        torch.cuda.empty_cache()
-
-    # ---- BASELINE configs[3]: the 10M-item catalog, item-sharded over the N GPUs (N = 1: the whole catalog, the anchor)
-    c4 = None
-    if not args.no_c4:
-        j4 = Job("c4", args.c4_batch, rank, world, device, "items", args.sweep)
-        for _ in range(2):
-            j4.step()
-        dt4 = timed(j4, args.c4_steps, world)
-        u4 = j4.B * world
-        ok4, fb4 = verify_job(j4)
-        c4 = {"metric": "scored user-item pairs/sec (whole node)", "value": u4 * j4.cfg.n_item * args.c4_steps / dt4,
-              "unit": "pairs/s", "n_gpus": world, "steps": args.c4_steps, "ms_per_step": dt4 / args.c4_steps * 1e3,
-              "scaling": "weak", "users_per_gpu": j4.B, "items_per_gpu": j4.eng.n_local,
-              "workload": f"c4: n_item={j4.cfg.n_item}, d={j4.cfg.emb_dim}, L={j4.cfg.max_len}, H={j4.cfg.n_heads}; one greedy "
-                          f"path-search step, top-100",
-              "parallelism": "single GPU holds the whole catalog" if world == 1 else
-                             f"item shards of {j4.eng.n_local} rows x {world}; per step: all-gather of {u4} x {j4.cfg.emb_dim} f32 rows, "
-                             f"one all_to_all of {u4} x 100 packed 64-bit keys per rank, merge"}
-        c4["verified"] = ok4
-        c4["verified_how"] = "4 rows of the last step: ring-sweep top-100 == float32-sweep top-100 (ids and value bits)"
-        c4["fallback_rows"] = fb4
-        ph = phase_times(j4)  # every rank runs it (the collectives inside need all of them); rank 0 reports
-        c4["phase_ms_rank0"] = ph
-        if not args.no_latency and 32 % world == 0:
-            # BASELINE configs[4] (C5), D1 (ii): beam-width-32 persuasion-path search over the 10M-item catalog for ONE
-            # user -- 32 windows decoded, scored (top-100 + exact log-sum-exp over the catalog) and re-ranked per step,
-            # 20 steps; p50 over 10 repetitions after 2 warm-ups, stream launches and the captured two-step hipGraph.
-            # N > 1: the SAME user on every rank (seeded windows), the 32 beam windows' decode split 32 / N per rank, rows
-            # all-gathered, every rank sweeps its item shard for all 32 rows, packed lists all-gathered and merged,
-            # log-sum-exp all-reduced, beam step replicated (irs_beam_search_sharded, split_decode); max over ranks.
-            fresh = gpu_windows(4, j4.cfg.max_len, j4.cfg.n_item, device, seed=7)
-            g5 = torch.Generator(device=device)
-            g5.manual_seed(5)
-            b_seq, b_hep = fresh[:1].contiguous(), j4.hep[:1].contiguous()
-            b_usr = torch.randint(0, j4.cfg.n_user, (1,), generator=g5, device=device, dtype=torch.int64)
-            c5 = {"workload": "c5: beam 32 x 20 steps, 1 user, n_item=10000000, d=256 (" +
-                              ("one GPU holds the whole catalog)" if world == 1 else
-                               f"{world} item shards of {j4.eng.n_local} rows; beam windows decoded {32 // world} per rank)"),
-                  "n_gpus": world}
-            for label, graph in (("stream", False), ("hipgraph", True)):
-                if graph and world > 1 and not SHARDED_GRAPH:
-                    continue
-                ts = []
-                for it in range(12):
-                    if world > 1:
-                        dist.barrier()
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    if world == 1:
-                        j4.eng.beam_search(b_seq, b_usr, b_hep, 20, 32, k=100, sweep=j4.sweep, use_graph=graph)
-                    else:
-                        j4.eng.beam_search_sharded(j4.comm, b_seq, b_usr, b_hep, 20, 32, k=100, sweep=j4.sweep, split_decode=True,
-                                                   use_graph=graph)
-                    torch.cuda.synchronize()
-                    dt5 = time.perf_counter() - t0
-                    if world > 1:
-                        t5 = torch.tensor([dt5], dtype=torch.float64, device=device)
-                        if dist.get_backend() == "gloo":
-                            h5 = t5.cpu()
-                            dist.all_reduce(h5, op=dist.ReduceOp.MAX)
-                            dt5 = float(h5.item())
-                        else:
-                            dist.all_reduce(t5, op=dist.ReduceOp.MAX)
-                            dt5 = float(t5.item())
-                    if it >= 2:
-                        ts.append(dt5 * 1e3)
-                c5[f"search_p50_ms_{label}"] = float(np.median(ts))
-                c5[f"step_p50_ms_{label}"] = float(np.median(ts)) / 20
-            # HBM floor of a step per GPU: its share of the fp32 catalog once (candidates + exact log-sum-exp out of one
-            # pass) + the 1/8 sample of the bf16 catalog the threshold comes from
-            c5["step_hbm_floor_ms"] = (j4.eng.n_local * j4.cfg.emb_dim * (4.0 + 2.0 / 8)) / (PEAK_HBM_GBS * 1e9) * 1e3
-            c4["c5_beam32"] = c5
-        del j4
-        torch.cuda.empty_cache()
-
-    if rank == 0:
+    def emit():
+        if rank != 0:
+            return
         out = {
             "metric": "scored user-item pairs/sec (whole node)",
             "value": value,
@@ -817,12 +730,131 @@ def main():
             "path_gen_ms_per_user_b128": lat128,
             "path_gen_ms_per_user_b1024": lat1024,
             "roofline": roof,
-            "scoring": scoring,
-            "c3_1M_items": c3,
-            "c4_item_sharded": c4,
+            "scoring": X["scoring"],
+            "c3_1M_items": X["c3"],
+            "c4_item_sharded": X["c4"],
             "cpu_baseline": cpu,
         }
+        if X["err"]:
+            out["extras_error"] = X["err"]
         print(json.dumps(out), flush=True)
+
+    def watchdog():
+        X["err"] = f"extra legs did not finish within {args.extras_timeout} s (stage: {X['stage']})"
+        emit()
+        os._exit(0)
+
+    wd = threading.Timer(args.extras_timeout, watchdog)
+    wd.daemon = True
+    wd.start()
+    try:
+        X["stage"] = "scoring"
+        if rank == 0 and world == 1 and not args.no_scoring:
+            X["scoring"] = scoring_legs(device)
+
+        # ---- BASELINE configs[2]: the 1M-item / d = 128 catalog (item-sharded when N > 1), 1024 users per rank per step
+        X["stage"] = "c3"
+        if not args.no_c3:
+            j3 = Job("c3", args.c3_batch, rank, world, device, "items", args.sweep)
+            for _ in range(2):
+                j3.step()
+            dt3 = timed(j3, args.c3_steps, world)
+            u3 = j3.B * world
+            ok3, fb3 = verify_job(j3)
+            X["c3"] = {"metric": "scored user-item pairs/sec (whole node)", "value": u3 * j3.cfg.n_item * args.c3_steps / dt3,
+                  "unit": "pairs/s", "n_gpus": world, "steps": args.c3_steps, "ms_per_step": dt3 / args.c3_steps * 1e3,
+                  "scaling": "weak", "users_per_gpu": j3.B, "items_per_gpu": j3.eng.n_local,
+                  "workload": f"c3: n_item={j3.cfg.n_item}, d={j3.cfg.emb_dim}, L={j3.cfg.max_len}, H={j3.cfg.n_heads}; one greedy "
+                              f"path-search step, top-100",
+                  "verified": ok3, "verified_how": "4 rows of the last step: ring-sweep top-100 == float32-sweep top-100 (ids and value bits)",
+                  "fallback_rows": fb3, "phase_ms_rank0": phase_times(j3)}
+            del j3
+            torch.cuda.empty_cache()
+
+        # ---- BASELINE configs[3]: the 10M-item catalog, item-sharded over the N GPUs (N = 1: the whole catalog, the anchor)
+        X["stage"] = "c4"
+        if not args.no_c4:
+            j4 = Job("c4", args.c4_batch, rank, world, device, "items", args.sweep)
+            for _ in range(2):
+                j4.step()
+            dt4 = timed(j4, args.c4_steps, world)
+            u4 = j4.B * world
+            ok4, fb4 = verify_job(j4)
+            c4 = {"metric": "scored user-item pairs/sec (whole node)", "value": u4 * j4.cfg.n_item * args.c4_steps / dt4,
+                  "unit": "pairs/s", "n_gpus": world, "steps": args.c4_steps, "ms_per_step": dt4 / args.c4_steps * 1e3,
+                  "scaling": "weak", "users_per_gpu": j4.B, "items_per_gpu": j4.eng.n_local,
+                  "workload": f"c4: n_item={j4.cfg.n_item}, d={j4.cfg.emb_dim}, L={j4.cfg.max_len}, H={j4.cfg.n_heads}; one greedy "
+                              f"path-search step, top-100",
+                  "parallelism": "single GPU holds the whole catalog" if world == 1 else
+                                 f"item shards of {j4.eng.n_local} rows x {world}; per step: all-gather of {u4} x {j4.cfg.emb_dim} f32 rows, "
+                                 f"one all_to_all of {u4} x 100 packed 64-bit keys per rank, merge"}
+            c4["verified"] = ok4
+            c4["verified_how"] = "4 rows of the last step: ring-sweep top-100 == float32-sweep top-100 (ids and value bits)"
+            c4["fallback_rows"] = fb4
+            ph = phase_times(j4)  # every rank runs it (the collectives inside need all of them); rank 0 reports
+            c4["phase_ms_rank0"] = ph
+            X["c4"] = c4
+            X["stage"] = "c5"
+            if not args.no_latency and 32 % world == 0:
+                # BASELINE configs[4] (C5), D1 (ii): beam-width-32 persuasion-path search over the 10M-item catalog for ONE
+                # user -- 32 windows decoded, scored (top-100 + exact log-sum-exp over the catalog) and re-ranked per step,
+                # 20 steps; p50 over 10 repetitions after 2 warm-ups, stream launches and the captured two-step hipGraph.
+                # N > 1: the SAME user on every rank (seeded windows), the 32 beam windows' decode split 32 / N per rank, rows
+                # all-gathered, every rank sweeps its item shard for all 32 rows, packed lists all-gathered and merged,
+                # log-sum-exp all-reduced, beam step replicated (irs_beam_search_sharded, split_decode); max over ranks.
+                fresh = gpu_windows(4, j4.cfg.max_len, j4.cfg.n_item, device, seed=7)
+                g5 = torch.Generator(device=device)
+                g5.manual_seed(5)
+                b_seq, b_hep = fresh[:1].contiguous(), j4.hep[:1].contiguous()
+                b_usr = torch.randint(0, j4.cfg.n_user, (1,), generator=g5, device=device, dtype=torch.int64)
+                c5 = {"workload": "c5: beam 32 x 20 steps, 1 user, n_item=10000000, d=256 (" +
+                                  ("one GPU holds the whole catalog)" if world == 1 else
+                                   f"{world} item shards of {j4.eng.n_local} rows; beam windows decoded {32 // world} per rank)"),
+                      "n_gpus": world}
+                for label, graph in (("stream", False), ("hipgraph", True)):
+                    if graph and world > 1 and not SHARDED_GRAPH:
+                        continue
+                    ts = []
+                    for it in range(12):
+                        if world > 1:
+                            dist.barrier()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        if world == 1:
+                            j4.eng.beam_search(b_seq, b_usr, b_hep, 20, 32, k=100, sweep=j4.sweep, use_graph=graph)
+                        else:
+                            j4.eng.beam_search_sharded(j4.comm, b_seq, b_usr, b_hep, 20, 32, k=100, sweep=j4.sweep, split_decode=True,
+                                                       use_graph=graph)
+                        torch.cuda.synchronize()
+                        dt5 = time.perf_counter() - t0
+                        if world > 1:
+                            t5 = torch.tensor([dt5], dtype=torch.float64, device=device)
+                            if dist.get_backend() == "gloo":
+                                h5 = t5.cpu()
+                                dist.all_reduce(h5, op=dist.ReduceOp.MAX)
+                                dt5 = float(h5.item())
+                            else:
+                                dist.all_reduce(t5, op=dist.ReduceOp.MAX)
+                                dt5 = float(t5.item())
+                        if it >= 2:
+                            ts.append(dt5 * 1e3)
+                    c5[f"search_p50_ms_{label}"] = float(np.median(ts))
+                    c5[f"step_p50_ms_{label}"] = float(np.median(ts)) / 20
+                # HBM floor of a step per GPU: its share of the fp32 catalog once (candidates + exact log-sum-exp out of one
+                # pass) + the 1/8 sample of the bf16 catalog the threshold comes from
+                c5["step_hbm_floor_ms"] = (j4.eng.n_local * j4.cfg.emb_dim * (4.0 + 2.0 / 8)) / (PEAK_HBM_GBS * 1e9) * 1e3
+                X["c4"] = dict(c4, c5_beam32=c5)
+                c4 = X["c4"]
+            del j4
+            torch.cuda.empty_cache()
+
+    except Exception as e:  # noqa: BLE001 -- the headline must survive a failing extra leg
+        X["err"] = f"{X['stage']}: {type(e).__name__}: {e}"
+        print("bench.py: extra leg failed: " + X["err"], file=sys.stderr, flush=True)
+    wd.cancel()
+    emit()
+    if X["err"] and world > 1:
+        os._exit(0)  # (the other ranks may sit in a collective of the failed leg: their own watchdogs end them)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
