@@ -3252,6 +3252,13 @@ __device__ __forceinline__ int attn16_vstride(int Lmax) {
 // off-diagonal tile is then unmasked unless it holds that token, so the per-pair mask words, the do/skip logic
 // and the live-tile bits of the general form reduce to two comparisons of the pair index with the block index.
 // The general form executed 5.3 scalar and 5.9 vector instructions and 1.2 branches per MFMA (PMC, round 2).
+#ifdef ATTN_STAMP // (lab: tools/attn_lab.hip) per wave: start, loads issued, LDS filled, end; blocks done
+__device__ unsigned long long g_attn_stamp[8 * 65536];
+#define ATTN_T(i_) do { if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    g_attn_stamp[((size_t)((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) & 65535) * 8 + (i_)] = t_; } } while (0)
+#else
+#define ATTN_T(i_)
+#endif
 template <int MAXT, bool FAST>
 __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
                                                 const float *__restrict__ r_u, float *__restrict__ out, int Lmax, int d,
@@ -3279,6 +3286,7 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
     // (sequence, head) -- the loads of a fill are all in flight together, and the IRN target column needs key L-1.
     const int zsplit = blockIdx.z;
     if (gridDim.z > 1 && 4 * zsplit >= NB16) return;
+    ATTN_T(0);
     // K / V of this (sequence, head) -> LDS.  8 consecutive lanes take the 8 16-byte chunks of one key row, so a
     // load instruction covers 8 whole 128-byte K_h (V_h) slices -- in-kernel timing showed the ISSUE of these
     // loads, not their latency, dominating the fill when every lane touched a different row.  K's ds_write_b128
@@ -3300,6 +3308,7 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
             }
         }
     }
+    ATTN_T(1);
     // (the assignment below and the first Q request run while the K / V rows are in flight)
     // longest-first assignment of the 16-query blocks (block qb costs qb + 1 key tiles) to the 4 waves
     unsigned int mine = 0;
@@ -3355,7 +3364,9 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
             }
         }
     }
+    ATTN_T(2);
     __syncthreads();
+    ATTN_T(3);
     // Scores are kept in the log2 domain (Q is pre-scaled by log2(e)/sqrt(hd), p = exp2(s - m)), and the IRN
     // mask's "+ r_u on every allowed key" is applied as "- r_u on the target column" instead (softmax is
     // shift-invariant over the unmasked keys): two VALU operations per score fewer.
@@ -3557,6 +3568,7 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
             }
         }
     }
+    ATTN_T(4);
 }
 
 // ------------------------------------------------------------------ attention, head dim 32, split-bf16 MFMAs

@@ -1,0 +1,66 @@
+// Development lab for the throughput attention kernel (not product code): k_attn16<16, FAST> on synthetic packed sequences
+// with in-kernel s_memtime stamps (-DATTN_STAMP): how a workgroup's life splits into issuing the K / V loads, waiting for
+// them + staging them into LDS, the barrier, and the query blocks.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DATTN_STAMP tools/attn_lab.hip -o tools/attn_lab ; run: tools/attn_lab [sequences=4096]
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "../influentialrs_amd/csrc/decoder.hip"
+void irs_prof_begin(irs_ctx *, int, hipStream_t) {}
+void irs_prof_end(irs_ctx *, int, hipStream_t, double, double) {}
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
+
+int main(int argc, char **argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    const int B = argc > 1 ? atoi(argv[1]) : 4096, L = 200, d = 128, H = 4;
+    const int lens[8] = {40, 70, 95, 110, 130, 95, 200, 180}; // mean 115: the bench's packed windows average 109-117
+    std::vector<int32_t> off(B), cnt(B), padq(B, -1);
+    long long M = 0;
+    for (int b = 0; b < B; ++b) { off[b] = (int32_t)M; cnt[b] = lens[(b * 5 + b / 8) & 7]; M += cnt[b]; }
+    std::vector<float> hq((size_t)M * 3 * d);
+    unsigned long long z = 88172645463325252ull;
+    for (auto &v : hq) { z ^= z << 13; z ^= z >> 7; z ^= z << 17; v = ((float)((z >> 40) & 0xFFFFFF) * (1.0f / 16777216.0f) * 2 - 1) * 0.7f; }
+    std::vector<int64_t> hseq((size_t)B * L, 1);
+    float *qkv, *out, *ru;
+    int64_t *seq;
+    int32_t *doff, *dcnt, *dpadq;
+    CK(hipMalloc(&qkv, hq.size() * 4)); CK(hipMemcpy(qkv, hq.data(), hq.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&out, ((size_t)M + 128) * d * 4)); CK(hipMemset(out, 0, ((size_t)M + 128) * d * 4));
+    CK(hipMalloc(&ru, B * 4)); CK(hipMemset(ru, 0, B * 4));
+    CK(hipMalloc(&seq, hseq.size() * 8)); CK(hipMemcpy(seq, hseq.data(), hseq.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMalloc(&doff, B * 4)); CK(hipMemcpy(doff, off.data(), B * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&dcnt, B * 4)); CK(hipMemcpy(dcnt, cnt.data(), B * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&dpadq, B * 4)); CK(hipMemcpy(dpadq, padq.data(), B * 4, hipMemcpyHostToDevice));
+    int S16 = (L + 7) & ~7;
+    if ((S16 & 15) != 8) S16 += 8;
+    const size_t lds16 = (size_t)32 * S16 * 4 + (size_t)((L + 15) & ~15) * 32 * 4 + 64;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 3; ++rep) {
+        float ms;
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_attn16<16, true>), dim3(H, B), dim3(256), lds16, 0, qkv, seq, ru, out, L, d, IRS_MASK_IRN, doff, dcnt, dpadq, 1);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("k_attn16<16, FAST>: %d sequences x %d heads, %lld packed rows: %8.1f us\n", B, H, M, ms * 1e3);
+    }
+#ifdef ATTN_STAMP
+    {
+        const size_t nw = (size_t)B * H * 4 < 65536 ? (size_t)B * H * 4 : 65536;
+        std::vector<unsigned long long> hs(nw * 8);
+        CK(hipMemcpyFromSymbol(hs.data(), HIP_SYMBOL(g_attn_stamp), nw * 64));
+        double t[5] = {0, 0, 0, 0, 0};
+        size_t n = 0;
+        for (size_t w = 0; w < nw; ++w) {
+            const unsigned long long *s = &hs[w * 8];
+            if (!s[0] || !s[4] || s[4] < s[0]) continue;
+            t[0] += (double)(s[1] - s[0]), t[1] += (double)(s[2] - s[1]), t[2] += (double)(s[3] - s[2]), t[3] += (double)(s[4] - s[3]), t[4] += (double)(s[4] - s[0]);
+            ++n;
+        }
+        printf("stamps (s_memtime ticks per wave, mean over %zu waves): life %.0f = issue K/V loads %.0f + wait for them, masks, stage into LDS %.0f + "
+               "barrier %.0f + query blocks %.0f\n", n, t[4] / n, t[0] / n, t[1] / n, t[2] / n, t[3] / n);
+    }
+#endif
+    return 0;
+}
