@@ -590,3 +590,48 @@ def test_split_bf16_attention_kernel_on_request(oracle, monkeypatch):
     for b in (0, 2, 9):
         ref = oracle.decode(sd, cfg, seqs[b], int(users[b]))[0][L - 2]
         assert np.abs(ref - rpb[b].cpu().numpy()).max() < X_TOL_X6
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_split_bf16_kernels_random_batches(seed):
+    """Randomly drawn batch sizes, history lengths (pads in front, a few all-pad and a few full windows), consumed
+    positions and layer counts through the throughput path in both decoder arithmetic modes: the consumed rows agree
+    within X_TOL_X6, NaN rows (nothing visible) are NaN in both, and the greedy next items agree wherever the float32
+    mode's best two scores are further apart than the score noise."""
+    from influentialrs_amd._lib import IRS_GEMM_F32, IRS_GEMM_X6
+    g = np.random.default_rng(1000 + seed)
+    n_layers = int(g.integers(2, 7))
+    cfg = synth.make_config("c2", n_layers=n_layers)
+    L = cfg.max_len
+    B = int(g.integers(170, 700))
+    sd = synth.irn_state_dict(cfg, 300 + seed)
+    seqs = np.zeros((B, L), dtype=np.int64)
+    for b in range(B):
+        n = int(min(L - 1, max(1, g.lognormal(4.5, 0.7))))
+        if b % 37 == 5:
+            n = L - 1
+        if b % 41 == 7:
+            n = 0
+        seqs[b, L - 1 - n:L - 1] = g.integers(1, cfg.n_item + 1, size=n)
+        seqs[b, L - 1] = int(g.integers(1, cfg.n_item + 1))
+    users = g.integers(0, cfg.n_user, size=B).astype(np.int64)
+    pos = np.full(B, L - 2, dtype=np.int32)
+    pos[::13] = g.integers(0, L, size=len(pos[::13]))
+    seq, u, p = torch.from_numpy(seqs).cuda(), torch.from_numpy(users).cuda(), torch.from_numpy(pos).cuda()
+    eng = make_engine(cfg, sd, max_rows=B, max_seqs=B)
+    out = {}
+    for mode in (IRS_GEMM_X6, IRS_GEMM_F32):
+        eng.decoder_gemm = mode
+        _, xr, _ = eng.decode(seq, u, want_x=False, pos=p)
+        val, ids, st = eng.score_topk(xr, 2, IRS_SWEEP_F32)
+        out[mode] = (xr.clone(), val.clone(), ids.clone())
+    eng.decoder_gemm = IRS_GEMM_X6
+    ra, va, ia = out[IRS_GEMM_X6]
+    rb, vb, ib = out[IRS_GEMM_F32]
+    assert torch.equal(torch.isnan(ra), torch.isnan(rb))
+    ok = torch.isfinite(ra) & torch.isfinite(rb)
+    assert (ra - rb)[ok].abs().max().item() < X_TOL_X6
+    fin = torch.isfinite(vb).all(dim=1)
+    sep = fin & ((vb[:, 0] - vb[:, 1]).abs() > 4 * TAU)
+    assert sep.sum().item() > B // 2
+    assert torch.equal(ia[sep, 0], ib[sep, 0])
