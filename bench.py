@@ -234,14 +234,64 @@ def gpu_state_dict(cfg, device, seed=1234, item_lo=0, item_hi=None, with_embeddi
     return sd
 
 
+_ZIPF_CDF = {}
+
+
+def zipf_distinct_ids(B, L, n_item, device, gen):
+    """[B, L] item ids drawn Zipf(s = 1) over the catalog WITHOUT repeats inside a row (the host generator
+    synth.user_histories draws the same law user by user): 4 L inverse-CDF draws per row, duplicates dropped keeping the first
+    occurrence, the first L distinct ones kept.  A row that still comes up short (a tiny catalog) is topped up from a random
+    permutation of the ids it lacks."""
+    import torch
+    key = (n_item, str(device))
+    if key not in _ZIPF_CDF:
+        p = 1.0 / torch.arange(1, n_item + 1, device=device, dtype=torch.float64)
+        _ZIPF_CDF.clear()
+        _ZIPF_CDF[key] = torch.cumsum(p / p.sum(), 0)
+    cdf = _ZIPF_CDF[key]
+    K = min(max(4 * L, 64), max(n_item, 1) * 4)
+    out = torch.zeros((B, L), dtype=torch.int64, device=device)
+    rows = torch.arange(B, device=device)[:, None].expand(B, K)
+    u = torch.rand((B, K), generator=gen, device=device, dtype=torch.float64)
+    cand = (torch.searchsorted(cdf, u.reshape(-1)).reshape(B, K) + 1).clamp(max=n_item)
+    sv, si = torch.sort(cand, dim=1, stable=True)
+    dup_s = torch.zeros_like(sv, dtype=torch.bool)
+    dup_s[:, 1:] = sv[:, 1:] == sv[:, :-1]
+    keep = ~torch.zeros_like(dup_s).scatter_(1, si, dup_s)
+    rank = keep.cumsum(1) - 1
+    m = keep & (rank < L)
+    out[rows[m], rank[m]] = cand[m]
+    short = (keep.sum(1) < L).nonzero().flatten().tolist()
+    for b in short:  # (rare: only when 4 L draws hold fewer than L distinct ids)
+        have = out[b][out[b] > 0]
+        lack = torch.ones(n_item + 1, dtype=torch.bool, device=device)
+        lack[0] = False
+        lack[have] = False
+        pool = lack.nonzero().flatten()
+        need = L - have.numel()
+        if pool.numel() >= need:
+            out[b, have.numel():] = pool[torch.randperm(pool.numel(), generator=gen, device=device)[:need]]
+        else:  # a catalog smaller than the window: repeats are unavoidable
+            out[b, have.numel():] = torch.randint(1, n_item + 1, (need,), generator=gen, device=device)
+    return out
+
+
 def gpu_windows(B, L, n_item, device, seed):
     """ml-1m-shaped evaluation windows: history length log-normal (median 95, sigma 0.95)
-    clipped to [18, 2276]; the window keeps the last L-1 history items, pre-padded, target last
-    (DataLoaderEvalIRS layout, reference data_provider.py:591-617)."""
+    clipped to [18, 2276]; items Zipf(s = 1) without repeats per user; the window keeps the last L-1 history items,
+    pre-padded, target last = a uniformly drawn item absent from the window
+    (DataLoaderEvalIRS layout, reference data_provider.py:591-617; target rule :427-429)."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    seqs = torch.randint(1, n_item + 1, (B, L), generator=g, device=device, dtype=torch.int64)
+    seqs = zipf_distinct_ids(B, L, n_item, device, g)
+    tgt = torch.randint(1, n_item + 1, (B,), generator=g, device=device, dtype=torch.int64)
+    for _ in range(8):
+        clash = (seqs[:, :L - 1] == tgt[:, None]).any(1)
+        if not bool(clash.any()):
+            break
+        tgt = torch.where(clash, torch.randint(1, n_item + 1, (B,), generator=g, device=device, dtype=torch.int64), tgt)
+    seqs[:, L - 1] = tgt
     ln = torch.exp(torch.randn((B, 1), generator=g, device=device) * 0.95 + float(np.log(95.0)))
     hl = ln.clamp(18, 2276).long().clamp(max=L - 1)  # items kept in the window
     col = torch.arange(L, device=device)[None, :]
@@ -294,6 +344,7 @@ class Job:
             lo, hi = shard_bounds(cfg.n_item, world, rank) if self.sharded else (0, cfg.n_item)
             sd = gpu_state_dict(cfg, device, 1234, lo, hi)
         self.eng.bind_state_dict(sd)
+        self.sd = sd
         self.seqs = gpu_windows(self.B, cfg.max_len, cfg.n_item, device, seed=100 + rank)
         self.users = torch.randint(0, cfg.n_user, (self.B,), device=device, dtype=torch.int64)
         self.hep = torch.full((self.B,), cfg.max_len - 2, dtype=torch.int32, device=device)
@@ -348,6 +399,61 @@ def verify_job(job, n=4):
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             ok = bool(t.item())
     return ok, int((st & 1).sum().item())
+
+
+def verify_headline(job, n=8):
+    """Self-check of the headline leg.  The windows are the ones the timed loop left behind; `n` sampled users' step is
+    run twice: (a) inside the full batch through the call the loop ran (throughput kernels: packed rows, fused layer
+    kernel in the engine's decoder arithmetic, packed-sequence attention, irs_score_topk), (b) `n` users per call on a
+    second engine over the same weight tensors in IRS_GEMM_F32 -- at that size irs_decode takes the small-batch float32-MFMA
+    kernels, the ones tests/test_gpu_decoder_path.py pins to the reference's goldens user by user.  Decoder rows must agree
+    within 4e-5 (the split-bf16 bar), top-100 values within 5e-5, top-100 ids position by position except inside runs of
+    (b)'s scores closer than 2e-5, and the greedy next item wherever (b)'s two best surviving scores are further apart."""
+    import torch
+    from influentialrs_amd._lib import IRS_GEMM_F32, IRS_MASK_IRN
+    from influentialrs_amd.engine import Engine
+    cfg, eng, dev = job.cfg, job.eng, job.device
+    B = job.B
+    n = min(n, B)
+    sel = torch.linspace(0, B - 1, n, device=dev).long()
+    _, xr, _ = eng.decode(job.seqs, job.users, want_x=False, pos=job.hep)
+    val, ids, _ = eng.score_topk(xr, job.k, job.sweep)
+    small = Engine(n_item=cfg.n_item, n_user=cfg.n_user, d=cfg.emb_dim, max_len=cfg.max_len, n_heads=cfg.n_heads,
+                   ffn_dim=cfg.ffn_dim, n_layers=cfg.n_layers, u_dim=cfg.u_emb_dim, mask_mode=IRS_MASK_IRN, device=dev,
+                   max_rows=n, max_seqs=n, max_k=job.k)
+    small.bind_state_dict(job.sd)
+    small.decoder_gemm = IRS_GEMM_F32
+    seq_s, usr_s, hep_s = job.seqs[sel].contiguous(), job.users[sel].contiguous(), job.hep[sel].contiguous()
+    _, xr_s, _ = small.decode(seq_s, usr_s, want_x=False, pos=hep_s)
+    val_s, ids_s, _ = small.score_topk(xr_s, job.k, job.sweep)
+    # greedy next items: the path step of both engines on copies of the windows
+    nxt = []
+    for e, sq, hp, v, i in ((eng, job.seqs.clone(), job.hep.clone(), val, ids), (small, seq_s.clone(), hep_s.clone(), val_s, ids_s)):
+        pth = torch.zeros((sq.shape[0], 1), dtype=torch.float32, device=dev)
+        stt = torch.zeros(sq.shape[0], dtype=torch.int32, device=dev)
+        e.path_step(sq, hp, v, i, 0, pth, stt)
+        nxt.append(pth[:, 0])
+    torch.cuda.synchronize()
+    row_err = float((xr[sel] - xr_s).abs().max().item())
+    val_err = float((val[sel] - val_s).abs().max().item())
+    vs, ia, ib = val_s.cpu().numpy(), ids[sel].cpu().numpy(), ids_s.cpu().numpy()
+    ids_ok = True
+    for b in range(n):
+        for j in np.nonzero(ia[b] != ib[b])[0]:
+            if (np.abs(vs[b] - vs[b, j]) < 2e-5).sum() <= 1 and j != job.k - 1:
+                ids_ok = False
+    na, nb = nxt[0][sel].cpu().numpy(), nxt[1].cpu().numpy()
+    next_ok = True
+    for b in range(n):
+        if na[b] == nb[b]:
+            continue
+        pa, pb = np.nonzero(ib[b] == int(na[b]) - 1)[0], np.nonzero(ib[b] == int(nb[b]) - 1)[0]
+        if not (len(pa) and len(pb) and abs(float(vs[b][pa[0]]) - float(vs[b][pb[0]])) < 2e-5):  # not a near-tie of (b)'s scores
+            next_ok = False
+    ok = bool(row_err < 4e-5 and val_err < 5e-5 and ids_ok and next_ok)
+    del small
+    return ok, {"users_checked": n, "max_row_diff": row_err, "max_top100_value_diff": val_err, "ids_agree_outside_near_ties": ids_ok,
+                "greedy_next_item_agrees": bool(next_ok)}
 
 
 def phase_times(job, steps=3):
@@ -487,7 +593,12 @@ def main():
                     help="the command rocprofv3 --pmc / --kernel-trace wraps (tools/r03_measure.sh): warm-up + timed steps of the "
                          "headline workload only -- no CPU legs, no instrumented pass, no other legs -- and the packed row "
                          "count of exactly those steps as a JSON line on stdout")
-    ap.add_argument("--c4-batch", type=int, default=1024, help="users per rank per step of the c4_item_sharded leg")
+    ap.add_argument("--c4-batch", type=int, default=0, help="users per step of the c4_item_sharded leg: per rank under --scaling "
+                    "weak (default 1024), in total under --scaling strong (default 8192)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: 'weak' = --batch / --c3-batch / --c4-batch users PER RANK (work grows with N); 'strong' = that many "
+                         "users IN TOTAL, divided over the ranks (C4: 8192 users over the 10M-item catalog whatever N is; C5 is one "
+                         "user's beam search either way)")
     ap.add_argument("--c4-steps", type=int, default=5)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N > 1 code path with several ranks on ONE GPU)")
@@ -524,6 +635,15 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    strong = args.scaling == "strong"
+    if not args.c4_batch:
+        args.c4_batch = 8192 if strong else 1024
+    if strong:
+        for nm in ("batch", "c3_batch", "c4_batch"):
+            tot = getattr(args, nm)
+            if tot % world:
+                sys.exit(f"--scaling strong: --{nm.replace('_', '-')} {tot} is not divisible by {world} ranks")
+            setattr(args, nm, tot // world)
     job = Job(args.workload, args.batch, rank, world, device, args.shard, args.sweep, args.n_item)
     cfg = job.cfg
     if args.pmc_run:
@@ -566,6 +686,20 @@ def main():
         scale = 0.5 * (f0 + f1) if name in ("linear", "attn", "layer") else 1.0
         fam[name] = dict(launches=n, ms=ms, flops=fl * scale, bytes=by, packed_fraction=scale)
     job.eng.prof_enable(IRS_PROF_NONE)
+    # self-check of the headline: sampled users of the last step against the golden-pinned small-batch float32 kernels
+    try:
+        head_ok, head_how = verify_headline(job)
+    except Exception as e:  # noqa: BLE001 -- reported, never hidden: verified stays false
+        head_ok, head_how = False, {"error": f"{type(e).__name__}: {e}"}
+    if world > 1:
+        hv = torch.tensor([1 if head_ok else 0], dtype=torch.int32, device=device)
+        if dist.get_backend() == "gloo":
+            hc = hv.cpu()
+            dist.all_reduce(hc, op=dist.ReduceOp.MIN)
+            head_ok = bool(hc.item())
+        else:
+            dist.all_reduce(hv, op=dist.ReduceOp.MIN)
+            head_ok = bool(hv.item())
     layer = fam.pop("layer")
     x6 = job.eng.decoder_gemm == IRS_GEMM_X6
 
@@ -697,7 +831,8 @@ def main():
                                 "and the last layer's rows on float32 MFMAs" if x6 else "float32 MFMAs"),
                "parallelism": "single GPU" if world == 1 else (
                    f"rows data-parallel + item-sharded x{world}: RCCL all-gather of rows, one all_to_all of packed 64-bit top-100 keys "
-                   f"(irs_generate_paths_sharded: collectives below the C ABI, captured step)"
+                   f"(irs_generate_paths_sharded: collectives below the C ABI, "
+                   f"{'step replayed from a captured hipGraph' if SHARDED_GRAPH and job.comm is not None and job.comm.is_rccl else 'plain stream launches'})"
                    if job.sharded else
                    f"users partitioned over {world} GPUs, catalog replicated ({cfg.n_item} items): no data-path collective")}
     del job
@@ -708,7 +843,14 @@ def main():
     #      printed, with "extras_error" saying which leg did not finish.
     X = {"scoring": None, "c3": None, "c4": None, "stage": None, "err": None}
 
+    emit_lock = threading.Lock()
+    emitted = [False]
+
     def emit():
+        with emit_lock:  # the watchdog thread and the main thread may both get here: ONE line
+            if emitted[0]:
+                return
+            emitted[0] = True
         if rank != 0:
             return
         out = {
@@ -720,11 +862,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": out_cfg,
+            "verified": head_ok,
+            "verified_how": dict(head_how, what="sampled users of the timed loop's last windows: full-batch throughput kernels vs the "
+                                 "same users 8 per call on the float32-MFMA small-batch kernels (the ones the reference goldens pin "
+                                 "user by user): rows < 4e-5, top-100 values < 5e-5, ids equal outside near-ties < 2e-5, same greedy item"),
             "path_gen_p50_ms_b1": lat,
             "path_gen_b1_window_tokens": lat_tokens,
             "path_gen_ms_per_user_b128": lat128,
@@ -733,6 +879,12 @@ def main():
             "scoring": X["scoring"],
             "c3_1M_items": X["c3"],
             "c4_item_sharded": X["c4"],
+            # what an N = 1 vs N = 8 comparison should read: BASELINE configs[3], the 10M-item catalog cut into N item shards
+            # (the C2 headline above replicates its 1.7 MB catalog: its N-GPU value scales trivially)
+            "scale_metric": (None if X["c4"] is None else
+                             {k: X["c4"].get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling",
+                                                          "users_per_gpu", "items_per_gpu", "workload", "parallelism", "verified",
+                                                          "verified_how", "fallback_rows", "phase_ms_rank0")}),
             "cpu_baseline": cpu,
         }
         if X["err"]:
@@ -740,9 +892,13 @@ def main():
         print(json.dumps(out), flush=True)
 
     def watchdog():
-        X["err"] = f"extra legs did not finish within {args.extras_timeout} s (stage: {X['stage']})"
+        # the headline line is still printed, but the process reports FAILURE (a hung collective or leg must not read as
+        # success to torchrun or to a `|| exit 1` chain); non-zero ranks leave the same way
+        if not X["err"]:
+            X["err"] = f"extra legs did not finish within {args.extras_timeout} s (stage: {X['stage']})"
         emit()
-        os._exit(0)
+        sys.stdout.flush()
+        os._exit(3)
 
     wd = threading.Timer(args.extras_timeout, watchdog)
     wd.daemon = True
@@ -763,7 +919,7 @@ def main():
             ok3, fb3 = verify_job(j3)
             X["c3"] = {"metric": "scored user-item pairs/sec (whole node)", "value": u3 * j3.cfg.n_item * args.c3_steps / dt3,
                   "unit": "pairs/s", "n_gpus": world, "steps": args.c3_steps, "ms_per_step": dt3 / args.c3_steps * 1e3,
-                  "scaling": "weak", "users_per_gpu": j3.B, "items_per_gpu": j3.eng.n_local,
+                  "scaling": args.scaling, "users_per_gpu": j3.B, "items_per_gpu": j3.eng.n_local,
                   "workload": f"c3: n_item={j3.cfg.n_item}, d={j3.cfg.emb_dim}, L={j3.cfg.max_len}, H={j3.cfg.n_heads}; one greedy "
                               f"path-search step, top-100",
                   "verified": ok3, "verified_how": "4 rows of the last step: ring-sweep top-100 == float32-sweep top-100 (ids and value bits)",
@@ -782,7 +938,7 @@ def main():
             ok4, fb4 = verify_job(j4)
             c4 = {"metric": "scored user-item pairs/sec (whole node)", "value": u4 * j4.cfg.n_item * args.c4_steps / dt4,
                   "unit": "pairs/s", "n_gpus": world, "steps": args.c4_steps, "ms_per_step": dt4 / args.c4_steps * 1e3,
-                  "scaling": "weak", "users_per_gpu": j4.B, "items_per_gpu": j4.eng.n_local,
+                  "scaling": args.scaling, "users_per_gpu": j4.B, "items_per_gpu": j4.eng.n_local,
                   "workload": f"c4: n_item={j4.cfg.n_item}, d={j4.cfg.emb_dim}, L={j4.cfg.max_len}, H={j4.cfg.n_heads}; one greedy "
                               f"path-search step, top-100",
                   "parallelism": "single GPU holds the whole catalog" if world == 1 else
@@ -810,7 +966,9 @@ def main():
                 c5 = {"workload": "c5: beam 32 x 20 steps, 1 user, n_item=10000000, d=256 (" +
                                   ("one GPU holds the whole catalog)" if world == 1 else
                                    f"{world} item shards of {j4.eng.n_local} rows; beam windows decoded {32 // world} per rank)"),
-                      "n_gpus": world}
+                      "n_gpus": world,
+                      "beam_oracle": "build-defined, no reference counterpart (the reference has no beam search: beam > 1 is pinned by "
+                                     "this repo's CPU statement oracle_np.beam_search only; beam = 1 equals the reference's greedy paths)"}
                 for label, graph in (("stream", False), ("hipgraph", True)):
                     if graph and world > 1 and not SHARDED_GRAPH:
                         continue
@@ -851,13 +1009,15 @@ def main():
     except Exception as e:  # noqa: BLE001 -- the headline must survive a failing extra leg
         X["err"] = f"{X['stage']}: {type(e).__name__}: {e}"
         print("bench.py: extra leg failed: " + X["err"], file=sys.stderr, flush=True)
-    wd.cancel()
     emit()
-    if X["err"] and world > 1:
-        os._exit(0)  # (the other ranks may sit in a collective of the failed leg: their own watchdogs end them)
+    if X["err"]:
+        sys.stdout.flush()
+        os._exit(3)  # (N > 1: the other ranks may sit in a collective of the failed leg; their own watchdogs end them, non-zero too)
     if world > 1:
+        X["stage"] = "final barrier"   # the watchdog stays armed: a peer that left through os._exit would block this forever
         dist.barrier()
         dist.destroy_process_group()
+    wd.cancel()
 
 
 if __name__ == "__main__":

@@ -323,6 +323,13 @@ int irs_comm_init_callbacks(irs_comm **out, int32_t rank, int32_t world, void *u
 void irs_comm_destroy(irs_comm *comm);
 const char *irs_comm_last_error(void);
 int irs_comm_is_rccl(const irs_comm *comm);
+/* how irs_exchange_topk moves the keys: 0 = caller-supplied callbacks, 1 = ncclAllToAll (an RCCL extension), 2 = grouped
+ * ncclSend / ncclRecv (libraries without the extension; IRS_RCCL_NO_ALLTOALL=1 in the environment at irs_comm_init_rccl
+ * forces it, so that the fallback can be tested on a library that has the extension) */
+int irs_comm_exchange_kind(const irs_comm *comm);
+/* NCCL version code of the librccl.so in use (0 before the first irs_comm_unique_id / irs_comm_init_rccl).  The library is
+ * refused at load time unless its major version is the one csrc/comm.hip was compiled against (rccl.h: 2.x). */
+int irs_comm_rccl_version(void);
 
 /* rows decoded data-parallel -> all rows on every rank, rank-major: dev_rows_all float [world * B, d]. */
 int irs_allgather_rows(irs_ctx *ctx, irs_comm *comm, const float *dev_rows_local, int32_t B, float *dev_rows_all, void *stream);

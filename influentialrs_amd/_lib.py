@@ -72,6 +72,8 @@ SIGNATURES = {
     "irs_comm_destroy": (None, [c_void_p]),
     "irs_comm_last_error": (c_char_p, []),
     "irs_comm_is_rccl": (c_int32, [c_void_p]),
+    "irs_comm_exchange_kind": (c_int32, [c_void_p]),
+    "irs_comm_rccl_version": (c_int32, []),
     "irs_allgather_rows": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "irs_exchange_topk": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "irs_generate_paths_sharded": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,

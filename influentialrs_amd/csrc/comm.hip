@@ -12,15 +12,19 @@
 
 #include "irs_internal.h"
 
-// ---- the few RCCL declarations used (rccl.h is not included: librccl.so -- 570 MB -- is loaded on demand only)
-typedef struct irs_nccl_comm *irs_nccl_comm_t;
-typedef struct {
-    char internal[IRS_COMM_ID_BYTES];
-} irs_nccl_uid;
-enum { IRS_NCCL_SUM = 0, IRS_NCCL_MAX = 2, IRS_NCCL_INT8 = 0, IRS_NCCL_FLOAT32 = 7 };
+// ---- RCCL: types and constants come from rccl.h (compile time); the LIBRARY (570 MB) is loaded on demand with dlopen and
+//      its functions are reached through the pointers below, so libirs_hip.so carries no link-time dependency on it.
+#include <rccl/rccl.h>
+typedef ncclComm_t irs_nccl_comm_t;
+typedef ncclUniqueId irs_nccl_uid;
+enum { IRS_NCCL_SUM = ncclSum, IRS_NCCL_MAX = ncclMax, IRS_NCCL_INT8 = ncclInt8, IRS_NCCL_FLOAT32 = ncclFloat32 };
+static_assert(sizeof(ncclUniqueId) == IRS_COMM_ID_BYTES, "include/irs_hip.h: IRS_COMM_ID_BYTES must equal NCCL_UNIQUE_ID_BYTES");
+static_assert(NCCL_MAJOR == 2, "the call signatures below are the NCCL 2.x ABI");
 
 struct irs_rccl_api {
     void *lib;
+    int version;
+    int (*GetVersion)(int *);
     int (*GetUniqueId)(irs_nccl_uid *);
     int (*CommInitRank)(irs_nccl_comm_t *, int, irs_nccl_uid, int);
     int (*CommDestroy)(irs_nccl_comm_t);
@@ -40,6 +44,7 @@ static char g_comm_err[512] = "";
 struct irs_comm {
     int rank, world;
     bool rccl;
+    bool p2p_alltoall; // exchange through grouped ncclSend / ncclRecv (the library lacks ncclAllToAll, or IRS_RCCL_NO_ALLTOALL=1)
     irs_nccl_comm_t nccl;
     void *user;
     irs_allgather_fn allgather;
@@ -73,6 +78,7 @@ static int load_rccl() {
             return IRS_E_STATE;                                                           \
         }                                                                                 \
     } while (0)
+    SYM(GetVersion, "ncclGetVersion", true);
     SYM(GetUniqueId, "ncclGetUniqueId", true);
     SYM(CommInitRank, "ncclCommInitRank", true);
     SYM(CommDestroy, "ncclCommDestroy", true);
@@ -85,6 +91,17 @@ static int load_rccl() {
     SYM(GroupEnd, "ncclGroupEnd", true);
     SYM(GetErrorString, "ncclGetErrorString", true);
 #undef SYM
+    // the library actually loaded (possibly the host process's own copy) must speak the ABI this file was compiled against:
+    // the enum values and call signatures are stable within NCCL major version 2
+    int ver = 0;
+    if (g_rccl.GetVersion(&ver) != 0 || ver / 10000 != NCCL_MAJOR) {
+        snprintf(g_comm_err, sizeof(g_comm_err), "librccl.so reports NCCL version code %d; this library was built against %d.%d (major %d required)",
+                 ver, NCCL_MAJOR, NCCL_MINOR, NCCL_MAJOR);
+        memset(&g_rccl, 0, sizeof(g_rccl));
+        dlclose(lib);
+        return IRS_E_STATE;
+    }
+    g_rccl.version = ver;
     g_rccl.lib = lib;
     return IRS_OK;
 }
@@ -121,6 +138,10 @@ extern "C" int irs_comm_init_rccl(irs_comm **out, const void *id128, int32_t ran
     c->rank = rank;
     c->world = world;
     c->rccl = true;
+    // ncclAllToAll is an RCCL extension: without it -- or on request, so that the fallback can be exercised on a library that
+    // has it -- the key exchange runs as grouped point-to-point transfers
+    const char *no_a2a = getenv("IRS_RCCL_NO_ALLTOALL");
+    c->p2p_alltoall = !g_rccl.AllToAll || (no_a2a && no_a2a[0] == '1');
     irs_nccl_uid id;
     memcpy(id.internal, id128, IRS_COMM_ID_BYTES);
     int r = g_rccl.CommInitRank(&c->nccl, world, id, rank);
@@ -135,7 +156,16 @@ extern "C" int irs_comm_init_rccl(irs_comm **out, const void *id128, int32_t ran
         char *t = (char *)tmp;
         r = g_rccl.AllGather(t, t + 256, 4, IRS_NCCL_INT8, c->nccl, nullptr);
         if (!r) r = g_rccl.AllReduce(t, t, 1, IRS_NCCL_FLOAT32, IRS_NCCL_SUM, c->nccl, nullptr);
-        if (!r && g_rccl.AllToAll) r = g_rccl.AllToAll(t + 256, t + 256 + (size_t)world * 128, 4, IRS_NCCL_INT8, c->nccl, nullptr);
+        if (!r && !c->p2p_alltoall) r = g_rccl.AllToAll(t + 256, t + 256 + (size_t)world * 128, 4, IRS_NCCL_INT8, c->nccl, nullptr);
+        if (!r && c->p2p_alltoall) { // the fallback's first use sets up the point-to-point channels
+            r = g_rccl.GroupStart();
+            for (int p = 0; p < world && !r; ++p) {
+                r = g_rccl.Send(t + 256 + (size_t)p * 4, 4, IRS_NCCL_INT8, p, c->nccl, nullptr);
+                if (!r) r = g_rccl.Recv(t + 256 + (size_t)world * 128 + (size_t)p * 4, 4, IRS_NCCL_INT8, p, c->nccl, nullptr);
+            }
+            int r2 = g_rccl.GroupEnd();
+            if (!r) r = r2;
+        }
         hipError_t he = hipStreamSynchronize(nullptr);
         (void)hipFree(tmp);
         if (r != 0 || he != hipSuccess) {
@@ -175,6 +205,9 @@ extern "C" void irs_comm_destroy(irs_comm *c) {
 }
 
 extern "C" int irs_comm_is_rccl(const irs_comm *c) { return c && c->rccl ? 1 : 0; }
+// 0: callbacks; 1: RCCL with ncclAllToAll; 2: RCCL with the grouped Send / Recv exchange
+extern "C" int irs_comm_exchange_kind(const irs_comm *c) { return !c || !c->rccl ? 0 : (c->p2p_alltoall ? 2 : 1); }
+extern "C" int irs_comm_rccl_version(void) { return g_rccl.lib ? g_rccl.version : 0; }
 
 // ---- collectives (bytes; stream-ordered)
 static int comm_allgather(irs_ctx *ctx, irs_comm *c, const void *send, void *recv, size_t bytes, hipStream_t s) {
@@ -190,7 +223,7 @@ static int comm_allgather(irs_ctx *ctx, irs_comm *c, const void *send, void *rec
 static int comm_alltoall(irs_ctx *ctx, irs_comm *c, const void *send, void *recv, size_t bytes, hipStream_t s) {
     if (c->rccl) {
         int r;
-        if (g_rccl.AllToAll) r = g_rccl.AllToAll(send, recv, bytes, IRS_NCCL_INT8, c->nccl, s);
+        if (!c->p2p_alltoall) r = g_rccl.AllToAll(send, recv, bytes, IRS_NCCL_INT8, c->nccl, s);
         else { // grouped point-to-point: the same exchange on any NCCL-compatible library
             r = g_rccl.GroupStart();
             for (int p = 0; p < c->world && !r; ++p) {

@@ -4292,12 +4292,10 @@ static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const
         // per step: the plane splits of p and of K / V make it VALU-bound, 14 % MFMA busy, and its LDS images allow two
         // workgroups per CU instead of three), so it runs only on request (IRS_ATTN_GEMM=x6 when the context is created).
         if (ctx->use_attn_x6 && grid.z == 1 && lds16x <= 160 * 1024) {
-            static bool attr = false;
-            if (!attr) {
+            IRS_ONCE_PER_DEVICE({
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn16x<16, true, ATTN16X_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn16x<16, false, ATTN16X_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr = true;
-            }
+            });
             if (tok_row)
                 hipLaunchKernelGGL((k_attn16x<16, true, ATTN16X_NW>), grid, dim3(64 * ATTN16X_NW), lds16x, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
                                    ctx->seq_padq, frag_out ? 1 : 0);
@@ -4377,12 +4375,11 @@ int irs_launch_pack_x6(irs_ctx *ctx, hipStream_t s) {
 }
 static constexpr int X6_LDS_BYTES = 3 * X6_STEP_B + 1792 * 4;
 static void x6_attr_once() { // (the kernels' dynamic LDS exceeds the default 64 KB limit)
-    static bool done = false;
-    if (done) return;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, X6_NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<1, X6_NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, X6_NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES);
-    done = true;
+    IRS_ONCE_PER_DEVICE({
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, X6_NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<1, X6_NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, X6_NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES);
+    });
 }
 
 size_t irs_small_frag_floats(const irs_ctx *ctx) {

@@ -9,6 +9,36 @@
 
 #include "../../include/irs_hip.h"
 
+// Lab switches.  The kernels carry measurement hooks (phase stamps, fragment dumps, "run without the MFMAs / DMA / barrier"
+// variants) that tools/*_lab.hip turn on by including a kernel source with the switch defined.  Several of them change what
+// a kernel COMPUTES, so a stray -D must never produce a library: every switch is legal only together with IRS_LAB, which
+// influentialrs_amd/build.py never defines (and tests/test_cabi.py checks that it does not).
+#if !defined(IRS_LAB) && (defined(X6_DUMP) || defined(X6_STAMP) || defined(X6_NO_SPLIT) || defined(X6_STAGGER) ||            \
+                          defined(X6_NO_MFMA) || defined(X6_NO_READS) || defined(X6_NO_DMA) || defined(X6_NO_BARRIER) ||       \
+                          defined(X6_NW) || defined(ATTN16X_NW) || defined(ATTN_STAMP) || defined(ATTNP_STAMP) ||               \
+                          defined(IRS_SMALL_TIMING) || defined(IRS_DIRECT_TIMING) || defined(SWEEP_LAB) || defined(X6D_STAMP))
+#error "a lab switch (X6_* / ATTN* / IRS_*_TIMING) is defined without IRS_LAB: the product library must be built without them"
+#endif
+
+#include <atomic>
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) and occupancy are PER DEVICE: the "done once" flags of the launchers are a
+// bit per device ordinal (setting the attribute twice from two host threads is harmless, so a plain atomic mask suffices)
+#define IRS_MAX_DEVICES 32
+static inline int irs_cur_dev() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= IRS_MAX_DEVICES) d = 0;
+    return d;
+}
+#define IRS_ONCE_PER_DEVICE(body_)                                                                                        \
+    do {                                                                                                                  \
+        static std::atomic<unsigned> once_mask_{0};                                                                       \
+        const unsigned once_bit_ = 1u << irs_cur_dev();                                                                   \
+        if (!(once_mask_.load(std::memory_order_acquire) & once_bit_)) {                                                  \
+            body_;                                                                                                        \
+            once_mask_.fetch_or(once_bit_, std::memory_order_release);                                                    \
+        }                                                                                                                 \
+    } while (0)
+
 #define IRS_MAX_LAYERS 16
 #define IRS_CAND_BUCKETS 64 // candidate lists per row (bucket = item tile mod 64)
 #define IRS_CAND_SLOTS 64   // entries per bucket

@@ -2644,11 +2644,14 @@ static void launch_ring(SweepArgs &a, hipStream_t s) {
     a.n_ublocks = (a.UT + NW * RT - 1) / (NW * RT);
     const size_t lds = (size_t)NSLOT * TPS * KS * 1024 + (size_t)NSLOT * TPS * 256 + (size_t)NW * (EMIT_Q * 12 + 16);
     auto kern = k_sweep_ring<KS, RT, TPS, NW, 2, NSLOT, MODE>;
-    static int slots = 0; // per instantiation
+    static std::atomic<int> slots_dev[IRS_MAX_DEVICES]; // per instantiation and device
+    const int dev_ = irs_cur_dev();
+    int slots = slots_dev[dev_].load(std::memory_order_acquire);
     if (!slots) {
         if (lds > 65536)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         slots = resident_workgroups(kern, NW * 64, lds);
+        slots_dev[dev_].store(slots, std::memory_order_release);
     }
     if (MODE == MODE_EMIT) {
         // Equal strips, sized so that the grid is just under a whole number of rounds of resident workgroups: the
@@ -2688,11 +2691,14 @@ static void launch_ring16(SweepArgs &a, hipStream_t s) {
     a.n_ublocks = (a.UT + NW * (RT16 / 2) - 1) / (NW * (RT16 / 2));
     const size_t lds = ring16_lds_bytes(KS, RT16, NW, NSLOT);
     auto kern = k_sweep_ring16<KS, RT16, NW, NSLOT, MODE>;
-    static int slots = 0; // per instantiation
+    static std::atomic<int> slots_dev[IRS_MAX_DEVICES]; // per instantiation and device
+    const int dev_ = irs_cur_dev();
+    int slots = slots_dev[dev_].load(std::memory_order_acquire);
     if (!slots) {
         if (lds > 65536)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         slots = resident_workgroups(kern, NW * 64, lds);
+        slots_dev[dev_].store(slots, std::memory_order_release);
     }
     if (MODE == MODE_EMIT) ring_emit_grid(a, slots);
     else a.tiles_per_wg = 0;
@@ -2848,12 +2854,10 @@ static int launch_lse_f32(irs_ctx *ctx, SweepArgs &a, hipStream_t s) {
         const int nwg = (a.n_strips + SPW - 1) / SPW;
         dim3 grid(((nwg + 7) / 8) * 8);
         const size_t lds = (size_t)LSE_RING_NW * LSE_RING_WAVE_B + (size_t)LSE_RING_NW * (EMIT_Q * 12 + 16);
-        static bool attr = false;
-        if (!attr) {
+        IRS_ONCE_PER_DEVICE({
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lse_ring<16, EMIT, LSE_RING_NW, LSE_RING_CK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lse_ring<8, EMIT, LSE_RING_NW, LSE_RING_CK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
+        });
         if (KS == 16) hipLaunchKernelGGL((k_lse_ring<16, EMIT, LSE_RING_NW, LSE_RING_CK>), grid, dim3(64 * LSE_RING_NW), lds, s, a);
         else hipLaunchKernelGGL((k_lse_ring<8, EMIT, LSE_RING_NW, LSE_RING_CK>), grid, dim3(64 * LSE_RING_NW), lds, s, a);
         IRS_CHECK_HIP(ctx, hipGetLastError());
@@ -2866,12 +2870,8 @@ static int launch_lse_f32(irs_ctx *ctx, SweepArgs &a, hipStream_t s) {
     const size_t lds = (size_t)UB * KS * 2048 + EMIT_Q_BYTES;
 #define L_(KS_, UB_, XR_)                                                                                                 \
     do {                                                                                                                  \
-        static bool attr = false;                                                                                         \
-        if (!attr) {                                                                                                      \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lse_f32<KS_, UB_, EMIT, XR_>),                     \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
-            attr = true;                                                                                                  \
-        }                                                                                                                 \
+        IRS_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lse_f32<KS_, UB_, EMIT, XR_>),     \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
         hipLaunchKernelGGL((k_lse_f32<KS_, UB_, EMIT, XR_>), grid, dim3(256), lds, s, a);                                 \
     } while (0)
     switch (KS) {

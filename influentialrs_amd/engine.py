@@ -426,12 +426,18 @@ class Engine:
         B = seqs.shape[0]
         paths = torch.zeros((B, beam, max_path_len), dtype=torch.float32, device=self.device)
         scores = torch.zeros((B, beam), dtype=torch.float64, device=self.device)
-        status = torch.zeros(B, dtype=torch.int32, device=self.device)
+        # the status pointer is part of the captured step's reuse key (capi: sh_ptr): a buffer of the engine's own, so that
+        # a replay does not depend on which address the allocator hands out; the caller receives a copy
+        if getattr(self, "_beam_status", None) is None or self._beam_status.numel() < B:
+            self._beam_status = torch.zeros(max(B, 64), dtype=torch.int32, device=self.device)
+        status = self._beam_status[:B]
+        status.zero_()
         fin = torch.empty((B, beam, self.L), dtype=torch.int64, device=self.device) if want_windows else None
         with torch.cuda.device(self.device):
             self._check(self.lib.irs_beam_search_sharded(self.h, comm.h, _ptr(seqs), _ptr(users), _ptr(hep), B, beam, max_path_len, k,
                                                          sweep, int(split_decode), int(use_graph), _ptr(paths), _ptr(scores),
                                                          _ptr(fin), _ptr(status), self._stream()))
+        status = status.clone()
         return (paths, scores, status, fin) if want_windows else (paths, scores, status)
 
     # ------------------------------------------------------------------ decoder GEMM arithmetic

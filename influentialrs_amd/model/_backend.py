@@ -62,7 +62,12 @@ class HipBackend:
     def _fingerprint(self):
         return tuple((t.data_ptr(), t._version) for t in self.net.state_dict(keep_vars=True).values())
 
-    def get(self, n_seqs: int, n_rows: int, for_training: bool = False) -> Engine:
+    def invalidate(self):
+        """Weights were changed behind autograd's back (`.data` writes outside a training step, which bump no version
+        counter): the next get() re-binds and re-derives (bf16 catalog, packed decoder streams, captured graphs)."""
+        self._stale = True
+
+    def get(self, n_seqs: int, n_rows: int, for_training: bool = False, may_update: bool = True) -> Engine:
         net = self.net
         dev = next(net.parameters()).device
         if dev.type != "cuda":
@@ -88,14 +93,16 @@ class HipBackend:
         if for_training and self._fp is not None and [a for a, _ in fp] == [a for a, _ in self._fp]:
             # same storage: the CE entry points read project.* in place, nothing derived is used -- but whatever the
             # caller does with the gradients (an optimizer step, also through .data, which bumps no version counter)
-            # leaves the bf16 catalog and the filter's norms behind: the next inference get() re-finalises
-            self._stale = True
+            # leaves the bf16 catalog and the filter's norms behind: the next inference get() re-finalises.  A loss that
+            # cannot reach an optimizer (no_grad / nothing requires grad: the Evaluator's eval-only loss, alternating with
+            # rankings batch after batch) changes no weight and must not cost a re-pack of a multi-GB catalog every batch.
+            self._stale = self._stale or may_update
             return self.engine
         if fp != self._fp or self._stale:
             sd = {k: v.detach() for k, v in net.state_dict(keep_vars=True).items() if v.dtype == torch.float32}
             self.engine.bind_state_dict(sd)
             self._fp = fp
-            self._stale = for_training
+            self._stale = for_training and may_update
         return self.engine
 
     # ---- row-level helpers (single shard or sharded group) ---------------
@@ -125,9 +132,9 @@ class _ProjectCE(torch.autograd.Function):
     CHUNK_BYTES = 1 << 30  # budget of the dL/dlogits chunk
 
     @staticmethod
-    def forward(ctx, x, weight, bias, labels0, backend):
+    def forward(ctx, x, weight, bias, labels0, backend, may_update):
         M = x.shape[0]
-        eng = backend.get(1, min(M, _ProjectCE.ROWS), for_training=True)
+        eng = backend.get(1, min(M, _ProjectCE.ROWS), for_training=True, may_update=may_update)
         xd = x.detach().contiguous()
         lse = torch.empty(M, dtype=torch.float32, device=x.device)
         tot = torch.zeros(3, dtype=torch.float64, device=x.device)
@@ -153,7 +160,7 @@ class _ProjectCE(torch.autograd.Function):
         M, d = xd.shape
         N = weight.shape[0]
         if ctx.n_valid == 0:
-            return torch.zeros_like(xd), torch.zeros_like(weight), torch.zeros(N, dtype=torch.float32, device=xd.device), None, None
+            return torch.zeros_like(xd), torch.zeros_like(weight), torch.zeros(N, dtype=torch.float32, device=xd.device), None, None, None
         eng = ctx.backend.get(1, min(M, _ProjectCE.ROWS), for_training=True)
         mc = max(32, min(_ProjectCE.ROWS, M, (_ProjectCE.CHUNK_BYTES // (4 * N)) // 32 * 32))
         G = torch.empty((mc, N), dtype=torch.float32, device=xd.device)
@@ -167,12 +174,14 @@ class _ProjectCE(torch.autograd.Function):
             dW.addmm_(Gc.t(), xd[c0:c1])
             db += Gc.sum(0)
         sc = (g.double() / tot[1]).to(torch.float32)  # dL/dloss / n_valid, kept on the device
-        return dx * sc, dW * sc, db * sc, None, None
+        return dx * sc, dW * sc, db * sc, None, None, None
 
 
 def project_ce(x: torch.Tensor, project: nn.Linear, labels0: torch.Tensor, backend: "HipBackend") -> torch.Tensor:
     """Scalar loss; x [M, d] rows of the decoder, labels0 [M] 0-based with -1 = ignored."""
-    return _ProjectCE.apply(x, project.weight, project.bias, labels0, backend)
+    # (grad mode is off inside Function.forward: whether this loss can lead to a weight update is decided here)
+    may_update = torch.is_grad_enabled() and (x.requires_grad or project.weight.requires_grad or project.bias.requires_grad)
+    return _ProjectCE.apply(x, project.weight, project.bias, labels0, backend, may_update)
 
 
 def pad_ragged_ids(lists: Sequence, device, minus: int = 1) -> torch.Tensor:

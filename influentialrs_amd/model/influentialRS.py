@@ -19,6 +19,7 @@ Behaviour pinned by the reference (file:line = /root/reference/model/influential
   * selection order is (score desc, id asc); torch's tie order is unspecified.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -29,6 +30,8 @@ import torch.optim as optim
 from .._lib import IRS_MASK_IRN, IRS_ROW_NO_CANDIDATE
 from ._backend import HipBackend, make_scheduler, pad_ragged_ids, project_ce
 from .layers import PositionalEncoding, get_item_index
+
+_SHARDED_GRAPH = os.environ.get("IRS_SHARDED_GRAPH", "0") == "1"  # captured sharded steps: opt-in (see _beam_paths)
 
 
 class InfluentialNet(nn.Module):
@@ -247,8 +250,11 @@ class IRSNN(nn.Module):
         else:  # item-sharded: the whole loop runs below the C ABI (irs_beam_search_sharded: row all-gather, packed top-100
             # all-to-all, log-sum-exp all-reduce per step, one stream-ordered sequence; captured into a hipGraph over RCCL)
             eng = hip.get(B * W, B * W * hip.world)
+            # (replaying the step from a hipGraph with the RCCL calls inside is covered by one-rank tests only: opt in with
+            #  IRS_SHARDED_GRAPH=1 once a multi-device capture run is on record -- the same switch bench.py honours)
             paths, scores, status = eng.beam_search_sharded(hip.comm, seqs.contiguous(), users, hep, max_path_len, W, k=100,
-                                                            sweep=hip.sweep, split_decode=False, use_graph=hip.comm.is_rccl)
+                                                            sweep=hip.sweep, split_decode=False,
+                                                            use_graph=hip.comm.is_rccl and _SHARDED_GRAPH)
         self.last_beams = (paths.detach().cpu().numpy(), scores.detach().cpu().numpy())
         return paths[:, 0].contiguous(), status
 

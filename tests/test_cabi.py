@@ -72,3 +72,18 @@ def test_product_has_no_cpu_path():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f
+
+
+def test_product_build_defines_no_lab_switch():
+    """The kernels' measurement hooks (X6_NO_MFMA, X6_DUMP, ATTN_STAMP ...) change what a kernel computes or writes; they
+    are legal only under IRS_LAB (csrc/irs_internal.h #errors otherwise) and the product build defines neither."""
+    from influentialrs_amd import build
+    assert not [f for f in build.FLAGS if f.startswith("-D")], build.FLAGS
+    with open(os.path.join(REPO, "influentialrs_amd", "csrc", "irs_internal.h")) as fh:
+        txt = fh.read()
+    assert "#if !defined(IRS_LAB)" in txt and "#error" in txt
+    import subprocess
+    src = os.path.join(REPO, "influentialrs_amd", "csrc", "path.hip")
+    r = subprocess.run([build.HIPCC, "--offload-arch=gfx950", "-std=c++17", "-DX6_NO_MFMA", "-fsyntax-only", src],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "IRS_LAB" in r.stderr

@@ -82,3 +82,61 @@ def test_sharded_entry_points_validate(comm):
     shard = make_engine(cfg, synth.irn_state_dict(cfg, 1234), max_rows=32, max_seqs=8, rank=0, world=2)
     with pytest.raises(IrsError, match="communicator is rank"):  # a one-rank communicator on a two-shard context
         shard.generate_paths_sharded(comm, seqs[:4].clone(), users[:4], hep[:4].clone(), 3)
+
+
+_PROBE = r"""
+import sys, faulthandler
+faulthandler.dump_traceback_later(100, exit=True)
+sys.path.insert(0, {repo!r}); sys.path.insert(0, {repo!r} + "/tests")
+import torch
+from influentialrs_amd import synth
+from influentialrs_amd._lib import IRS_SWEEP_BF16
+from influentialrs_amd.engine import Comm
+from gpu_util import make_engine
+from test_gpu_comm import _windows
+dev = torch.device("cuda:0")
+comm = Comm(dev, backend="nccl")
+print("stage init", comm.lib.irs_comm_rccl_version(), comm.lib.irs_comm_exchange_kind(comm.h), flush=True)
+assert comm.lib.irs_comm_rccl_version() // 10000 == 2 and comm.lib.irs_comm_exchange_kind(comm.h) == {kind}
+cfg = synth.make_config("tiny")
+eng = make_engine(cfg, synth.irn_state_dict(cfg, 1234), max_rows=16, max_seqs=16)
+k = torch.randint(0, 2 ** 62, (1, 7, 9), device="cuda", dtype=torch.int64)
+assert torch.equal(eng.exchange_topk(comm, k), k)
+torch.cuda.synchronize()
+print("stage exchange", flush=True)
+seqs, users = _windows(cfg, 9, 11)
+hep = torch.full((9,), cfg.max_len - 2, dtype=torch.int32, device="cuda")
+for use_graph in (False, True):
+    p1, s1 = eng.generate_paths(seqs.clone(), users, hep.clone(), 5, k=100, sweep=IRS_SWEEP_BF16)
+    p2, s2 = eng.generate_paths_sharded(comm, seqs.clone(), users, hep.clone(), 5, k=100, sweep=IRS_SWEEP_BF16, use_graph=use_graph)
+    torch.cuda.synchronize()
+    assert torch.equal(p1, p2) and torch.equal(s1, s2)
+    print("stage loop graph=%d state=%d" % (use_graph, eng.lib.irs_sharded_graph_state(eng.h)), flush=True)
+print("done", flush=True)
+"""
+
+
+@pytest.mark.parametrize("forced", [False, True])
+def test_rccl_version_gate_and_forced_send_recv_exchange(forced):
+    """The loaded librccl.so speaks the ABI comm.hip was compiled against (rccl.h constants, major version 2, checked at
+    load time), and the key exchange's fallback for libraries WITHOUT the ncclAllToAll extension -- grouped ncclSend /
+    ncclRecv -- runs when IRS_RCCL_NO_ALLTOALL=1 forces it: same bytes out, and the sharded greedy loop over it equals the
+    single-device loop.  Runs in a child process under a time limit: a transport that stalls is a failure of THIS test (with
+    the stage it reached), not a hang of the suite."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("IRS_RCCL_NO_ALLTOALL", None)
+    if forced:
+        env["IRS_RCCL_NO_ALLTOALL"] = "1"
+    proc = subprocess.Popen([sys.executable, "-c", _PROBE.format(repo=repo, kind=2 if forced else 1)], env=env,
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        out, _ = proc.communicate(timeout=150)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        out, _ = proc.communicate()
+        pytest.fail("exchange probe (forced=%s) did not finish in 150 s; output so far:\n%s" % (forced, out))
+    assert proc.returncode == 0 and "done" in out, out

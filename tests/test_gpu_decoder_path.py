@@ -12,6 +12,7 @@ import torch
 from influentialrs_amd import synth
 from influentialrs_amd._lib import IRS_SWEEP_BF16, IRS_SWEEP_F32
 from gpu_util import make_engine
+from parity_record import check_exact
 from rank_check import check_ranked
 
 pytestmark = pytest.mark.gpu
@@ -80,13 +81,16 @@ def test_decoder_rows_vs_golden_and_oracle(oracle, golden, name, cfgname):
 
 
 STRICT = {}
+# golden users whose top-100 ids differ from the reference's inside a run of reference gaps < TAU; every other user must be
+# identical id for id (an exact count, like tests/test_oracle_golden.py:18; observed sets in profiles/r04/parity_counts.json)
+NEAR_TIE_USERS = {"irn_tiny": [], "irn_default": [], "irn_c1": [], "irn_c2": [20], "irn_c3": []}
 
 
 @pytest.mark.parametrize("name,cfgname", GOLDENS)
 def test_topk_vs_reference_goldens(golden, name, cfgname):
     """Top-100 ids of the reference (torch topk / sort of its own float32 logits) in order: every position holds the
-    reference's id, except inside a run of reference scores closer than TAU (rank_check.check_ranked).  The number of
-    users that are id-for-id identical is asserted per config and over all configs (test below)."""
+    reference's id, except inside a run of reference scores closer than TAU (rank_check.check_ranked).  The SET of users
+    that are not id-for-id identical is asserted exactly per config (NEAR_TIE_USERS), the total over all configs below."""
     g = golden(name)
     cfg, sd, eng = _engine(cfgname)
     raws, seqs, users, targets, labels = _irn_inputs(g)
@@ -96,20 +100,23 @@ def test_topk_vs_reference_goldens(golden, name, cfgname):
     val, ids, st = eng.score_topk(xr, 100, IRS_SWEEP_BF16)
     ids = ids.cpu().numpy()
     val = val.cpu().numpy()
-    strict = 0
+    near = []
     for i in range(B):
         assert np.abs(val[i] - g["top_vals"][i][:100]).max() < 5e-5
-        strict += check_ranked(ids[i], g["top_ids0"][i], g["top_gaps"][i], TAU)
-    STRICT[name] = (strict, B)
-    assert strict >= 0.9 * B, f"{name}: only {strict} of {B} users id-for-id identical to the reference"
+        if not check_ranked(ids[i], g["top_ids0"][i], g["top_gaps"][i], TAU):
+            near.append(i)
+    STRICT[name] = (B - len(near), B)
+    check_exact(f"small_batch/{name}", near, NEAR_TIE_USERS[name], B)
 
 
 def test_topk_vs_reference_goldens_coverage():
-    """>= 90 % of >= 100 reference-pinned users are compared (and equal) id for id, every config included."""
+    """All of the >= 100 reference-pinned users are compared id for id, every config included, and all but the recorded
+    near-tie users are identical."""
     assert set(STRICT) == {n for n, _ in GOLDENS}, "run together with test_topk_vs_reference_goldens"
     strict = sum(v[0] for v in STRICT.values())
     users = sum(v[1] for v in STRICT.values())
-    assert users >= 100 and strict >= 0.9 * users, STRICT
+    from parity_record import RECORD_ONLY
+    assert users >= 100 and (RECORD_ONLY or strict == users - sum(len(v) for v in NEAR_TIE_USERS.values())), STRICT
 
 
 @pytest.mark.parametrize("name,cfgname", GOLDENS)

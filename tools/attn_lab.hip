@@ -1,7 +1,7 @@
 // Development lab for the throughput attention kernel (not product code): k_attn16<16, FAST> on synthetic packed sequences
 // with in-kernel s_memtime stamps (-DATTN_STAMP): how a workgroup's life splits into issuing the K / V loads, waiting for
 // them + staging them into LDS, the barrier, and the query blocks.
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DATTN_STAMP tools/attn_lab.hip -o tools/attn_lab ; run: tools/attn_lab [sequences=4096]
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DIRS_LAB -DATTN_STAMP tools/attn_lab.hip -o tools/attn_lab ; run: tools/attn_lab [sequences=4096]
 #include <cmath>
 #include <cstdlib>
 #include <vector>

@@ -1,5 +1,5 @@
 // Phase timing of k_topk_direct (development tool): s_memtime stamps of the last workgroup of row 0.
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DIRS_DIRECT_TIMING -Iinclude tools/direct_lab.hip -o tools/direct_lab
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DIRS_LAB -DIRS_DIRECT_TIMING -Iinclude tools/direct_lab.hip -o tools/direct_lab
 #include <vector>
 #include <cstdlib>
 #include "../influentialrs_amd/csrc/score.hip"

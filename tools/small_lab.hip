@@ -1,5 +1,5 @@
 // Phase timing of the 16-token layer kernel (development tool): s_memtime stamps of workgroup 0.
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DIRS_SMALL_TIMING tools/small_lab.hip -o tools/small_lab
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DIRS_LAB -DIRS_SMALL_TIMING tools/small_lab.hip -o tools/small_lab
 #include <vector>
 #include <cstdlib>
 #include "../influentialrs_amd/csrc/decoder.hip"

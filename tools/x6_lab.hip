@@ -1,6 +1,6 @@
 // Development lab for the split-bf16 fused layer kernel (not product code): k_block<true, true> (float32 MFMAs) against
 // k_block_x6 on the same random tile inputs and weights -- element-wise difference of x' and qkv', and kernel times.
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/x6_lab.hip -o tools/x6_lab ; run: tools/x6_lab [tokens=131072]
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DIRS_LAB -DX6_STAMP | -DX6_DUMP | -DX6_NO_MFMA ...] tools/x6_lab.hip -o tools/x6_lab ; run: tools/x6_lab [tokens=131072]
 #include <cmath>
 #include <cstdlib>
 #include <vector>
