@@ -3259,7 +3259,19 @@ __device__ unsigned long long g_attn_stamp[8 * 65536];
 #else
 #define ATTN_T(i_)
 #endif
-template <int MAXT, bool FAST>
+// DMA (round 4; the production form): K and V of the (sequence, head) go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4), 8
+// whole 128-byte key rows per instruction, straight from the row-major q | k | v rows the layer kernel writes -- no VGPR
+// staging, no ds_write pass, no transposed copy.  The DMA writes LDS lane-linearly, so the two swizzles live on the SOURCE
+// side (lane (row jl, chunk p) fetches the row's chunk p ^ sw): K keeps its conflict-free ds_read_b128 image (sw = (key & 7)
+// ^ ((key >> 3) & 1)); V stays ROW-major [key][32] with the two 64-byte halves of a row exchanged on keys with bit 2 set
+// (sw = 4 ((key >> 2) & 1)): the O^T += V^T P^T step reads its A operand V[4 gq + j][16 ct + lq] as four ds_read_b32 (two
+// ds_read2_b32), and a 32-lane half (lane groups gq and gq + 1: keys 4 apart) then covers 32 distinct banks.  The register
+// form's transposed V^T image cost ~1K cycles of 8-way conflicted ds_write_b32 per wave and fill, its staging loads'
+// issue dominated a fill (39 % of a wave's life, profiles/r03/attn16_lab_stamps.txt), and PMC showed an LDS conflict
+// ratio of 0.47.  Keys in [L, L16) re-read row L - 1 (finite values times p = 0).
+typedef __attribute__((address_space(3))) void attn_lds_void;
+typedef const __attribute__((address_space(1))) void attn_glb_void;
+template <int MAXT, bool FAST, bool DMA = false>
 __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
                                                 const float *__restrict__ r_u, float *__restrict__ out, int Lmax, int d,
                                                 int mask_mode, const int32_t *__restrict__ off,
@@ -3270,8 +3282,8 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int L = cnt ? cnt[blockIdx.y] : Lmax;
     const int S = attn16_vstride(Lmax);
-    float *Vt = reinterpret_cast<float *>(smem);                 // [32][S]
-    float *Ks = Vt + 32 * S;                                     // [Lmax rounded to 16][32], swizzled chunks
+    float *Vt = reinterpret_cast<float *>(smem);                 // [32][S]   (DMA: V [Lmax rounded to 16][32], halves swizzled)
+    float *Ks = Vt + (DMA ? ((Lmax + 15) & ~15) * HD : 32 * S);  // [Lmax rounded to 16][32], swizzled chunks
     unsigned int *padbits = reinterpret_cast<unsigned int *>(Ks + (size_t)((Lmax + 15) & ~15) * HD); // [ceil(L/32)]
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -3286,15 +3298,26 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
     // (sequence, head) -- the loads of a fill are all in flight together, and the IRN target column needs key L-1.
     const int zsplit = blockIdx.z;
     if (gridDim.z > 1 && 4 * zsplit >= NB16) return;
+    if (L <= 0) return; // (a plan never yields an empty sequence: the consumed row always counts)
     ATTN_T(0);
+    if constexpr (DMA) {
+        const int jl = lane >> 3, p = lane & 7;
+        for (int i = wave; i < (L16 >> 3); i += 4) { // 8 key rows per instruction; the LDS destination is wave-uniform
+            const int j = 8 * i + jl;
+            const float *row = qkv + (base + (j < L ? j : L - 1)) * ld + h * HD;
+            const int swk = (j & 7) ^ ((j >> 3) & 1), swv = ((j >> 2) & 1) << 2;
+            __builtin_amdgcn_global_load_lds((attn_glb_void *)(row + d + 4 * (p ^ swk)), (attn_lds_void *)(Ks + i * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((attn_glb_void *)(row + 2 * d + 4 * (p ^ swv)), (attn_lds_void *)(Vt + i * 256), 16, 0, 0);
+        }
+    }
     // K / V of this (sequence, head) -> LDS.  8 consecutive lanes take the 8 16-byte chunks of one key row, so a
     // load instruction covers 8 whole 128-byte K_h (V_h) slices -- in-kernel timing showed the ISSUE of these
     // loads, not their latency, dominating the fill when every lane touched a different row.  K's ds_write_b128
     // stays conflict-free; the transposed V^T ds_write_b32 are 8-way conflicted (a row stride S = 8 mod 16 puts
     // all 8 chunks of a key on one bank), ~1K cycles per wave once, cheaper than the slow loads were.  ALL global
     // loads are issued before the first LDS store (one memory round trip per workgroup).
-    float4 kv[MAXT / 2], vv[MAXT / 2];
-    {
+    float4 kv[DMA ? 1 : MAXT / 2], vv[DMA ? 1 : MAXT / 2];
+    if constexpr (!DMA) {
         const int jl = tid >> 3, c4 = tid & 7; // 8 lanes per key row: 128-byte contiguous K_h / V_h slices
 #pragma unroll
         for (int it = 0; it < MAXT / 2; ++it) {
@@ -3348,7 +3371,9 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
         const unsigned long long bal = __ballot(masked);
         if (lane == 0) padbits[kb] = (unsigned int)bal;
     }
-    {
+    if constexpr (DMA) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's DMA pieces have landed (the barrier below publishes them)
+    } else {
         const int jl = tid >> 3, c4 = tid & 7;
 #pragma unroll
         for (int it = 0; it < MAXT / 2; ++it) {
@@ -3516,9 +3541,16 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
             const float pt = __builtin_amdgcn_exp2f(st - m);
             l = (gq == 0) ? pt : 0.f; // the four lanes of a query are summed at the end
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
+            for (int ct = 0; ct < 2; ++ct) {
+                if constexpr (DMA) {
+                    const int jt = L - 1;
+                    const float4 vt4 = *reinterpret_cast<const float4 *>(Vt + jt * HD + (((4 * ct + gq) ^ (((jt >> 2) & 1) << 2)) << 2));
+                    o[0][ct][0] = pt * vt4.x, o[0][ct][1] = pt * vt4.y, o[0][ct][2] = pt * vt4.z, o[0][ct][3] = pt * vt4.w;
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[0][ct][r] = pt * Vt[(16 * ct + 4 * gq + r) * S + L - 1];
+                    for (int r = 0; r < 4; ++r) o[0][ct][r] = pt * Vt[(16 * ct + 4 * gq + r) * S + L - 1];
+                }
+            }
         }
 #pragma unroll
         for (int kg = 0; kg < MAXT / 4; ++kg) {
@@ -3535,7 +3567,12 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
                 }
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    const float4 v4 = *reinterpret_cast<const float4 *>(Vt + (16 * ct + lq) * S + kt * 16 + 4 * gq);
+                    float4 v4;
+                    if constexpr (DMA) { // V[kt 16 + 4 gq + j][16 ct + lq], j = 0 .. 3 (rows 128 bytes apart)
+                        const float *vb = Vt + (kt * 16 + 4 * gq) * HD + ((16 * ct + lq) ^ ((gq & 1) << 4));
+                        v4 = make_float4(vb[0], vb[HD], vb[2 * HD], vb[3 * HD]);
+                    } else
+                        v4 = *reinterpret_cast<const float4 *>(Vt + (16 * ct + lq) * S + kt * 16 + 4 * gq);
                     f32x4 oo = o[kt & 1][ct];
                     oo = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.x, pa[0], oo, 0, 0, 0);
                     oo = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.y, pa[1], oo, 0, 0, 0);
@@ -4286,6 +4323,7 @@ static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const
         int S16 = (L + 7) & ~7; // attn16_vstride
         if ((S16 & 15) != 8) S16 += 8;
         const size_t lds16 = (size_t)32 * S16 * 4 + (size_t)((L + 15) & ~15) * 32 * 4 + 64;
+        const size_t lds16d = (size_t)2 * ((L + 15) & ~15) * 32 * 4 + 64; // LDS-DMA form: V row-major like K
         if (H * B <= 64) grid.z = (((L + 15) / 16) + 3) / 4; // latency path: one query block per wave
         const size_t lds16x = (size_t)6 * ((L + 15) & ~15) * 64 + 64;
         // The same kernel on split-bf16 MFMAs: measured SLOWER than the float32-MFMA kernel on C2 (2.24 vs 1.92 ms of attention
@@ -4302,11 +4340,18 @@ static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const
             else
                 hipLaunchKernelGGL((k_attn16x<16, false, ATTN16X_NW>), grid, dim3(64 * ATTN16X_NW), lds16x, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
                                    nullptr, frag_out ? 1 : 0);
+        } else if (g_attn16 == 2) { // (lab A/B: the register-staged fill with the transposed V^T image)
+            if (tok_row)
+                hipLaunchKernelGGL((k_attn16<16, true, false>), grid, dim3(256), lds16, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
+                                   ctx->seq_padq, frag_out ? 1 : 0);
+            else
+                hipLaunchKernelGGL((k_attn16<16, false, false>), grid, dim3(256), lds16, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
+                                   nullptr, frag_out ? 1 : 0);
         } else if (tok_row)
-            hipLaunchKernelGGL((k_attn16<16, true>), grid, dim3(256), lds16, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
+            hipLaunchKernelGGL((k_attn16<16, true, true>), grid, dim3(256), lds16d, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
                                ctx->seq_padq, frag_out ? 1 : 0);
         else
-            hipLaunchKernelGGL((k_attn16<16, false>), grid, dim3(256), lds16, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
+            hipLaunchKernelGGL((k_attn16<16, false, true>), grid, dim3(256), lds16d, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
                                nullptr, frag_out ? 1 : 0);
         irs_prof_end(ctx, IRS_PROF_ATTN, s, 2.0 * B * (double)H * L * L * hd, 4.0 * 4.0 * B * (double)L * d);
         IRS_CHECK_HIP(ctx, hipGetLastError());

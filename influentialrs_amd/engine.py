@@ -408,6 +408,7 @@ class Engine:
         status = self._inplace(status, torch.int32, "generate_paths_sharded: status")
         if paths.shape != (B, max_path_len):
             raise IrsError("generate_paths_sharded: paths must be [B, max_path_len]")
+        self._comm_ref = comm  # a captured step holds RCCL nodes of this communicator: it must outlive the context's graphs
         with torch.cuda.device(self.device):
             self._check(self.lib.irs_generate_paths_sharded(self.h, comm.h, _ptr(seqs), _ptr(users), _ptr(hep), B, max_path_len, k,
                                                             sweep, int(sample), sample_k, seed, int(use_graph), _ptr(paths),
@@ -433,6 +434,7 @@ class Engine:
         status = self._beam_status[:B]
         status.zero_()
         fin = torch.empty((B, beam, self.L), dtype=torch.int64, device=self.device) if want_windows else None
+        self._comm_ref = comm  # (see generate_paths_sharded)
         with torch.cuda.device(self.device):
             self._check(self.lib.irs_beam_search_sharded(self.h, comm.h, _ptr(seqs), _ptr(users), _ptr(hep), B, beam, max_path_len, k,
                                                          sweep, int(split_decode), int(use_graph), _ptr(paths), _ptr(scores),
@@ -506,6 +508,9 @@ class Comm:
 
     def __del__(self):
         try:
+            import sys
+            if sys.is_finalizing():
+                return  # interpreter shutdown: the HIP runtime may already be going down under ncclCommDestroy (observed: a hang)
             if getattr(self, "h", None):
                 self.lib.irs_comm_destroy(self.h)
                 self.h = None

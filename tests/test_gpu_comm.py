@@ -112,6 +112,9 @@ for use_graph in (False, True):
     torch.cuda.synchronize()
     assert torch.equal(p1, p2) and torch.equal(s1, s2)
     print("stage loop graph=%d state=%d" % (use_graph, eng.lib.irs_sharded_graph_state(eng.h)), flush=True)
+del eng            # the context (and its captured steps, which hold RCCL nodes) goes before the communicator
+torch.cuda.synchronize()
+del comm
 print("done", flush=True)
 """
 

@@ -195,7 +195,7 @@ def _worker_catalog(rank, world, port, ret):
         torch.cuda.set_device(dev)
         cfg = synth.make_config("c3")
         B, W, P = 8, 32, 3
-        rows = max(world * B, W)
+        rows = world * W  # split_decode: the world's B * W beam rows pass through every shard's sweep
 
         def engine(r, w):
             lo, hi = shard_bounds(cfg.n_item, w, r)

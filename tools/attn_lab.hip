@@ -17,7 +17,8 @@ int main(int argc, char **argv) {
     const int lens[8] = {40, 70, 95, 110, 130, 95, 200, 180}; // mean 115: the bench's packed windows average 109-117
     std::vector<int32_t> off(B), cnt(B), padq(B, -1);
     long long M = 0;
-    for (int b = 0; b < B; ++b) { off[b] = (int32_t)M; cnt[b] = lens[(b * 5 + b / 8) & 7]; M += cnt[b]; }
+    const int fixed_len = argc > 3 ? atoi(argv[3]) : 0; // > 0: every sequence has this many tokens
+    for (int b = 0; b < B; ++b) { off[b] = (int32_t)M; cnt[b] = fixed_len > 0 ? fixed_len : lens[(b * 5 + b / 8) & 7]; M += cnt[b]; }
     std::vector<float> hq((size_t)M * 3 * d);
     unsigned long long z = 88172645463325252ull;
     for (auto &v : hq) { z ^= z << 13; z ^= z >> 7; z ^= z << 17; v = ((float)((z >> 40) & 0xFFFFFF) * (1.0f / 16777216.0f) * 2 - 1) * 0.7f; }
@@ -37,13 +38,37 @@ int main(int argc, char **argv) {
     const size_t lds16 = (size_t)32 * S16 * 4 + (size_t)((L + 15) & ~15) * 32 * 4 + 64;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int rep = 0; rep < 3; ++rep) {
+    // A/B in one process, interleaved (guide rule 24): the register-staged fill with the transposed V^T image against the
+    // LDS-DMA fill with the row-major V image; outputs compared bit for bit (same MFMA chains, same operands)
+    const size_t lds16d = (size_t)2 * ((L + 15) & ~15) * 32 * 4 + 64;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn16<16, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16d));
+    float *out2;
+    CK(hipMalloc(&out2, ((size_t)M + 128) * d * 4)); CK(hipMemset(out2, 0, ((size_t)M + 128) * d * 4));
+    const int variant = argc > 2 ? atoi(argv[2]) : 2; // 0: register fill only, 1: DMA only, 2: both interleaved
+    for (int rep = 0; rep < 5; ++rep) {
         float ms;
-        CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((k_attn16<16, true>), dim3(H, B), dim3(256), lds16, 0, qkv, seq, ru, out, L, d, IRS_MASK_IRN, doff, dcnt, dpadq, 1);
-        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
-        CK(hipEventElapsedTime(&ms, e0, e1));
-        printf("k_attn16<16, FAST>: %d sequences x %d heads, %lld packed rows: %8.1f us\n", B, H, M, ms * 1e3);
+        if (variant != 1) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL((k_attn16<16, true, false>), dim3(H, B), dim3(256), lds16, 0, qkv, seq, ru, out, L, d, IRS_MASK_IRN, doff, dcnt, dpadq, 1);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("k_attn16<16, FAST> register fill: %d sequences x %d heads, %lld packed rows: %8.1f us\n", B, H, M, ms * 1e3);
+        }
+        if (variant != 0) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL((k_attn16<16, true, true>), dim3(H, B), dim3(256), lds16d, 0, qkv, seq, ru, out2, L, d, IRS_MASK_IRN, doff, dcnt, dpadq, 1);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("k_attn16<16, FAST> LDS-DMA fill : %d sequences x %d heads, %lld packed rows: %8.1f us\n", B, H, M, ms * 1e3);
+        }
+    }
+    if (variant == 2) {
+        std::vector<float> h1((size_t)M * d), h2((size_t)M * d);
+        CK(hipMemcpy(h1.data(), out, h1.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(h2.data(), out2, h2.size() * 4, hipMemcpyDeviceToHost));
+        size_t nd = 0; double md = 0;
+        for (size_t i = 0; i < h1.size(); ++i) { if (memcmp(&h1[i], &h2[i], 4)) { ++nd; md = fmax(md, fabs((double)h1[i] - h2[i])); } }
+        printf("outputs: %zu of %zu values differ (max abs %.3g)\n", nd, h1.size(), md);
     }
 #ifdef ATTN_STAMP
     {
