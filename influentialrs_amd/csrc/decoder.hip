@@ -3271,12 +3271,22 @@ __device__ unsigned long long g_attn_stamp[8 * 65536];
 // ratio of 0.47.  Keys in [L, L16) re-read row L - 1 (finite values times p = 0).
 typedef __attribute__((address_space(3))) void attn_lds_void;
 typedef const __attribute__((address_space(1))) void attn_glb_void;
-template <int MAXT, bool FAST, bool DMA = false>
-__global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
+// NW = waves per workgroup (4).  Measured and not kept (tools/attn_lab, profiles/r04/attn_lab_variants_r04.txt): NW = 8 -- the
+// same LDS images serving twice the waves, two workgroups per CU, four waves per SIMD -- is 45 % SLOWER (the block phase is
+// MFMA-issue bound at three waves per SIMD already: 94 % of the pipe's cycles while three waves are in their blocks); touching
+// the K / V rows of the workgroup 256 or 768 dispatch slots ahead with dropped loads (an L2 prefetch) is 4 % slower.
+// Also measured and not kept: ONE workgroup for the four heads of a short sequence (wave = head, the other three workgroups
+// of the group returning at once): 227 vs 129 us on a batch of 40-token sequences -- a launch of short sequences is bound by
+// the rate at which workgroups are DISPATCHED (~8 ns per workgroup chip-wide: 16384 workgroups = 129 us whatever they do), and
+// workgroups that return at once are dispatched all the same.  What that regime needs is fewer dispatches: a persistent
+// grid over a work list built by the plan kernel (profiles/r04/README.md).
+template <int MAXT, bool FAST, bool DMA = false, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) k_attn16(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
                                                 const float *__restrict__ r_u, float *__restrict__ out, int Lmax, int d,
                                                 int mask_mode, const int32_t *__restrict__ off,
                                                 const int32_t *__restrict__ cnt, const int32_t *__restrict__ padq,
                                                 int out_frag) {
+    static_assert(NW == 4 || DMA, "the register-staged fill is written for four waves");
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     constexpr int HD = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -3302,7 +3312,7 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
     ATTN_T(0);
     if constexpr (DMA) {
         const int jl = lane >> 3, p = lane & 7;
-        for (int i = wave; i < (L16 >> 3); i += 4) { // 8 key rows per instruction; the LDS destination is wave-uniform
+        for (int i = wave; i < (L16 >> 3); i += NW) { // 8 key rows per instruction; the LDS destination is wave-uniform
             const int j = 8 * i + jl;
             const float *row = qkv + (base + (j < L ? j : L - 1)) * ld + h * HD;
             const int swk = (j & 7) ^ ((j >> 3) & 1), swv = ((j >> 2) & 1) << 2;
@@ -3339,13 +3349,17 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
         const int v = 4 * zsplit + wave;
         if (v < NB16) mine = 1u << (NB16 - 1 - v);
     } else {
-        int load[4] = {0, 0, 0, 0};
+        int load[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) load[w] = 0;
         for (int qb = NB16 - 1; qb >= 0; --qb) {
             int w = 0;
-            if (load[1] < load[w]) w = 1;
-            if (load[2] < load[w]) w = 2;
-            if (load[3] < load[w]) w = 3;
-            load[w] += qb + 1;
+#pragma unroll
+            for (int v = 1; v < NW; ++v)
+                if (load[v] < load[w]) w = v;
+#pragma unroll
+            for (int v = 0; v < NW; ++v) // (static indices: a run-time index would send the array to scratch)
+                if (v == w) load[v] += qb + 1;
             if (w == wave) mine |= 1u << qb;
         }
     }
@@ -3363,7 +3377,7 @@ __global__ void __launch_bounds__(256, 3) k_attn16(const float *__restrict__ qkv
     // masked-key bitmask of each 32-key block.  A packed sequence holds no pads except possibly its pos token
     // (index padq[b], recorded by the plan): no global loads on that path.
     const int pq = padq ? padq[b] : -1;
-    for (int kb = wave; kb < (L + 31) / 32; kb += 4) {
+    for (int kb = wave; kb < (L + 31) / 32; kb += NW) {
         const int j = kb * 32 + (lane & 31);
         bool masked = (j >= L) || (irn && j == L - 1);
         if (padq) masked = masked || (j == pq);

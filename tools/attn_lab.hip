@@ -44,23 +44,20 @@ int main(int argc, char **argv) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn16<16, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16d));
     float *out2;
     CK(hipMalloc(&out2, ((size_t)M + 128) * d * 4)); CK(hipMemset(out2, 0, ((size_t)M + 128) * d * 4));
-    const int variant = argc > 2 ? atoi(argv[2]) : 2; // 0: register fill only, 1: DMA only, 2: both interleaved
-    for (int rep = 0; rep < 5; ++rep) {
+    const int variant = argc > 2 ? atoi(argv[2]) : 2; // 0: register fill only, 1: DMA only, 2: both interleaved, 3: the DMA family
+    auto timed = [&](const char *name, auto launch) {
         float ms;
-        if (variant != 1) {
-            CK(hipEventRecord(e0));
-            hipLaunchKernelGGL((k_attn16<16, true, false>), dim3(H, B), dim3(256), lds16, 0, qkv, seq, ru, out, L, d, IRS_MASK_IRN, doff, dcnt, dpadq, 1);
-            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
-            CK(hipEventElapsedTime(&ms, e0, e1));
-            printf("k_attn16<16, FAST> register fill: %d sequences x %d heads, %lld packed rows: %8.1f us\n", B, H, M, ms * 1e3);
-        }
-        if (variant != 0) {
-            CK(hipEventRecord(e0));
-            hipLaunchKernelGGL((k_attn16<16, true, true>), dim3(H, B), dim3(256), lds16d, 0, qkv, seq, ru, out2, L, d, IRS_MASK_IRN, doff, dcnt, dpadq, 1);
-            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
-            CK(hipEventElapsedTime(&ms, e0, e1));
-            printf("k_attn16<16, FAST> LDS-DMA fill : %d sequences x %d heads, %lld packed rows: %8.1f us\n", B, H, M, ms * 1e3);
-        }
+        CK(hipEventRecord(e0));
+        launch();
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-44s %d sequences x %d heads, %lld packed rows: %8.1f us\n", name, B, H, M, ms * 1e3);
+    };
+    for (int rep = 0; rep < 5; ++rep) {
+        if (variant == 0 || variant == 2)
+            timed("k_attn16<16, FAST> register fill:", [&] { hipLaunchKernelGGL((k_attn16<16, true, false>), dim3(H, B), dim3(256), lds16, 0, qkv, seq, ru, out, L, d, IRS_MASK_IRN, doff, dcnt, dpadq, 1); });
+        if (variant >= 1)
+            timed("k_attn16<16, FAST> LDS-DMA fill :", [&] { hipLaunchKernelGGL((k_attn16<16, true, true>), dim3(H, B), dim3(256), lds16d, 0, qkv, seq, ru, out2, L, d, IRS_MASK_IRN, doff, dcnt, dpadq, 1); });
     }
     if (variant == 2) {
         std::vector<float> h1((size_t)M * d), h2((size_t)M * d);
