@@ -590,7 +590,7 @@ def main():
     ap.add_argument("--c3-batch", type=int, default=1024, help="users per rank per step of the c3 leg")
     ap.add_argument("--c3-steps", type=int, default=10)
     ap.add_argument("--pmc-run", action="store_true",
-                    help="the command rocprofv3 --pmc / --kernel-trace wraps (tools/r03_measure.sh): warm-up + timed steps of the "
+                    help="the command rocprofv3 --pmc / --kernel-trace wraps (tools/r04_measure.sh): warm-up + timed steps of the "
                          "headline workload only -- no CPU legs, no instrumented pass, no other legs -- and the packed row "
                          "count of exactly those steps as a JSON line on stdout")
     ap.add_argument("--c4-batch", type=int, default=0, help="users per step of the c4_item_sharded leg: per rank under --scaling "
@@ -756,7 +756,7 @@ def main():
         # per-launch mean of the committed rocprofv3 passes of this same command (FETCH_SIZE doubled per the gfx950
         # note + WRITE_SIZE, separate --pmc passes), valid for the default workload only.  It is reported together with
         # the packed row count it was measured at; `algorithmic_bytes_per_launch` is quoted at that SAME row count.
-        pmc_file = os.path.join(REPO, "profiles", "r03", "c2_b4096_pmc.json")
+        pmc_file = os.path.join(REPO, "profiles", "r04", "c2_b4096_pmc.json")
         if dom == "linear" and world == 1 and args.workload == "c2" and args.batch == 4096 and not args.n_item and os.path.exists(pmc_file):
             try:
                 with open(pmc_file) as fh:
@@ -764,7 +764,7 @@ def main():
                 kb = pm["kernels"]["k_block_x6" if x6 and "k_block_x6" in pm["kernels"] else "k_block"]
                 roof["traffic"] = float(kb["hbm_bytes_per_launch"])
                 roof["traffic_measured_at_packed_rows"] = float(pm["packed_rows_mean"])
-                roof["traffic_source"] = ("profiles/r03/c2_b4096_pmc.json (tools/r03_measure.sh: this round's binary, `bench.py "
+                roof["traffic_source"] = ("profiles/r04/c2_b4096_pmc.json (tools/r04_measure.sh: this round's binary, `bench.py "
                                           "--pmc-run` under rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in separate passes, "
                                           "2 x FETCH_SIZE + WRITE_SIZE per the gfx950 note): the fused layer kernel, at "
                                           "that run's own mean packed row count")
@@ -772,7 +772,7 @@ def main():
                 roof["mfma_busy_pmc"] = kb.get("mfma_busy")
                 roof["packed_rows_this_run"] = fam[dom]["packed_fraction"] * job.B * cfg.max_len
             except Exception as e:  # a malformed profile file must not cost the bench line
-                roof["traffic_source"] = f"profiles/r03/c2_b4096_pmc.json unreadable: {e}"
+                roof["traffic_source"] = f"profiles/r04/c2_b4096_pmc.json unreadable: {e}"
         roof["flops_counted"] = "executed (dense-shape flops x packed non-pad row fraction %.3f)" % fam[dom].get("packed_fraction", 1.0)
         roof["time_basis"] = ("HIP events around every launch of the family (a second pass over the SAME K steps: the windows are "
                               "reset to their state at the start of the timed region), scaled by %.4f so that the four families "

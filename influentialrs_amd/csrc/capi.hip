@@ -254,8 +254,9 @@ static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
     p->x = take(RL * D.d * 4);
     p->y = take(RL * D.d * 4);
     const size_t RLf = ((RL + 127) / 128) * 128; // 128-token tiles x 128 padded columns
-    p->xf = take(RLf * 128 * 4);
-    p->yf = take(RLf * 128 * 4);
+    const size_t fcols = D.d > 128 ? (size_t)((D.d + 31) / 32) * 32 : 128; // (d = 256: eight column tiles per token tile)
+    p->xf = take(RLf * fcols * 4);
+    p->yf = take(RLf * fcols * 4);
     p->qkv = take(RL * 3 * D.d * 4);
     p->qkv_b1 = take((RL < 256 ? RL : 256) * 3 * D.d * 4);
     p->ao = take(RL * D.d * 4);

@@ -268,12 +268,13 @@ __global__ void __launch_bounds__(256) k_embed_frag(const int64_t *__restrict__ 
 }
 
 // out[b, :] = act[rowidx[b], :] read from the fragment-major layout
+// (nt = column tiles of 32 per token tile: 4 for every width up to 128 -- the image is padded to 128 columns --, d / 32 beyond)
 __global__ void k_gather_rows_frag(const float *__restrict__ xf, const int32_t *__restrict__ rowidx,
-                                   float *__restrict__ out, int d) {
+                                   float *__restrict__ out, int d, int nt) {
     const int row = rowidx[blockIdx.x];
     for (int c = threadIdx.x; c < d; c += blockDim.x)
         out[(int64_t)blockIdx.x * d + c] =
-            xf[(((size_t)(row >> 5) * 4 + (c >> 5)) * 4 + ((c >> 3) & 3)) * 256 + ((c >> 2) & 1) * 128 + (row & 31) * 4 + (c & 3)];
+            xf[(((size_t)(row >> 5) * nt + (c >> 5)) * 4 + ((c >> 3) & 3)) * 256 + ((c >> 2) & 1) * 128 + (row & 31) * 4 + (c & 3)];
 }
 
 // ------------------------------------------------------------------ linear
@@ -1204,30 +1205,46 @@ typedef __attribute__((ext_vector_type(4))) unsigned int x6_u32x4;
 #define X6_STEP_B 24576
 #define X6_NSTEP 32
 #define X6_LAYER_BYTES (X6_NSTEP * X6_STEP_B)
+// NT = d / 32 accumulator tiles per token (4: d = 128; 8: d = 256, round 4), HT = NT / 4 "halves": a step is always 24 KB =
+// 8 groups x 3 planes, so at NT = 8 a k tile's eight output tiles take two four-tile steps and a one-tile product over
+// K = 256 takes two one-tile steps (k tiles 0-3, 4-7).  Steps per layer: NT HT (out-projection) + 8 (2 HT) (feed-forward:
+// per hidden tile HT FFN-1 steps, then HT FFN-2 steps) + 3 NT HT (q | k | v): 32 at NT = 4, 96 at NT = 8.
+__host__ __device__ constexpr int x6_npre(int NT) { return NT * (NT / 4) + 16 * (NT / 4); } // steps in front of the q | k | v region
+__host__ __device__ constexpr int x6_nstep(int NT) { return x6_npre(NT) + 3 * NT * (NT / 4); }
+__host__ __device__ constexpr size_t x6_layer_bytes(int NT) { return (size_t)x6_nstep(NT) * X6_STEP_B; }
+__host__ __device__ constexpr int x6_lds_bytes(int NT) { return 3 * X6_STEP_B + (256 + 12 * 32 * NT) * 4; }
 #ifndef X6_NW
 #define X6_NW 4 // waves per workgroup of k_block_x6 (tools/x6_lab measures both)
 #endif
 
 // one layer's weights -> the kernel's step stream.  Thread = one 16-byte fragment piece (8 bf16 of one lane).
+template <int NT = 4>
 __global__ void __launch_bounds__(256) k_pack_x6(const float *__restrict__ Wo, const float *__restrict__ W1,
                                                  const float *__restrict__ W2, const float *__restrict__ Win,
                                                  uint4 *__restrict__ out) {
-    const int gid = blockIdx.x * 256 + threadIdx.x; // < 32 steps * 24 pieces * 64 lanes
-    if (gid >= X6_NSTEP * 24 * 64) return;
+    constexpr int D = 32 * NT, HT = NT / 4, NPRE = x6_npre(NT), NOUT = NT * HT;
+    const int gid = blockIdx.x * 256 + threadIdx.x; // < steps * 24 pieces * 64 lanes
+    if (gid >= x6_nstep(NT) * 24 * 64) return;
     const int lane = gid & 63, piece = (gid >> 6) % 24, step = gid / (24 * 64);
     // piece = 3 g + plane in the kernel's consumption order.  "Four-tile" steps (out-projection, FFN-2): group g =
-    // (k-step s = g >> 2, output tile nt = g & 3) of one 32-wide k tile; "one-tile" steps (FFN-1, QKV): ONE output tile over
-    // the whole K = 128, group g = (k tile g >> 1, k-step s = g & 1).
+    // (k-step s = g >> 2, output tile nt = g & 3) of one 32-wide k tile and one output half oh (tiles 4 oh .. 4 oh + 3);
+    // "one-tile" steps (FFN-1, QKV): ONE output tile over 128 of the K = d columns (k half kh), group g = (k tile 4 kh +
+    // (g >> 1), k-step s = g & 1).
     const int p = piece % 3, g = piece / 3;
     const int r = lane & 31, hh = lane >> 5;
     const float *W;
     int ld, n, kb, s;
-    if (step < 4) W = Wo, ld = 128, s = g >> 2, n = 32 * (g & 3) + r, kb = 32 * step;
-    else if (step < 20) {
-        const int ft = (step - 4) >> 1;
-        if (((step - 4) & 1) == 0) W = W1, ld = 128, s = g & 1, n = 32 * ft + r, kb = 32 * (g >> 1); // FFN-1, hidden tile ft
-        else W = W2, ld = 256, s = g >> 2, n = 32 * (g & 3) + r, kb = 32 * ft;                       // FFN-2, k tile ft
-    } else W = Win, ld = 128, s = g & 1, n = 32 * (step - 20) + r, kb = 32 * (g >> 1); // q | k | v output tile step - 20 (one-tile)
+    if (step < NOUT) { // out-projection: k tile step / HT, output half step % HT
+        const int t = step / HT, oh = step % HT;
+        W = Wo, ld = D, s = g >> 2, n = 32 * (4 * oh + (g & 3)) + r, kb = 32 * t;
+    } else if (step < NPRE) {
+        const int ft = (step - NOUT) / (2 * HT), q = (step - NOUT) % (2 * HT);
+        if (q < HT) W = W1, ld = D, s = g & 1, n = 32 * ft + r, kb = 32 * (4 * q + (g >> 1));            // FFN-1, hidden tile ft, k half q
+        else W = W2, ld = 256, s = g >> 2, n = 32 * (4 * (q - HT) + (g & 3)) + r, kb = 32 * ft;          // FFN-2, k tile ft, output half q - HT
+    } else { // q | k | v output tile (step - NPRE) / HT, k half (step - NPRE) % HT (one-tile)
+        const int qt = (step - NPRE) / HT, kh = (step - NPRE) % HT;
+        W = Win, ld = D, s = g & 1, n = 32 * qt + r, kb = 32 * (4 * kh + (g >> 1));
+    }
     unsigned int hw[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1306,6 +1323,17 @@ __device__ __forceinline__ x6_u32x4 x6_rd(unsigned int base) {
     return v;
 }
 
+// the same read with its wait inside the statement: the value is valid when the statement ends, whatever the register
+// allocator does next (at NT = 8 the prologue runs at ~270 live registers and the compiler parked the four first fragments
+// in AGPRs right behind their reads -- copies of registers whose data had not landed: rows wrong by ~1e-4, found by scanning
+// the ISA for uses of pending read destinations)
+template <int OFF>
+__device__ __forceinline__ x6_u32x4 x6_rd_sync(unsigned int base) {
+    x6_u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(base), "i"(OFF));
+    return v;
+}
+
 // QP0 = 0: the tail computes q | k | v; 1: k | v only (feeding the rows-only last layer)
 #ifdef X6_STAMP
 #define X6_T(v_) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); v_ = t_; }
@@ -1316,11 +1344,15 @@ __device__ __forceinline__ x6_u32x4 x6_rd(unsigned int base) {
 // EMBED: the kernel in front of layer 0 -- the accumulator tiles are filled with the embedded tokens (k_embed_frag's
 // arithmetic) instead of a layer's result, written to Xf, and only the q | k | v steps (20 .. 31 of a stream whose other
 // blocks are unused) run: the same ring, the same step code.
-template <int QP0, int NW, bool EMBED>
-__global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
-    constexpr int D = 128, F = 256, NSLOT = 3, PPW = 24 / NW;
-    constexpr int S0 = EMBED ? 20 : 0; // first step of the sequence
+// NT = 8 (d = 256, round 4): 8 accumulator tiles per token -- 128 registers of accumulators, 192 of cached planes -- so ONE
+// wave per SIMD (512 registers per lane), one workgroup per CU; the step stream has 96 steps (x6_nstep).
+template <int QP0, int NW, bool EMBED, int NT = 4>
+__global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Args a) {
+    constexpr int D = 32 * NT, F = 256, NSLOT = 3, PPW = 24 / NW, HT = NT / 4;
+    constexpr int NPRE = x6_npre(NT), NOUT = NT * HT;
+    constexpr int S0 = EMBED ? NPRE : 0; // first step of the sequence
     constexpr int V_B1 = 0, V_B2 = F, V_G = F + D, V_B = F + 2 * D, V_BIN = F + 3 * D, V_O = F + 3 * D + 3 * D;
+    static_assert(NT == 4 || NT == 8, "d = 128 or 256");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *vecs = reinterpret_cast<float *>(smem + NSLOT * X6_STEP_B); // b1[256], b2, g, b, b_in[384], b_o, g1, b1n, c, g2, b2n
     const int tid = threadIdx.x;
@@ -1331,23 +1363,41 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
     const int m0 = blockIdx.x * (32 * NW);
     const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M;
     if (m0 >= M) return;
-    if (tid < 256) {
-        if (!EMBED) vecs[V_B1 + tid] = a.b1[tid];
-        vecs[V_BIN + tid] = a.bin[tid];
-    }
-    if (EMBED) {
-        if (tid < D) vecs[V_BIN + 256 + tid] = a.bin[256 + tid];
-    } else if (tid < D) {
-        vecs[V_B2 + tid] = a.b2[tid];
-        vecs[V_G + tid] = a.g[tid];
-        vecs[V_B + tid] = a.b[tid];
-        vecs[V_BIN + 256 + tid] = a.bin[256 + tid];
-        vecs[V_O + 0 * D + tid] = a.bo ? a.bo[tid] : 0.f;
-        vecs[V_O + 1 * D + tid] = a.g1[tid];
-        vecs[V_O + 2 * D + tid] = a.b1n[tid];
-        vecs[V_O + 3 * D + tid] = a.c ? a.c[tid] : 0.f;
-        vecs[V_O + 4 * D + tid] = a.c ? a.g2[tid] : 0.f;
-        vecs[V_O + 5 * D + tid] = a.c ? a.b2n[tid] : 0.f;
+    if constexpr (NT == 4) {
+        if (tid < 256) {
+            if (!EMBED) vecs[V_B1 + tid] = a.b1[tid];
+            vecs[V_BIN + tid] = a.bin[tid];
+        }
+        if (EMBED) {
+            if (tid < D) vecs[V_BIN + 256 + tid] = a.bin[256 + tid];
+        } else if (tid < D) {
+            vecs[V_B2 + tid] = a.b2[tid];
+            vecs[V_G + tid] = a.g[tid];
+            vecs[V_B + tid] = a.b[tid];
+            vecs[V_BIN + 256 + tid] = a.bin[256 + tid];
+            vecs[V_O + 0 * D + tid] = a.bo ? a.bo[tid] : 0.f;
+            vecs[V_O + 1 * D + tid] = a.g1[tid];
+            vecs[V_O + 2 * D + tid] = a.b1n[tid];
+            vecs[V_O + 3 * D + tid] = a.c ? a.c[tid] : 0.f;
+            vecs[V_O + 4 * D + tid] = a.c ? a.g2[tid] : 0.f;
+            vecs[V_O + 5 * D + tid] = a.c ? a.b2n[tid] : 0.f;
+        }
+    } else {
+        for (int i = tid; i < 3 * D; i += 64 * NW) vecs[V_BIN + i] = a.bin[i];
+        if (!EMBED) {
+            for (int i = tid; i < F; i += 64 * NW) vecs[V_B1 + i] = a.b1[i];
+            for (int i = tid; i < D; i += 64 * NW) {
+                vecs[V_B2 + i] = a.b2[i];
+                vecs[V_G + i] = a.g[i];
+                vecs[V_B + i] = a.b[i];
+                vecs[V_O + 0 * D + i] = a.bo ? a.bo[i] : 0.f;
+                vecs[V_O + 1 * D + i] = a.g1[i];
+                vecs[V_O + 2 * D + i] = a.b1n[i];
+                vecs[V_O + 3 * D + i] = a.c ? a.c[i] : 0.f;
+                vecs[V_O + 4 * D + i] = a.c ? a.g2[i] : 0.f;
+                vecs[V_O + 5 * D + i] = a.c ? a.b2n[i] : 0.f;
+            }
+        }
     }
 #ifdef X6_STAGGER
     if (blockIdx.x >= 256 && blockIdx.x < 512)
@@ -1355,19 +1405,19 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
 #endif
     const int mtile = (m0 >> 5) + wave;
     const int mt = m0 + wave * 32 + li;
-    const size_t fbase = (size_t)mtile * 16 * 64 + lane;
+    const size_t fbase = (size_t)mtile * (4 * NT) * 64 + lane;
     const unsigned int lds0 = (unsigned int)(size_t)(__attribute__((address_space(3))) char *)smem;
     const unsigned int fr_addr = lds0 + lane * 16; // + slot * X6_STEP_B + piece * 1024
     const unsigned int vecs_addr = lds0 + NSLOT * X6_STEP_B + 16 * lk; // this lane's float4 of a 32-value tile's group g: + 32 g bytes
-    constexpr int nsteps = X6_NSTEP - 4 * QP0;  // executed steps; step i of the sequence is stream block i (+ 4 past the FFN when QP0)
-    constexpr int qoff = 4 * QP0;
+    constexpr int qoff = NOUT * QP0;                // the q tiles' steps (NT tiles x HT) are skipped when QP0
+    constexpr int nsteps = x6_nstep(NT) - qoff;     // executed steps; step i of the sequence is stream block i (+ qoff past the FFN)
     // DMA of sequence step i into slot i % NSLOT: this wave's pieces PPW wave .. PPW wave + PPW - 1.  The slot holds the
     // step's block in stream order, and the instruction's immediate offset moves the global source AND the LDS destination
     // (tools/dma_probe.hip), so the pieces share one address register pair and one M0: base = the middle piece, offsets
     // -(PPW / 2) .. PPW / 2 - 1 KB (13-bit signed immediates).
     const uint4 *dma_src = a.Wx + (PPW * wave + PPW / 2) * 64 + lane;
     auto issue = [&](int i) __attribute__((always_inline)) {
-        const int blk = i < 20 ? i : i + qoff;
+        const int blk = i < NPRE ? i : i + qoff;
         const uint4 *src = dma_src + (size_t)blk * (X6_STEP_B / 16);
         char *dst = smem + (i % NSLOT) * X6_STEP_B + (PPW * wave + PPW / 2) * 1024;
         x6_static_for<0, PPW>([&](auto jc) __attribute__((always_inline)) {
@@ -1377,21 +1427,21 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
         });
     };
     // accumulators start from the residual x; the attention output tile 0 is requested with it
-    f32x16 acc[4];
-    f32x16 at[4]; // attention output tiles (B operand source of the out-projection): all four requested here, so that
-                  // the steps carry no plain global load (its wait would be a vmcnt(0) behind the DMA pieces)
+    f32x16 acc[NT];
+    f32x16 at[NT]; // attention output tiles (B operand source of the out-projection): all requested here, so that
+                   // the steps carry no plain global load (its wait would be a vmcnt(0) behind the DMA pieces)
     if constexpr (!EMBED) {
         const float4 *rfrag = reinterpret_cast<const float4 *>(a.Rf) + fbase;
         const float4 *afrag = reinterpret_cast<const float4 *>(a.Af) + fbase;
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 t4 = rfrag[(tn * 4 + g) * 64];
                 acc[tn][4 * g + 0] = t4.x, acc[tn][4 * g + 1] = t4.y, acc[tn][4 * g + 2] = t4.z, acc[tn][4 * g + 3] = t4.w;
             }
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 t4 = afrag[(tn * 4 + g) * 64];
@@ -1407,7 +1457,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
         const float *pp_ = a.pe + (int64_t)(orig % a.L) * D;
         float4 *xo = reinterpret_cast<float4 *>(a.Xf) + fbase;
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = tn * 32 + 8 * g + 4 * lk;
@@ -1435,11 +1485,18 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[q]));
     };
-    af[0] = x6_rd<(S0 % NSLOT) * X6_STEP_B>(fr_addr);
-    af[1] = x6_rd<(S0 % NSLOT) * X6_STEP_B + 1024>(fr_addr);
-    af[2] = x6_rd<(S0 % NSLOT) * X6_STEP_B + 2048>(fr_addr);
-    af[3] = x6_rd<(S0 % NSLOT) * X6_STEP_B + 2048>(fr_addr); // (its own read: a register copy of af[2] would be taken before the data has landed)
-    landed_all();
+    if constexpr (NT == 8) {
+        af[0] = x6_rd_sync<(S0 % NSLOT) * X6_STEP_B>(fr_addr);
+        af[1] = x6_rd_sync<(S0 % NSLOT) * X6_STEP_B + 1024>(fr_addr);
+        af[2] = x6_rd_sync<(S0 % NSLOT) * X6_STEP_B + 2048>(fr_addr);
+        af[3] = x6_rd_sync<(S0 % NSLOT) * X6_STEP_B + 2048>(fr_addr);
+    } else {
+        af[0] = x6_rd<(S0 % NSLOT) * X6_STEP_B>(fr_addr);
+        af[1] = x6_rd<(S0 % NSLOT) * X6_STEP_B + 1024>(fr_addr);
+        af[2] = x6_rd<(S0 % NSLOT) * X6_STEP_B + 2048>(fr_addr);
+        af[3] = x6_rd<(S0 % NSLOT) * X6_STEP_B + 2048>(fr_addr); // (its own read: a register copy of af[2] would be taken before the data has landed)
+        landed_all();
+    }
 
     const float invn = 1.0f / (float)D;
     x6_bf16x8 X[3];
@@ -1522,18 +1579,19 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
     // (reads past the last step of the sequence fetch a stale slot and are never multiplied: the counted waits assume
     // every read of the schedule is in flight)
 
-    // ---- out-projection: acc += W_o . ao^T, k tile tn = step
+    // ---- out-projection: acc += W_o . ao^T, k tile t, output half oh: step t HT + oh
     if constexpr (!EMBED) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            X6_STEP(t, at[t], acc[0], acc[1], acc[2], acc[3])
+        for (int t = 0; t < NT; ++t) {
+            X6_STEP(t * HT, at[t], acc[0], acc[1], acc[2], acc[3])
+            if constexpr (HT == 2) { X6_STEP(t * HT + 1, at[t], acc[4], acc[5], acc[6], acc[7]) }
         }
     }
     // ---- + b_o, LN1, + c, LN2: register-local (64 of the 128 values here, 64 in lane ^ 32)
     auto layer_norm = [&](int vb, int vg, int vbeta, int vadd) __attribute__((always_inline)) {
         float sum = 0.f;
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (vb >= 0) {
@@ -1546,7 +1604,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
         const float mu = lanes_sum<32>(sum) * invn;
         float qs = 0.f;
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float dlt = acc[tn][r] - mu;
@@ -1554,7 +1612,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
             }
         const float rstd = 1.0f / sqrtf(lanes_sum<32>(qs) * invn + 1e-5f);
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = tn * 32 + 8 * g + 4 * lk;
@@ -1569,6 +1627,9 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
+    // (NT = 8: the LayerNorm phases run at full register pressure and the compiler parks the fragments read ahead for the next
+    //  step in AGPRs across them -- copies taken before the data has landed unless the reads are waited for first)
+    if constexpr (NT == 8) landed_all();
     X6_T(st_p[1])
     if constexpr (!EMBED) {
         layer_norm(V_O + 0 * D, V_O + 1 * D, V_O + 2 * D, V_O + 3 * D);
@@ -1581,10 +1642,10 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
     //      accumulator), bias + relu on the 16 values, FFN-2 step acc += W2[:, 32 ft ..] h_ft^T.  (The round-2 order --
     //      all eight hidden tiles, then FFN-2 -- keeps 128 registers of h beside the 64 of y: with the split's
     //      temporaries that is ~265 of the 256 registers two waves per SIMD have: 173 spilled.)
-    x6_bf16x8 Yp[4][2][3];
+    x6_bf16x8 Yp[NT][2][3];
     if constexpr (!EMBED) {
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 x6_split(acc[tn], s2, Yp[tn][s2]);
@@ -1660,19 +1721,31 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
             f32x16 hft, bt;
 #pragma unroll
             for (int r = 0; r < 16; ++r) hft[r] = 0.f;
-            X6_STEP1(4 + 2 * ft, Yp, hft)
+            X6_STEP1(NOUT + 2 * HT * ft, Yp, hft)
+            if constexpr (HT == 2) {
+                // k tiles 4 .. 7 onto a zero-started accumulator of their own (small products first again), then one
+                // rounded addition: the first half's full-size sum is not truncated 48 more times
+                f32x16 hf2;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hf2[r] = 0.f;
+                X6_STEP1(NOUT + 4 * ft + 1, (&Yp[4]), hf2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hft[r] += hf2[r];
+            }
             bias_tile(bt, V_B1 + ft * 32);
 #pragma unroll
             for (int r = 0; r < 16; ++r) hft[r] = fmaxf(hft[r] + bt[r], 0.f);
-            X6_STEP(5 + 2 * ft, hft, acc[0], acc[1], acc[2], acc[3])
+            X6_STEP(NOUT + 2 * HT * ft + HT, hft, acc[0], acc[1], acc[2], acc[3])
+            if constexpr (HT == 2) { X6_STEP(NOUT + 4 * ft + 3, hft, acc[4], acc[5], acc[6], acc[7]) }
         }
     }
+    if constexpr (NT == 8) landed_all();
     X6_T(st_p[3])
     // ---- + b2, LN3 -> x' (fragment-major store), then split ONCE into the plane registers as the QKV tail's B operand
     if constexpr (!EMBED) {
         float sum = 0.f;
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 bb = *reinterpret_cast<const float4 *>(vecs + V_B2 + tn * 32 + 8 * g + 4 * lk);
@@ -1683,7 +1756,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
         const float mu = lanes_sum<32>(sum) * invn;
         float qs = 0.f;
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float dlt = acc[tn][r] - mu;
@@ -1691,7 +1764,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
             }
         const float rstd = 1.0f / sqrtf(lanes_sum<32>(qs) * invn + 1e-5f);
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = tn * 32 + 8 * g + 4 * lk;
@@ -1699,13 +1772,13 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
                 const float4 be = *reinterpret_cast<const float4 *>(vecs + V_B + n);
                 const float4 o = make_float4((acc[tn][4 * g + 0] - mu) * rstd * gg.x + be.x, (acc[tn][4 * g + 1] - mu) * rstd * gg.y + be.y,
                                              (acc[tn][4 * g + 2] - mu) * rstd * gg.z + be.z, (acc[tn][4 * g + 3] - mu) * rstd * gg.w + be.w);
-                if (a.Xf) reinterpret_cast<float4 *>(a.Xf)[((size_t)(mtile * 4 + tn) * 4 + g) * 64 + lane] = o;
+                if (a.Xf) reinterpret_cast<float4 *>(a.Xf)[((size_t)(mtile * NT + tn) * 4 + g) * 64 + lane] = o;
                 acc[tn][4 * g + 0] = o.x, acc[tn][4 * g + 1] = o.y, acc[tn][4 * g + 2] = o.z, acc[tn][4 * g + 3] = o.w;
                 __builtin_amdgcn_sched_barrier(0);
             }
     }
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
+    for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             x6_split(acc[tn], s2, Yp[tn][s2]);
@@ -1713,17 +1786,25 @@ __global__ void __launch_bounds__(64 * NW, 2) k_block_x6(BlockX6Args a) {
         }
     X6_T(st_p[4])
     unsigned long long st_q0 = 0, st_q1 = 0, st_qst = 0;
-    // ---- the next layer's QKV: passes of 128 output columns (4 tiles), k tile tn; sequence steps 20 ..
+    // ---- the next layer's QKV: passes of d output columns (NT tiles); sequence steps NPRE ..
 #pragma unroll
     for (int pp = 0; pp < 3; ++pp) {
         if (pp >= 3 - QP0) break;
-        const int c0 = 128 * (pp + QP0);
+        const int c0 = D * (pp + QP0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { // output tile 4 pp + i: columns c0 + 32 i ..
+        for (int i = 0; i < NT; ++i) { // output tile NT pp + i: columns c0 + 32 i ..
             f32x16 qt, bt;
 #pragma unroll
             for (int r = 0; r < 16; ++r) qt[r] = 0.f;
-            X6_STEP1(20 + 4 * pp + i, Yp, qt)
+            X6_STEP1(NPRE + HT * (NT * pp + i), Yp, qt)
+            if constexpr (HT == 2) {
+                f32x16 q2;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) q2[r] = 0.f;
+                X6_STEP1(NPRE + 2 * (NT * pp + i) + 1, (&Yp[4]), q2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) qt[r] += q2[r];
+            }
             bias_tile(bt, V_BIN + c0 + i * 32); // (its wait lands every fragment register too: control flow ahead)
             X6_T(st_q0)
             if (mt < M) {
@@ -3603,7 +3684,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) k_attn16(const float
         if (qi < L) {
             if (out_frag) { // fragment-major image (d = 128: column block tn = head): the fused block kernel's B operand
                 const int64_t tk = base + qi;
-                float4 *of = reinterpret_cast<float4 *>(out) + ((size_t)(tk >> 5) * 4 + h) * 4 * 64 + (gq & 1) * 32 + (tk & 31);
+                float4 *of = reinterpret_cast<float4 *>(out) + ((size_t)(tk >> 5) * gridDim.x + h) * 4 * 64 + (gq & 1) * 32 + (tk & 31);
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
                     of[(2 * ct + (gq >> 1)) * 64] =
@@ -3964,7 +4045,7 @@ const float *__restrict__ qkv, const int64_t *__restrict__ seq,
         if (qi < L) {
             if (out_frag) {
                 const int64_t tk = base + qi;
-                float4 *of = reinterpret_cast<float4 *>(out) + ((size_t)(tk >> 5) * 4 + h) * 4 * 64 + (gq & 1) * 32 + (tk & 31);
+                float4 *of = reinterpret_cast<float4 *>(out) + ((size_t)(tk >> 5) * gridDim.x + h) * 4 * 64 + (gq & 1) * 32 + (tk & 31);
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
                     of[(2 * ct + (gq >> 1)) * 64] =
@@ -4414,30 +4495,39 @@ int irs_launch_cross_const(irs_ctx *ctx, hipStream_t s) {
 // split-bf16 fused layer kernel (k_block_x6): one 768 KB step stream per layer that has a successor (d = 128, F = 256,
 // head dim 32: the shapes k_block<true, true> serves)
 static bool x6_shape(const irs_ctx *ctx) {
-    return ctx->dims.d == 128 && ctx->dims.ffn_dim == 256 && ctx->dims.d / ctx->dims.n_heads == 32 && ctx->dims.n_layers >= 2;
+    return (ctx->dims.d == 128 || ctx->dims.d == 256) && ctx->dims.ffn_dim == 256 && ctx->dims.d / ctx->dims.n_heads == 32 &&
+           ctx->dims.n_layers >= 2;
 }
+static size_t x6_layer_b(const irs_ctx *ctx) { return x6_layer_bytes(ctx->dims.d / 32); }
 // streams 0 .. n_layers - 2: layer l's out-projection / FFN and layer l + 1's q | k | v; stream n_layers - 1: layer 0's
 // q | k | v alone (the embed kernel's; its other blocks are zero and never fetched)
-size_t irs_x6_bytes(const irs_ctx *ctx) { return x6_shape(ctx) ? (size_t)ctx->dims.n_layers * X6_LAYER_BYTES : 0; }
+size_t irs_x6_bytes(const irs_ctx *ctx) { return x6_shape(ctx) ? (size_t)ctx->dims.n_layers * x6_layer_b(ctx) : 0; }
 int irs_launch_pack_x6(irs_ctx *ctx, hipStream_t s) {
     if (!ctx->w_x6) return IRS_OK;
-    const int nl = ctx->dims.n_layers;
+    const int nl = ctx->dims.n_layers, NT = ctx->dims.d / 32;
+    const size_t lb16 = x6_layer_b(ctx) / 16;
+    const dim3 pgrid(x6_nstep(NT) * 24 * 64 / 256);
+    auto pack = [&](const float *Wo, const float *W1, const float *W2, const float *Win, uint4 *out) {
+        if (NT == 8) hipLaunchKernelGGL(k_pack_x6<8>, pgrid, dim3(256), 0, s, Wo, W1, W2, Win, out);
+        else hipLaunchKernelGGL(k_pack_x6<4>, pgrid, dim3(256), 0, s, Wo, W1, W2, Win, out);
+    };
     for (int l = 0; l + 1 < nl; ++l) {
         const irs_layer_w &w = ctx->layer[l];
-        hipLaunchKernelGGL(k_pack_x6, dim3(X6_NSTEP * 24 * 64 / 256), dim3(256), 0, s, w.sa_out_w, w.l1_w, w.l2_w,
-                           ctx->layer[l + 1].sa_in_w, ctx->w_x6 + (size_t)l * (X6_LAYER_BYTES / 16));
+        pack(w.sa_out_w, w.l1_w, w.l2_w, ctx->layer[l + 1].sa_in_w, ctx->w_x6 + (size_t)l * lb16);
     }
-    hipLaunchKernelGGL(k_pack_x6, dim3(X6_NSTEP * 24 * 64 / 256), dim3(256), 0, s, (const float *)nullptr, (const float *)nullptr,
-                       (const float *)nullptr, ctx->layer[0].sa_in_w, ctx->w_x6 + (size_t)(nl - 1) * (X6_LAYER_BYTES / 16));
+    pack(nullptr, nullptr, nullptr, ctx->layer[0].sa_in_w, ctx->w_x6 + (size_t)(nl - 1) * lb16);
     IRS_CHECK_HIP(ctx, hipGetLastError());
     return IRS_OK;
 }
-static constexpr int X6_LDS_BYTES = 3 * X6_STEP_B + 1792 * 4;
+static constexpr int X6_LDS_BYTES = x6_lds_bytes(4);
 static void x6_attr_once() { // (the kernels' dynamic LDS exceeds the default 64 KB limit)
     IRS_ONCE_PER_DEVICE({
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, X6_NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<1, X6_NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, X6_NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, 4, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds_bytes(8));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<1, 4, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds_bytes(8));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, 4, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds_bytes(8));
     });
 }
 
@@ -4486,6 +4576,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     int rc;
     // rows-only decode of a few sequences: the plan kernel also computes r_u (and hands the step counter over)
     const bool small_plan = (x_out == nullptr) && pos && xrows && L >= 4 && B <= 64;
+    const bool rows_only = (x_out == nullptr) && pos && xrows && L >= 4;
     if (ctx->step_pair && !small_plan) IRS_FAIL(ctx, IRS_E_STATE, "merged path step needs the single-workgroup plan kernel");
     if (!small_plan && (rc = irs_launch_pif(ctx, user, B, ctx->act_ru, s)) != IRS_OK) return rc;
     float *x = ctx->act_x, *y = ctx->act_y;
@@ -4493,7 +4584,6 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     // non-pad tokens (k_plan), every kernel clamping its row count to the device-side total, and (2) the
     // LAST layer is evaluated for the one consumed row per sequence (all earlier layers need every valid
     // row: they feed the next layer's keys and values).
-    const bool rows_only = (x_out == nullptr) && pos && xrows && L >= 4;
     const int32_t *off = nullptr, *cnt = nullptr, *tok = nullptr, *qrow = nullptr, *m_dev = nullptr;
     // throughput shapes keep x / y ONLY in the fragment-major layout between the layers (see frag_index): the
     // LN-fused GEMMs write it, read their residual from it, and the QKV / FFN1 GEMMs load it as their X operand
@@ -4505,7 +4595,12 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     // default (d = 30, L = 60) 235 vs 582 us at 64 users, 859 vs 1055 at 1024; config 1 (d = 64, L = 50) 259 vs 653
     // at 64 users, 888 vs 1040 at 1024 -- ahead over the whole tested range
     const bool any_cfg = small_any_shape(d, F) && ctx->w_frag16 && rows <= 65536;
-    const bool frag = d <= LIN_BN && d % 32 == 0 && rows > 2048 && !small_cfg && !any_cfg;
+    // d = 256 (C4's decoder), rows-only decode of a throughput batch: the split-bf16 fused layer kernel at 8 accumulator tiles
+    // per token (k_block_x6<.., NT = 8>) with fragment-major activations, like d = 128.  Everything else at d = 256 (full
+    // decodes, small batches, IRS_GEMM_F32) keeps the per-GEMM float32 kernels.
+    const bool x6d = d == 256 && F == 256 && ctx->use_x6 && ctx->w_x6 && rows_only && rows >= 32768 && ctx->dims.n_layers > 1 &&
+                     attn16_ok(ctx, ctx->act_qkv, ctx->act_yf);
+    const bool frag = (d <= LIN_BN && d % 32 == 0 && rows > 2048 && !small_cfg && !any_cfg) || x6d;
     // one sequence (the reference IRN's own regime, and the latency metric's): self-attention runs inside the layer
     // kernel; q | k | v alternate between two buffers so that the last (rows-only) layer reads ctx->act_qkv
     const bool att_fused = small_cfg && rows_only && B == 1 && ctx->dims.n_heads == 4 && L <= 256 && ctx->act_qkv_b1 &&
@@ -4534,16 +4629,18 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         m_dev = ctx->m_dev;
     }
     bool qkv0_done = false;
-    if (frag && d == 128 && ctx->dims.n_layers > 1) { // embed + layer 0's QKV in one kernel
+    if (frag && (d == 128 || x6d) && ctx->dims.n_layers > 1) { // embed + layer 0's QKV in one kernel
         EmbedQkvArgs ea{seq, ctx->item_emb, ctx->pe, tok, m_dev, rows, L, sqrtf((float)d), ctx->dims.n_item, xf,
                         ctx->layer[0].sa_in_w, ctx->layer[0].sa_in_b, ctx->act_qkv};
         irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
         if (ctx->use_x6 && ctx->w_x6) { // the same kernel on split-bf16 MFMAs: k_block_x6's q | k | v steps behind an embed prologue
             BlockX6Args xa{};
-            xa.Wx = ctx->w_x6 + (size_t)(ctx->dims.n_layers - 1) * (X6_LAYER_BYTES / 16);
+            xa.Wx = ctx->w_x6 + (size_t)(ctx->dims.n_layers - 1) * (x6_layer_b(ctx) / 16);
             xa.bin = ctx->layer[0].sa_in_b, xa.Xf = xf, xa.QKV = ctx->act_qkv, xa.M = rows, xa.m_dev = m_dev;
             xa.seq = seq, xa.E = ctx->item_emb, xa.pe = ctx->pe, xa.tok_row = tok, xa.L = L, xa.sqrtd = sqrtf((float)d), xa.n_item = ctx->dims.n_item;
             x6_attr_once();
+            if (x6d) hipLaunchKernelGGL((k_block_x6<0, 4, true, 8>), dim3((rows + 127) / 128), dim3(256), x6_lds_bytes(8), s, xa);
+            else
             hipLaunchKernelGGL((k_block_x6<0, X6_NW, true>), dim3((rows + 32 * X6_NW - 1) / (32 * X6_NW)), dim3(64 * X6_NW), X6_LDS_BYTES, s, xa);
         } else
         hipLaunchKernelGGL(k_embed_qkv, dim3((rows + 127) / 128), dim3(256), 0, s, ea);
@@ -4617,7 +4714,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             float *h_r = ctx->act_h;                   // [B, F]
             const float *q_r = nullptr;
             if (q_split) { // the previous layer's kernel wrote k | v only: queries for the B consumed rows here
-                hipLaunchKernelGGL(k_gather_rows_frag, dim3(B), dim3(64), 0, s, xf, qrow, x_r, d);
+                hipLaunchKernelGGL(k_gather_rows_frag, dim3(B), dim3(64), 0, s, xf, qrow, x_r, d, d > 128 ? d / 32 : 4);
                 if ((rc = launch_linear(ctx, x_r, w.sa_in_w, w.sa_in_b, nullptr, h_r, B, d, d, false, s))) return rc;
                 q_r = h_r;
             }
@@ -4632,7 +4729,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             const bool fused_tail = d == 128 && F == 256;
             const bool any_tail = small_any_shape(d, F) && ctx->w_frag16 && !frag && B <= 2048;
             const bool idx_res = (fused_tail || any_tail) && !frag; // the layer kernel reads the residual rows x[qrow[b]] itself
-            if (frag && !q_split) hipLaunchKernelGGL(k_gather_rows_frag, dim3(B), dim3(64), 0, s, xf, qrow, x_r, d);
+            if (frag && !q_split) hipLaunchKernelGGL(k_gather_rows_frag, dim3(B), dim3(64), 0, s, xf, qrow, x_r, d, d > 128 ? d / 32 : 4);
             else if (!frag && !idx_res) hipLaunchKernelGGL(k_gather_rows_idx, dim3(B), dim3(64), 0, s, x, qrow, x_r, d);
             if (fused_tail) { // one launch for the rest of the layer on the B consumed rows
                 SmallBlockArgs sb{ao_r, idx_res ? x : x_r, w.sa_out_w, w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, w.l1_w, w.l1_b, w.l2_w, w.l2_b,
@@ -4670,13 +4767,13 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         }
         // d = 128, F = 256, head dim 32: attention writes its output fragment-major and ONE kernel does the rest of
         // the layer (out-projection + LN1/LN2, feed-forward + LN3, the next layer's QKV) with y, h, x' in registers
-        const bool fuse_block = frag && d == 128 && F == 256 && attn16_ok(ctx, ctx->act_qkv, yf);
+        const bool fuse_block = frag && (d == 128 || x6d) && F == 256 && attn16_ok(ctx, ctx->act_qkv, yf);
         if (!att_fused &&
             (rc = launch_attn(ctx, ctx->act_qkv, seq, ctx->act_ru, fuse_block ? yf : ctx->act_ao, B, s, off, cnt, tok, fuse_block)))
             return rc;
         if (frag) {
             const bool last = l + 1 == ctx->dims.n_layers;
-            const bool tail = !last && d == 128 && F == 256;
+            const bool tail = !last && (d == 128 || x6d) && F == 256;
             BlockArgs ba{};
             ba.W1 = w.l1_w, ba.b1 = w.l1_b, ba.W2 = w.l2_w, ba.b2 = w.l2_b, ba.g = w.n3_w, ba.b = w.n3_b;
             ba.Xf = last ? nullptr : xf, ba.Y = last ? x : nullptr, ba.M = rows, ba.m_dev = m_dev;
@@ -4693,13 +4790,18 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                 irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
                 if (tail) irs_prof_begin(ctx, IRS_PROF_LAYER, s); // (one family is enabled at a time)
                 if (tail && ctx->use_x6 && ctx->w_x6) { // the same layer tail on split-bf16 MFMAs
-                    BlockX6Args xa{yf, xf, ctx->w_x6 + (size_t)l * (X6_LAYER_BYTES / 16), w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b,
+                    BlockX6Args xa{yf, xf, ctx->w_x6 + (size_t)l * (x6_layer_b(ctx) / 16), w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b,
                                    w.l1_b, w.l2_b, w.n3_w, w.n3_b, ctx->layer[l + 1].sa_in_b, xf, ctx->act_qkv, rows, m_dev, kv_only ? 1 : 0};
                     x6_attr_once();
                     const dim3 x6_grid((rows + 32 * X6_NW - 1) / (32 * X6_NW));
+                    if (x6d) {
+                        if (kv_only) hipLaunchKernelGGL((k_block_x6<1, 4, false, 8>), dim3((rows + 127) / 128), dim3(256), x6_lds_bytes(8), s, xa);
+                        else hipLaunchKernelGGL((k_block_x6<0, 4, false, 8>), dim3((rows + 127) / 128), dim3(256), x6_lds_bytes(8), s, xa);
+                    } else
                     if (kv_only) hipLaunchKernelGGL((k_block_x6<1, X6_NW, false>), x6_grid, dim3(64 * X6_NW), X6_LDS_BYTES, s, xa);
                     else hipLaunchKernelGGL((k_block_x6<0, X6_NW, false>), x6_grid, dim3(64 * X6_NW), X6_LDS_BYTES, s, xa);
-                } else if (tail) hipLaunchKernelGGL((k_block<true, true>), dim3((rows + 127) / 128), dim3(256), 0, s, ba);
+                } else if (x6d) IRS_FAIL(ctx, IRS_E_STATE, "d = 256 fused layer kernel without a successor layer");
+                else if (tail) hipLaunchKernelGGL((k_block<true, true>), dim3((rows + 127) / 128), dim3(256), 0, s, ba);
                 else hipLaunchKernelGGL((k_block<true, false>), dim3((rows + 127) / 128), dim3(256), 0, s, ba);
                 irs_prof_end(ctx, IRS_PROF_LINEAR, s, ffn_flops + 2.0 * rows * (double)d * d, (8.0 + 4.0 + (tail ? 12.0 : 0.0)) * rows * (double)d);
                 if (tail) irs_prof_end(ctx, IRS_PROF_LAYER, s, ffn_flops + 2.0 * rows * (double)d * d, (8.0 + 4.0 + 12.0) * rows * (double)d);

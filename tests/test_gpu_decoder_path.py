@@ -642,3 +642,44 @@ def test_split_bf16_kernels_random_batches(seed):
     sep = fin & ((vb[:, 0] - vb[:, 1]).abs() > 4 * TAU)
     assert sep.sum().item() > B // 2
     assert torch.equal(ia[sep, 0], ib[sep, 0])
+
+
+@pytest.mark.parametrize("B", [168, 1031])
+def test_split_bf16_layer_kernel_d256(oracle, B):
+    """C4's decoder shape (d = 256, 8 heads of 32, ffn 256) on the split-bf16 fused layer kernel at 8 accumulator tiles per
+    token (k_block_x6<.., NT = 8>: one wave per SIMD, a 96-step weight stream per layer; rows-only decodes of >= 32768 token
+    rows) against the per-GEMM float32-MFMA kernels (IRS_GEMM_F32) on the same batch and against the numpy oracle; B = 1031
+    leaves a partially filled last token tile.  Consumed positions include the first and the last token and an all-pad
+    window."""
+    from influentialrs_amd._lib import IRS_GEMM_F32, IRS_GEMM_X6
+    cfg = synth.make_config("c2", emb_dim=256, n_heads=8)
+    L = cfg.max_len
+    sd = synth.irn_state_dict(cfg, 779)
+    eng = make_engine(cfg, sd, max_rows=B, max_seqs=B)
+    hists = synth.user_histories(B, cfg.n_item, seed=51)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=53)
+    _, seqs, users, targets, _ = synth.collate_eval_irs(rows, L, gap_len=1)
+    seqs[1, :] = 0
+    seqs[1, -1] = targets[1]
+    seqs[2, seqs[2] == 0] = 3
+    pos = np.full(B, L - 2, dtype=np.int32)
+    pos[3], pos[4], pos[5] = 0, L - 1, L // 2
+    seq, u, p = torch.from_numpy(seqs).cuda(), torch.from_numpy(users).cuda(), torch.from_numpy(pos).cuda()
+    out = {}
+    for mode in (IRS_GEMM_X6, IRS_GEMM_F32):
+        eng.decoder_gemm = mode
+        out[mode] = eng.decode(seq, u, want_x=False, pos=p)[1].clone()
+    eng.decoder_gemm = IRS_GEMM_X6
+    a, b = out[IRS_GEMM_X6], out[IRS_GEMM_F32]
+    assert not torch.equal(a, b), "the two modes must not be the same code path"
+    assert torch.equal(torch.isnan(a), torch.isnan(b))
+    ok = torch.isfinite(a) & torch.isfinite(b)
+    assert (a - b)[ok].abs().max().item() < X_TOL_X6 * 1.5  # (K = 256 contractions: twice the d = 128 accumulation length)
+    for i in (0, 2, 5, B - 1):
+        ref = oracle.decode(sd, cfg, seqs[i], int(users[i]))[0][pos[i]]
+        assert np.abs(ref - a[i].cpu().numpy()).max() < X_TOL_X6 * 1.5, i
+    # the captured path-search step follows the mode at this shape too
+    hep = torch.full((B,), L - 2, dtype=torch.int32, device="cuda")
+    pg, _ = eng.generate_paths(seq.clone(), u, hep.clone(), 3, use_graph=True)[:2]
+    ps, _ = eng.generate_paths(seq.clone(), u, hep.clone(), 3, use_graph=False)[:2]
+    assert torch.equal(pg, ps)

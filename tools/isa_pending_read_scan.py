@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Scan a kernel's ISA for uses of registers whose inline-asm LDS read has not been waited for.
+
+The fused layer kernels issue their fragment reads as inline-asm `ds_read_b128` and wait for them with hand-counted
+`s_waitcnt lgkmcnt(N)` statements (csrc/decoder.hip: k_block_x6, csrc/score.hip: the ring sweeps).  The compiler does not
+know the destination is pending: under register pressure it may copy such a register (a move into an AGPR, a live-range
+split) between the read and its wait, and the copy holds whatever the register held before.  This tool walks the
+instruction stream, keeps the destinations of reads that no `lgkmcnt` wait has retired yet, and prints every instruction
+that touches one.  Round 4: it found the cause of 1e-4 errors in the d = 256 layer kernel (fragments read ahead across a
+LayerNorm phase were parked in AGPRs); the d = 128 kernels scan clean.
+
+usage: hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only influentialrs_amd/csrc/decoder.hip -o dec.s
+       tools/isa_pending_read_scan.py dec.s <mangled-kernel-name-prefix> [...]"""
+import re
+import sys
+
+
+def regs_of(tok):
+    out = set()
+    for m in re.finditer(r"\b([va])\[(\d+):(\d+)\]", tok):
+        out |= {m.group(1) + str(i) for i in range(int(m.group(2)), int(m.group(3)) + 1)}
+    for m in re.finditer(r"\b([va])(\d+)\b", tok):
+        out.add(m.group(1) + m.group(2))
+    return out
+
+
+def kernel_lines(lines, prefix):
+    on, out = False, []
+    for l in lines:
+        if l.startswith(prefix) and l.rstrip().endswith(":") or (l.startswith(prefix) and ":" in l.split()[0]):
+            on = True
+        if on:
+            out.append(l)
+            if "s_endpgm" in l:
+                break
+    return out
+
+
+def scan(lines, limit=40):
+    pending, flags = [], 0
+    for i, l in enumerate(lines):
+        t = l.strip()
+        if not t or t[0] in ";.":
+            continue
+        parts = t.split(None, 1)
+        op, ops = parts[0], parts[1] if len(parts) > 1 else ""
+        if op.startswith("ds_read") or op.startswith("ds_load"):
+            pending.append((regs_of(ops.split(",")[0]), i, t))
+            continue
+        if op == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", t)
+            if m:
+                n = int(m.group(1))
+                pending = pending[len(pending) - n:] if n > 0 else []
+            continue
+        used = regs_of(ops)
+        for r, ln, tt in pending:
+            if used & r:
+                flags += 1
+                if flags <= limit:
+                    print(f"  line {i}: {t}    <-- register of the pending read at line {ln}: {tt}")
+    return flags
+
+
+def main():
+    lines = open(sys.argv[1]).read().split("\n")
+    bad = 0
+    for prefix in sys.argv[2:]:
+        k = kernel_lines(lines, prefix)
+        n = scan(k)
+        print(f"{prefix}: {len(k)} lines, {n} uses of pending read destinations")
+        bad += n
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

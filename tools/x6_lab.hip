@@ -43,7 +43,7 @@ int main(int argc, char **argv) {
     }
     uint4 *Wx;
     CK(hipMalloc(&Wx, X6_LAYER_BYTES));
-    hipLaunchKernelGGL(k_pack_x6, dim3(X6_NSTEP * 24 * 64 / 256), dim3(256), 0, 0, Wo, W1, W2, Win, Wx);
+    hipLaunchKernelGGL(k_pack_x6<4>, dim3(X6_NSTEP * 24 * 64 / 256), dim3(256), 0, 0, Wo, W1, W2, Win, Wx);
     CK(hipDeviceSynchronize());
     BlockArgs ba{};
     ba.Af = Af, ba.Rf = Rf, ba.Wo = Wo, ba.bo = bo, ba.g1 = g1, ba.b1n = b1n, ba.c = c, ba.g2 = g2, ba.b2n = b2n;
