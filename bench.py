@@ -963,7 +963,8 @@ def main():
                 g5.manual_seed(5)
                 b_seq, b_hep = fresh[:1].contiguous(), j4.hep[:1].contiguous()
                 b_usr = torch.randint(0, j4.cfg.n_user, (1,), generator=g5, device=device, dtype=torch.int64)
-                c5 = {"workload": "c5: beam 32 x 20 steps, 1 user, n_item=10000000, d=256 (" +
+                c5 = {"window_tokens": int((b_seq != 0).sum().item()),
+                      "workload": "c5: beam 32 x 20 steps, 1 user, n_item=10000000, d=256 (" +
                                   ("one GPU holds the whole catalog)" if world == 1 else
                                    f"{world} item shards of {j4.eng.n_local} rows; beam windows decoded {32 // world} per rank)"),
                       "n_gpus": world,
