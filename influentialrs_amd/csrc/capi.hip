@@ -74,6 +74,8 @@ extern "C" int irs_create(irs_ctx **out, const irs_dims *dims, const irs_shard *
         c->use_x6 = e ? (strcmp(e, "f32") != 0) : 1;
         const char *ea = getenv("IRS_ATTN_GEMM");
         c->use_attn_x6 = ea ? (strcmp(ea, "x6") == 0) : 0;
+        const char *ep = getenv("IRS_ATTN_PERSIST");
+        c->attn_persist = ep ? (atoi(ep) != 0) : 0;
         const char *er = getenv("IRS_LSE_RING");
         c->lse_no_ring = er ? (strcmp(er, "0") == 0) : 0;
     }
@@ -238,7 +240,7 @@ extern "C" int irs_finalize_weights(irs_ctx *ctx, void *arena, size_t bytes, voi
 // ------------------------------------------------------------------ workspace
 struct ws_plan {
     size_t x, y, xf, yf, qkv, qkv_b1, ao, h, ru, xb, eps, thr, gm, cnt, cand, lse, ref, xrows, tval, tids, status, step, pos;
-    size_t bseq[2], bhep[2], bcum[2], bpaths[2], buser, lmax, lsum, tokrow, scnt, soff, sqrow, spadq, mdev, xlocal, ksend, krecv, gmax, fbcount, fblist, exhkeys, total;
+    size_t bseq[2], bhep[2], bcum[2], bpaths[2], buser, lmax, lsum, tokrow, scnt, soff, sqrow, spadq, aorder, atab, mdev, xlocal, ksend, krecv, gmax, fbcount, fblist, exhkeys, total;
 };
 
 static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
@@ -293,6 +295,8 @@ static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
     p->soff = take((size_t)ctx->max_seqs * 4);
     p->sqrow = take((size_t)ctx->max_seqs * 4);
     p->spadq = take((size_t)ctx->max_seqs * 4);
+    p->aorder = take((size_t)ctx->max_seqs * 4);
+    p->atab = take(512);
     p->mdev = take(256);
     p->xlocal = take((size_t)ctx->max_seqs * D.d * 4);
     p->ksend = take((size_t)ctx->max_rows * D.max_k * 8); // exchange buffers of the item-sharded loops (comm.hip)
@@ -358,6 +362,8 @@ extern "C" int irs_bind_workspace(irs_ctx *ctx, void *ws, size_t bytes) {
     ctx->seq_off = (int32_t *)(b + p.soff);
     ctx->seq_qrow = (int32_t *)(b + p.sqrow);
     ctx->seq_padq = (int32_t *)(b + p.spadq);
+    ctx->att_order = (int32_t *)(b + p.aorder);
+    ctx->att_tab = (int32_t *)(b + p.atab);
     ctx->m_dev = (int32_t *)(b + p.mdev);
     ctx->x_local = (float *)(b + p.xlocal);
     ctx->keys_send = (uint64_t *)(b + p.ksend);

@@ -114,6 +114,51 @@ __global__ void __launch_bounds__(1024) k_plan_scan(const int32_t *__restrict__ 
     if (tid == 0) m_dev[0] = s_base;
 }
 
+// Work list of the persistent attention kernel (k_attn16<.., PERSIST>): the sequences sorted by their number of 16-token
+// tiles, LONGEST FIRST (a counting sort over the 16 classes; the order inside a class is whatever the atomics give --
+// it only decides which workgroup takes which item, every item is computed independently), and per class where its
+// sequences and its work items start.  A sequence is H items, one per head; a short one -- four padded sequences fit the
+// LDS images of one workgroup -- is H / 4 items, each a group of four heads (wave = head).
+//   tab[0] = number of items; tab[1 + j], tab[18 + j] (j = 0 .. 16): first sequence rank / first item of class nb16 = 16 - j
+//   (j = 16: the totals); tab[40 + l]: the work counter of layer l's launch (zeroed here, once per decode).
+#define ATT_TAB_WORDS 64
+__device__ __forceinline__ bool attn_share_class(int nb16, int Lcap16, int H) { return (H & 3) == 0 && 4 * 16 * nb16 <= Lcap16; }
+__global__ void __launch_bounds__(1024) k_plan_attn_order(const int32_t *__restrict__ cnt, int B, int Lcap16, int H,
+                                                          int32_t *__restrict__ order, int32_t *__restrict__ tab) {
+    __shared__ int s_hist[17], s_start[18], s_fill[17];
+    const int tid = threadIdx.x;
+    if (tid < 17) s_hist[tid] = 0, s_fill[tid] = 0;
+    __syncthreads();
+    for (int b = tid; b < B; b += 1024) {
+        int nb = (cnt[b] + 15) >> 4;
+        nb = nb < 1 ? 1 : (nb > 16 ? 16 : nb);
+        atomicAdd(&s_hist[nb], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int rank = 0, item = 0;
+        for (int j = 0; j < 16; ++j) { // class nb16 = 16 - j
+            const int nb = 16 - j;
+            s_start[j] = rank;
+            tab[1 + j] = rank;
+            tab[18 + j] = item;
+            rank += s_hist[nb];
+            item += s_hist[nb] * (attn_share_class(nb, Lcap16, H) ? H / 4 : H);
+        }
+        s_start[16] = rank;
+        tab[1 + 16] = rank;
+        tab[18 + 16] = item;
+        tab[0] = item;
+    }
+    if (tid < IRS_MAX_LAYERS) tab[40 + tid] = 0;
+    __syncthreads();
+    for (int b = tid; b < B; b += 1024) {
+        int nb = (cnt[b] + 15) >> 4;
+        nb = nb < 1 ? 1 : (nb > 16 ? 16 : nb);
+        order[s_start[16 - nb] + atomicAdd(&s_fill[nb], 1)] = b;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_plan_fill(const int64_t *__restrict__ seq, const int32_t *__restrict__ pos, int B,
                                                    int L, const int32_t *__restrict__ off, int32_t *__restrict__ qrow,
                                                    int32_t *__restrict__ tok_row, int32_t *__restrict__ padq) {
@@ -3361,39 +3406,77 @@ typedef const __attribute__((address_space(1))) void attn_glb_void;
 // the rate at which workgroups are DISPATCHED (~8 ns per workgroup chip-wide: 16384 workgroups = 129 us whatever they do), and
 // workgroups that return at once are dispatched all the same.  What that regime needs is fewer dispatches: a persistent
 // grid over a work list built by the plan kernel (profiles/r04/README.md).
-template <int MAXT, bool FAST, bool DMA = false, int NW = 4>
+// PERSIST (round 4; packed sequences of a throughput batch): a grid of RESIDENT workgroups (three per CU) walks the work
+// list of k_plan_attn_order -- sequences longest first, one item per (sequence, head), or per (sequence, group of four heads)
+// when the sequence is short enough for four padded copies of its K / V images to share the workgroup's LDS (then wave =
+// head) -- taking items off an atomic counter whose next value is requested while the current item is computed.  What it
+// buys over one workgroup per (sequence, head): (1) no dispatch bound -- 16384 workgroups cost ~8 ns each to dispatch
+// chip-wide, which alone is the run time of a batch of short sequences; (2) longest-first dynamic balance instead of
+// dispatch order; (3) a short sequence pays one fill latency for four heads.  (The earlier attempt at (3) with one
+// workgroup per group and three workgroups returning at once was SLOWER: returning workgroups are dispatched all the same.)
+template <int MAXT, bool FAST, bool DMA = false, int NW = 4, bool PERSIST = false>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) k_attn16(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
                                                 const float *__restrict__ r_u, float *__restrict__ out, int Lmax, int d,
                                                 int mask_mode, const int32_t *__restrict__ off,
                                                 const int32_t *__restrict__ cnt, const int32_t *__restrict__ padq,
-                                                int out_frag) {
+                                                int out_frag, int H, const int32_t *__restrict__ order = nullptr,
+                                                int32_t *__restrict__ tab = nullptr, int layer = 0) {
     static_assert(NW == 4 || DMA, "the register-staged fill is written for four waves");
+    static_assert(!PERSIST || (DMA && FAST && NW == 4), "the persistent form is the packed LDS-DMA kernel");
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     constexpr int HD = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int L = cnt ? cnt[blockIdx.y] : Lmax;
     const int S = attn16_vstride(Lmax);
-    float *Vt = reinterpret_cast<float *>(smem);                 // [32][S]   (DMA: V [Lmax rounded to 16][32], halves swizzled)
-    float *Ks = Vt + (DMA ? ((Lmax + 15) & ~15) * HD : 32 * S);  // [Lmax rounded to 16][32], swizzled chunks
-    unsigned int *padbits = reinterpret_cast<unsigned int *>(Ks + (size_t)((Lmax + 15) & ~15) * HD); // [ceil(L/32)]
-    const int h = blockIdx.x, b = blockIdx.y;
+    const int Lcap16 = (Lmax + 15) & ~15;
+    float *const Vt0 = reinterpret_cast<float *>(smem);             // [32][S]   (DMA: V [Lmax rounded to 16][32], halves swizzled)
+    float *const Ks0 = Vt0 + (DMA ? Lcap16 * HD : 32 * S);          // [Lmax rounded to 16][32], swizzled chunks
+    unsigned int *padbits = reinterpret_cast<unsigned int *>(Ks0 + (size_t)Lcap16 * HD); // [ceil(L/32)] (+ the work item at word 12)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 15, gq = lane >> 4;
-    const int64_t base = off ? (int64_t)off[b] : (int64_t)b * Lmax;
     const int ld = 3 * d;
     const bool irn = (mask_mode == IRS_MASK_IRN);
+    // Static assignment, no work counter: the list is sorted longest first, and workgroup w takes items w, 2G - 1 - w, 2G + w,
+    // 4G - 1 - w, ... (G = grid size) -- a boustrophedon walk, so every workgroup gets one item out of each stretch of G
+    // similar lengths, alternately from its long and its short end.  (A shared atomic counter was measured first: ~16K
+    // returning atomics on one address cost more than the balance they buy -- 387 vs 348 us on the bench's mix.)
+    const int n_items = PERSIST ? tab[0] : 0;
+    for (int trip = 0;; ++trip) { // PERSIST: one trip per work item; otherwise exactly one trip
+    int h = blockIdx.x, b = blockIdx.y;
+    bool share = false;
+    if constexpr (PERSIST) {
+        const int G = gridDim.x;
+        const int item = trip * G + ((trip & 1) ? G - 1 - (int)blockIdx.x : (int)blockIdx.x);
+        if (item >= n_items) break; // (its later trips lie further out still: (trip + 1) G > trip G + G - 1 - w)
+        if (trip) __syncthreads(); // every wave is past the previous item's LDS reads
+        int j = 0;
+        while (j < 15 && item >= tab[18 + j + 1]) ++j; // class nb16 = 16 - j (longest first)
+        share = attn_share_class(16 - j, Lcap16, H);
+        const int ipc = share ? H / 4 : H, rel = item - tab[18 + j];
+        b = order[tab[1 + j] + rel / ipc];
+        h = share ? 4 * (rel % ipc) + wave : rel % ipc;
+    }
+    const int L = cnt ? cnt[b] : Lmax;
+    const int64_t base = off ? (int64_t)off[b] : (int64_t)b * Lmax;
     const int L16 = (L + 15) & ~15, NB16 = L16 >> 4;
+    float *Vt = Vt0, *Ks = Ks0;
+    if (share) Vt += wave * L16 * HD, Ks += wave * L16 * HD; // wave = head: its own quarter of the images
+    if constexpr (PERSIST) {
+        if (L <= 0) continue; // (never: the consumed row always counts)
+    }
+    (void)layer;
     // gridDim.z > 1 (few sequences, the latency path): the query blocks of a (sequence, head) are dealt one per wave
     // over 4 gridDim.z waves, largest first -- a wave's dependent chain is then one block instead of three, on
     // three times as many CUs.  Workgroup z owns blocks NB16-1-4z .. NB16-4-4z; each stages the whole K / V of the
     // (sequence, head) -- the loads of a fill are all in flight together, and the IRN target column needs key L-1.
     const int zsplit = blockIdx.z;
-    if (gridDim.z > 1 && 4 * zsplit >= NB16) return;
-    if (L <= 0) return; // (a plan never yields an empty sequence: the consumed row always counts)
+    if constexpr (!PERSIST) {
+        if (gridDim.z > 1 && 4 * zsplit >= NB16) return;
+        if (L <= 0) return; // (a plan never yields an empty sequence: the consumed row always counts)
+    }
     ATTN_T(0);
     if constexpr (DMA) {
         const int jl = lane >> 3, p = lane & 7;
-        for (int i = wave; i < (L16 >> 3); i += NW) { // 8 key rows per instruction; the LDS destination is wave-uniform
+        for (int i = share ? 0 : wave; i < (L16 >> 3); i += share ? 1 : NW) { // 8 key rows per instruction; the LDS destination is wave-uniform
             const int j = 8 * i + jl;
             const float *row = qkv + (base + (j < L ? j : L - 1)) * ld + h * HD;
             const int swk = (j & 7) ^ ((j >> 3) & 1), swv = ((j >> 2) & 1) << 2;
@@ -3426,7 +3509,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) k_attn16(const float
     // (the assignment below and the first Q request run while the K / V rows are in flight)
     // longest-first assignment of the 16-query blocks (block qb costs qb + 1 key tiles) to the 4 waves
     unsigned int mine = 0;
-    if (gridDim.z > 1) {
+    if (share) mine = (1u << NB16) - 1u; // wave = head: every block of this head
+    else if (!PERSIST && gridDim.z > 1) {
         const int v = 4 * zsplit + wave;
         if (v < NB16) mine = 1u << (NB16 - 1 - v);
     } else {
@@ -3684,7 +3768,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) k_attn16(const float
         if (qi < L) {
             if (out_frag) { // fragment-major image (d = 128: column block tn = head): the fused block kernel's B operand
                 const int64_t tk = base + qi;
-                float4 *of = reinterpret_cast<float4 *>(out) + ((size_t)(tk >> 5) * gridDim.x + h) * 4 * 64 + (gq & 1) * 32 + (tk & 31);
+                float4 *of = reinterpret_cast<float4 *>(out) + ((size_t)(tk >> 5) * H + h) * 4 * 64 + (gq & 1) * 32 + (tk & 31);
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
                     of[(2 * ct + (gq >> 1)) * 64] =
@@ -3701,6 +3785,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) k_attn16(const float
         }
     }
     ATTN_T(4);
+    if constexpr (!PERSIST) break;
+    } // work items
 }
 
 // ------------------------------------------------------------------ attention, head dim 32, split-bf16 MFMAs
@@ -4402,9 +4488,16 @@ static bool attn16_ok(const irs_ctx *ctx, const float *qkv, const float *out) {
     return g_attn16 && d % H == 0 && d / H == 32 && L <= 256 && d % 4 == 0 && ((((uintptr_t)qkv) | ((uintptr_t)out)) & 15) == 0;
 }
 
+// the persistent attention needs the plan's work list: packed rows-only decodes planned by k_plan_count / scan / fill (more
+// than 64 sequences), head dim 32, L <= 256, and enough (sequence, head) pairs to be worth a resident grid
+static bool attn_persist_ok(const irs_ctx *ctx, int B) {
+    const int L = ctx->dims.max_len, d = ctx->dims.d, H = ctx->dims.n_heads;
+    return ctx->attn_persist && B > 64 && d % H == 0 && d / H == 32 && L <= 256 && ctx->dims.n_layers <= IRS_MAX_LAYERS && (long long)B * H >= 1024;
+}
+static int g_attn_persist = 1; // (lab switch; the context's attn_persist decides in the product)
 static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const float *r_u, float *out, int B,
                        hipStream_t s, const int32_t *off = nullptr, const int32_t *cnt = nullptr,
-                       const int32_t *tok_row = nullptr, bool frag_out = false) {
+                       const int32_t *tok_row = nullptr, bool frag_out = false, int layer = -1) {
     const int L = ctx->dims.max_len, d = ctx->dims.d, H = ctx->dims.n_heads, hd = d / H;
     const int HDP = hd <= 8 ? 8 : hd <= 16 ? 16 : hd <= 32 ? 32 : 64;
     const int Lp = ((L + 31) / 32) * 32, VW = HDP < 32 ? 32 : HDP;
@@ -4438,16 +4531,31 @@ static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const
         } else if (g_attn16 == 2) { // (lab A/B: the register-staged fill with the transposed V^T image)
             if (tok_row)
                 hipLaunchKernelGGL((k_attn16<16, true, false>), grid, dim3(256), lds16, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
-                                   ctx->seq_padq, frag_out ? 1 : 0);
+                                   ctx->seq_padq, frag_out ? 1 : 0, H);
             else
                 hipLaunchKernelGGL((k_attn16<16, false, false>), grid, dim3(256), lds16, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
-                                   nullptr, frag_out ? 1 : 0);
+                                   nullptr, frag_out ? 1 : 0, H);
+        } else if (tok_row && layer >= 0 && g_attn_persist && attn_persist_ok(ctx, B)) {
+            // resident grid over the plan's work list (k_plan_attn_order ran with this decode's plan)
+            static std::atomic<int> slots_dev[IRS_MAX_DEVICES];
+            const int dev_ = irs_cur_dev();
+            int slots = slots_dev[dev_].load(std::memory_order_acquire);
+            if (!slots) {
+                int ncu = 256;
+                hipDeviceProp_t prop;
+                if (hipGetDeviceProperties(&prop, dev_) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+                slots = 3 * ncu; // three workgroups per CU (53 KB of LDS each)
+                slots_dev[dev_].store(slots, std::memory_order_release);
+            }
+            const int nwg = H * B < slots ? H * B : slots;
+            hipLaunchKernelGGL((k_attn16<16, true, true, 4, true>), dim3(nwg), dim3(256), lds16d, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
+                               ctx->seq_padq, frag_out ? 1 : 0, H, ctx->att_order, ctx->att_tab, layer);
         } else if (tok_row)
             hipLaunchKernelGGL((k_attn16<16, true, true>), grid, dim3(256), lds16d, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
-                               ctx->seq_padq, frag_out ? 1 : 0);
+                               ctx->seq_padq, frag_out ? 1 : 0, H);
         else
             hipLaunchKernelGGL((k_attn16<16, false, true>), grid, dim3(256), lds16d, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
-                               nullptr, frag_out ? 1 : 0);
+                               nullptr, frag_out ? 1 : 0, H);
         irs_prof_end(ctx, IRS_PROF_ATTN, s, 2.0 * B * (double)H * L * L * hd, 4.0 * 4.0 * B * (double)L * d);
         IRS_CHECK_HIP(ctx, hipGetLastError());
         return IRS_OK;
@@ -4621,6 +4729,9 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, s, ctx->seq_cnt, B, ctx->seq_off, ctx->m_dev);
             hipLaunchKernelGGL(k_plan_fill, dim3((B + 3) / 4), dim3(256), 0, s, seq, pos, B, L, ctx->seq_off, ctx->seq_qrow,
                                ctx->tok_row, ctx->seq_padq);
+            if (g_attn_persist && attn_persist_ok(ctx, B))
+                hipLaunchKernelGGL(k_plan_attn_order, dim3(1), dim3(1024), 0, s, ctx->seq_cnt, B, (L + 15) & ~15, ctx->dims.n_heads,
+                                   ctx->att_order, ctx->att_tab);
         }
         off = ctx->seq_off;
         cnt = ctx->seq_cnt;
@@ -4769,7 +4880,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         // the layer (out-projection + LN1/LN2, feed-forward + LN3, the next layer's QKV) with y, h, x' in registers
         const bool fuse_block = frag && (d == 128 || x6d) && F == 256 && attn16_ok(ctx, ctx->act_qkv, yf);
         if (!att_fused &&
-            (rc = launch_attn(ctx, ctx->act_qkv, seq, ctx->act_ru, fuse_block ? yf : ctx->act_ao, B, s, off, cnt, tok, fuse_block)))
+            (rc = launch_attn(ctx, ctx->act_qkv, seq, ctx->act_ru, fuse_block ? yf : ctx->act_ao, B, s, off, cnt, tok, fuse_block,
+                              rows_only && !small_plan ? l : -1)))
             return rc;
         if (frag) {
             const bool last = l + 1 == ctx->dims.n_layers;

@@ -85,6 +85,8 @@ struct irs_ctx {
     uint4 *w_x6;      // split-bf16 step streams of the fused layer kernel k_block_x6 ([n_layers - 1] x 768 KB), or null
     int use_x6;       // decoder GEMMs of the throughput path on split-bf16 MFMAs (IRS_DECODER_GEMM=x6|f32)
     int use_attn_x6;  // head-dim-32 attention of the throughput path on split-bf16 MFMAs (IRS_ATTN_GEMM=x6; default off: slower)
+    int attn_persist; // packed throughput attention as a resident grid over a length-sorted work list (IRS_ATTN_PERSIST=1; default off:
+                      // faster on short sequences only -- 94 vs 116 us at 40 tokens, 352 vs 285 at 110 -- profiles/r04/README.md)
     int lse_no_ring;  // IRS_LSE_RING=0: the register-fragment log-sum-exp kernel at <= 32 rows too (A/B measurements, tests)
     bool finalized;
     bool proj_stale;  // a training entry point ran since irs_finalize_weights: wp / wnorm_max may lag project.*
@@ -100,6 +102,8 @@ struct irs_ctx {
     int32_t *tok_row;  // [max_seqs * L] packed index -> b*L + t
     int32_t *seq_cnt, *seq_off, *seq_qrow; // [max_seqs]
     int32_t *seq_padq; // [max_seqs] index within the packed sequence of the one pad token it may hold (pos), or -1
+    int32_t *att_order; // [max_seqs] sequences sorted by length, longest first: the persistent attention kernel's work order
+    int32_t *att_tab;   // class starts, item count and per-layer work counters of that kernel (decoder.hip: k_plan_attn_order)
     int32_t *m_dev;    // [1] number of packed rows
     // scoring
     uint4 *xb;          // packed bf16 rows [m_pad/32][KS][64] x 16 B

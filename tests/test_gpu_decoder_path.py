@@ -683,3 +683,32 @@ def test_split_bf16_layer_kernel_d256(oracle, B):
     pg, _ = eng.generate_paths(seq.clone(), u, hep.clone(), 3, use_graph=True)[:2]
     ps, _ = eng.generate_paths(seq.clone(), u, hep.clone(), 3, use_graph=False)[:2]
     assert torch.equal(pg, ps)
+
+
+def test_persistent_attention_on_request(monkeypatch):
+    """IRS_ATTN_PERSIST=1 (read when a context is created) runs the packed throughput attention as a resident grid over the
+    plan's length-sorted work list (k_plan_attn_order; short sequences as groups of four heads per workgroup).  Off by
+    default: it measured faster on short sequences only (profiles/r04/README.md).  Same MFMA chains on the same operands:
+    the consumed rows must equal the default kernel's BIT FOR BIT, at d = 128 (4 heads) and d = 256 (8 heads: two groups)."""
+    for over in ({}, {"emb_dim": 256, "n_heads": 8}):
+        cfg = synth.make_config("c2", **over)
+        L, B = cfg.max_len, 300
+        sd = synth.irn_state_dict(cfg, 780)
+        hists = synth.user_histories(B, cfg.n_item, seed=55)
+        rows = synth.eval_rows(hists, cfg.n_item, seed=57)
+        _, seqs, users, targets, _ = synth.collate_eval_irs(rows, L, gap_len=0)
+        seqs[1, :] = 0
+        seqs[1, -1] = targets[1]              # an all-pad window
+        seqs[2, seqs[2] == 0] = 3             # a full window
+        seqs[3, : L - 20] = 0                 # short windows: the four-heads-per-workgroup items
+        seqs[4, : L - 40] = 0
+        seq, u = torch.from_numpy(seqs).cuda(), torch.from_numpy(users).cuda()
+        pos = torch.full((B,), L - 2, dtype=torch.int32, device="cuda")
+        base = make_engine(cfg, sd, max_rows=B, max_seqs=B)
+        ra = base.decode(seq, u, want_x=False, pos=pos)[1].clone()
+        monkeypatch.setenv("IRS_ATTN_PERSIST", "1")
+        eng = make_engine(cfg, sd, max_rows=B, max_seqs=B)
+        monkeypatch.delenv("IRS_ATTN_PERSIST")
+        rb = eng.decode(seq, u, want_x=False, pos=pos)[1]
+        assert torch.equal(torch.isnan(ra), torch.isnan(rb))
+        assert torch.equal(ra.view(torch.int32), rb.view(torch.int32)), over
