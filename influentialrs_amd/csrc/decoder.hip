@@ -1460,15 +1460,21 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
     // step's block in stream order, and the instruction's immediate offset moves the global source AND the LDS destination
     // (tools/dma_probe.hip), so the pieces share one address register pair and one M0: base = the middle piece, offsets
     // -(PPW / 2) .. PPW / 2 - 1 KB (13-bit signed immediates).
-    const uint4 *dma_src = a.Wx + (PPW * wave + PPW / 2) * 64 + lane;
+    // (NW < 4 -- few tokens, a workgroup per 32 or 64 of them so that more CUs take part: the wave's 12 or 24 pieces go out in
+    //  groups of six, one base per group)
+    constexpr int PPG = PPW > 6 ? 6 : PPW, NGRP = PPW / PPG;
+    const uint4 *dma_src = a.Wx + (PPW * wave + PPG / 2) * 64 + lane;
     auto issue = [&](int i) __attribute__((always_inline)) {
         const int blk = i < NPRE ? i : i + qoff;
-        const uint4 *src = dma_src + (size_t)blk * (X6_STEP_B / 16);
-        char *dst = smem + (i % NSLOT) * X6_STEP_B + (PPW * wave + PPW / 2) * 1024;
-        x6_static_for<0, PPW>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int off = (decltype(jc)::value - PPW / 2) * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)dst, 16, off, 0);
+        x6_static_for<0, NGRP>([&](auto gc) __attribute__((always_inline)) {
+            constexpr int grp = decltype(gc)::value;
+            const uint4 *src = dma_src + (size_t)blk * (X6_STEP_B / 16) + grp * PPG * 64;
+            char *dst = smem + (i % NSLOT) * X6_STEP_B + (PPW * wave + grp * PPG + PPG / 2) * 1024;
+            x6_static_for<0, PPG>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int off = (decltype(jc)::value - PPG / 2) * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)dst, 16, off, 0);
+            });
         });
     };
     // accumulators start from the residual x; the attention output tile 0 is requested with it
@@ -4636,6 +4642,9 @@ static void x6_attr_once() { // (the kernels' dynamic LDS exceeds the default 64
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, 4, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds_bytes(8));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<1, 4, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds_bytes(8));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, 4, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds_bytes(8));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, 1, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds_bytes(8));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<1, 1, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds_bytes(8));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, 1, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds_bytes(8));
     });
 }
 
@@ -4706,8 +4715,10 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     // d = 256 (C4's decoder), rows-only decode of a throughput batch: the split-bf16 fused layer kernel at 8 accumulator tiles
     // per token (k_block_x6<.., NT = 8>) with fragment-major activations, like d = 128.  Everything else at d = 256 (full
     // decodes, small batches, IRS_GEMM_F32) keeps the per-GEMM float32 kernels.
-    const bool x6d = d == 256 && F == 256 && ctx->use_x6 && ctx->w_x6 && rows_only && rows >= 32768 && ctx->dims.n_layers > 1 &&
+    static const int x6d_min_rows = [] { const char *e = getenv("IRS_X6D_MIN_ROWS"); return e ? atoi(e) : 32768; }(); // (lab: crossover probe)
+    const bool x6d = d == 256 && F == 256 && ctx->use_x6 && ctx->w_x6 && rows_only && rows >= x6d_min_rows && ctx->dims.n_layers > 1 &&
                      attn16_ok(ctx, ctx->act_qkv, ctx->act_yf);
+    const bool x6d_small = x6d && rows < 32768; // one wave (32 tokens) per workgroup: a few thousand tokens still reach every CU
     const bool frag = (d <= LIN_BN && d % 32 == 0 && rows > 2048 && !small_cfg && !any_cfg) || x6d;
     // one sequence (the reference IRN's own regime, and the latency metric's): self-attention runs inside the layer
     // kernel; q | k | v alternate between two buffers so that the last (rows-only) layer reads ctx->act_qkv
@@ -4750,7 +4761,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             xa.bin = ctx->layer[0].sa_in_b, xa.Xf = xf, xa.QKV = ctx->act_qkv, xa.M = rows, xa.m_dev = m_dev;
             xa.seq = seq, xa.E = ctx->item_emb, xa.pe = ctx->pe, xa.tok_row = tok, xa.L = L, xa.sqrtd = sqrtf((float)d), xa.n_item = ctx->dims.n_item;
             x6_attr_once();
-            if (x6d) hipLaunchKernelGGL((k_block_x6<0, 4, true, 8>), dim3((rows + 127) / 128), dim3(256), x6_lds_bytes(8), s, xa);
+            if (x6d_small) hipLaunchKernelGGL((k_block_x6<0, 1, true, 8>), dim3((rows + 31) / 32), dim3(64), x6_lds_bytes(8), s, xa);
+            else if (x6d) hipLaunchKernelGGL((k_block_x6<0, 4, true, 8>), dim3((rows + 127) / 128), dim3(256), x6_lds_bytes(8), s, xa);
             else
             hipLaunchKernelGGL((k_block_x6<0, X6_NW, true>), dim3((rows + 32 * X6_NW - 1) / (32 * X6_NW)), dim3(64 * X6_NW), X6_LDS_BYTES, s, xa);
         } else
@@ -4906,7 +4918,10 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                                    w.l1_b, w.l2_b, w.n3_w, w.n3_b, ctx->layer[l + 1].sa_in_b, xf, ctx->act_qkv, rows, m_dev, kv_only ? 1 : 0};
                     x6_attr_once();
                     const dim3 x6_grid((rows + 32 * X6_NW - 1) / (32 * X6_NW));
-                    if (x6d) {
+                    if (x6d_small) {
+                        if (kv_only) hipLaunchKernelGGL((k_block_x6<1, 1, false, 8>), dim3((rows + 31) / 32), dim3(64), x6_lds_bytes(8), s, xa);
+                        else hipLaunchKernelGGL((k_block_x6<0, 1, false, 8>), dim3((rows + 31) / 32), dim3(64), x6_lds_bytes(8), s, xa);
+                    } else if (x6d) {
                         if (kv_only) hipLaunchKernelGGL((k_block_x6<1, 4, false, 8>), dim3((rows + 127) / 128), dim3(256), x6_lds_bytes(8), s, xa);
                         else hipLaunchKernelGGL((k_block_x6<0, 4, false, 8>), dim3((rows + 127) / 128), dim3(256), x6_lds_bytes(8), s, xa);
                     } else
