@@ -2695,6 +2695,190 @@ __global__ void __launch_bounds__(64 * SB_NW) k_block_small16(SmallBlockArgs a) 
     STAMP(8);
 }
 
+// ------------------------------------------------------------------ small-batch fused layer tail, wide models (d = 256; round 4)
+// k_block_small16's chain for the width of C4 / C5's decoder: one workgroup of 8 waves owns 16 tokens and runs
+// out-projection + LN1 / LN2, FFN-1, FFN-2 + LN3 and the next layer's q | k | v on v_mfma_f32_16x16x4_f32, the waves
+// splitting the output columns of every GEMM, activation tiles passing through LDS.  At d = 256 a wave's share of the
+// weights is 48 "tile-rounds" (16 output columns x 64 k = 16 registers per lane each) -- far more than the register file
+// holds at once -- so the four GEMMs run as ONE stream of tile-rounds through a ring of LA register sets: tile-round i + LA
+// is requested as soon as tile-round i has been multiplied, across the LayerNorm exchanges and barriers (the weights do
+// not depend on the activations).  C5's beam step decodes 32 windows (~3.5K packed tokens): ~50 per-GEMM launches per
+// step before, 6 now.  Weights: fragment-packed copies (k_pack_frag16), [Wo | W1 | W2] per layer, then the [Win].
+template <int D, bool QKV>
+__global__ void __launch_bounds__(512) k_block_small_wide(SmallBlockArgs a) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    constexpr int F = 256, NWV = 8, LDA = D + 4, LDH = F + 4;
+    constexpr int TO = D / 16 / NWV, TH = F / 16 / NWV, TQ = 3 * D / 16 / NWV; // 16-column tiles per wave: d-wide, F-wide, 3d-wide outputs
+    constexpr int RD = D / 64, RF = F / 64;                                      // 64-k rounds of a K = d / K = F contraction
+    constexpr int N0 = RD * TO, N1 = RD * TH, N2 = RF * TO, N3 = QKV ? RD * TQ : 0, NTR = N0 + N1 + N2 + N3;
+    constexpr int LA = 8; // tile-rounds in flight (128 registers)
+    static_assert(D % 128 == 0 && TO >= 1, "width: a multiple of 128");
+    __shared__ __attribute__((aligned(16))) float bufA[16 * LDA]; // ao -> y -> x'
+    __shared__ __attribute__((aligned(16))) float bufH[16 * LDH]; // h
+    __shared__ float part[2][NWV][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 15, gq = lane >> 4;
+    const int m0 = blockIdx.x * 16, mt = m0 + lq;
+    const float *WfO = a.Wf, *WfH = a.Wf + (size_t)D * D, *Wf2 = a.Wf + (size_t)D * D + (size_t)F * D, *WfQ = a.Wfin;
+    // tile-round i of this wave: (phase, round r, tile t), rounds outermost inside a phase (a round's B fragments serve its tiles)
+    float4 w[LA][4];
+    auto tr_load = [&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < NTR) {
+            constexpr int ph = i < N0 ? 0 : i < N0 + N1 ? 1 : i < N0 + N1 + N2 ? 2 : 3;
+            constexpr int li = i - (ph == 0 ? 0 : ph == 1 ? N0 : ph == 2 ? N0 + N1 : N0 + N1 + N2);
+            constexpr int T = ph == 0 ? TO : ph == 1 ? TH : ph == 2 ? TO : TQ, K = ph == 2 ? F : D;
+            constexpr int r = li / T, t = li % T;
+            const float *W = ph == 0 ? WfO : ph == 1 ? WfH : ph == 2 ? Wf2 : WfQ;
+            const float *wfr = W + ((size_t)((wave * T + t) * (K / 64) + r) * 4) * 256 + lane * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[i % LA][j] = *reinterpret_cast<const float4 *>(wfr + 256 * j);
+        }
+    };
+    // the activation tile and the residual rows first (a wave's loads return in order), then the first LA tile-rounds
+    constexpr int NAO = 16 * (D / 4) / (64 * NWV);
+    float4 aov[NAO];
+#pragma unroll
+    for (int u = 0; u < NAO; ++u) {
+        const int i = tid + u * 64 * NWV, rr = i / (D / 4), c4 = i % (D / 4);
+        aov[u] = *reinterpret_cast<const float4 *>(a.AO + (int64_t)min(m0 + rr, a.M - 1) * D + 4 * c4);
+    }
+    const int xrow = a.xidx ? a.xidx[min(mt, a.M - 1)] : min(mt, a.M - 1);
+    const int nO = wave * 16 * TO; // this wave's first column of a d-wide output
+    float4 res[TO];
+#pragma unroll
+    for (int t = 0; t < TO; ++t) res[t] = *reinterpret_cast<const float4 *>(a.X + (int64_t)xrow * D + nO + 16 * t + 4 * gq);
+    __builtin_amdgcn_sched_barrier(0);
+    x6_static_for<0, LA>(tr_load);
+    __builtin_amdgcn_sched_barrier(0);
+    const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M;
+    if (m0 >= M) return;
+    const bool live = mt < M;
+    auto vec4 = [&](const float *p, int n) { return p ? *reinterpret_cast<const float4 *>(p + n) : make_float4(0.f, 0.f, 0.f, 0.f); };
+#pragma unroll
+    for (int u = 0; u < NAO; ++u) {
+        const int i = tid + u * 64 * NWV, rr = i / (D / 4), c4 = i % (D / 4);
+        *reinterpret_cast<float4 *>(bufA + rr * LDA + 4 * c4) = (m0 + rr < M) ? aov[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    auto row_total = [&](float v, int slot) { // sum over the d columns of this lane's token (8 waves x 4 k-slot lanes)
+        v = lanes_sum<48>(v);
+        if (gq == 0) part[slot][wave][lq] = v;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NWV; ++wv) t += part[slot][wv][lq];
+        return t; // (no second barrier: the two slots strictly alternate, see k_block_small16)
+    };
+    const float invn = 1.0f / (float)D;
+    auto layer_norm = [&](float (&z)[TO][4], const float *g, const float *b, const float *add) {
+        float mu = 0.f;
+#pragma unroll
+        for (int t = 0; t < TO; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mu += z[t][r];
+        mu = row_total(mu, 0) * invn;
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < TO; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q += (z[t][r] - mu) * (z[t][r] - mu);
+        const float rstd = 1.0f / sqrtf(row_total(q, 1) * invn + 1e-5f);
+#pragma unroll
+        for (int t = 0; t < TO; ++t) {
+            const float4 gg = vec4(g, nO + 16 * t + 4 * gq), bb = vec4(b, nO + 16 * t + 4 * gq), ad = vec4(add, nO + 16 * t + 4 * gq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[t][r] = (z[t][r] - mu) * rstd * (&gg.x)[r] + (&bb.x)[r] + (&ad.x)[r];
+        }
+    };
+    auto to_lds = [&](const float (&z)[TO][4], float *buf, int ld) {
+#pragma unroll
+        for (int t = 0; t < TO; ++t)
+            *reinterpret_cast<float4 *>(buf + lq * ld + nO + 16 * t + 4 * gq) = make_float4(z[t][0], z[t][1], z[t][2], z[t][3]);
+    };
+    // one phase: acc[t] += W-tile-rounds . B rounds; tile-round indices I0 .. I0 + R T - 1
+    f32x4 accO[TO], accH[TH], accQ[QKV ? TQ : 1];
+    auto run_phase = [&](auto i0c, auto rc, auto tc, auto &acc, const float *B, int ldb) __attribute__((always_inline)) {
+        constexpr int I0 = decltype(i0c)::value, R = decltype(rc)::value, T = decltype(tc)::value;
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+        x6_static_for<0, R>([&](auto rr) __attribute__((always_inline)) {
+            constexpr int r = decltype(rr)::value;
+            float4 bf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const float4 *>(B + lq * ldb + 4 * gq + 64 * r + 16 * j);
+            x6_static_for<0, T>([&](auto tt) __attribute__((always_inline)) {
+                constexpr int t = decltype(tt)::value, i = I0 + r * T + t;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i % LA][j].x, bf[j].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i % LA][j].y, bf[j].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i % LA][j].z, bf[j].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i % LA][j].w, bf[j].w, acc[t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                tr_load(std::integral_constant<int, i + LA>{}); // the set just multiplied is free again
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    };
+    using IC = std::integral_constant<int, 0>;
+    float z[TO][4];
+    // ---- y = LN2(LN1(x + ao W_o^T + b_o) + c)
+    run_phase(IC{}, std::integral_constant<int, RD>{}, std::integral_constant<int, TO>{}, accO, bufA, LDA);
+#pragma unroll
+    for (int t = 0; t < TO; ++t) {
+        const float4 bo = vec4(a.bo, nO + 16 * t + 4 * gq);
+        const float4 rs = live ? res[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+        z[t][0] = accO[t][0] + bo.x + rs.x, z[t][1] = accO[t][1] + bo.y + rs.y, z[t][2] = accO[t][2] + bo.z + rs.z, z[t][3] = accO[t][3] + bo.w + rs.w;
+    }
+    layer_norm(z, a.g1, a.b1n, a.c);
+    if (a.c) layer_norm(z, a.g2, a.b2n, nullptr);
+    to_lds(z, bufA, LDA); // (every wave is past its last read of the ao tile: row_total's barriers)
+    __syncthreads();
+    // ---- h = relu(y W1^T + b1)
+    run_phase(std::integral_constant<int, N0>{}, std::integral_constant<int, RD>{}, std::integral_constant<int, TH>{}, accH, bufA, LDA);
+#pragma unroll
+    for (int t = 0; t < TH; ++t) {
+        const int n = wave * 16 * TH + 16 * t + 4 * gq;
+        const float4 b1 = vec4(a.b1, n);
+        *reinterpret_cast<float4 *>(bufH + lq * LDH + n) = make_float4(fmaxf(accH[t][0] + b1.x, 0.f), fmaxf(accH[t][1] + b1.y, 0.f),
+                                                                       fmaxf(accH[t][2] + b1.z, 0.f), fmaxf(accH[t][3] + b1.w, 0.f));
+    }
+    __syncthreads();
+    // ---- x' = LN3(y + h W2^T + b2)
+    run_phase(std::integral_constant<int, N0 + N1>{}, std::integral_constant<int, RF>{}, std::integral_constant<int, TO>{}, accO, bufH, LDH);
+#pragma unroll
+    for (int t = 0; t < TO; ++t) {
+        const float4 b2 = vec4(a.b2, nO + 16 * t + 4 * gq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[t][r] = accO[t][r] + (&b2.x)[r] + z[t][r];
+    }
+    layer_norm(z, a.g3, a.b3n, nullptr);
+    if (live) {
+#pragma unroll
+        for (int t = 0; t < TO; ++t)
+            *reinterpret_cast<float4 *>(a.Xo + (int64_t)mt * D + nO + 16 * t + 4 * gq) = make_float4(z[t][0], z[t][1], z[t][2], z[t][3]);
+    }
+    if constexpr (QKV) {
+        // ---- qkv' = x' W_in^T + b_in
+        to_lds(z, bufA, LDA); // (LN3's barriers: every wave is past FFN-1's reads of the y tile)
+        __syncthreads();
+        run_phase(std::integral_constant<int, N0 + N1 + N2>{}, std::integral_constant<int, RD>{}, std::integral_constant<int, TQ>{}, accQ, bufA, LDA);
+        if (live) {
+#pragma unroll
+            for (int t = 0; t < TQ; ++t) {
+                const int n = wave * 16 * TQ + 16 * t + 4 * gq;
+                const float4 bi = vec4(a.bin, n);
+                *reinterpret_cast<float4 *>(a.QKV + (int64_t)mt * (3 * D) + n) =
+                    make_float4(accQ[t][0] + bi.x, accQ[t][1] + bi.y, accQ[t][2] + bi.z, accQ[t][3] + bi.w);
+            }
+        }
+    }
+}
+static inline size_t small_wide_layer_floats(int d, int F) { return (size_t)d * d + 2 * (size_t)F * d; } // Wo | W1 | W2
+static inline bool small_wide_shape(int d, int F) { return d == 256 && F == 256; }
+
 // arguments of the embedding + layer-0 in-projection kernels of the latency paths
 struct SmallEmbedArgs {
     const int64_t *seq;
@@ -4651,6 +4835,7 @@ static void x6_attr_once() { // (the kernels' dynamic LDS exceeds the default 64
 size_t irs_small_frag_floats(const irs_ctx *ctx) {
     const int d = ctx->dims.d, F = ctx->dims.ffn_dim;
     if (small_any_shape(d, F)) return (size_t)ctx->dims.n_layers * small_any_layer_floats(d, F);
+    if (small_wide_shape(d, F)) return (size_t)ctx->dims.n_layers * (small_wide_layer_floats(d, F) + (size_t)3 * d * d);
     if (d != 128 || F != 256) return 0;
     return (size_t)ctx->dims.n_layers * (SMALL_WF_LAYER + SMALL_WF_WIN);
 }
@@ -4670,6 +4855,23 @@ int irs_launch_pack_small(irs_ctx *ctx, hipStream_t s) {
             pk(w.l1_w, o + (size_t)dp * dp, F, d, Fp, dp);
             pk(w.l2_w, o + (size_t)dp * dp + (size_t)Fp * dp, d, F, dp, Fp);
             pk(w.sa_in_w, o + small_any_win_off(d, F), 3 * d, d, Qp, dp);
+        }
+        IRS_CHECK_HIP(ctx, hipGetLastError());
+        return IRS_OK;
+    }
+    if (small_wide_shape(ctx->dims.d, ctx->dims.ffn_dim)) { // [n_layers][Wo | W1 | W2], then [n_layers][Win]
+        const int d = ctx->dims.d, F = ctx->dims.ffn_dim;
+        const size_t lf = small_wide_layer_floats(d, F);
+        auto pk = [&](const float *W, float *out, int N, int K) {
+            hipLaunchKernelGGL(k_pack_frag16, dim3((N * K / 4 + 255) / 256), dim3(256), 0, s, W, out, N, K);
+        };
+        for (int l = 0; l < nl; ++l) {
+            const irs_layer_w &w = ctx->layer[l];
+            float *o = ctx->w_frag16 + (size_t)l * lf;
+            pk(w.sa_out_w, o, d, d);
+            pk(w.l1_w, o + (size_t)d * d, F, d);
+            pk(w.l2_w, o + (size_t)d * d + (size_t)F * d, d, F);
+            pk(w.sa_in_w, ctx->w_frag16 + (size_t)nl * lf + (size_t)l * 3 * d * d, 3 * d, d);
         }
         IRS_CHECK_HIP(ctx, hipGetLastError());
         return IRS_OK;
@@ -4718,7 +4920,11 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     static const int x6d_min_rows = [] { const char *e = getenv("IRS_X6D_MIN_ROWS"); return e ? atoi(e) : 32768; }(); // (lab: crossover probe)
     const bool x6d = d == 256 && F == 256 && ctx->use_x6 && ctx->w_x6 && rows_only && rows >= x6d_min_rows && ctx->dims.n_layers > 1 &&
                      attn16_ok(ctx, ctx->act_qkv, ctx->act_yf);
-    const bool x6d_small = x6d && rows < 32768; // one wave (32 tokens) per workgroup: a few thousand tokens still reach every CU
+    const bool x6d_small = x6d && rows < 32768;
+    // d = 256 below the throughput regime (C5's 32 beam windows, single users): the 16-token fused layer kernel for wide
+    // models (k_block_small_wide) instead of ~8 per-GEMM launches per layer
+    const bool wide_cfg = small_wide_shape(d, F) && ctx->w_frag16 && !x6d && rows < 32768;
+    const size_t wide_lf = small_wide_layer_floats(d, F); // one wave (32 tokens) per workgroup: a few thousand tokens still reach every CU
     const bool frag = (d <= LIN_BN && d % 32 == 0 && rows > 2048 && !small_cfg && !any_cfg) || x6d;
     // one sequence (the reference IRN's own regime, and the latency metric's): self-attention runs inside the layer
     // kernel; q | k | v alternate between two buffers so that the last (rows-only) layer reads ctx->act_qkv
@@ -4851,7 +5057,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             irs_prof_end(ctx, IRS_PROF_ATTN, s, 4.0 * B * (double)L * d, 4.0 * 3.0 * B * (double)L * d);
             const bool fused_tail = d == 128 && F == 256;
             const bool any_tail = small_any_shape(d, F) && ctx->w_frag16 && !frag && B <= 2048;
-            const bool idx_res = (fused_tail || any_tail) && !frag; // the layer kernel reads the residual rows x[qrow[b]] itself
+            const bool wide_tail = small_wide_shape(d, F) && ctx->w_frag16 && !frag && !q_split;
+            const bool idx_res = (fused_tail || any_tail || wide_tail) && !frag; // the layer kernel reads the residual rows x[qrow[b]] itself
             if (frag && !q_split) hipLaunchKernelGGL(k_gather_rows_frag, dim3(B), dim3(64), 0, s, xf, qrow, x_r, d, d > 128 ? d / 32 : 4);
             else if (!frag && !idx_res) hipLaunchKernelGGL(k_gather_rows_idx, dim3(B), dim3(64), 0, s, x, qrow, x_r, d);
             if (fused_tail) { // one launch for the rest of the layer on the B consumed rows
@@ -4861,6 +5068,13 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                 irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
                 if (B > 2048) hipLaunchKernelGGL((k_block_small16<false, 2>), dim3((B + 31) / 32), dim3(64 * SB_NW), 0, s, sb);
                 else hipLaunchKernelGGL((k_block_small16<false, 1>), dim3((B + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
+                irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * B * ((double)d * d + 2.0 * d * F), 4.0 * 3.0 * B * (double)d);
+            } else if (wide_tail) { // the same for d = 256
+                SmallBlockArgs sb{ao_r, x, w.sa_out_w, w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, w.l1_w, w.l1_b, w.l2_w, w.l2_b,
+                                  w.n3_w, w.n3_b, xrows, nullptr, nullptr, nullptr, B, nullptr, qrow,
+                                  ctx->w_frag16 + (size_t)l * wide_lf, nullptr};
+                irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
+                hipLaunchKernelGGL((k_block_small_wide<256, false>), dim3((B + 15) / 16), dim3(512), 0, s, sb);
                 irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * B * ((double)d * d + 2.0 * d * F), 4.0 * 3.0 * B * (double)d);
             } else if (any_tail) {
                 SmallBlockArgs sb{ao_r, x, w.sa_out_w, w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, w.l1_w, w.l1_b, w.l2_w, w.l2_b,
@@ -4982,6 +5196,22 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                 if (sb.Win) hipLaunchKernelGGL((k_block_small16<true, 1>), dim3((rows + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
                 else hipLaunchKernelGGL((k_block_small16<false, 1>), dim3((rows + 15) / 16), dim3(64 * SB_NW), 0, s, sb);
             }
+            irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * rows * ((double)d * d + 2.0 * d * F + (last ? 0.0 : 3.0 * d * d)),
+                         4.0 * (3.0 + (last ? 0.0 : 3.0)) * rows * (double)d);
+            qkv_done = !last;
+            float *tswap = x; // the new x lives in the other buffer
+            x = y;
+            y = tswap;
+        } else if (wide_cfg) {
+            // d = 256, small batches: the rest of the layer (and the next layer's QKV) in one launch per 16 tokens; x -> y buffer
+            const bool last = l + 1 == ctx->dims.n_layers;
+            SmallBlockArgs sb{ctx->act_ao, x, w.sa_out_w, w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b, w.l1_w, w.l1_b, w.l2_w, w.l2_b,
+                              w.n3_w, w.n3_b, y, last ? nullptr : ctx->layer[l + 1].sa_in_w, last ? nullptr : ctx->layer[l + 1].sa_in_b,
+                              ctx->act_qkv, rows, m_dev, nullptr, ctx->w_frag16 + (size_t)l * wide_lf,
+                              last ? nullptr : ctx->w_frag16 + (size_t)ctx->dims.n_layers * wide_lf + (size_t)(l + 1) * 3 * d * d};
+            irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
+            if (last) hipLaunchKernelGGL((k_block_small_wide<256, false>), dim3((rows + 15) / 16), dim3(512), 0, s, sb);
+            else hipLaunchKernelGGL((k_block_small_wide<256, true>), dim3((rows + 15) / 16), dim3(512), 0, s, sb);
             irs_prof_end(ctx, IRS_PROF_LINEAR, s, 2.0 * rows * ((double)d * d + 2.0 * d * F + (last ? 0.0 : 3.0 * d * d)),
                          4.0 * (3.0 + (last ? 0.0 : 3.0)) * rows * (double)d);
             qkv_done = !last;
