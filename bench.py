@@ -691,15 +691,13 @@ def main():
         head_ok, head_how = verify_headline(job)
     except Exception as e:  # noqa: BLE001 -- reported, never hidden: verified stays false
         head_ok, head_how = False, {"error": f"{type(e).__name__}: {e}"}
-    if world > 1:
-        hv = torch.tensor([1 if head_ok else 0], dtype=torch.int32, device=device)
-        if dist.get_backend() == "gloo":
-            hc = hv.cpu()
-            dist.all_reduce(hc, op=dist.ReduceOp.MIN)
-            head_ok = bool(hc.item())
-        else:
-            dist.all_reduce(hv, op=dist.ReduceOp.MIN)
-            head_ok = bool(hv.item())
+    if world > 1:  # the flag is the AND over ranks; a failing rank's own findings travel with it
+        box = [None] * world
+        dist.all_gather_object(box, (bool(head_ok), head_how))
+        head_ok = all(ok_ for ok_, _ in box)
+        bad = {str(r_): how_ for r_, (ok_, how_) in enumerate(box) if not ok_}
+        if bad:
+            head_how = dict(head_how, failed_ranks=bad)
     layer = fam.pop("layer")
     x6 = job.eng.decoder_gemm == IRS_GEMM_X6
 
