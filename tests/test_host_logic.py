@@ -142,3 +142,21 @@ def test_cpu_training_trunk_reproduces_the_reference_run(golden):
     assert np.allclose(tr, g["irn_train"], rtol=1e-5, atol=0), (tr, g["irn_train"])
     assert np.abs(net.project.bias.detach().numpy() - g["irn_bias_after"]).max() < 1e-4
     assert net.user_embedder.weight.grad is None  # the reference passes r_u through float(): no gradient
+
+
+def test_bench_windows_are_zipf_without_repeats():
+    """bench.py's synthetic windows: pre-padded, target last and absent from the window, history items
+    drawn Zipf(1) over the catalog WITHOUT repeats per user, history lengths clipped to the window."""
+    import torch
+    import bench
+    L, N, B = 50, 3415, 256
+    s = bench.gpu_windows(B, L, N, torch.device("cpu"), seed=5).numpy()
+    assert s.shape == (B, L) and s.min() >= 0 and s.max() <= N
+    assert (s[:, -1] > 0).all()
+    for r in s:
+        v = r[r > 0]
+        assert len(set(v.tolist())) == len(v), "an item repeats inside a window"
+        nz = np.nonzero(r)[0]
+        assert nz[0] == L - len(v), "pads must sit in front (pre-padded window)"
+    counts = np.bincount(s[:, :-1].ravel(), minlength=N + 1)[1:]
+    assert counts[:10].sum() > 20 * max(counts[1000:1010].sum(), 1) / 10, "head items must dominate (Zipf)"
