@@ -625,7 +625,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from influentialrs_amd._lib import (IRS_GEMM_X6, IRS_PROF_ATTN, IRS_PROF_LAYER, IRS_PROF_LINEAR, IRS_PROF_NONE, IRS_PROF_REFINE,
+    from influentialrs_amd._lib import (IRS_GEMM_H3, IRS_GEMM_X6, IRS_PROF_ATTN, IRS_PROF_LAYER, IRS_PROF_LINEAR, IRS_PROF_NONE, IRS_PROF_REFINE,
                                         IRS_PROF_SWEEP, IRS_SWEEP_BF16)
     device = torch.device("cuda", 0 if args.same_device else local_rank)
     torch.cuda.set_device(device)
@@ -699,7 +699,9 @@ def main():
         if bad:
             head_how = dict(head_how, failed_ranks=bad)
     layer = fam.pop("layer")
-    x6 = job.eng.decoder_gemm == IRS_GEMM_X6
+    gemm_mode = job.eng.decoder_gemm
+    x6 = gemm_mode in (IRS_GEMM_X6, IRS_GEMM_H3)  # a split-precision mode of the fused layer kernel
+    nprod = 3.0 if gemm_mode == IRS_GEMM_H3 else 6.0  # matrix instructions' products per float32 product
 
     roof = None
     if rank == 0:
@@ -721,20 +723,23 @@ def main():
         if dom == "linear" and layer["launches"] > 0:
             # the family's dominant KERNEL: the fused layer kernel (5 of the 8 launches of a C2 step, ~80 % of the
             # family's time).  Flops are the algorithmic ones (2 per float32 multiply-add of the dense shapes, x the packed
-            # row fraction).  IRS_GEMM_X6 executes SIX bf16 MFMA products per float32 product, so the peak that bounds it
-            # is the dense bf16 peak / 6; IRS_GEMM_F32 is bounded by the float32-MFMA peak.
+            # row fraction).  IRS_GEMM_X6 executes SIX bf16 MFMA products per float32 product, IRS_GEMM_H3 THREE float16 ones
+            # (the same instruction rate), so the peak that bounds the kernel is the dense 16-bit MFMA peak / 6 resp. / 3;
+            # IRS_GEMM_F32 is bounded by the float32-MFMA peak.
             layer["ms_instrumented"] = layer["ms"]
             layer["ms"] = layer["ms"] * fscale
             f = layer
             per_launch_ms = f["ms"] / max(f["launches"], 1)
             ach = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
-            peak = PEAK_BF16_TFLOPS / 6.0 if x6 else PEAK_F32_MATRIX_TFLOPS
-            roof = {"kernel": ("k_block_x6 (fused decoder layer: out-projection, layer norms, feed-forward, next q|k|v; split-bf16 "
-                               "MFMA, 6 bf16 products per float32 product)" if x6 else
+            peak = PEAK_BF16_TFLOPS / nprod if x6 else PEAK_F32_MATRIX_TFLOPS
+            roof = {"kernel": ("k_block_x6 (fused decoder layer: out-projection, layer norms, feed-forward, next q|k|v; "
+                               + ("split-float16 MFMA, 3 f16 products per float32 product)" if gemm_mode == IRS_GEMM_H3 else
+                                  "split-bf16 MFMA, 6 bf16 products per float32 product)") if x6 else
                                "k_block (fused decoder layer: out-projection, layer norms, feed-forward, next q|k|v; float32 MFMA)"),
                     "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                    "peak_basis": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 products" if x6 else "float32 MFMA dense peak"),
-                    "executed_mfma_tflops": ach * (6.0 if x6 else 1.0)}
+                    "peak_basis": ("dense 16-bit MFMA peak 2500 TFLOP/s / %d products" % int(nprod) if x6 else "float32 MFMA dense peak"),
+                    "executed_mfma_tflops": ach * (nprod if x6 else 1.0),
+                    "float32_equivalent_vs_f32_matrix_peak": ach / PEAK_F32_MATRIX_TFLOPS}
         elif dom in ("linear", "attn"):
             ach = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
             roof = {"kernel": {"linear": "k_block + k_linear (decoder fp32 MFMA GEMM family: fused layer kernel, layer-0 QKV)",
@@ -824,8 +829,10 @@ def main():
                           "(packed rows), results identical",
                "packed_row_fraction": fam["linear"]["packed_fraction"],
                "sweep": args.sweep + (" filter + exact f32 re-score" if args.sweep == "bf16" else ""),
-               "decoder_gemm": ("x6: float32 operands split exactly into three bf16 planes, six plane products per float32 product on "
-                                "v_mfma_f32_32x32x16_bf16, float32 accumulation (fused layer kernel and embed + layer-0 q|k|v); attention "
+               "decoder_gemm": (("h3: float32 operands split into two float16 planes (22 of 24 significand bits), three plane products per "
+                                 "float32 product on v_mfma_f32_32x32x16_f16" if gemm_mode == IRS_GEMM_H3 else
+                                 "x6: float32 operands split exactly into three bf16 planes, six plane products per float32 product on "
+                                 "v_mfma_f32_32x32x16_bf16") + ", float32 accumulation (fused layer kernel and embed + layer-0 q|k|v); attention "
                                 "and the last layer's rows on float32 MFMAs" if x6 else "float32 MFMAs"),
                "parallelism": "single GPU" if world == 1 else (
                    f"rows data-parallel + item-sharded x{world}: RCCL all-gather of rows, one all_to_all of packed 64-bit top-100 keys "

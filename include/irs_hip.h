@@ -365,18 +365,23 @@ int irs_sharded_graph_state(const irs_ctx *ctx);
 
 /* ---- decoder GEMM arithmetic -------------------------------------------
  * The throughput path's fused layer kernel (d = 128, ffn = 256: out-projection, both layer norms, feed-forward, the
- * next layer's q | k | v) multiplies in one of two ways; both accumulate in float32 and agree to ~1e-6 relative on the
+ * next layer's q | k | v) multiplies in one of three ways; all accumulate in float32 and agree to ~1e-6 relative on the
  * decoder rows (tests/test_gpu_decoder_path.py holds the bound):
- *   IRS_GEMM_X6  (default) every float32 operand is split exactly into three bf16 planes (h + m + l) and the six
+ *   IRS_GEMM_H3  (default since round 4) two float16 planes per operand, three products: see the constant below;
+ *   IRS_GEMM_X6  every float32 operand is split exactly into three bf16 planes (h + m + l) and the six
  *                leading products hh, hm, mh, hl, lh, mm are summed on v_mfma_f32_32x32x16_bf16: float32-grade products
  *                at 6/16 of the float32-MFMA instruction time;
  *   IRS_GEMM_F32 v_mfma_f32_32x32x2f32.
- * The initial mode is IRS_GEMM_X6 unless the environment holds IRS_DECODER_GEMM=f32 when the context is created.
+ * The initial mode is IRS_GEMM_H3 unless the environment holds IRS_DECODER_GEMM=x6 or =f32 when the context is created.
  * Changing the mode drops the context's captured steps (they are re-captured on the next graph call).
  * (IRS_ATTN_GEMM=x6 in the environment at creation additionally moves the head-dim-32 attention of the throughput
  * path to split-bf16 MFMAs; it measured slower than the float32-MFMA attention and is off by default.) */
 #define IRS_GEMM_F32 0
 #define IRS_GEMM_X6 1
+/* IRS_GEMM_H3 (round 4): two FLOAT16 planes per float32 operand (h = f16(x), l = f16(x - h): 22 significand bits) and the three
+ * leading products hh, hl, lh on v_mfma_f32_32x32x16_f16 -- half the matrix instructions of IRS_GEMM_X6, what is dropped is
+ * 2^-22 relative (the class of the float32 accumulation's own rounding).  Needs |weights|, |activations| < 65504 (float16). */
+#define IRS_GEMM_H3 2
 int irs_set_decoder_gemm(irs_ctx *ctx, int32_t mode);
 int irs_get_decoder_gemm(const irs_ctx *ctx);
 

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "libirs_hip.so")
 IRS_MASK_IRN, IRS_MASK_CAUSAL = 0, 1
 IRS_SWEEP_BF16, IRS_SWEEP_F32, IRS_SWEEP_EXHAUSTIVE = 0, 1, 2
 IRS_ROW_FALLBACK, IRS_ROW_NO_CANDIDATE, IRS_ROW_FEWER_THAN_K = 1, 2, 4
-IRS_GEMM_F32, IRS_GEMM_X6 = 0, 1
+IRS_GEMM_F32, IRS_GEMM_X6, IRS_GEMM_H3 = 0, 1, 2
 IRS_PROF_NONE, IRS_PROF_LINEAR, IRS_PROF_ATTN, IRS_PROF_SWEEP, IRS_PROF_REFINE, IRS_PROF_SWEEP_EMIT, IRS_PROF_LAYER = 0, 1, 2, 3, 4, 5, 6
 
 

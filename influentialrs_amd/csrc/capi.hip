@@ -71,7 +71,7 @@ extern "C" int irs_create(irs_ctx **out, const irs_dims *dims, const irs_shard *
     {   // decoder GEMMs of the throughput path: split-bf16 MFMAs (k_block_x6, the default) or float32 MFMAs (k_block);
         // the environment variable sets the initial mode, irs_set_decoder_gemm() changes it on a live context
         const char *e = getenv("IRS_DECODER_GEMM");
-        c->use_x6 = e ? (strcmp(e, "f32") != 0) : 1;
+        c->use_x6 = e ? (strcmp(e, "f32") == 0 ? IRS_GEMM_F32 : strcmp(e, "x6") == 0 ? IRS_GEMM_X6 : IRS_GEMM_H3) : IRS_GEMM_H3;
         const char *ea = getenv("IRS_ATTN_GEMM");
         c->use_attn_x6 = ea ? (strcmp(ea, "x6") == 0) : 0;
         const char *ep = getenv("IRS_ATTN_PERSIST");
@@ -404,7 +404,8 @@ static void drop_graphs(irs_ctx *ctx) { // captured steps hold kernel choices an
 
 extern "C" int irs_set_decoder_gemm(irs_ctx *ctx, int32_t mode) {
     if (!ctx) return IRS_E_INVALID;
-    if (mode != IRS_GEMM_F32 && mode != IRS_GEMM_X6) IRS_FAIL(ctx, IRS_E_INVALID, "decoder GEMM mode %d (IRS_GEMM_F32 or IRS_GEMM_X6)", mode);
+    if (mode != IRS_GEMM_F32 && mode != IRS_GEMM_X6 && mode != IRS_GEMM_H3)
+        IRS_FAIL(ctx, IRS_E_INVALID, "decoder GEMM mode %d (IRS_GEMM_F32, IRS_GEMM_X6 or IRS_GEMM_H3)", mode);
     if (ctx->use_x6 != mode) {
         ctx->use_x6 = mode;
         drop_graphs(ctx);

@@ -1256,26 +1256,35 @@ typedef __attribute__((ext_vector_type(4))) unsigned int x6_u32x4;
 // per hidden tile HT FFN-1 steps, then HT FFN-2 steps) + 3 NT HT (q | k | v): 32 at NT = 4, 96 at NT = 8.
 __host__ __device__ constexpr int x6_npre(int NT) { return NT * (NT / 4) + 16 * (NT / 4); } // steps in front of the q | k | v region
 __host__ __device__ constexpr int x6_nstep(int NT) { return x6_npre(NT) + 3 * NT * (NT / 4); }
-__host__ __device__ constexpr size_t x6_layer_bytes(int NT) { return (size_t)x6_nstep(NT) * X6_STEP_B; }
-__host__ __device__ constexpr int x6_lds_bytes(int NT) { return 3 * X6_STEP_B + (256 + 12 * 32 * NT) * 4; }
+// NPL = planes per float32 operand.  3 (round 3): bf16 planes h + m + l = the value exactly, six plane products per float32
+// product.  2 (round 4, "h3"): FLOAT16 planes h = f16(x), l = f16(x - h) -- 22 of the 24 significand bits (f16 carries 11),
+// three plane products (hh, hl, lh; what is dropped is 2^-22 relative: the float32 accumulation's own rounding class) on
+// v_mfma_f32_32x32x16_f16, same shapes and lane maps: HALF the matrix instructions, 2/3 of the weight stream, a cheaper split
+// (v_cvt_pk_f16_f32: 3 vector instructions per value instead of 5.5).  Float16's range is the price: |operand| < 65504 (weights
+// are O(0.1), activations behind a LayerNorm O(10), embedded tokens |E| sqrt(d) + 1); tiny values fall into f16 subnormals,
+// whose ABSOLUTE spacing 2^-24 is what matters for a sum of products.  A step is 8 groups x NPL planes = 8 NPL KB.
+__host__ __device__ constexpr int x6_step_b(int NPL) { return 8 * NPL * 1024; }
+__host__ __device__ constexpr size_t x6_layer_bytes(int NT, int NPL = 3) { return (size_t)x6_nstep(NT) * x6_step_b(NPL); }
+__host__ __device__ constexpr int x6_lds_bytes(int NT, int NPL = 3) { return 3 * x6_step_b(NPL) + (256 + 12 * 32 * NT) * 4; }
+typedef __attribute__((ext_vector_type(8))) _Float16 x6_f16x8;
 #ifndef X6_NW
 #define X6_NW 4 // waves per workgroup of k_block_x6 (tools/x6_lab measures both)
 #endif
 
 // one layer's weights -> the kernel's step stream.  Thread = one 16-byte fragment piece (8 bf16 of one lane).
-template <int NT = 4>
+template <int NT = 4, int NPL = 3>
 __global__ void __launch_bounds__(256) k_pack_x6(const float *__restrict__ Wo, const float *__restrict__ W1,
                                                  const float *__restrict__ W2, const float *__restrict__ Win,
                                                  uint4 *__restrict__ out) {
-    constexpr int D = 32 * NT, HT = NT / 4, NPRE = x6_npre(NT), NOUT = NT * HT;
-    const int gid = blockIdx.x * 256 + threadIdx.x; // < steps * 24 pieces * 64 lanes
-    if (gid >= x6_nstep(NT) * 24 * 64) return;
-    const int lane = gid & 63, piece = (gid >> 6) % 24, step = gid / (24 * 64);
+    constexpr int D = 32 * NT, HT = NT / 4, NPRE = x6_npre(NT), NOUT = NT * HT, NP = 8 * NPL;
+    const int gid = blockIdx.x * 256 + threadIdx.x; // < steps * NP pieces * 64 lanes
+    if (gid >= x6_nstep(NT) * NP * 64) return;
+    const int lane = gid & 63, piece = (gid >> 6) % NP, step = gid / (NP * 64);
     // piece = 3 g + plane in the kernel's consumption order.  "Four-tile" steps (out-projection, FFN-2): group g =
     // (k-step s = g >> 2, output tile nt = g & 3) of one 32-wide k tile and one output half oh (tiles 4 oh .. 4 oh + 3);
     // "one-tile" steps (FFN-1, QKV): ONE output tile over 128 of the K = d columns (k half kh), group g = (k tile 4 kh +
     // (g >> 1), k-step s = g & 1).
-    const int p = piece % 3, g = piece / 3;
+    const int p = piece % NPL, g = piece / NPL;
     const int r = lane & 31, hh = lane >> 5;
     const float *W;
     int ld, n, kb, s;
@@ -1296,12 +1305,18 @@ __global__ void __launch_bounds__(256) k_pack_x6(const float *__restrict__ Wo, c
         const int k = kb + 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
         float v = W ? W[(size_t)n * ld + k] : 0.f;
         unsigned int bits = 0;
+        if constexpr (NPL == 3) {
 #pragma unroll
-        for (int q = 0; q <= p; ++q) { // plane q = bf16(v - the planes before it), round to nearest even
-            unsigned int u = __float_as_uint(v);
-            u += 0x7FFFu + ((u >> 16) & 1u);
-            bits = u >> 16;
-            v -= __uint_as_float(bits << 16);
+            for (int q = 0; q <= p; ++q) { // plane q = bf16(v - the planes before it), round to nearest even
+                unsigned int u = __float_as_uint(v);
+                u += 0x7FFFu + ((u >> 16) & 1u);
+                bits = u >> 16;
+                v -= __uint_as_float(bits << 16);
+            }
+        } else { // float16 planes: h = f16(v), l = f16(v - h), round to nearest even (the conversion instruction's mode)
+            _Float16 hv = (_Float16)v;
+            if (p == 1) hv = (_Float16)(v - (float)hv);
+            bits = (unsigned int)__builtin_bit_cast(unsigned short, hv);
         }
         hw[j] = bits;
     }
@@ -1333,6 +1348,21 @@ struct BlockX6Args {
 };
 
 // float32 accumulator tile -> the three bf16 planes of its k-step s (registers 8s .. 8s+7) as B fragments
+__device__ __forceinline__ void x6_split(const f32x16 &t, int s, x6_f16x8 (&X)[2]) { // float16 planes (NPL = 2)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = t[8 * s + j];
+        const _Float16 h = (_Float16)v;
+        X[0][j] = h;
+        X[1][j] = (_Float16)(v - (float)h);
+    }
+}
+__device__ __forceinline__ f32x16 x6_mma(const x6_bf16x8 &w, const x6_bf16x8 &x, const f32x16 &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 x6_mma(const x6_f16x8 &w, const x6_f16x8 &x, const f32x16 &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, c, 0, 0, 0);
+}
 __device__ __forceinline__ void x6_split(const f32x16 &t, int s, x6_bf16x8 (&X)[3]) {
 #ifdef X6_NO_SPLIT
 #pragma unroll
@@ -1391,15 +1421,17 @@ __device__ __forceinline__ x6_u32x4 x6_rd_sync(unsigned int base) {
 // blocks are unused) run: the same ring, the same step code.
 // NT = 8 (d = 256, round 4): 8 accumulator tiles per token -- 128 registers of accumulators, 192 of cached planes -- so ONE
 // wave per SIMD (512 registers per lane), one workgroup per CU; the step stream has 96 steps (x6_nstep).
-template <int QP0, int NW, bool EMBED, int NT = 4>
+template <int QP0, int NW, bool EMBED, int NT = 4, int NPL = 3>
 __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Args a) {
-    constexpr int D = 32 * NT, F = 256, NSLOT = 3, PPW = 24 / NW, HT = NT / 4;
+    constexpr int NP = 8 * NPL, STEP_B = x6_step_b(NPL); // pieces (fragments) and bytes of a step
+    using x6_plane = typename std::conditional<NPL == 2, x6_f16x8, x6_bf16x8>::type;
+    constexpr int D = 32 * NT, F = 256, NSLOT = 3, PPW = NP / NW, HT = NT / 4;
     constexpr int NPRE = x6_npre(NT), NOUT = NT * HT;
     constexpr int S0 = EMBED ? NPRE : 0; // first step of the sequence
     constexpr int V_B1 = 0, V_B2 = F, V_G = F + D, V_B = F + 2 * D, V_BIN = F + 3 * D, V_O = F + 3 * D + 3 * D;
     static_assert(NT == 4 || NT == 8, "d = 128 or 256");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *vecs = reinterpret_cast<float *>(smem + NSLOT * X6_STEP_B); // b1[256], b2, g, b, b_in[384], b_o, g1, b1n, c, g2, b2n
+    float *vecs = reinterpret_cast<float *>(smem + NSLOT * STEP_B); // b1[256], b2, g, b, b_in[384], b_o, g1, b1n, c, g2, b2n
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lk = lane >> 5;
@@ -1453,7 +1485,7 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
     const size_t fbase = (size_t)mtile * (4 * NT) * 64 + lane;
     const unsigned int lds0 = (unsigned int)(size_t)(__attribute__((address_space(3))) char *)smem;
     const unsigned int fr_addr = lds0 + lane * 16; // + slot * X6_STEP_B + piece * 1024
-    const unsigned int vecs_addr = lds0 + NSLOT * X6_STEP_B + 16 * lk; // this lane's float4 of a 32-value tile's group g: + 32 g bytes
+    const unsigned int vecs_addr = lds0 + NSLOT * STEP_B + 16 * lk; // this lane's float4 of a 32-value tile's group g: + 32 g bytes
     constexpr int qoff = NOUT * QP0;                // the q tiles' steps (NT tiles x HT) are skipped when QP0
     constexpr int nsteps = x6_nstep(NT) - qoff;     // executed steps; step i of the sequence is stream block i (+ qoff past the FFN)
     // DMA of sequence step i into slot i % NSLOT: this wave's pieces PPW wave .. PPW wave + PPW - 1.  The slot holds the
@@ -1462,14 +1494,15 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
     // -(PPW / 2) .. PPW / 2 - 1 KB (13-bit signed immediates).
     // (NW < 4 -- few tokens, a workgroup per 32 or 64 of them so that more CUs take part: the wave's 12 or 24 pieces go out in
     //  groups of six, one base per group)
-    constexpr int PPG = PPW > 6 ? 6 : PPW, NGRP = PPW / PPG;
+    constexpr int PPG = PPW <= 6 ? PPW : (PPW % 6 == 0 ? 6 : 4), NGRP = PPW / PPG;
+    static_assert(PPW * NW == NP && PPG * NGRP == PPW, "a step's pieces divide over the waves and their issue groups");
     const uint4 *dma_src = a.Wx + (PPW * wave + PPG / 2) * 64 + lane;
     auto issue = [&](int i) __attribute__((always_inline)) {
         const int blk = i < NPRE ? i : i + qoff;
         x6_static_for<0, NGRP>([&](auto gc) __attribute__((always_inline)) {
             constexpr int grp = decltype(gc)::value;
-            const uint4 *src = dma_src + (size_t)blk * (X6_STEP_B / 16) + grp * PPG * 64;
-            char *dst = smem + (i % NSLOT) * X6_STEP_B + (PPW * wave + grp * PPG + PPG / 2) * 1024;
+            const uint4 *src = dma_src + (size_t)blk * (STEP_B / 16) + grp * PPG * 64;
+            char *dst = smem + (i % NSLOT) * STEP_B + (PPW * wave + grp * PPG + PPG / 2) * 1024;
             x6_static_for<0, PPG>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int off = (decltype(jc)::value - PPG / 2) * 1024;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
@@ -1537,20 +1570,20 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
         for (int q = 0; q < 4; ++q) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[q]));
     };
     if constexpr (NT == 8) {
-        af[0] = x6_rd_sync<(S0 % NSLOT) * X6_STEP_B>(fr_addr);
-        af[1] = x6_rd_sync<(S0 % NSLOT) * X6_STEP_B + 1024>(fr_addr);
-        af[2] = x6_rd_sync<(S0 % NSLOT) * X6_STEP_B + 2048>(fr_addr);
-        af[3] = x6_rd_sync<(S0 % NSLOT) * X6_STEP_B + 2048>(fr_addr);
+        af[0] = x6_rd_sync<(S0 % NSLOT) * STEP_B>(fr_addr);
+        af[1] = x6_rd_sync<(S0 % NSLOT) * STEP_B + 1024>(fr_addr);
+        af[2] = x6_rd_sync<(S0 % NSLOT) * STEP_B + 2048>(fr_addr);
+        af[3] = x6_rd_sync<(S0 % NSLOT) * STEP_B + 2048>(fr_addr);
     } else {
-        af[0] = x6_rd<(S0 % NSLOT) * X6_STEP_B>(fr_addr);
-        af[1] = x6_rd<(S0 % NSLOT) * X6_STEP_B + 1024>(fr_addr);
-        af[2] = x6_rd<(S0 % NSLOT) * X6_STEP_B + 2048>(fr_addr);
-        af[3] = x6_rd<(S0 % NSLOT) * X6_STEP_B + 2048>(fr_addr); // (its own read: a register copy of af[2] would be taken before the data has landed)
+        af[0] = x6_rd<(S0 % NSLOT) * STEP_B>(fr_addr);
+        af[1] = x6_rd<(S0 % NSLOT) * STEP_B + 1024>(fr_addr);
+        af[2] = x6_rd<(S0 % NSLOT) * STEP_B + 2048>(fr_addr);
+        af[3] = x6_rd<(S0 % NSLOT) * STEP_B + 2048>(fr_addr); // (its own read: a register copy of af[2] would be taken before the data has landed)
         landed_all();
     }
 
     const float invn = 1.0f / (float)D;
-    x6_bf16x8 X[3];
+    x6_plane X[NPL];
     unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_wait = 0, st_bar = 0, st_iss = 0, st_0 = 0, st_1 = 0, st_steps = 0;
     X6_T(st_0)
     // one pipeline step: 8 groups x 6 MFMAs onto T[0..3]; the mid-step barrier publishes step i + 1 and frees the slot
@@ -1560,11 +1593,11 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
 #ifdef X6_NO_MFMA
 #define X6_MM(W_, X_, T_) asm volatile("" :: "v"(W_), "v"(X_))
 #else
-#define X6_MM(W_, X_, T_) T_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W_, X_, T_, 0, 0, 0)
+#define X6_MM(W_, X_, T_) T_ = x6_mma(W_, X_, T_)
 #endif
-#define X6_MFMA(Wreg, Xp, T_) X6_MM(__builtin_bit_cast(x6_bf16x8, Wreg), X[Xp], T_)
+#define X6_MFMA(Wreg, Xp, T_) X6_MM(__builtin_bit_cast(x6_plane, Wreg), X[Xp], T_)
 #ifdef X6_DUMP
-#define X6_DUMP_FRAG(I_, f_) if (blockIdx.x == 0 && wave == 0) a.dbg[((I_) * 24 + (f_)) * 64 + lane] = __builtin_bit_cast(uint4, af[(f_) & 3]);
+#define X6_DUMP_FRAG(I_, f_) if (blockIdx.x == 0 && wave == 0) a.dbg[((I_) * NP + (f_)) * 64 + lane] = __builtin_bit_cast(uint4, af[(f_) & 3]);
 #else
 #define X6_DUMP_FRAG(I_, f_)
 #endif
@@ -1572,8 +1605,8 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
 #define X6_READ_AHEAD(f_) asm volatile("" : "+v"(af[(f_) & 3]));
 #else
 #define X6_READ_AHEAD(f_)                                                                                                \
-    if constexpr ((f_) + 3 < 24) af[((f_) + 3) & 3] = x6_rd<((f_) + 3) * 1024>(sb_);                                     \
-    else af[((f_) + 3) & 3] = x6_rd<((f_) + 3 - 24) * 1024>(sn_); /* next step's head (behind this step's barrier) */    \
+    if constexpr ((f_) + 3 < NP) af[((f_) + 3) & 3] = x6_rd<((f_) + 3) * 1024>(sb_);                                     \
+    else af[((f_) + 3) & 3] = x6_rd<((f_) + 3 - NP) * 1024>(sn_); /* next step's head (behind this step's barrier) */    \
     asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(af[(f_) & 3]));                                                           \
     X6_DUMP_FRAG(step_, f_)
 #endif
@@ -1602,26 +1635,21 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
         const int step_ = (I_);                                                                                          \
         unsigned long long sq_0 = 0, sq_1 = 0;                                                                           \
         X6_T(sq_0)                                                                                                       \
-        const unsigned int sb_ = fr_addr + (unsigned int)((step_ % NSLOT) * X6_STEP_B);                                  \
-        const unsigned int sn_ = fr_addr + (unsigned int)(((step_ + 1) % NSLOT) * X6_STEP_B);                            \
-        x6_static_for<0, 24>([&](auto fc_) __attribute__((always_inline)) {                                              \
-            constexpr int f_ = decltype(fc_)::value, g_ = f_ / 3, pl_ = f_ % 3;                                          \
+        const unsigned int sb_ = fr_addr + (unsigned int)((step_ % NSLOT) * STEP_B);                                     \
+        const unsigned int sn_ = fr_addr + (unsigned int)(((step_ + 1) % NSLOT) * STEP_B);                               \
+        x6_static_for<0, NP>([&](auto fc_) __attribute__((always_inline)) {                                              \
+            constexpr int f_ = decltype(fc_)::value, g_ = f_ / NPL, pl_ = f_ % NPL;                                      \
             if constexpr (f_ == 0) x6_split(SRC, 0, X);                                                                  \
-            if constexpr (f_ == 12) {                                                                                    \
+            if constexpr (f_ == NP / 2) {                                                                                \
                 X6_PUBLISH(step_)                                                                                        \
                 x6_split(SRC, 1, X);                                                                                     \
             }                                                                                                            \
             X6_READ_AHEAD(f_)                                                                                            \
             f32x16 &T_ = (g_ & 3) == 0 ? T0 : (g_ & 3) == 1 ? T1 : (g_ & 3) == 2 ? T2 : T3;                              \
-            if constexpr (pl_ == 0) {                                                                                    \
-                X6_MFMA(af[f_ & 3], 2, T_);                                                                              \
-                X6_MFMA(af[f_ & 3], 1, T_);                                                                              \
-                X6_MFMA(af[f_ & 3], 0, T_);                                                                              \
-            } else if constexpr (pl_ == 1) {                                                                             \
-                X6_MFMA(af[f_ & 3], 1, T_);                                                                              \
-                X6_MFMA(af[f_ & 3], 0, T_);                                                                              \
-            } else                                                                                                       \
-                X6_MFMA(af[f_ & 3], 0, T_);                                                                              \
+            /* weight plane pl_ x activation planes NPL - 1 - pl_ .. 0 (the products up to the dropped order), small first */ \
+            x6_static_for<0, NPL - pl_>([&](auto qc_) __attribute__((always_inline)) {                                   \
+                X6_MFMA(af[f_ & 3], NPL - 1 - pl_ - decltype(qc_)::value, T_);                                           \
+            });                                                                                                          \
         });                                                                                                              \
         X6_T(sq_1)                                                                                                       \
         st_steps += sq_1 - sq_0;                                                                                         \
@@ -1693,7 +1721,7 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
     //      accumulator), bias + relu on the 16 values, FFN-2 step acc += W2[:, 32 ft ..] h_ft^T.  (The round-2 order --
     //      all eight hidden tiles, then FFN-2 -- keeps 128 registers of h beside the 64 of y: with the split's
     //      temporaries that is ~265 of the 256 registers two waves per SIMD have: 173 spilled.)
-    x6_bf16x8 Yp[NT][2][3];
+    x6_plane Yp[NT][2][NPL];
     if constexpr (!EMBED) {
 #pragma unroll
         for (int tn = 0; tn < NT; ++tn)
@@ -1728,9 +1756,9 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
 #define X6_WAIT_V(v_) asm volatile("" : "+v"(af[(v_) & 3]));
 #else
 #define X6_RD_V(v_)                                                                                                      \
-    if constexpr ((v_) < 24) af[(v_) & 3] = x6_rd<(v_) * 1024>(sb_);                                                     \
-    else if constexpr ((v_) < 32) af[(v_) & 3] = x6_rd<3 * ((v_) - 24) * 1024>(sb_);                                     \
-    else af[(v_) & 3] = x6_rd<((v_) - 32) * 1024>(sn_); /* next step's head (behind this step's barrier) */
+    if constexpr ((v_) < NP) af[(v_) & 3] = x6_rd<(v_) * 1024>(sb_);                                                     \
+    else if constexpr ((v_) < NP + 8) af[(v_) & 3] = x6_rd<NPL * ((v_) - NP) * 1024>(sb_);                               \
+    else af[(v_) & 3] = x6_rd<((v_) - NP - 8) * 1024>(sn_); /* next step's head (behind this step's barrier) */
 #define X6_WAIT_V(v_) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(af[(v_) & 3]));
 #endif
 #define X6_STEP1(I_, XP_, T_)                                                                                            \
@@ -1738,27 +1766,24 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
         const int step_ = (I_);                                                                                          \
         unsigned long long sq_0 = 0, sq_1 = 0;                                                                           \
         X6_T(sq_0)                                                                                                       \
-        const unsigned int sb_ = fr_addr + (unsigned int)((step_ % NSLOT) * X6_STEP_B);                                  \
-        const unsigned int sn_ = fr_addr + (unsigned int)(((step_ + 1) % NSLOT) * X6_STEP_B);                            \
-        x6_static_for<0, 32>([&](auto vc_) __attribute__((always_inline)) {                                              \
+        const unsigned int sb_ = fr_addr + (unsigned int)((step_ % NSLOT) * STEP_B);                                     \
+        const unsigned int sn_ = fr_addr + (unsigned int)(((step_ + 1) % NSLOT) * STEP_B);                               \
+        x6_static_for<0, NP + 8>([&](auto vc_) __attribute__((always_inline)) {                                          \
             constexpr int v_ = decltype(vc_)::value;                                                                     \
-            if constexpr (v_ == 16) { X6_PUBLISH(step_) }                                                                \
+            if constexpr (v_ == (NP + 8) / 2) { X6_PUBLISH(step_) }                                                      \
             X6_RD_V(v_ + 3)                                                                                              \
             X6_WAIT_V(v_)                                                                                                \
-            const x6_bf16x8 w_ = __builtin_bit_cast(x6_bf16x8, af[v_ & 3]);                                              \
-            if constexpr (v_ < 24) {                                                                                     \
-                constexpr int g_ = v_ / 3, pl_ = v_ % 3;                                                                 \
+            const x6_plane w_ = __builtin_bit_cast(x6_plane, af[v_ & 3]);                                                \
+            if constexpr (v_ < NP) {                                                                                     \
+                constexpr int g_ = v_ / NPL, pl_ = v_ % NPL;                                                             \
                 X6_DUMP_FRAG(step_, v_)                                                                                  \
-                if constexpr (pl_ == 0) {                                                                                \
-                    X6_MM(w_, XP_[g_ >> 1][g_ & 1][2], T_);                                                              \
-                    X6_MM(w_, XP_[g_ >> 1][g_ & 1][1], T_);                                                              \
-                } else if constexpr (pl_ == 1) {                                                                         \
-                    X6_MM(w_, XP_[g_ >> 1][g_ & 1][1], T_);                                                              \
-                    X6_MM(w_, XP_[g_ >> 1][g_ & 1][0], T_);                                                              \
-                } else                                                                                                   \
-                    X6_MM(w_, XP_[g_ >> 1][g_ & 1][0], T_);                                                              \
+                /* the small products of weight plane pl_: activation planes NPL - 1 - pl_ .. (the h.h product waits) */ \
+                x6_static_for<0, NPL - pl_>([&](auto qc_) __attribute__((always_inline)) {                               \
+                    constexpr int xp_ = NPL - 1 - pl_ - decltype(qc_)::value;                                            \
+                    if constexpr (pl_ > 0 || xp_ > 0) X6_MM(w_, XP_[g_ >> 1][g_ & 1][xp_], T_);                          \
+                });                                                                                                      \
             } else {                                                                                                     \
-                constexpr int g_ = v_ - 24;                                                                              \
+                constexpr int g_ = v_ - NP;                                                                              \
                 X6_MM(w_, XP_[g_ >> 1][g_ & 1][0], T_);                                                                  \
             }                                                                                                            \
         });                                                                                                              \
@@ -4784,40 +4809,60 @@ static bool x6_shape(const irs_ctx *ctx) {
     return (ctx->dims.d == 128 || ctx->dims.d == 256) && ctx->dims.ffn_dim == 256 && ctx->dims.d / ctx->dims.n_heads == 32 &&
            ctx->dims.n_layers >= 2;
 }
-static size_t x6_layer_b(const irs_ctx *ctx) { return x6_layer_bytes(ctx->dims.d / 32); }
+static size_t x6_layer_b(const irs_ctx *ctx, int npl = 3) { return x6_layer_bytes(ctx->dims.d / 32, npl); }
+// the float16 two-plane streams (IRS_GEMM_H3) follow the bf16 three-plane ones in the arena
+static const uint4 *x6_stream(const irs_ctx *ctx, int npl, int layer) {
+    const uint4 *base = ctx->w_x6;
+    if (npl == 2) base += (size_t)ctx->dims.n_layers * (x6_layer_b(ctx, 3) / 16);
+    return base + (size_t)layer * (x6_layer_b(ctx, npl) / 16);
+}
 // streams 0 .. n_layers - 2: layer l's out-projection / FFN and layer l + 1's q | k | v; stream n_layers - 1: layer 0's
 // q | k | v alone (the embed kernel's; its other blocks are zero and never fetched)
-size_t irs_x6_bytes(const irs_ctx *ctx) { return x6_shape(ctx) ? (size_t)ctx->dims.n_layers * x6_layer_b(ctx) : 0; }
+size_t irs_x6_bytes(const irs_ctx *ctx) {
+    return x6_shape(ctx) ? (size_t)ctx->dims.n_layers * (x6_layer_b(ctx, 3) + x6_layer_b(ctx, 2)) : 0;
+}
 int irs_launch_pack_x6(irs_ctx *ctx, hipStream_t s) {
     if (!ctx->w_x6) return IRS_OK;
     const int nl = ctx->dims.n_layers, NT = ctx->dims.d / 32;
-    const size_t lb16 = x6_layer_b(ctx) / 16;
-    const dim3 pgrid(x6_nstep(NT) * 24 * 64 / 256);
-    auto pack = [&](const float *Wo, const float *W1, const float *W2, const float *Win, uint4 *out) {
-        if (NT == 8) hipLaunchKernelGGL(k_pack_x6<8>, pgrid, dim3(256), 0, s, Wo, W1, W2, Win, out);
-        else hipLaunchKernelGGL(k_pack_x6<4>, pgrid, dim3(256), 0, s, Wo, W1, W2, Win, out);
-    };
-    for (int l = 0; l + 1 < nl; ++l) {
-        const irs_layer_w &w = ctx->layer[l];
-        pack(w.sa_out_w, w.l1_w, w.l2_w, ctx->layer[l + 1].sa_in_w, ctx->w_x6 + (size_t)l * lb16);
+    for (int npl = 3; npl >= 2; --npl) { // bf16 three-plane streams, then float16 two-plane streams
+        const dim3 pgrid(x6_nstep(NT) * 8 * npl * 64 / 256);
+        auto pack = [&](const float *Wo, const float *W1, const float *W2, const float *Win, uint4 *out) {
+            if (NT == 8 && npl == 3) hipLaunchKernelGGL((k_pack_x6<8, 3>), pgrid, dim3(256), 0, s, Wo, W1, W2, Win, out);
+            else if (NT == 8) hipLaunchKernelGGL((k_pack_x6<8, 2>), pgrid, dim3(256), 0, s, Wo, W1, W2, Win, out);
+            else if (npl == 3) hipLaunchKernelGGL((k_pack_x6<4, 3>), pgrid, dim3(256), 0, s, Wo, W1, W2, Win, out);
+            else hipLaunchKernelGGL((k_pack_x6<4, 2>), pgrid, dim3(256), 0, s, Wo, W1, W2, Win, out);
+        };
+        for (int l = 0; l + 1 < nl; ++l) {
+            const irs_layer_w &w = ctx->layer[l];
+            pack(w.sa_out_w, w.l1_w, w.l2_w, ctx->layer[l + 1].sa_in_w, const_cast<uint4 *>(x6_stream(ctx, npl, l)));
+        }
+        pack(nullptr, nullptr, nullptr, ctx->layer[0].sa_in_w, const_cast<uint4 *>(x6_stream(ctx, npl, nl - 1)));
     }
-    pack(nullptr, nullptr, nullptr, ctx->layer[0].sa_in_w, ctx->w_x6 + (size_t)(nl - 1) * lb16);
     IRS_CHECK_HIP(ctx, hipGetLastError());
     return IRS_OK;
 }
 static constexpr int X6_LDS_BYTES = x6_lds_bytes(4);
-static void x6_attr_once() { // (the kernels' dynamic LDS exceeds the default 64 KB limit)
-    IRS_ONCE_PER_DEVICE({
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, X6_NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<1, X6_NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, X6_NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, 4, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds_bytes(8));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<1, 4, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds_bytes(8));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, 4, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds_bytes(8));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, 1, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds_bytes(8));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<1, 1, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds_bytes(8));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, 1, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds_bytes(8));
-    });
+// one launcher for every instantiation of the fused layer kernel: QP0 (k | v-only tail), EMBED, NT (4: d = 128, 8: d = 256),
+// NPL (3: bf16 six-product, 2: float16 three-product), NW (4; 1 = the lab's one-wave workgroups at NT = 8, bf16 only)
+template <int QP0, int NW, bool EMBED, int NT, int NPL>
+static void x6_launch_one(int rows, const BlockX6Args &xa, hipStream_t s) {
+    auto kern = k_block_x6<QP0, NW, EMBED, NT, NPL>;
+    constexpr int lds = x6_lds_bytes(NT, NPL);
+    IRS_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3((rows + 32 * NW - 1) / (32 * NW)), dim3(64 * NW), lds, s, xa);
+}
+static void x6_launch(int qp0, bool embed, int nt, int npl, bool one_wave, int rows, const BlockX6Args &xa, hipStream_t s) {
+#define X6_L(Q_, E_) do {                                                                                                 \
+        if (nt == 8 && one_wave) x6_launch_one<Q_, 1, E_, 8, 3>(rows, xa, s);                                             \
+        else if (nt == 8 && npl == 2) x6_launch_one<Q_, 4, E_, 8, 2>(rows, xa, s);                                        \
+        else if (nt == 8) x6_launch_one<Q_, 4, E_, 8, 3>(rows, xa, s);                                                    \
+        else if (npl == 2) x6_launch_one<Q_, 4, E_, 4, 2>(rows, xa, s);                                                   \
+        else x6_launch_one<Q_, X6_NW, E_, 4, 3>(rows, xa, s);                                                             \
+    } while (0)
+    if (embed) X6_L(0, true);
+    else if (qp0) X6_L(1, false);
+    else X6_L(0, false);
+#undef X6_L
 }
 
 size_t irs_small_frag_floats(const irs_ctx *ctx) {
@@ -4951,14 +4996,11 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
         if (ctx->use_x6 && ctx->w_x6) { // the same kernel on split-bf16 MFMAs: k_block_x6's q | k | v steps behind an embed prologue
             BlockX6Args xa{};
-            xa.Wx = ctx->w_x6 + (size_t)(ctx->dims.n_layers - 1) * (x6_layer_b(ctx) / 16);
+            const int npl = (ctx->use_x6 == IRS_GEMM_H3 && !x6d_small) ? 2 : 3;
+            xa.Wx = x6_stream(ctx, npl, ctx->dims.n_layers - 1);
             xa.bin = ctx->layer[0].sa_in_b, xa.Xf = xf, xa.QKV = ctx->act_qkv, xa.M = rows, xa.m_dev = m_dev;
             xa.seq = seq, xa.E = ctx->item_emb, xa.pe = ctx->pe, xa.tok_row = tok, xa.L = L, xa.sqrtd = sqrtf((float)d), xa.n_item = ctx->dims.n_item;
-            x6_attr_once();
-            if (x6d_small) hipLaunchKernelGGL((k_block_x6<0, 1, true, 8>), dim3((rows + 31) / 32), dim3(64), x6_lds_bytes(8), s, xa);
-            else if (x6d) hipLaunchKernelGGL((k_block_x6<0, 4, true, 8>), dim3((rows + 127) / 128), dim3(256), x6_lds_bytes(8), s, xa);
-            else
-            hipLaunchKernelGGL((k_block_x6<0, X6_NW, true>), dim3((rows + 32 * X6_NW - 1) / (32 * X6_NW)), dim3(64 * X6_NW), X6_LDS_BYTES, s, xa);
+            x6_launch(0, true, x6d ? 8 : 4, npl, x6d_small, rows, xa, s);
         } else
         hipLaunchKernelGGL(k_embed_qkv, dim3((rows + 127) / 128), dim3(256), 0, s, ea);
         irs_prof_end(ctx, IRS_PROF_LINEAR, s, 6.0 * rows * (double)d * d, 4.0 * 4.0 * rows * (double)d);
@@ -5116,19 +5158,10 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                 irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
                 if (tail) irs_prof_begin(ctx, IRS_PROF_LAYER, s); // (one family is enabled at a time)
                 if (tail && ctx->use_x6 && ctx->w_x6) { // the same layer tail on split-bf16 MFMAs
-                    BlockX6Args xa{yf, xf, ctx->w_x6 + (size_t)l * (x6_layer_b(ctx) / 16), w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b,
+                    const int npl = (ctx->use_x6 == IRS_GEMM_H3 && !x6d_small) ? 2 : 3;
+                    BlockX6Args xa{yf, xf, x6_stream(ctx, npl, l), w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b,
                                    w.l1_b, w.l2_b, w.n3_w, w.n3_b, ctx->layer[l + 1].sa_in_b, xf, ctx->act_qkv, rows, m_dev, kv_only ? 1 : 0};
-                    x6_attr_once();
-                    const dim3 x6_grid((rows + 32 * X6_NW - 1) / (32 * X6_NW));
-                    if (x6d_small) {
-                        if (kv_only) hipLaunchKernelGGL((k_block_x6<1, 1, false, 8>), dim3((rows + 31) / 32), dim3(64), x6_lds_bytes(8), s, xa);
-                        else hipLaunchKernelGGL((k_block_x6<0, 1, false, 8>), dim3((rows + 31) / 32), dim3(64), x6_lds_bytes(8), s, xa);
-                    } else if (x6d) {
-                        if (kv_only) hipLaunchKernelGGL((k_block_x6<1, 4, false, 8>), dim3((rows + 127) / 128), dim3(256), x6_lds_bytes(8), s, xa);
-                        else hipLaunchKernelGGL((k_block_x6<0, 4, false, 8>), dim3((rows + 127) / 128), dim3(256), x6_lds_bytes(8), s, xa);
-                    } else
-                    if (kv_only) hipLaunchKernelGGL((k_block_x6<1, X6_NW, false>), x6_grid, dim3(64 * X6_NW), X6_LDS_BYTES, s, xa);
-                    else hipLaunchKernelGGL((k_block_x6<0, X6_NW, false>), x6_grid, dim3(64 * X6_NW), X6_LDS_BYTES, s, xa);
+                    x6_launch(kv_only ? 1 : 0, false, x6d ? 8 : 4, npl, x6d_small, rows, xa, s);
                 } else if (x6d) IRS_FAIL(ctx, IRS_E_STATE, "d = 256 fused layer kernel without a successor layer");
                 else if (tail) hipLaunchKernelGGL((k_block<true, true>), dim3((rows + 127) / 128), dim3(256), 0, s, ba);
                 else hipLaunchKernelGGL((k_block<true, false>), dim3((rows + 127) / 128), dim3(256), 0, s, ba);

@@ -445,7 +445,8 @@ class Engine:
     # ------------------------------------------------------------------ decoder GEMM arithmetic
     @property
     def decoder_gemm(self) -> int:
-        """IRS_GEMM_X6 (split-bf16 MFMAs, the default) or IRS_GEMM_F32 (float32 MFMAs): include/irs_hip.h."""
+        """IRS_GEMM_H3 (split-float16 MFMAs, the default), IRS_GEMM_X6 (split-bf16 MFMAs) or IRS_GEMM_F32 (float32 MFMAs):
+        include/irs_hip.h."""
         return int(self.lib.irs_get_decoder_gemm(self.h))
 
     @decoder_gemm.setter

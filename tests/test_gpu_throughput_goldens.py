@@ -4,11 +4,11 @@ layer kernel k_block_x6 / k_block, the packed-sequence attention) pinned DIRECTL
 tests/test_gpu_decoder_path.py runs the goldens' 32 (c2) / 8 (c3) users per call, i.e. 6400 / 1600 token rows: below the
 32768-row switch of irs_launch_decode, so those tests exercise the small-batch kernels.  Here the golden users are tiled
 (c2 x 6 = 192 windows = 38400 token rows; c3 x 24 = 192 windows), shuffled, and sent through irs_decode +
-irs_score_topk + irs_generate_paths (stream and hipGraph) in BOTH decoder arithmetic modes (IRS_GEMM_X6, the default, and
-IRS_GEMM_F32): decoder rows, ranked top-100 ids, 20-step paths and the early-success count are compared with what the
+irs_score_topk + irs_generate_paths (stream and hipGraph) in ALL decoder arithmetic modes (IRS_GEMM_H3, the default,
+IRS_GEMM_X6 and IRS_GEMM_F32): decoder rows, ranked top-100 ids, 20-step paths and the early-success count are compared with what the
 unmodified reference produced for those users (reference model/influentialRS.py:412-450, 340-390).
 
-Tolerances: decoder rows 2e-5 (float32 MFMAs) / 4e-5 (split-bf16 MFMAs) absolute on O(1) LayerNorm outputs; top-100
+Tolerances: decoder rows 2e-5 (float32 MFMAs) / 4e-5 (split-float16 and split-bf16 MFMAs) absolute on O(1) LayerNorm outputs; top-100
 values 5e-5; ranked ids order-exact outside runs of reference scores closer than TAU (rank_check.py), with the set of
 users that are NOT id-for-id identical asserted exactly (NEAR_TIE_USERS); paths and early successes exact."""
 import numpy as np
@@ -16,21 +16,21 @@ import pytest
 import torch
 
 from influentialrs_amd import synth
-from influentialrs_amd._lib import IRS_GEMM_F32, IRS_GEMM_X6, IRS_SWEEP_BF16
+from influentialrs_amd._lib import IRS_GEMM_F32, IRS_GEMM_H3, IRS_GEMM_X6, IRS_SWEEP_BF16
 from gpu_util import make_engine
 from parity_record import check_exact
 from rank_check import check_ranked
 
 pytestmark = pytest.mark.gpu
 
-X_TOL = {IRS_GEMM_F32: 2e-5, IRS_GEMM_X6: 4e-5}
+X_TOL = {IRS_GEMM_F32: 2e-5, IRS_GEMM_X6: 4e-5, IRS_GEMM_H3: 4e-5}
 TAU = 2e-5
-MODES = {"x6": IRS_GEMM_X6, "f32": IRS_GEMM_F32}
+MODES = {"h3": IRS_GEMM_H3, "x6": IRS_GEMM_X6, "f32": IRS_GEMM_F32}
 # golden users whose top-100 ids differ from the reference's inside a run of reference gaps < TAU (everything else is
 # identical id for id); filled from a recording run (IRS_RECORD_PARITY=1), see profiles/r04/parity_counts.json
 NEAR_TIE_USERS = {
-    ("irn_c2", "x6"): [20], ("irn_c2", "f32"): [],
-    ("irn_c3", "x6"): [], ("irn_c3", "f32"): [],
+    ("irn_c2", "h3"): [], ("irn_c2", "x6"): [20], ("irn_c2", "f32"): [],
+    ("irn_c3", "h3"): [], ("irn_c3", "x6"): [], ("irn_c3", "f32"): [],
 }
 _ENG = {}
 
@@ -55,7 +55,7 @@ def _trim_after_target(paths, targets):
 
 
 @pytest.mark.parametrize("name,cfgname,reps", [("irn_c2", "c2", 6), ("irn_c3", "c3", 24)])
-@pytest.mark.parametrize("mode", ["x6", "f32"])
+@pytest.mark.parametrize("mode", ["h3", "x6", "f32"])
 def test_throughput_kernels_reproduce_reference_goldens(golden, name, cfgname, reps, mode):
     g = golden(name)
     B0, L = g["seqs"].shape
@@ -105,4 +105,4 @@ def test_throughput_kernels_reproduce_reference_goldens(golden, name, cfgname, r
             assert np.array_equal(trimmed, g["paths"][src]), (name, mode, use_graph)
             assert n_early == reps * int(g["n_early_success"]) and n_early > 0
     finally:
-        eng.decoder_gemm = IRS_GEMM_X6
+        eng.decoder_gemm = IRS_GEMM_H3

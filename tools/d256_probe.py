@@ -6,7 +6,7 @@ sys.path.insert(0, ".")
 import numpy as np, torch
 import bench
 from influentialrs_amd import synth
-from influentialrs_amd._lib import IRS_GEMM_F32, IRS_GEMM_X6, IRS_MASK_IRN
+from influentialrs_amd._lib import IRS_GEMM_F32, IRS_GEMM_H3, IRS_GEMM_X6, IRS_MASK_IRN
 from influentialrs_amd.engine import Engine
 from oracle import oracle_np as O
 
@@ -23,7 +23,7 @@ seqs = bench.gpu_windows(B, cfg.max_len, cfg.n_item, dev, seed=3)
 users = torch.randint(0, cfg.n_user, (B,), device=dev)
 pos = torch.full((B,), cfg.max_len - 2, dtype=torch.int32, device=dev)
 out = {}
-for mode, name in ((IRS_GEMM_X6, "x6"), (IRS_GEMM_F32, "f32"), (IRS_GEMM_X6, "x6")):
+for mode, name in ((IRS_GEMM_X6, "x6"), (IRS_GEMM_H3, "h3"), (IRS_GEMM_F32, "f32"), (IRS_GEMM_X6, "x6"), (IRS_GEMM_H3, "h3")):
     eng.decoder_gemm = mode
     for _ in range(3):
         _, xr, _ = eng.decode(seqs, users, want_x=False, pos=pos)
@@ -34,9 +34,10 @@ for mode, name in ((IRS_GEMM_X6, "x6"), (IRS_GEMM_F32, "f32"), (IRS_GEMM_X6, "x6
     torch.cuda.synchronize()
     print(f"{name}: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms per decode of {B} users (d = {d}, {nl} layers)", flush=True)
     out[name] = xr.clone()
-dd = (out["x6"] - out["f32"]).abs()
-print("x6 vs f32 over the consumed rows: max %.3g  mean %.3g  99.9%% %.3g" % (float(dd.max()), float(dd.mean()), float(dd.flatten().kthvalue(int(dd.numel() * 0.999)).values)))
+for nm in ("x6", "h3"):
+    dd = (out[nm] - out["f32"]).abs()
+    print("%s vs f32 over the consumed rows: max %.3g  mean %.3g  99.9%% %.3g" % (nm, float(dd.max()), float(dd.mean()), float(dd.flatten().kthvalue(int(dd.numel() * 0.999)).values)))
 hs, hu = seqs.cpu().numpy(), users.cpu().numpy()
 for b in (0, 1, 2, 3):
     ref = O.decode(sd_np, cfg, hs[b], int(hu[b]))[0][cfg.max_len - 2]
-    print("user %d vs numpy oracle: x6 %.3g  f32 %.3g" % (b, np.abs(ref - out["x6"][b].cpu().numpy()).max(), np.abs(ref - out["f32"][b].cpu().numpy()).max()))
+    print("user %d vs numpy oracle: x6 %.3g  h3 %.3g  f32 %.3g" % (b, np.abs(ref - out["x6"][b].cpu().numpy()).max(), np.abs(ref - out["h3"][b].cpu().numpy()).max(), np.abs(ref - out["f32"][b].cpu().numpy()).max()))
