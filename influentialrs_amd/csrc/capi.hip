@@ -74,6 +74,7 @@ extern "C" int irs_create(irs_ctx **out, const irs_dims *dims, const irs_shard *
         c->use_x6 = e ? (strcmp(e, "f32") == 0 ? IRS_GEMM_F32 : strcmp(e, "x6") == 0 ? IRS_GEMM_X6 : IRS_GEMM_H3) : IRS_GEMM_H3;
         const char *ea = getenv("IRS_ATTN_GEMM");
         c->use_attn_x6 = ea ? (strcmp(ea, "x6") == 0) : 0;
+        c->use_attn_h3 = ea ? (strcmp(ea, "h3") == 0) : 1; // (IRS_ATTN_GEMM=f32: float32 K / V rows and the float32-MFMA attention)
         const char *ep = getenv("IRS_ATTN_PERSIST");
         c->attn_persist = ep ? (atoi(ep) != 0) : 0;
         const char *er = getenv("IRS_LSE_RING");

@@ -1339,6 +1339,11 @@ struct BlockX6Args {
     int L;
     float sqrtd;
     int64_t n_item;
+    // != 0 (with the q tail, QP0 = 0): the V section of a q | k | v row is written as float16 PLANE PAIRS -- per
+    // (token, head) [32 f16 h | 32 f16 l], h = f16(v), l = f16(v - h), the same 128 bytes as 32 floats -- the operand format
+    // of k_attn16h; the q and k sections stay float32.  (The k | v-only tail that feeds the rows-only last layer keeps float32:
+    // k_attn_row32 reads it.)
+    int kv_planes;
 #ifdef X6_DUMP
     uint4 *dbg;            // (lab) the fragments workgroup 0 / wave 0 consumed, [step][fragment][lane]
 #endif
@@ -1873,10 +1878,28 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
             X6_T(st_q0)
             if (mt < M) {
                 float *qrow = a.QKV + (int64_t)mt * (3 * D) + c0 + i * 32 + 4 * lk;
+                if (QP0 == 0 && a.kv_planes && pp == 2) { // V head i of this token as two float16 planes
+                    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+                    char *slot = reinterpret_cast<char *>(a.QKV + (int64_t)mt * (3 * D) + c0 + i * 32) + 8 * lk;
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4 *>(qrow + 8 * g) = make_float4(qt[4 * g + 0] + bt[4 * g + 0], qt[4 * g + 1] + bt[4 * g + 1],
-                                                                            qt[4 * g + 2] + bt[4 * g + 2], qt[4 * g + 3] + bt[4 * g + 3]);
+                    for (int g = 0; g < 4; ++g) {
+                        f16x4 hp, lp;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = qt[4 * g + e] + bt[4 * g + e];
+                            const _Float16 hv = (_Float16)v;
+                            hp[e] = hv;
+                            lp[e] = (_Float16)(v - (float)hv);
+                        }
+                        *reinterpret_cast<f16x4 *>(slot + 16 * g) = hp;       // channels 8 g + 4 lk .. + 3 of plane h
+                        *reinterpret_cast<f16x4 *>(slot + 64 + 16 * g) = lp;  // ... of plane l
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4 *>(qrow + 8 * g) = make_float4(qt[4 * g + 0] + bt[4 * g + 0], qt[4 * g + 1] + bt[4 * g + 1],
+                                                                                qt[4 * g + 2] + bt[4 * g + 2], qt[4 * g + 3] + bt[4 * g + 3]);
+                }
             }
             X6_T(st_q1)
             st_qst += st_q1 - st_q0;
@@ -4352,6 +4375,331 @@ const float *__restrict__ qkv, const int64_t *__restrict__ seq,
     }
 }
 
+// ------------------------------------------------------------------ attention, head dim 32, split-float16 MFMAs (round 4)
+// k_attn16 with O^T += V^T P^T on the 16-bit matrix pipe the way the layer kernel's IRS_GEMM_H3 mode multiplies: two FLOAT16
+// planes per float32 operand (h = f16(x), l = f16(x - h): 22 of 24 significand bits), three plane products (h.l, l.h, h.h)
+// on v_mfma_f32_16x16x32_f16 -- a pair of key tiles costs 6 matrix instructions of 16 cycles instead of 16 of 32.  The SCORES
+// stay on the exact float32 chain (v_mfma_f32_16x16x4_f32 on a float32 K image, as in k_attn16): an error in a score is
+// exponentiated, and a first form with K and q on float16 planes as well -- 26-37 % faster in the lab -- was 1e-3 off on rows
+// whose logits are large (layer 0 of the synthetic models: |q||k| ~ 2000, so 2^-22 |q||k| is 5e-4 in the exponent); an error
+// in p or V is not amplified.  What made the bf16 form of round 3 (k_attn16x) lose is gone:
+//   * V arrives ALREADY SPLIT: the layer kernel's q | k | v tail (k_block_x6, kv_planes) writes each (token, head) V
+//     row as [32 f16 h | 32 f16 l] -- the same 128 bytes as 32 floats -- so the fill is pure LDS-DMA (16 key rows x 64 B of
+//     one plane per instruction, chunks swizzled on the source side) and costs no vector instruction;
+//   * two planes are 256 B per key, the float32 images' footprint: three workgroups per CU as before;
+//   * p = exp2(s - m) is split into two planes (3 vector instructions per value: v_cvt_pk_f16_f32, back, subtract, again).
+// Everything else is k_attn16x's structure: [plane][key][64 B] images, V in front of K, V^T operands by the transposing
+// ds_read_b64_tr_b16, the two score tiles of a pair side by side as the 32-key B operand, two-pass softmax, LPT blocks.
+__device__ __forceinline__ void attn_split8h(const float (&v)[8], x6_f16x8 (&P)[2]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 h = (_Float16)v[j];
+        P[0][j] = h;
+        P[1][j] = (_Float16)(v[j] - (float)h);
+    }
+}
+template <int MAXT, bool FAST, int NW>
+__global__ void __launch_bounds__(64 * NW, 3) k_attn16h(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
+                                                       const float *__restrict__ r_u, float *__restrict__ out, int Lmax, int d,
+                                                       int mask_mode, const int32_t *__restrict__ off,
+                                                       const int32_t *__restrict__ cnt, const int32_t *__restrict__ padq,
+                                                       int out_frag) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    constexpr int HD = 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int L = cnt ? cnt[blockIdx.y] : Lmax;
+    const int L16max = (Lmax + 15) & ~15;
+    const int PL = L16max * 64;                 // bytes of one plane image
+    char *Vp = smem;                            // V: [2 planes][L16][64 B]
+    float *Ks = reinterpret_cast<float *>(smem + 2 * PL); // K: float32 [L16][32], chunk-swizzled like k_attn16's (256 B per key in all)
+    unsigned int *padbits = reinterpret_cast<unsigned int *>(smem + 4 * PL); // [ceil(L/32)]
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 15, gq = lane >> 4;
+    const int64_t base = off ? (int64_t)off[b] : (int64_t)b * Lmax;
+    const int ld = 3 * d;
+    const bool irn = (mask_mode == IRS_MASK_IRN);
+    const int L16 = (L + 15) & ~15, NB16 = L16 >> 4;
+    if (L <= 0) return;
+    // Fill by LDS-DMA.  K: float32 rows, 8 key rows x 128 B per instruction, chunk p of key j from source chunk p ^ (j & 7) ^
+    // ((j >> 3) & 1) (k_attn16's conflict-free ds_read_b128 image).  V: the two float16 planes the layer kernel wrote, 16 key
+    // rows x 64 B of ONE plane per instruction (4 lanes per row), chunks swizzled by ((key >> 2) & 1) << 1 for the transposing
+    // reads.  Keys in [L, L16) re-read row L - 1 (finite values times p = 0); the pair partner of an odd last tile is not
+    // read at all (its operand half is zero).
+    {
+        const char *qb8 = reinterpret_cast<const char *>(qkv);
+        const int jl8 = lane >> 3, p8 = lane & 7;
+        for (int i = wave; i < (L16 >> 3); i += NW) {
+            const int j = 8 * i + jl8;
+            const float *row = qkv + (base + (j < L ? j : L - 1)) * ld + h * HD;
+            const int swk = (j & 7) ^ ((j >> 3) & 1);
+            __builtin_amdgcn_global_load_lds((attn_glb_void *)(row + d + 4 * (p8 ^ swk)), (attn_lds_void *)(Ks + i * 256), 16, 0, 0);
+        }
+        const int jl = lane >> 2, c = lane & 3;
+        for (int i = wave; i < NB16; i += NW) {
+            const int j = 16 * i + jl;
+            const char *row = qb8 + ((base + (j < L ? j : L - 1)) * ld) * 4 + h * 128;
+            const int swv = ((j >> 2) & 1) << 1;
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                __builtin_amdgcn_global_load_lds((attn_glb_void *)(row + 2 * d * 4 + p * 64 + ((c ^ swv) << 4)),
+                                                 (attn_lds_void *)(Vp + p * PL + i * 1024), 16, 0, 0);
+        }
+    }
+    // longest-first assignment of the 16-query blocks (block qb costs qb + 1 key tiles) to the NW waves
+    unsigned int mine = 0;
+    {
+        int load[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) load[w] = 0;
+        for (int qb = NB16 - 1; qb >= 0; --qb) {
+            int w = 0;
+#pragma unroll
+            for (int v = 1; v < NW; ++v)
+                if (load[v] < load[w]) w = v;
+#pragma unroll
+            for (int v = 0; v < NW; ++v)
+                if (v == w) load[v] += qb + 1;
+            if (w == wave) mine |= 1u << qb;
+        }
+    }
+    auto load_q = [&](int qb, float4 &t0, float4 &t1) {
+        const int qi = qb * 16 + lq;
+        const float *qrow = qkv + (base + (qi < L ? qi : L - 1)) * ld + h * HD + 8 * gq;
+        t0 = *reinterpret_cast<const float4 *>(qrow);
+        t1 = *reinterpret_cast<const float4 *>(qrow + 4);
+    };
+    float4 qn0 = make_float4(0.f, 0.f, 0.f, 0.f), qn1 = qn0;
+    int qb_next = mine ? 31 - __builtin_clz(mine) : -1;
+    if (qb_next >= 0) load_q(qb_next, qn0, qn1);
+    const int pq = padq ? padq[b] : -1;
+    for (int kb = wave; kb < (L + 31) / 32; kb += NW) {
+        const int j = kb * 32 + (lane & 31);
+        bool masked = (j >= L) || (irn && j == L - 1);
+        if (padq) masked = masked || (j == pq);
+        else masked = masked || (seq[base + (j < L ? j : L - 1)] == 0);
+        const unsigned long long bal = __ballot(masked);
+        if (lane == 0) padbits[kb] = (unsigned int)bal;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's DMA pieces have landed (the barrier publishes them)
+    __syncthreads();
+    const float LOG2E = 1.4426950408889634f;
+    const float tgt_add = irn ? (1.0f - r_u[b]) * LOG2E : 0.f;
+    const float scale = LOG2E / sqrtf((float)HD);
+    const bool tgt_ok = irn && (seq[(int64_t)b * Lmax + Lmax - 1] != 0);
+    // this lane's addresses: K row read (key = 16 kt + lq, chunk gq), V transposed read (block row (lane & 15) >> 2, columns
+    // 16 ct + 4 (lane & 3) ..)
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+
+    while (qb_next >= 0) {
+        const int qb = qb_next;
+        mine &= ~(1u << qb);
+        const int qi = qb * 16 + lq;
+        float qf[8];
+        {
+            const float4 t0 = qn0, t1 = qn1;
+            qb_next = mine ? 31 - __builtin_clz(mine) : -1;
+            if (qb_next >= 0) load_q(qb_next, qn0, qn1);
+            const float sc = qi < L ? scale : 0.f;
+            qf[0] = t0.x * sc, qf[1] = t0.y * sc, qf[2] = t0.z * sc, qf[3] = t0.w * sc;
+            qf[4] = t1.x * sc, qf[5] = t1.y * sc, qf[6] = t1.z * sc, qf[7] = t1.w * sc;
+        }
+        f32x4 sacc[MAXT];
+        float mx = -INFINITY;
+        auto score_tile = [&](int kt, f32x4 &sa) __attribute__((always_inline)) {
+            const int key = kt * 16 + lq;
+            const float *kr = Ks + key * HD;
+            const int sw = (key & 7) ^ ((key >> 3) & 1);
+            const float4 k0 = *reinterpret_cast<const float4 *>(kr + (((2 * gq) ^ sw) << 2));
+            const float4 k1 = *reinterpret_cast<const float4 *>(kr + (((2 * gq + 1) ^ sw) << 2));
+            sa = {0.f, 0.f, 0.f, 0.f};
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.x, qf[0], sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.y, qf[1], sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.z, qf[2], sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.w, qf[3], sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.x, qf[4], sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.y, qf[5], sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.z, qf[6], sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.w, qf[7], sa, 0, 0, 0);
+        };
+        auto mask_tile = [&](int kt, unsigned int pm, f32x4 &sa) __attribute__((always_inline)) {
+            if (pm == 0u && kt < qb) {
+                mx = fmaxf(fmaxf(mx, sa[0]), fmaxf(sa[1], fmaxf(sa[2], sa[3])));
+            } else {
+                const unsigned int pmk = pm >> (4 * gq);
+                const int qlim = (kt < qb) ? 64 : lq - 4 * gq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = !((pmk >> r) & 1u) && (r <= qlim);
+                    const float v = ok ? sa[r] : -INFINITY;
+                    sa[r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        };
+        unsigned int live = 0;
+        if (FAST) {
+            const int pq_pair = pq >= 0 ? pq >> 5 : -1;
+            auto pad_fix = [&](int kt, f32x4 &sa) __attribute__((always_inline)) {
+                if ((pq >> 4) == kt) {
+                    const bool mine_ = ((pq >> 2) & 3) == gq;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sa[r] = (mine_ && (pq & 3) == r) ? -INFINITY : sa[r];
+                }
+            };
+            const unsigned int pm_diag = (padbits[qb >> 1] >> (16 * (qb & 1))) & 0xFFFFu;
+#pragma unroll
+            for (int kg = 0; kg < MAXT / 4; ++kg) {
+                if (4 * kg <= qb) {
+#pragma unroll
+                    for (int kp = 2 * kg; kp < 2 * kg + 2; ++kp) {
+                        const int k0t = 2 * kp, k1t = 2 * kp + 1;
+                        if (k1t <= qb) {
+                            score_tile(k0t, sacc[k0t]);
+                            score_tile(k1t, sacc[k1t]);
+                            if (kp == pq_pair) {
+                                pad_fix(k0t, sacc[k0t]);
+                                if (k1t < qb) pad_fix(k1t, sacc[k1t]);
+                            }
+                            mx = fmaxf(fmaxf(mx, sacc[k0t][0]), fmaxf(sacc[k0t][1], fmaxf(sacc[k0t][2], sacc[k0t][3])));
+                            if (k1t < qb) mx = fmaxf(fmaxf(mx, sacc[k1t][0]), fmaxf(sacc[k1t][1], fmaxf(sacc[k1t][2], sacc[k1t][3])));
+                            else mask_tile(k1t, pm_diag, sacc[k1t]);
+                        } else if (k0t == qb) {
+                            score_tile(k0t, sacc[k0t]);
+                            mask_tile(k0t, pm_diag, sacc[k0t]);
+                        }
+                    }
+                }
+            }
+            live = (2u << qb) - 1u;
+        } else {
+#pragma unroll
+            for (int kp = 0; kp < MAXT / 2; ++kp) {
+                const int k0t = 2 * kp, k1t = 2 * kp + 1;
+                const unsigned int pw = (k0t <= qb) ? padbits[kp] : 0xFFFFFFFFu;
+                const unsigned int pm0 = pw & 0xFFFFu, pm1 = pw >> 16;
+                const bool do0 = pm0 != 0xFFFFu, do1 = (k1t <= qb) && pm1 != 0xFFFFu;
+                if (do0) {
+                    score_tile(k0t, sacc[k0t]);
+                    mask_tile(k0t, pm0, sacc[k0t]);
+                    live |= 1u << k0t;
+                }
+                if (do1) {
+                    score_tile(k1t, sacc[k1t]);
+                    mask_tile(k1t, pm1, sacc[k1t]);
+                    live |= 2u << k0t;
+                }
+            }
+        }
+        // ---- the IRN target column (key L-1, +1.0, visible to every query): float32 arithmetic on the summed planes
+        float st = -INFINITY;
+        float vt[8]; // V[L-1][16 ct + 4 gq + r], ct = 0, 1
+        if (tgt_ok) {
+            const int jt = L - 1;
+            const float *kr = Ks + jt * HD;
+            const int sw = (jt & 7) ^ ((jt >> 3) & 1);
+            const float4 k0 = *reinterpret_cast<const float4 *>(kr + (((2 * gq) ^ sw) << 2));
+            const float4 k1 = *reinterpret_cast<const float4 *>(kr + (((2 * gq + 1) ^ sw) << 2));
+            float part = qf[0] * k0.x;
+            part = __fmaf_rn(qf[1], k0.y, part);
+            part = __fmaf_rn(qf[2], k0.z, part);
+            part = __fmaf_rn(qf[3], k0.w, part);
+            part = __fmaf_rn(qf[4], k1.x, part);
+            part = __fmaf_rn(qf[5], k1.y, part);
+            part = __fmaf_rn(qf[6], k1.z, part);
+            part = __fmaf_rn(qf[7], k1.w, part);
+            st = quad16_sum(part) + tgt_add;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) { // columns 16 ct + 4 gq .. + 3: chunk 2 ct + (gq >> 1), half gq & 1
+                typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+                const char *vr = Vp + jt * 64 + ((((2 * ct + (gq >> 1)) ^ (((jt >> 2) & 1) << 1))) << 4) + 8 * (gq & 1);
+                const f16x4 b0 = *reinterpret_cast<const f16x4 *>(vr), b1 = *reinterpret_cast<const f16x4 *>(vr + PL);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vt[4 * ct + r] = (float)b0[r] + (float)b1[r];
+            }
+        }
+        mx = quad16_max(mx);
+        float m = fmaxf(mx, st);
+        if (m == -INFINITY) m = 0.f;
+        // ---- pass 2: p = exp2(s - m); O^T += V^T P^T, one 32-key MFMA step per pair of tiles
+        float l = 0.f;
+        f32x4 o[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[i][ct][r] = 0.f;
+        float ot[8]; // the target column's contribution (float32, added at the end)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ot[e] = 0.f;
+        if (tgt_ok) {
+            const float pt = __builtin_amdgcn_exp2f(st - m);
+            l = (gq == 0) ? pt : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ot[e] = pt * vt[e];
+        }
+#pragma unroll
+        for (int kp = 0; kp < MAXT / 2; ++kp) {
+            const int k0t = 2 * kp, k1t = 2 * kp + 1;
+            const bool on0 = FAST ? (k0t <= qb) : (((live >> k0t) & 1u) != 0u);
+            const bool on1 = FAST ? (k1t <= qb) : (((live >> k1t) & 1u) != 0u);
+            if (on0 || on1) { // wave-uniform
+                float pa[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pa[r] = on0 ? __builtin_amdgcn_exp2f(sacc[k0t][r] - m) : 0.f;
+                    pa[4 + r] = on1 ? __builtin_amdgcn_exp2f(sacc[k1t][r] - m) : 0.f;
+                    l += pa[r] + pa[4 + r];
+                }
+                x6_f16x8 P[2];
+                attn_split8h(pa, P);
+                const int r0 = k0t * 16 + 4 * gq + tq, r1 = r0 + 16;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const int o0 = r0 * 64 + ((((2 * ct + (tp >> 1)) ^ (((r0 >> 2) & 1) << 1))) << 4) + 8 * (tp & 1);
+                    const int o1 = r1 * 64 + ((((2 * ct + (tp >> 1)) ^ (((r1 >> 2) & 1) << 1))) << 4) + 8 * (tp & 1);
+                    x6_f16x8 V[2];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const attn_s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) attn_s16x4 *)(Vp + p * PL + o0));
+                        attn_s16x4 a1 = {0, 0, 0, 0}; // (wave-uniform: a pair whose second tile does not exist reads nothing past the image)
+                        if (on1) a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) attn_s16x4 *)(Vp + p * PL + o1));
+                        typedef __attribute__((ext_vector_type(8))) short s16x8;
+                        const s16x8 both = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                        V[p] = __builtin_bit_cast(x6_f16x8, both);
+                    }
+                    f32x4 oo = o[kp & 1][ct];
+                    oo = __builtin_amdgcn_mfma_f32_16x16x32_f16(V[0], P[1], oo, 0, 0, 0);
+                    oo = __builtin_amdgcn_mfma_f32_16x16x32_f16(V[1], P[0], oo, 0, 0, 0);
+                    oo = __builtin_amdgcn_mfma_f32_16x16x32_f16(V[0], P[0], oo, 0, 0, 0);
+                    o[kp & 1][ct] = oo;
+                }
+            }
+        }
+        const float lt = quad16_sum(l);
+        const float inv = 1.0f / lt;
+        if (qi < L) {
+            if (out_frag) {
+                const int64_t tk = base + qi;
+                float4 *of = reinterpret_cast<float4 *>(out) + ((size_t)(tk >> 5) * gridDim.x + h) * 4 * 64 + (gq & 1) * 32 + (tk & 31);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    of[(2 * ct + (gq >> 1)) * 64] =
+                        make_float4(((o[0][ct][0] + o[1][ct][0]) + ot[4 * ct + 0]) * inv, ((o[0][ct][1] + o[1][ct][1]) + ot[4 * ct + 1]) * inv,
+                                    ((o[0][ct][2] + o[1][ct][2]) + ot[4 * ct + 2]) * inv, ((o[0][ct][3] + o[1][ct][3]) + ot[4 * ct + 3]) * inv);
+            } else {
+                float *orow = out + (base + qi) * d + h * HD + 4 * gq;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    *reinterpret_cast<float4 *>(orow + 16 * ct) =
+                        make_float4(((o[0][ct][0] + o[1][ct][0]) + ot[4 * ct + 0]) * inv, ((o[0][ct][1] + o[1][ct][1]) + ot[4 * ct + 1]) * inv,
+                                    ((o[0][ct][2] + o[1][ct][2]) + ot[4 * ct + 2]) * inv, ((o[0][ct][3] + o[1][ct][3]) + ot[4 * ct + 3]) * inv);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ single-query attention (last layer, rows-only decode)
 // Only row pos[b] of the last layer is consumed by the scoring step (the reference computes all L
 // rows and uses output[index][history_end_pos], influentialRS.py:374,421).  One wave per (sequence,
@@ -4700,7 +5048,7 @@ static bool attn_persist_ok(const irs_ctx *ctx, int B) {
 static int g_attn_persist = 1; // (lab switch; the context's attn_persist decides in the product)
 static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const float *r_u, float *out, int B,
                        hipStream_t s, const int32_t *off = nullptr, const int32_t *cnt = nullptr,
-                       const int32_t *tok_row = nullptr, bool frag_out = false, int layer = -1) {
+                       const int32_t *tok_row = nullptr, bool frag_out = false, int layer = -1, bool kv_planes = false) {
     const int L = ctx->dims.max_len, d = ctx->dims.d, H = ctx->dims.n_heads, hd = d / H;
     const int HDP = hd <= 8 ? 8 : hd <= 16 ? 16 : hd <= 32 ? 32 : 64;
     const int Lp = ((L + 31) / 32) * 32, VW = HDP < 32 ? 32 : HDP;
@@ -4720,7 +5068,15 @@ static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const
         // The same kernel on split-bf16 MFMAs: measured SLOWER than the float32-MFMA kernel on C2 (2.24 vs 1.92 ms of attention
         // per step: the plane splits of p and of K / V make it VALU-bound, 14 % MFMA busy, and its LDS images allow two
         // workgroups per CU instead of three), so it runs only on request (IRS_ATTN_GEMM=x6 when the context is created).
-        if (ctx->use_attn_x6 && grid.z == 1 && lds16x <= 160 * 1024) {
+        if (kv_planes) { // K / V arrive as float16 plane pairs (k_block_x6's tail): the split-float16 attention
+            if (grid.z != 1) IRS_FAIL(ctx, IRS_E_STATE, "plane-format K / V on the latency path");
+            if (tok_row)
+                hipLaunchKernelGGL((k_attn16h<16, true, 4>), grid, dim3(256), lds16d, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
+                                   ctx->seq_padq, frag_out ? 1 : 0);
+            else
+                hipLaunchKernelGGL((k_attn16h<16, false, 4>), grid, dim3(256), lds16d, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
+                                   nullptr, frag_out ? 1 : 0);
+        } else if (ctx->use_attn_x6 && grid.z == 1 && lds16x <= 160 * 1024) {
             IRS_ONCE_PER_DEVICE({
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn16x<16, true, ATTN16X_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn16x<16, false, ATTN16X_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -4954,6 +5310,9 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     const bool x6d = d == 256 && F == 256 && ctx->use_x6 && ctx->w_x6 && rows_only && rows >= x6d_min_rows && ctx->dims.n_layers > 1 &&
                      attn16_ok(ctx, ctx->act_qkv, ctx->act_yf);
     const bool x6d_small = x6d && rows < 32768;
+    // the split-precision layer kernels hand K / V to the attention as float16 plane pairs (k_attn16h) unless switched off
+    const bool kv_planes = ctx->use_attn_h3 && ctx->use_x6 && ctx->w_x6 && (d == 128 || x6d) && F == 256 && ctx->dims.n_layers > 1 &&
+                           !x6d_small && rows * (long long)ctx->dims.n_heads > 64 * (long long)L; // (not the z-split latency grid)
     // d = 256 below the throughput regime (C5's 32 beam windows, single users): the 16-token fused layer kernel for wide
     // models (k_block_small_wide) instead of ~8 per-GEMM launches per layer
     const bool wide_cfg = small_wide_shape(d, F) && ctx->w_frag16 && !x6d && rows < 32768;
@@ -5000,6 +5359,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             xa.Wx = x6_stream(ctx, npl, ctx->dims.n_layers - 1);
             xa.bin = ctx->layer[0].sa_in_b, xa.Xf = xf, xa.QKV = ctx->act_qkv, xa.M = rows, xa.m_dev = m_dev;
             xa.seq = seq, xa.E = ctx->item_emb, xa.pe = ctx->pe, xa.tok_row = tok, xa.L = L, xa.sqrtd = sqrtf((float)d), xa.n_item = ctx->dims.n_item;
+            xa.kv_planes = kv_planes ? 1 : 0;
             x6_launch(0, true, x6d ? 8 : 4, npl, x6d_small, rows, xa, s);
         } else
         hipLaunchKernelGGL(k_embed_qkv, dim3((rows + 127) / 128), dim3(256), 0, s, ea);
@@ -5137,7 +5497,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         const bool fuse_block = frag && (d == 128 || x6d) && F == 256 && attn16_ok(ctx, ctx->act_qkv, yf);
         if (!att_fused &&
             (rc = launch_attn(ctx, ctx->act_qkv, seq, ctx->act_ru, fuse_block ? yf : ctx->act_ao, B, s, off, cnt, tok, fuse_block,
-                              rows_only && !small_plan ? l : -1)))
+                              rows_only && !small_plan ? l : -1, kv_planes && fuse_block && ctx->use_x6 && ctx->w_x6)))
             return rc;
         if (frag) {
             const bool last = l + 1 == ctx->dims.n_layers;
@@ -5161,6 +5521,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                     const int npl = (ctx->use_x6 == IRS_GEMM_H3 && !x6d_small) ? 2 : 3;
                     BlockX6Args xa{yf, xf, x6_stream(ctx, npl, l), w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b,
                                    w.l1_b, w.l2_b, w.n3_w, w.n3_b, ctx->layer[l + 1].sa_in_b, xf, ctx->act_qkv, rows, m_dev, kv_only ? 1 : 0};
+                    xa.kv_planes = kv_planes ? 1 : 0;
                     x6_launch(kv_only ? 1 : 0, false, x6d ? 8 : 4, npl, x6d_small, rows, xa, s);
                 } else if (x6d) IRS_FAIL(ctx, IRS_E_STATE, "d = 256 fused layer kernel without a successor layer");
                 else if (tail) hipLaunchKernelGGL((k_block<true, true>), dim3((rows + 127) / 128), dim3(256), 0, s, ba);

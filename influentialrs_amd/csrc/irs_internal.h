@@ -85,6 +85,7 @@ struct irs_ctx {
     uint4 *w_x6;      // split-bf16 step streams of the fused layer kernel k_block_x6 ([n_layers - 1] x 768 KB), or null
     int use_x6;       // decoder GEMMs of the throughput path on split-bf16 MFMAs (IRS_DECODER_GEMM=x6|f32)
     int use_attn_x6;  // head-dim-32 attention of the throughput path on split-bf16 MFMAs (IRS_ATTN_GEMM=x6; default off: slower)
+    int use_attn_h3;  // throughput attention on split-float16 MFMAs over K / V planes written by the layer kernel (default on; IRS_ATTN_GEMM=f32 off)
     int attn_persist; // packed throughput attention as a resident grid over a length-sorted work list (IRS_ATTN_PERSIST=1; default off:
                       // faster on short sequences only -- 94 vs 116 us at 40 tokens, 352 vs 285 at 110 -- profiles/r04/README.md)
     int lse_no_ring;  // IRS_LSE_RING=0: the register-fragment log-sum-exp kernel at <= 32 rows too (A/B measurements, tests)

@@ -11,6 +11,20 @@ void irs_prof_begin(irs_ctx *, int, hipStream_t) {}
 void irs_prof_end(irs_ctx *, int, hipStream_t, double, double) {}
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
 
+// K and V sections of q | k | v rows -> float16 plane pairs per (token, head) (what k_block_x6's tail writes with kv_planes)
+__global__ void k_lab_to_planes(const float *in, float *outp, long long rows, int d) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; // one (row, section, head, channel)
+    if (i >= rows * 2 * d) return;
+    const long long row = i / (2 * d);
+    const int rem = (int)(i % (2 * d)), sec = rem / d, c = rem % d, head = c / 32, ch = c % 32;
+    if (sec == 0) return; // (K stays float32: the scores run on the exact chain)
+    const float v = in[row * 3 * d + (1 + sec) * d + c];
+    const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
+    _Float16 *slot = reinterpret_cast<_Float16 *>(outp + row * 3 * d + (1 + sec) * d + head * 32);
+    slot[ch] = h;
+    slot[32 + ch] = l;
+}
+
 int main(int argc, char **argv) {
     setvbuf(stdout, nullptr, _IONBF, 0);
     const int B = argc > 1 ? atoi(argv[1]) : 4096, L = 200, d = 128, H = 4;
@@ -60,12 +74,33 @@ int main(int argc, char **argv) {
     for (int rep = 0; rep < 5; ++rep) {
         if (variant == 0 || variant == 2)
             timed("k_attn16<16, FAST> register fill:", [&] { hipLaunchKernelGGL((k_attn16<16, true, false>), dim3(H, B), dim3(256), lds16, 0, qkv, seq, ru, out, L, d, IRS_MASK_IRN, doff, dcnt, dpadq, 1, H); });
-        if (variant >= 1) {
+        if (variant >= 1 && variant != 4) {
             hipLaunchKernelGGL(k_plan_attn_order, dim3(1), dim3(1024), 0, 0, dcnt, B, (L + 15) & ~15, H, dorder, dtab);
             timed("k_attn16<16, FAST> persistent work list:", [&] { hipLaunchKernelGGL((k_attn16<16, true, true, 4, true>), dim3(768), dim3(256), lds16d, 0, qkv, seq, ru, out3, L, d, IRS_MASK_IRN, doff, dcnt, dpadq, 1, H, dorder, dtab, 0); });
         }
-        if (variant >= 1)
+        if (variant >= 1 && variant != 4)
             timed("k_attn16<16, FAST> LDS-DMA fill :", [&] { hipLaunchKernelGGL((k_attn16<16, true, true>), dim3(H, B), dim3(256), lds16d, 0, qkv, seq, ru, out2, L, d, IRS_MASK_IRN, doff, dcnt, dpadq, 1, H); });
+    }
+    if (variant == 4) { // the split-float16 attention on plane-format K / V against the float32 kernel on the same values
+        float *qkvp, *out4;
+        CK(hipMalloc(&qkvp, hq.size() * 4)); CK(hipMemcpy(qkvp, qkv, hq.size() * 4, hipMemcpyDeviceToDevice));
+        CK(hipMalloc(&out4, ((size_t)M + 128) * d * 4)); CK(hipMemset(out4, 0, ((size_t)M + 128) * d * 4));
+        hipLaunchKernelGGL(k_lab_to_planes, dim3((unsigned)((M * 2 * d + 255) / 256)), dim3(256), 0, 0, qkv, qkvp, M, d);
+        for (int rep = 0; rep < 3; ++rep) {
+            timed("k_attn16<16, FAST> LDS-DMA fill, float32:", [&] { hipLaunchKernelGGL((k_attn16<16, true, true>), dim3(H, B), dim3(256), lds16d, 0, qkv, seq, ru, out2, L, d, IRS_MASK_IRN, doff, dcnt, dpadq, 1, H); });
+            timed("k_attn16h<16, FAST> split-float16 planes:", [&] { hipLaunchKernelGGL((k_attn16h<16, true, 4>), dim3(H, B), dim3(256), lds16d, 0, qkvp, seq, ru, out4, L, d, IRS_MASK_IRN, doff, dcnt, dpadq, 1); });
+        }
+        std::vector<float> h1((size_t)M * d), h2((size_t)M * d);
+        CK(hipMemcpy(h1.data(), out2, h1.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(h2.data(), out4, h2.size() * 4, hipMemcpyDeviceToHost));
+        double md = 0, sum = 0; size_t worst = 0, n4 = 0;
+        for (size_t i = 0; i < h1.size(); ++i) { const double e = fabs((double)h1[i] - h2[i]); sum += e; if (e > md) md = e, worst = i; if (e > 1e-4) ++n4; }
+        // fragment-major output: float4 index ((tile * H + head) * 4 + g) * 64 + lane -> token = tile * 32 + (lane & 31)
+        const size_t f4 = worst / 4, lane_ = f4 % 64, tile_ = f4 / (64 * 4 * H), head_ = (f4 / (64 * 4)) % H;
+        const long long tok = (long long)tile_ * 32 + (lane_ & 31);
+        int sb = 0; while (sb + 1 < B && off[sb + 1] <= tok) ++sb;
+        printf("split-float16 vs float32 attention: max %.3g  mean %.3g  values > 1e-4: %zu; worst at token %lld = sequence %d (length %d) position %lld head %zu: %g vs %g\n",
+               md, sum / h1.size(), n4, tok, sb, cnt[sb], tok - off[sb], head_, h2[worst], h1[worst]);
     }
     if (variant == 2) {
         std::vector<float> h1((size_t)M * d), h2((size_t)M * d);
