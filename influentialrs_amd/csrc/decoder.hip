@@ -1267,6 +1267,12 @@ __host__ __device__ constexpr int x6_step_b(int NPL) { return 8 * NPL * 1024; }
 __host__ __device__ constexpr size_t x6_layer_bytes(int NT, int NPL = 3) { return (size_t)x6_nstep(NT) * x6_step_b(NPL); }
 __host__ __device__ constexpr int x6_lds_bytes(int NT, int NPL = 3) { return 3 * x6_step_b(NPL) + (256 + 12 * 32 * NT) * 4; }
 typedef __attribute__((ext_vector_type(8))) _Float16 x6_f16x8;
+#ifndef X6_RING4
+#define X6_RING4 8 // fragment register sets of k_block_x6 at d = 128 (lab: 4 = rounds 3's three reads ahead)
+#endif
+#ifndef X6_SPLIT_ACC4
+#define X6_SPLIT_ACC4 1 // one-tile steps at d = 128: h.h products on their own accumulator instead of a second read of W_h
+#endif
 #ifndef X6_NW
 #define X6_NW 4 // waves per workgroup of k_block_x6 (tools/x6_lab measures both)
 #endif
@@ -1354,6 +1360,10 @@ struct BlockX6Args {
 
 // float32 accumulator tile -> the three bf16 planes of its k-step s (registers 8s .. 8s+7) as B fragments
 __device__ __forceinline__ void x6_split(const f32x16 &t, int s, x6_f16x8 (&X)[2]) { // float16 planes (NPL = 2)
+#ifdef X6_NO_SPLIT
+    for (int p = 0; p < 2; ++p) X[p] = __builtin_bit_cast(x6_f16x8, make_float4(t[8 * s + p], t[8 * s + p + 1], t[8 * s + p + 2], t[8 * s + p + 3]));
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float v = t[8 * s + j];
@@ -1569,23 +1579,25 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
 
     // fragment reads: the stream of a step is 8 groups x (plane 0, 1, 2) = 24 reads in consumption order (k_pack_x6); a
     // ring of four register sets, three reads ahead
-    x6_u32x4 af[4];
+    // (round 4: RING register sets, RA = RING - 1 reads ahead.  Four sets -- three reads = 3-6 MFMAs = 100-200 cycles ahead --
+    //  no longer cover a ds_read_b128 that queues behind seven other waves' reads once float16 planes halve the MFMAs
+    //  between two reads; eight sets at d = 128 with float16 planes, where two waves per SIMD leave the registers (236 of 256).  The ring index of a fragment
+    //  must not change across a step boundary: NP and NP + 8 are multiples of RING.)
+    constexpr int RING = (NT == 4 && NPL == 2) ? X6_RING4 : 4, RA = RING - 1;
+    constexpr bool SPLIT_ACC = NT == 4 && NPL == 2 && X6_SPLIT_ACC4; // one-tile steps: the h.h products on their own accumulator (below)
+    static_assert(NP % RING == 0 && (NP + 8) % RING == 0 && RA <= NP / 2, "ring index continuity; next-step reads stay behind the barrier");
+    x6_u32x4 af[RING];
     auto landed_all = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[q]));
+        for (int q = 0; q < RING; ++q) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[q]));
     };
-    if constexpr (NT == 8) {
-        af[0] = x6_rd_sync<(S0 % NSLOT) * STEP_B>(fr_addr);
-        af[1] = x6_rd_sync<(S0 % NSLOT) * STEP_B + 1024>(fr_addr);
-        af[2] = x6_rd_sync<(S0 % NSLOT) * STEP_B + 2048>(fr_addr);
-        af[3] = x6_rd_sync<(S0 % NSLOT) * STEP_B + 2048>(fr_addr);
-    } else {
-        af[0] = x6_rd<(S0 % NSLOT) * STEP_B>(fr_addr);
-        af[1] = x6_rd<(S0 % NSLOT) * STEP_B + 1024>(fr_addr);
-        af[2] = x6_rd<(S0 % NSLOT) * STEP_B + 2048>(fr_addr);
-        af[3] = x6_rd<(S0 % NSLOT) * STEP_B + 2048>(fr_addr); // (its own read: a register copy of af[2] would be taken before the data has landed)
-        landed_all();
-    }
+    x6_static_for<0, RING>([&](auto qc) __attribute__((always_inline)) {
+        // (the last set gets its own read of the fragment before it: a register copy would be taken before the data has landed)
+        constexpr int q = decltype(qc)::value, off = (S0 % NSLOT) * STEP_B + (q < RA ? q : RA - 1) * 1024;
+        if constexpr (NT == 8) af[q] = x6_rd_sync<off>(fr_addr);
+        else af[q] = x6_rd<off>(fr_addr);
+    });
+    if constexpr (NT != 8) landed_all();
 
     const float invn = 1.0f / (float)D;
     x6_plane X[NPL];
@@ -1602,17 +1614,17 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
 #endif
 #define X6_MFMA(Wreg, Xp, T_) X6_MM(__builtin_bit_cast(x6_plane, Wreg), X[Xp], T_)
 #ifdef X6_DUMP
-#define X6_DUMP_FRAG(I_, f_) if (blockIdx.x == 0 && wave == 0) a.dbg[((I_) * NP + (f_)) * 64 + lane] = __builtin_bit_cast(uint4, af[(f_) & 3]);
+#define X6_DUMP_FRAG(I_, f_) if (blockIdx.x == 0 && wave == 0) a.dbg[((I_) * NP + (f_)) * 64 + lane] = __builtin_bit_cast(uint4, af[(f_) & RA]);
 #else
 #define X6_DUMP_FRAG(I_, f_)
 #endif
 #ifdef X6_NO_READS
-#define X6_READ_AHEAD(f_) asm volatile("" : "+v"(af[(f_) & 3]));
+#define X6_READ_AHEAD(f_) asm volatile("" : "+v"(af[(f_) & RA]));
 #else
 #define X6_READ_AHEAD(f_)                                                                                                \
-    if constexpr ((f_) + 3 < NP) af[((f_) + 3) & 3] = x6_rd<((f_) + 3) * 1024>(sb_);                                     \
-    else af[((f_) + 3) & 3] = x6_rd<((f_) + 3 - NP) * 1024>(sn_); /* next step's head (behind this step's barrier) */    \
-    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(af[(f_) & 3]));                                                           \
+    if constexpr ((f_) + RA < NP) af[((f_) + RA) & RA] = x6_rd<((f_) + RA) * 1024>(sb_);                                 \
+    else af[((f_) + RA) & RA] = x6_rd<((f_) + RA - NP) * 1024>(sn_); /* next step's head (behind this step's barrier) */ \
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af[(f_) & RA]) : "i"(RA));                                               \
     X6_DUMP_FRAG(step_, f_)
 #endif
 #ifdef X6_NO_DMA
@@ -1653,7 +1665,7 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
             f32x16 &T_ = (g_ & 3) == 0 ? T0 : (g_ & 3) == 1 ? T1 : (g_ & 3) == 2 ? T2 : T3;                              \
             /* weight plane pl_ x activation planes NPL - 1 - pl_ .. 0 (the products up to the dropped order), small first */ \
             x6_static_for<0, NPL - pl_>([&](auto qc_) __attribute__((always_inline)) {                                   \
-                X6_MFMA(af[f_ & 3], NPL - 1 - pl_ - decltype(qc_)::value, T_);                                           \
+                X6_MFMA(af[f_ & RA], NPL - 1 - pl_ - decltype(qc_)::value, T_);                                           \
             });                                                                                                          \
         });                                                                                                              \
         X6_T(sq_1)                                                                                                       \
@@ -1743,7 +1755,8 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
         x6_u32x4 bq[4];
         const unsigned int ba_ = vecs_addr + (unsigned int)(vo * 4);
         bq[0] = x6_rd<0>(ba_), bq[1] = x6_rd<32>(ba_), bq[2] = x6_rd<64>(ba_), bq[3] = x6_rd<96>(ba_);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
+        landed_all();
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 bb = __builtin_bit_cast(float4, bq[g]);
@@ -1756,15 +1769,21 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
     // into the zero-started accumulator, where they and their truncation are 2^-8 of the result, and the 8 h.h products
     // last: 8 full-size truncations per output instead of 48 (the W_h fragments are read from the slot a second time: the
     // step's virtual read sequence is its 24 fragments, then fragments 0, 3, .., 21 again).
+    // (round 4, SPLIT_ACC at d = 128: instead of the second read of the W_h fragments the h.h products run on the step's
+    //  accumulator and the small products on a zero-started second one, added once at the end of the step -- the same eight
+    //  full-size truncations per output, a third fewer LDS reads in these steps (with float16 planes a one-tile step was 24
+    //  reads for 24 MFMAs: every wave of the CU asking the LDS pipe for 1 KB per 32 matrix cycles is the pipe's whole
+    //  bandwidth), and two independent MFMA chains instead of one.)
+    constexpr int NV = SPLIT_ACC ? NP : NP + 8; // fragment reads of a one-tile step
 #ifdef X6_NO_READS
 #define X6_RD_V(v_)
-#define X6_WAIT_V(v_) asm volatile("" : "+v"(af[(v_) & 3]));
+#define X6_WAIT_V(v_) asm volatile("" : "+v"(af[(v_) & RA]));
 #else
 #define X6_RD_V(v_)                                                                                                      \
-    if constexpr ((v_) < NP) af[(v_) & 3] = x6_rd<(v_) * 1024>(sb_);                                                     \
-    else if constexpr ((v_) < NP + 8) af[(v_) & 3] = x6_rd<NPL * ((v_) - NP) * 1024>(sb_);                               \
-    else af[(v_) & 3] = x6_rd<((v_) - NP - 8) * 1024>(sn_); /* next step's head (behind this step's barrier) */
-#define X6_WAIT_V(v_) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(af[(v_) & 3]));
+    if constexpr ((v_) < NP) af[(v_) & RA] = x6_rd<(v_) * 1024>(sb_);                                                    \
+    else if constexpr ((v_) < NV) af[(v_) & RA] = x6_rd<NPL * ((v_) - NP) * 1024>(sb_);                                  \
+    else af[(v_) & RA] = x6_rd<((v_) - NV) * 1024>(sn_); /* next step's head (behind this step's barrier) */
+#define X6_WAIT_V(v_) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af[(v_) & RA]) : "i"(RA));
 #endif
 #define X6_STEP1(I_, XP_, T_)                                                                                            \
     {                                                                                                                    \
@@ -1773,25 +1792,35 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
         X6_T(sq_0)                                                                                                       \
         const unsigned int sb_ = fr_addr + (unsigned int)((step_ % NSLOT) * STEP_B);                                     \
         const unsigned int sn_ = fr_addr + (unsigned int)(((step_ + 1) % NSLOT) * STEP_B);                               \
-        x6_static_for<0, NP + 8>([&](auto vc_) __attribute__((always_inline)) {                                          \
+        f32x16 ts_;                                                                                                      \
+        if constexpr (SPLIT_ACC) {                                                                                       \
+            _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) ts_[r_] = 0.f;                                             \
+        }                                                                                                                \
+        x6_static_for<0, NV>([&](auto vc_) __attribute__((always_inline)) {                                              \
             constexpr int v_ = decltype(vc_)::value;                                                                     \
-            if constexpr (v_ == (NP + 8) / 2) { X6_PUBLISH(step_) }                                                      \
-            X6_RD_V(v_ + 3)                                                                                              \
+            if constexpr (v_ == NV / 2) { X6_PUBLISH(step_) }                                                            \
+            X6_RD_V(v_ + RA)                                                                                             \
             X6_WAIT_V(v_)                                                                                                \
-            const x6_plane w_ = __builtin_bit_cast(x6_plane, af[v_ & 3]);                                                \
+            const x6_plane w_ = __builtin_bit_cast(x6_plane, af[v_ & RA]);                                               \
             if constexpr (v_ < NP) {                                                                                     \
                 constexpr int g_ = v_ / NPL, pl_ = v_ % NPL;                                                             \
                 X6_DUMP_FRAG(step_, v_)                                                                                  \
                 /* the small products of weight plane pl_: activation planes NPL - 1 - pl_ .. (the h.h product waits) */ \
                 x6_static_for<0, NPL - pl_>([&](auto qc_) __attribute__((always_inline)) {                               \
                     constexpr int xp_ = NPL - 1 - pl_ - decltype(qc_)::value;                                            \
-                    if constexpr (pl_ > 0 || xp_ > 0) X6_MM(w_, XP_[g_ >> 1][g_ & 1][xp_], T_);                          \
+                    if constexpr (pl_ > 0 || xp_ > 0) {                                                                  \
+                        if constexpr (SPLIT_ACC) { X6_MM(w_, XP_[g_ >> 1][g_ & 1][xp_], ts_); }                          \
+                        else { X6_MM(w_, XP_[g_ >> 1][g_ & 1][xp_], T_); }                                               \
+                    } else if constexpr (SPLIT_ACC) { X6_MM(w_, XP_[g_ >> 1][g_ & 1][0], T_); }                          \
                 });                                                                                                      \
             } else {                                                                                                     \
                 constexpr int g_ = v_ - NP;                                                                              \
                 X6_MM(w_, XP_[g_ >> 1][g_ & 1][0], T_);                                                                  \
             }                                                                                                            \
         });                                                                                                              \
+        if constexpr (SPLIT_ACC) {                                                                                       \
+            _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) T_[r_] += ts_[r_];                                         \
+        }                                                                                                                \
         X6_T(sq_1)                                                                                                       \
         st_steps += sq_1 - sq_0;                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                               \

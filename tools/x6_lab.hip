@@ -8,6 +8,11 @@
 #include "../influentialrs_amd/csrc/decoder.hip"
 void irs_prof_begin(irs_ctx *, int, hipStream_t) {}
 void irs_prof_end(irs_ctx *, int, hipStream_t, double, double) {}
+#ifndef X6_LAB_NPL
+#define X6_LAB_NPL 3 // planes per float32 operand: 3 = bf16 (x6), 2 = float16 (h3)
+#endif
+constexpr int LNPL = X6_LAB_NPL;
+constexpr size_t LAB_LAYER_B = x6_layer_bytes(4, LNPL);
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
 
 static float *dev_rand(size_t n, float scale, unsigned long long &z, float offset = 0.f) {
@@ -42,8 +47,8 @@ int main(int argc, char **argv) {
         CK(hipMemset(QKV[i], 0, (size_t)M * 3 * D * 4));
     }
     uint4 *Wx;
-    CK(hipMalloc(&Wx, X6_LAYER_BYTES));
-    hipLaunchKernelGGL(k_pack_x6<4>, dim3(X6_NSTEP * 24 * 64 / 256), dim3(256), 0, 0, Wo, W1, W2, Win, Wx);
+    CK(hipMalloc(&Wx, LAB_LAYER_B));
+    hipLaunchKernelGGL((k_pack_x6<4, LNPL>), dim3(X6_NSTEP * 8 * LNPL * 64 / 256), dim3(256), 0, 0, Wo, W1, W2, Win, Wx);
     CK(hipDeviceSynchronize());
     BlockArgs ba{};
     ba.Af = Af, ba.Rf = Rf, ba.Wo = Wo, ba.bo = bo, ba.g1 = g1, ba.b1n = b1n, ba.c = c, ba.g2 = g2, ba.b2n = b2n;
@@ -58,11 +63,11 @@ int main(int argc, char **argv) {
     CK(hipMemset(xa.stamps, 0, nwave * 64));
 #endif
 #ifdef X6_DUMP
-    CK(hipMalloc(&xa.dbg, X6_LAYER_BYTES));
-    CK(hipMemset(xa.dbg, 0xEE, X6_LAYER_BYTES));
+    CK(hipMalloc(&xa.dbg, LAB_LAYER_B));
+    CK(hipMemset(xa.dbg, 0xEE, LAB_LAYER_B));
 #endif
-    constexpr int x6_lds = 3 * X6_STEP_B + 1792 * 4;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, X6_NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds));
+    constexpr int x6_lds = x6_lds_bytes(4, LNPL);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_block_x6<0, X6_NW, false, 4, LNPL>), hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -76,7 +81,7 @@ int main(int argc, char **argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         printf("k_block<f32>  %8.1f us\n", ms * 1e3);
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((k_block_x6<0, X6_NW, false>), dim3((M + 32 * X6_NW - 1) / (32 * X6_NW)), dim3(64 * X6_NW), x6_lds, 0, xa);
+        hipLaunchKernelGGL((k_block_x6<0, X6_NW, false, 4, LNPL>), dim3((M + 32 * X6_NW - 1) / (32 * X6_NW)), dim3(64 * X6_NW), x6_lds, 0, xa);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         CK(hipGetLastError());
@@ -100,14 +105,14 @@ int main(int argc, char **argv) {
     };
 #ifdef X6_DUMP
     {
-        std::vector<unsigned> hw(X6_LAYER_BYTES / 4), hd(X6_LAYER_BYTES / 4);
-        CK(hipMemcpy(hw.data(), Wx, X6_LAYER_BYTES, hipMemcpyDeviceToHost));
-        CK(hipMemcpy(hd.data(), xa.dbg, X6_LAYER_BYTES, hipMemcpyDeviceToHost));
+        std::vector<unsigned> hw(LAB_LAYER_B / 4), hd(LAB_LAYER_B / 4);
+        CK(hipMemcpy(hw.data(), Wx, LAB_LAYER_B, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hd.data(), xa.dbg, LAB_LAYER_B, hipMemcpyDeviceToHost));
         for (int st = 0; st < X6_NSTEP; ++st) {
             printf("step %2d:", st);
-            for (int f = 0; f < 24; ++f) {
+            for (int f = 0; f < 8 * LNPL; ++f) {
                 int bad = 0;
-                for (int i = 0; i < 256; ++i) bad += hw[(st * 24 + f) * 256 + i] != hd[(st * 24 + f) * 256 + i];
+                for (int i = 0; i < 256; ++i) bad += hw[(st * 8 * LNPL + f) * 256 + i] != hd[(st * 8 * LNPL + f) * 256 + i];
                 printf(" %s", bad == 0 ? "." : bad == 256 ? "X" : "x");
             }
             printf("\n");
