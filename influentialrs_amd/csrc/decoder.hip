@@ -1265,13 +1265,22 @@ __host__ __device__ constexpr int x6_nstep(int NT) { return x6_npre(NT) + 3 * NT
 // whose ABSOLUTE spacing 2^-24 is what matters for a sum of products.  A step is 8 groups x NPL planes = 8 NPL KB.
 __host__ __device__ constexpr int x6_step_b(int NPL) { return 8 * NPL * 1024; }
 __host__ __device__ constexpr size_t x6_layer_bytes(int NT, int NPL = 3) { return (size_t)x6_nstep(NT) * x6_step_b(NPL); }
-__host__ __device__ constexpr int x6_lds_bytes(int NT, int NPL = 3) { return 3 * x6_step_b(NPL) + (256 + 12 * 32 * NT) * 4; }
+// ring slots (X6_NSLOT2 for float16 planes: their steps are 16 KB, so four fit twice per CU -- two steps of DMA in flight
+// behind the one being multiplied)
+#ifndef X6_NSLOT2
+#define X6_NSLOT2 4
+#endif
+__host__ __device__ constexpr int x6_nslot(int NPL) { return NPL == 2 ? X6_NSLOT2 : 3; }
+__host__ __device__ constexpr int x6_lds_bytes(int NT, int NPL = 3) { return x6_nslot(NPL) * x6_step_b(NPL) + (256 + 12 * 32 * NT) * 4; }
 typedef __attribute__((ext_vector_type(8))) _Float16 x6_f16x8;
+#ifndef X6_RESID_LATE
+#define X6_RESID_LATE 1
+#endif
 #ifndef X6_RING4
-#define X6_RING4 8 // fragment register sets of k_block_x6 at d = 128 (lab: 4 = rounds 3's three reads ahead)
+#define X6_RING4 4 // fragment register sets of k_block_x6 at d = 128, float16 planes (lab: 8 measured no faster, 16 more registers)
 #endif
 #ifndef X6_SPLIT_ACC4
-#define X6_SPLIT_ACC4 1 // one-tile steps at d = 128: h.h products on their own accumulator instead of a second read of W_h
+#define X6_SPLIT_ACC4 0 // one-tile steps at d = 128: 1 = h.h products on their own accumulator instead of a second read of W_h (lab: no faster, 16 more registers)
 #endif
 #ifndef X6_NW
 #define X6_NW 4 // waves per workgroup of k_block_x6 (tools/x6_lab measures both)
@@ -1440,7 +1449,16 @@ template <int QP0, int NW, bool EMBED, int NT = 4, int NPL = 3>
 __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Args a) {
     constexpr int NP = 8 * NPL, STEP_B = x6_step_b(NPL); // pieces (fragments) and bytes of a step
     using x6_plane = typename std::conditional<NPL == 2, x6_f16x8, x6_bf16x8>::type;
-    constexpr int D = 32 * NT, F = 256, NSLOT = 3, PPW = NP / NW, HT = NT / 4;
+    constexpr int D = 32 * NT, F = 256, NSLOT = x6_nslot(NPL), LEAD = NSLOT - 1, PPW = NP / NW, HT = NT / 4;
+    // RESID_LATE (round 4, d = 128 with float16 planes): the workgroup's start no longer waits for its 128 KB of inputs.  The
+    // first three steps' DMA goes out FIRST, then the attention tiles; the residual goes to its OWN tiles, requested behind the
+    // second step's barrier (when two attention tiles are dead: all three sets at once spill) and added with b_o in front of
+    // LayerNorm 1 -- the out-projection accumulates from zero.  The start barrier waits for step 0's pieces only: vector memory
+    // operations retire in order, so "all but the newest 8 + 16" is exactly that, and the first four steps' counted waits
+    // allow one tile set beside the newest DMA group; the compiler's own waits bring each attention tile in when its step
+    // splits it.  (tools/x6_lab stamps: the start was 16.8 K of a wave's 100 K cycles.)
+    constexpr bool RESID_LATE = X6_RESID_LATE && NPL == 2 && NT == 4 && !EMBED && NSLOT == 4 && NW == 4;
+    constexpr int NLOAD = 4 * NT; // plain global loads of one set of a wave's input tiles (attention output; residual)
     constexpr int NPRE = x6_npre(NT), NOUT = NT * HT;
     constexpr int S0 = EMBED ? NPRE : 0; // first step of the sequence
     constexpr int V_B1 = 0, V_B2 = F, V_G = F + D, V_B = F + 2 * D, V_BIN = F + 3 * D, V_O = F + 3 * D + 3 * D;
@@ -1529,16 +1547,25 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
     f32x16 acc[NT];
     f32x16 at[NT]; // attention output tiles (B operand source of the out-projection): all requested here, so that
                    // the steps carry no plain global load (its wait would be a vmcnt(0) behind the DMA pieces)
+    f32x16 res[RESID_LATE ? NT : 1]; // (RESID_LATE) the residual, added in front of LayerNorm 1
     if constexpr (!EMBED) {
         const float4 *rfrag = reinterpret_cast<const float4 *>(a.Rf) + fbase;
         const float4 *afrag = reinterpret_cast<const float4 *>(a.Af) + fbase;
+        if constexpr (RESID_LATE) {
+            // (compiler barriers: exactly the 2 x 16 tile loads lie between the DMA issue and the counted wait below)
+            asm volatile("" ::: "memory");
+            x6_static_for<0, LEAD>([&](auto ic) __attribute__((always_inline)) { issue(S0 + decltype(ic)::value); });
+            asm volatile("" ::: "memory");
+        }
+        if constexpr (!RESID_LATE) {
 #pragma unroll
-        for (int tn = 0; tn < NT; ++tn)
+            for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 t4 = rfrag[(tn * 4 + g) * 64];
-                acc[tn][4 * g + 0] = t4.x, acc[tn][4 * g + 1] = t4.y, acc[tn][4 * g + 2] = t4.z, acc[tn][4 * g + 3] = t4.w;
-            }
+                for (int g = 0; g < 4; ++g) {
+                    const float4 t4 = rfrag[(tn * 4 + g) * 64];
+                    acc[tn][4 * g + 0] = t4.x, acc[tn][4 * g + 1] = t4.y, acc[tn][4 * g + 2] = t4.z, acc[tn][4 * g + 3] = t4.w;
+                }
+        }
 #pragma unroll
         for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
@@ -1546,6 +1573,12 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
                 const float4 t4 = afrag[(tn * 4 + g) * 64];
                 at[tn][4 * g + 0] = t4.x, at[tn][4 * g + 1] = t4.y, at[tn][4 * g + 2] = t4.z, at[tn][4 * g + 3] = t4.w;
             }
+        if constexpr (RESID_LATE) {
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tn][r] = 0.f;
+        }
     } else { // this lane's token, columns 32 tn + 8 g + 4 lk + e (k_embed_frag's arithmetic: the bits k_embed_qkv writes)
         const bool live = mt < M;
         const int orig = live ? (a.tok_row ? a.tok_row[mt] : mt) : 0;
@@ -1570,12 +1603,30 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
                 acc[tn][4 * g + 0] = v.x, acc[tn][4 * g + 1] = v.y, acc[tn][4 * g + 2] = v.z, acc[tn][4 * g + 3] = v.w;
             }
     }
-    issue(S0);
-    // everything older than this point has landed (the compiler is free to order the plain loads above around the DMA
-    // issue, so no counted wait here), the vecs stores too; the second step goes out behind the barrier
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    issue(S0 + 1);
+    auto load_res = [&]() __attribute__((always_inline)) {
+        if constexpr (RESID_LATE) {
+            const float4 *rfrag = reinterpret_cast<const float4 *>(a.Rf) + fbase;
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 t4 = rfrag[(tn * 4 + g) * 64];
+                    res[tn][4 * g + 0] = t4.x, res[tn][4 * g + 1] = t4.y, res[tn][4 * g + 2] = t4.z, res[tn][4 * g + 3] = t4.w;
+                }
+        }
+    };
+    if constexpr (RESID_LATE) {
+        // step S0's pieces have landed once at most the two later steps' pieces and the tile loads are in flight; the vecs stores too
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(PPW * (LEAD - 1) + NLOAD) : "memory");
+        __builtin_amdgcn_s_barrier();
+    } else {
+        issue(S0);
+        // everything older than this point has landed (the compiler is free to order the plain loads above around the DMA
+        // issue, so no counted wait here), the vecs stores too; the later steps go out behind the barrier
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        x6_static_for<1, LEAD>([&](auto ic) __attribute__((always_inline)) { issue(S0 + decltype(ic)::value); });
+    }
 
     // fragment reads: the stream of a step is 8 groups x (plane 0, 1, 2) = 24 reads in consumption order (k_pack_x6); a
     // ring of four register sets, three reads ahead
@@ -1633,16 +1684,23 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
 #define X6_ISSUE(i_) issue(i_)
 #endif
 #ifdef X6_NO_BARRIER
-#define X6_PUBLISH(I_) if ((I_) + 2 < nsteps) X6_ISSUE((I_) + 2);
+#define X6_PUBLISH(I_) if ((I_) + LEAD < nsteps) X6_ISSUE((I_) + LEAD);
 #else
+    // mid-step I: step I + 1 must have landed before the barrier.  With three slots that is this wave's newest DMA group
+    // (vmcnt(0)); with four, the group of step I + 2 went out behind it and may stay in flight: vector memory operations
+    // retire in order, so "all but the newest PPW" covers step I + 1 whatever plain loads or stores were issued since (they
+    // only make the wait stricter).
 #define X6_PUBLISH(I_)                                                                                                   \
     if ((I_) + 1 < nsteps) {                                                                                             \
         X6_T(st_a)                                                                                                       \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                 \
+        if (RESID_LATE && (I_) < 4) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PPW * (LEAD - 2) + NLOAD) : "memory"); /* (one tile set lies between the DMA groups) */ \
+        else if (LEAD > 2 && (I_) + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PPW * (LEAD - 2)) : "memory");      \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
         X6_T(st_b)                                                                                                       \
         __builtin_amdgcn_s_barrier();                                                                                    \
         X6_T(st_c)                                                                                                       \
-        if ((I_) + 2 < nsteps) X6_ISSUE((I_) + 2);                                                                       \
+        if ((I_) + LEAD < nsteps) X6_ISSUE((I_) + LEAD);                                                                 \
+        if constexpr (RESID_LATE) { if ((I_) == 1) load_res(); }                                                         \
         X6_T(st_d)                                                                                                       \
         st_wait += st_b - st_a, st_bar += st_c - st_b, st_iss += st_d - st_c;                                            \
     }
@@ -1683,20 +1741,61 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
             if constexpr (HT == 2) { X6_STEP(t * HT + 1, at[t], acc[4], acc[5], acc[6], acc[7]) }
         }
     }
+    // ---- the parameter vectors of the LayerNorm phases (d = 128): inline-asm LDS reads at immediate offsets from ONE base
+    // register, two or three groups ahead of their use through a small register ring with counted waits.  (Compiler-visible
+    // reads: every one waits for the DMA in flight -- the compiler cannot tell the ring from the vectors --, their 48 addresses
+    // are computed steps ahead into 48 registers, and only scheduling barriers kept the reads themselves from being hoisted.)
+    // use(gc, p0, p1, p2): group gi = 4 tn + g of the lane's 16 float4 groups; array k's float4 at vecs[Ok + 32 tn + 8 g + 4 lk].
+    auto vec_stream = [&](auto na_c, auto o0_c, auto o1_c, auto o2_c, auto &&use) __attribute__((always_inline)) {
+        constexpr int NA = decltype(na_c)::value, O0 = decltype(o0_c)::value, O1 = decltype(o1_c)::value, O2 = decltype(o2_c)::value;
+        constexpr int NG = 4 * NT, AH = NA == 1 ? 3 : 2, RG = AH + 1;
+        x6_u32x4 pr[RG][NA];
+        auto rd = [&](auto gc) __attribute__((always_inline)) {
+            constexpr int gi = decltype(gc)::value, goff = ((gi >> 2) * 32 + (gi & 3) * 8) * 4;
+            pr[gi % RG][0] = x6_rd<O0 * 4 + goff>(vecs_addr);
+            if constexpr (NA > 1) pr[gi % RG][1] = x6_rd<O1 * 4 + goff>(vecs_addr);
+            if constexpr (NA > 2) pr[gi % RG][2] = x6_rd<O2 * 4 + goff>(vecs_addr);
+        };
+        x6_static_for<0, AH>(rd);
+        x6_static_for<0, NG>([&](auto gc) __attribute__((always_inline)) {
+            constexpr int gi = decltype(gc)::value, newer = NA * (gi + AH < NG ? AH : NG - 1 - gi);
+            if constexpr (gi + AH < NG) rd(std::integral_constant<int, gi + AH>{});
+            if constexpr (NA == 1) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(pr[gi % RG][0]) : "i"(newer));
+            if constexpr (NA == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(pr[gi % RG][0]), "+v"(pr[gi % RG][1]) : "i"(newer));
+            if constexpr (NA == 3) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(pr[gi % RG][0]), "+v"(pr[gi % RG][1]), "+v"(pr[gi % RG][2]) : "i"(newer));
+            use(gc, __builtin_bit_cast(float4, pr[gi % RG][0]), __builtin_bit_cast(float4, pr[gi % RG][NA > 1 ? 1 : 0]),
+                __builtin_bit_cast(float4, pr[gi % RG][NA > 2 ? 2 : 0]));
+        });
+    };
+    constexpr bool ASM_VECS = NT == 4;
+    using x6_ic0 = std::integral_constant<int, 0>;
     // ---- + b_o, LN1, + c, LN2: register-local (64 of the 128 values here, 64 in lane ^ 32)
-    auto layer_norm = [&](int vb, int vg, int vbeta, int vadd) __attribute__((always_inline)) {
+    auto layer_norm = [&](auto vb_c, auto vg_c, auto vbeta_c, auto vadd_c) __attribute__((always_inline)) {
+        constexpr int vb = decltype(vb_c)::value, vg = decltype(vg_c)::value, vbeta = decltype(vbeta_c)::value, vadd = decltype(vadd_c)::value;
         float sum = 0.f;
-#pragma unroll
-        for (int tn = 0; tn < NT; ++tn)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (vb >= 0) {
-                    const float4 bb = *reinterpret_cast<const float4 *>(vecs + vb + tn * 32 + 8 * g + 4 * lk);
-                    acc[tn][4 * g + 0] += bb.x, acc[tn][4 * g + 1] += bb.y, acc[tn][4 * g + 2] += bb.z, acc[tn][4 * g + 3] += bb.w;
+        if constexpr (ASM_VECS && vb >= 0) {
+            vec_stream(std::integral_constant<int, 1>{}, vb_c, x6_ic0{}, x6_ic0{}, [&](auto gc, const float4 bb, const float4, const float4) __attribute__((always_inline)) {
+                constexpr int tn = decltype(gc)::value >> 2, g = decltype(gc)::value & 3;
+                if constexpr (RESID_LATE) {
+                    acc[tn][4 * g + 0] += res[tn][4 * g + 0], acc[tn][4 * g + 1] += res[tn][4 * g + 1];
+                    acc[tn][4 * g + 2] += res[tn][4 * g + 2], acc[tn][4 * g + 3] += res[tn][4 * g + 3];
                 }
+                acc[tn][4 * g + 0] += bb.x, acc[tn][4 * g + 1] += bb.y, acc[tn][4 * g + 2] += bb.z, acc[tn][4 * g + 3] += bb.w;
                 sum += (acc[tn][4 * g + 0] + acc[tn][4 * g + 1]) + (acc[tn][4 * g + 2] + acc[tn][4 * g + 3]);
-                __builtin_amdgcn_sched_barrier(0); // (the scheduler otherwise hoists every parameter read of the phase: ~480 registers)
-            }
+            });
+        } else {
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if constexpr (vb >= 0) {
+                        const float4 bb = *reinterpret_cast<const float4 *>(vecs + vb + tn * 32 + 8 * g + 4 * lk);
+                        acc[tn][4 * g + 0] += bb.x, acc[tn][4 * g + 1] += bb.y, acc[tn][4 * g + 2] += bb.z, acc[tn][4 * g + 3] += bb.w;
+                    }
+                    sum += (acc[tn][4 * g + 0] + acc[tn][4 * g + 1]) + (acc[tn][4 * g + 2] + acc[tn][4 * g + 3]);
+                    if constexpr (!ASM_VECS) __builtin_amdgcn_sched_barrier(0); // (the scheduler otherwise hoists every parameter read of the phase: ~480 registers)
+                }
+        }
         const float mu = lanes_sum<32>(sum) * invn;
         float qs = 0.f;
 #pragma unroll
@@ -1707,29 +1806,44 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
                 qs += dlt * dlt;
             }
         const float rstd = 1.0f / sqrtf(lanes_sum<32>(qs) * invn + 1e-5f);
-#pragma unroll
-        for (int tn = 0; tn < NT; ++tn)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = tn * 32 + 8 * g + 4 * lk;
-                const float4 gg = *reinterpret_cast<const float4 *>(vecs + vg + n);
-                const float4 be = *reinterpret_cast<const float4 *>(vecs + vbeta + n);
-                float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (vadd >= 0) ad = *reinterpret_cast<const float4 *>(vecs + vadd + n);
+        if constexpr (ASM_VECS) {
+            auto norm = [&](auto gc, const float4 gg, const float4 be, const float4 ad_) __attribute__((always_inline)) {
+                constexpr int tn = decltype(gc)::value >> 2, g = decltype(gc)::value & 3;
+                const float4 ad = vadd >= 0 ? ad_ : make_float4(0.f, 0.f, 0.f, 0.f);
                 acc[tn][4 * g + 0] = (acc[tn][4 * g + 0] - mu) * rstd * gg.x + be.x + ad.x;
                 acc[tn][4 * g + 1] = (acc[tn][4 * g + 1] - mu) * rstd * gg.y + be.y + ad.y;
                 acc[tn][4 * g + 2] = (acc[tn][4 * g + 2] - mu) * rstd * gg.z + be.z + ad.z;
                 acc[tn][4 * g + 3] = (acc[tn][4 * g + 3] - mu) * rstd * gg.w + be.w + ad.w;
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            };
+            if constexpr (vadd >= 0) vec_stream(std::integral_constant<int, 3>{}, vg_c, vbeta_c, vadd_c, norm);
+            else vec_stream(std::integral_constant<int, 2>{}, vg_c, vbeta_c, x6_ic0{}, norm);
+        } else {
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = tn * 32 + 8 * g + 4 * lk;
+                    const float4 gg = *reinterpret_cast<const float4 *>(vecs + vg + n);
+                    const float4 be = *reinterpret_cast<const float4 *>(vecs + vbeta + n);
+                    float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (vadd >= 0) ad = *reinterpret_cast<const float4 *>(vecs + vadd + n);
+                    acc[tn][4 * g + 0] = (acc[tn][4 * g + 0] - mu) * rstd * gg.x + be.x + ad.x;
+                    acc[tn][4 * g + 1] = (acc[tn][4 * g + 1] - mu) * rstd * gg.y + be.y + ad.y;
+                    acc[tn][4 * g + 2] = (acc[tn][4 * g + 2] - mu) * rstd * gg.z + be.z + ad.z;
+                    acc[tn][4 * g + 3] = (acc[tn][4 * g + 3] - mu) * rstd * gg.w + be.w + ad.w;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
     };
     // (NT = 8: the LayerNorm phases run at full register pressure and the compiler parks the fragments read ahead for the next
     //  step in AGPRs across them -- copies taken before the data has landed unless the reads are waited for first)
     if constexpr (NT == 8) landed_all();
     X6_T(st_p[1])
     if constexpr (!EMBED) {
-        layer_norm(V_O + 0 * D, V_O + 1 * D, V_O + 2 * D, V_O + 3 * D);
-        if (a.c) layer_norm(-1, V_O + 4 * D, V_O + 5 * D, -1);
+        using x6_icn = std::integral_constant<int, -1>;
+        layer_norm(std::integral_constant<int, V_O + 0 * D>{}, std::integral_constant<int, V_O + 1 * D>{},
+                   std::integral_constant<int, V_O + 2 * D>{}, std::integral_constant<int, V_O + 3 * D>{});
+        if (a.c) layer_norm(x6_icn{}, std::integral_constant<int, V_O + 4 * D>{}, std::integral_constant<int, V_O + 5 * D>{}, x6_icn{});
     }
     X6_T(st_p[2])
 
@@ -1849,6 +1963,14 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
     // ---- + b2, LN3 -> x' (fragment-major store), then split ONCE into the plane registers as the QKV tail's B operand
     if constexpr (!EMBED) {
         float sum = 0.f;
+        if constexpr (ASM_VECS) {
+            vec_stream(std::integral_constant<int, 1>{}, std::integral_constant<int, V_B2>{}, x6_ic0{}, x6_ic0{},
+                       [&](auto gc, const float4 bb, const float4, const float4) __attribute__((always_inline)) {
+                constexpr int tn = decltype(gc)::value >> 2, g = decltype(gc)::value & 3;
+                acc[tn][4 * g + 0] += bb.x, acc[tn][4 * g + 1] += bb.y, acc[tn][4 * g + 2] += bb.z, acc[tn][4 * g + 3] += bb.w;
+                sum += (acc[tn][4 * g + 0] + acc[tn][4 * g + 1]) + (acc[tn][4 * g + 2] + acc[tn][4 * g + 3]);
+            });
+        } else {
 #pragma unroll
         for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
@@ -1858,6 +1980,7 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
                 sum += (acc[tn][4 * g + 0] + acc[tn][4 * g + 1]) + (acc[tn][4 * g + 2] + acc[tn][4 * g + 3]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
         const float mu = lanes_sum<32>(sum) * invn;
         float qs = 0.f;
 #pragma unroll
@@ -1868,6 +1991,16 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
                 qs += dlt * dlt;
             }
         const float rstd = 1.0f / sqrtf(lanes_sum<32>(qs) * invn + 1e-5f);
+        if constexpr (ASM_VECS) {
+            vec_stream(std::integral_constant<int, 2>{}, std::integral_constant<int, V_G>{}, std::integral_constant<int, V_B>{}, x6_ic0{},
+                       [&](auto gc, const float4 gg, const float4 be, const float4) __attribute__((always_inline)) {
+                constexpr int tn = decltype(gc)::value >> 2, g = decltype(gc)::value & 3;
+                const float4 o = make_float4((acc[tn][4 * g + 0] - mu) * rstd * gg.x + be.x, (acc[tn][4 * g + 1] - mu) * rstd * gg.y + be.y,
+                                             (acc[tn][4 * g + 2] - mu) * rstd * gg.z + be.z, (acc[tn][4 * g + 3] - mu) * rstd * gg.w + be.w);
+                if (a.Xf) reinterpret_cast<float4 *>(a.Xf)[((size_t)(mtile * NT + tn) * 4 + g) * 64 + lane] = o;
+                acc[tn][4 * g + 0] = o.x, acc[tn][4 * g + 1] = o.y, acc[tn][4 * g + 2] = o.z, acc[tn][4 * g + 3] = o.w;
+            });
+        } else {
 #pragma unroll
         for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
@@ -1881,6 +2014,7 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
                 acc[tn][4 * g + 0] = o.x, acc[tn][4 * g + 1] = o.y, acc[tn][4 * g + 2] = o.z, acc[tn][4 * g + 3] = o.w;
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
     }
 #pragma unroll
     for (int tn = 0; tn < NT; ++tn)
@@ -1905,7 +2039,12 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
             if constexpr (HT == 2) { X6_STEP1(NPRE + 2 * (NT * pp + i) + 1, (&Yp[4]), qt) }
             bias_tile(bt, V_BIN + c0 + i * 32); // (its wait lands every fragment register too: control flow ahead)
             X6_T(st_q0)
+#ifdef X6_NO_QKV_STORE
+            asm volatile("" :: "v"(qt[0]), "v"(qt[5]), "v"(qt[10]), "v"(qt[15]), "v"(bt[0]));
+            if (mt < M && a.M < 0) {
+#else
             if (mt < M) {
+#endif
                 float *qrow = a.QKV + (int64_t)mt * (3 * D) + c0 + i * 32 + 4 * lk;
                 if (QP0 == 0 && a.kv_planes && pp == 2) { // V head i of this token as two float16 planes
                     typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;

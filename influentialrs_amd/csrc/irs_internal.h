@@ -16,7 +16,9 @@
 #if !defined(IRS_LAB) && (defined(X6_DUMP) || defined(X6_STAMP) || defined(X6_NO_SPLIT) || defined(X6_STAGGER) ||            \
                           defined(X6_NO_MFMA) || defined(X6_NO_READS) || defined(X6_NO_DMA) || defined(X6_NO_BARRIER) ||       \
                           defined(X6_NW) || defined(ATTN16X_NW) || defined(ATTN_STAMP) || defined(ATTNP_STAMP) ||               \
-                          defined(IRS_SMALL_TIMING) || defined(IRS_DIRECT_TIMING) || defined(SWEEP_LAB) || defined(X6D_STAMP))
+                          defined(IRS_SMALL_TIMING) || defined(IRS_DIRECT_TIMING) || defined(SWEEP_LAB) || defined(X6D_STAMP) ||              \
+                          defined(X6_NO_QKV_STORE) || defined(X6_NSLOT2) || defined(X6_RESID_LATE) || defined(X6_RING4) ||      \
+                          defined(X6_SPLIT_ACC4))
 #error "a lab switch (X6_* / ATTN* / IRS_*_TIMING) is defined without IRS_LAB: the product library must be built without them"
 #endif
 

@@ -1,6 +1,7 @@
 // Development lab for the split-bf16 fused layer kernel (not product code): k_block<true, true> (float32 MFMAs) against
 // k_block_x6 on the same random tile inputs and weights -- element-wise difference of x' and qkv', and kernel times.
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DIRS_LAB -DX6_STAMP | -DX6_DUMP | -DX6_NO_MFMA ...] tools/x6_lab.hip -o tools/x6_lab ; run: tools/x6_lab [tokens=131072]
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DIRS_LAB -DX6_STAMP | -DX6_DUMP | -DX6_NO_MFMA ...] tools/x6_lab.hip -o tools/x6_lab ; run: tools/x6_lab [tokens=131072] [zero-mask=0] [grid=0: one workgroup per 128 tokens]
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -31,6 +32,8 @@ int main(int argc, char **argv) {
     setvbuf(stdout, nullptr, _IONBF, 0);
     const int M = argc > 1 ? atoi(argv[1]) : 131072;
     const int zero = argc > 2 ? atoi(argv[2]) : 0; // bit 0: W_o = 0, bit 1: W1 = W2 = 0, bit 2: W_in = 0 (bisecting a wrong result)
+    const int full_grid = (M + 32 * X6_NW - 1) / (32 * X6_NW);
+    const int grid = argc > 3 && atoi(argv[3]) > 0 ? std::min(atoi(argv[3]), full_grid) : full_grid; // (< full: persistent workgroups, float16 planes only)
     unsigned long long z = 88172645463325252ull;
     const int D = 128, F = 256;
     float *Af = dev_rand((size_t)M * D, 1.0f, z), *Rf = dev_rand((size_t)M * D, 1.0f, z);
@@ -81,7 +84,7 @@ int main(int argc, char **argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         printf("k_block<f32>  %8.1f us\n", ms * 1e3);
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((k_block_x6<0, X6_NW, false, 4, LNPL>), dim3((M + 32 * X6_NW - 1) / (32 * X6_NW)), dim3(64 * X6_NW), x6_lds, 0, xa);
+        hipLaunchKernelGGL((k_block_x6<0, X6_NW, false, 4, LNPL>), dim3(grid), dim3(64 * X6_NW), x6_lds, 0, xa);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         CK(hipGetLastError());
