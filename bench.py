@@ -740,6 +740,26 @@ def main():
                     "peak_basis": ("dense 16-bit MFMA peak 2500 TFLOP/s / %d products" % int(nprod) if x6 else "float32 MFMA dense peak"),
                     "executed_mfma_tflops": ach * (nprod if x6 else 1.0),
                     "float32_equivalent_vs_f32_matrix_peak": ach / PEAK_F32_MATRIX_TFLOPS}
+            # Which roof binds?  Per packed row the kernel's algorithmic HBM bytes are 6 d floats (in: attention output and
+            # residual; out: x' and the next q | k | v).  With float16 planes the matrix floor (flops / (2500 / 3)) drops below
+            # the HBM floor (bytes / 8 TB/s): the kernel is then an HBM-bound one by the roofline's own definition and the line
+            # says so -- `achieved` = algorithmic bytes / launch time against the 8 TB/s peak -- with the matrix-side numbers kept
+            # under `mfma_side`.
+            rows_launch = fam[dom].get("packed_fraction", 1.0) * job.B * cfg.max_len
+            nl_ = max(cfg.n_layers, 2)  # n_layers - 2 launches write q | k | v (6 d floats per row), the last one k | v only (5 d)
+            alg_bytes = rows_launch * (6 * (nl_ - 2) + 5) / (nl_ - 1) * cfg.emb_dim * 4
+            flops_launch = f["flops"] / max(f["launches"], 1)
+            floor_hbm_ms = alg_bytes / (PEAK_HBM_GBS * 1e9) * 1e3
+            floor_mfma_ms = flops_launch / (peak * 1e12) * 1e3
+            roof["floor_ms"] = {"hbm": floor_hbm_ms, "mfma": floor_mfma_ms}
+            if floor_hbm_ms > floor_mfma_ms and per_launch_ms > 0:
+                mfma_side = {k: roof[k] for k in ("achieved", "peak", "unit", "frac", "peak_basis", "executed_mfma_tflops",
+                                                  "float32_equivalent_vs_f32_matrix_peak")}
+                ach_gbs = alg_bytes / (per_launch_ms * 1e-3) / 1e9
+                roof.update({"bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach_gbs / PEAK_HBM_GBS,
+                             "peak_basis": "HBM3E 8 TB/s; algorithmic bytes = packed rows x 6 d x 4 B (5 d for the k | v-only launch)", "mfma_side": mfma_side})
+                for k in ("executed_mfma_tflops", "float32_equivalent_vs_f32_matrix_peak"):
+                    roof.pop(k, None)
         elif dom in ("linear", "attn"):
             ach = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
             roof = {"kernel": {"linear": "k_block + k_linear (decoder fp32 MFMA GEMM family: fused layer kernel, layer-0 QKV)",
