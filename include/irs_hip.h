@@ -374,8 +374,11 @@ int irs_sharded_graph_state(const irs_ctx *ctx);
  *   IRS_GEMM_F32 v_mfma_f32_32x32x2f32.
  * The initial mode is IRS_GEMM_H3 unless the environment holds IRS_DECODER_GEMM=x6 or =f32 when the context is created.
  * Changing the mode drops the context's captured steps (they are re-captured on the next graph call).
- * (IRS_ATTN_GEMM=x6 in the environment at creation additionally moves the head-dim-32 attention of the throughput
- * path to split-bf16 MFMAs; it measured slower than the float32-MFMA attention and is off by default.) */
+ * Attention of the throughput path at head dim 32 behind a split-precision layer kernel (environment IRS_ATTN_GEMM, read at
+ * creation): default "h3" -- scores on the float32 matrix chain, O^T += V^T P^T on float16 plane pairs, the V section of a
+ * q | k | v row being WRITTEN as [32 f16 h | 32 f16 l] per (token, head) by the layer kernel (same 128 bytes; rows within 6e-6
+ * of the float32 attention's); "f32": the float32-MFMA attention on float32 q | k | v rows; "x6": split-bf16 attention (measured
+ * slower, kept for comparison).  The q | k | v buffer is internal to irs_decode: no caller sees the plane format. */
 #define IRS_GEMM_F32 0
 #define IRS_GEMM_X6 1
 /* IRS_GEMM_H3 (round 4): two FLOAT16 planes per float32 operand (h = f16(x), l = f16(x - h): 22 significand bits) and the three

@@ -702,6 +702,7 @@ def test_persistent_attention_on_request(monkeypatch):
     plan's length-sorted work list (k_plan_attn_order; short sequences as groups of four heads per workgroup).  Off by
     default: it measured faster on short sequences only (profiles/r04/README.md).  Same MFMA chains on the same operands:
     the consumed rows must equal the default kernel's BIT FOR BIT, at d = 128 (4 heads) and d = 256 (8 heads: two groups)."""
+    monkeypatch.setenv("IRS_ATTN_GEMM", "f32")  # (the persistent grid is a form of the float32 attention kernel)
     for over in ({}, {"emb_dim": 256, "n_heads": 8}):
         cfg = synth.make_config("c2", **over)
         L, B = cfg.max_len, 300
@@ -724,3 +725,34 @@ def test_persistent_attention_on_request(monkeypatch):
         rb = eng.decode(seq, u, want_x=False, pos=pos)[1]
         assert torch.equal(torch.isnan(ra), torch.isnan(rb))
         assert torch.equal(ra.view(torch.int32), rb.view(torch.int32)), over
+
+
+@pytest.mark.gpu
+def test_float16_plane_attention_equals_float32_attention(monkeypatch):
+    """The default attention behind a split-precision layer kernel (k_attn16h: scores on float32 MFMAs, O^T += V^T P^T on the
+    float16 plane pairs the layer kernel writes in place of float32 V rows) against IRS_ATTN_GEMM=f32 (k_attn16 on float32
+    q | k | v rows) on the same batch: consumed rows after six layers within 1e-5 (measured 5.5e-6), NaN rows (all-pad windows)
+    in the same places, at d = 128 and d = 256, with full, short and all-pad windows in the batch."""
+    for over in ({}, {"emb_dim": 256, "n_heads": 8}):
+        cfg = synth.make_config("c2", **over)
+        L, B = cfg.max_len, 300
+        sd = synth.irn_state_dict(cfg, 781)
+        hists = synth.user_histories(B, cfg.n_item, seed=58)
+        rows = synth.eval_rows(hists, cfg.n_item, seed=59)
+        _, seqs, users, targets, _ = synth.collate_eval_irs(rows, L, gap_len=0)
+        seqs[1, :] = 0
+        seqs[1, -1] = targets[1]
+        seqs[2, seqs[2] == 0] = 3
+        seqs[3, : L - 17] = 0                 # 17 tokens: an odd number of key tiles (the pair partner of the last tile is absent)
+        seqs[4, : L - 33] = 0
+        seq, u = torch.from_numpy(seqs).cuda(), torch.from_numpy(users).cuda()
+        pos = torch.full((B,), L - 2, dtype=torch.int32, device="cuda")
+        base = make_engine(cfg, sd, max_rows=B, max_seqs=B)
+        ra = base.decode(seq, u, want_x=False, pos=pos)[1].clone()
+        monkeypatch.setenv("IRS_ATTN_GEMM", "f32")
+        eng = make_engine(cfg, sd, max_rows=B, max_seqs=B)
+        monkeypatch.delenv("IRS_ATTN_GEMM")
+        rb = eng.decode(seq, u, want_x=False, pos=pos)[1]
+        assert torch.equal(torch.isnan(ra), torch.isnan(rb))
+        ok = ~torch.isnan(ra)
+        assert float((ra[ok] - rb[ok]).abs().max()) < 1e-5, over
