@@ -387,6 +387,12 @@ int irs_sharded_graph_state(const irs_ctx *ctx);
 #define IRS_GEMM_H3 2
 int irs_set_decoder_gemm(irs_ctx *ctx, int32_t mode);
 int irs_get_decoder_gemm(const irs_ctx *ctx);
+/* Float16 planes overflow at 65504.  irs_finalize_weights bounds every operand of the float16-plane kernels from the bound
+ * weights (embedded tokens, LayerNorm outputs, hidden activations, V rows, the weights themselves) and keeps half the range as
+ * margin: a model whose bound is 32752 or more runs IRS_GEMM_X6 (no range limit) wherever IRS_GEMM_H3 is selected, with float32
+ * V rows -- irs_get_decoder_gemm reports the mode that RUNS.  irs_h3_range_bound returns the bound (-1 before finalisation).
+ * (The reference has no counterpart: model/influentialRS.py:67-74 multiplies in float32 throughout.) */
+float irs_h3_range_bound(const irs_ctx *ctx);
 
 /* ---- measurement hooks (bench.py only) ---------------------------------
  * While enabled, every launch of the named kernel family is bracketed by HIP

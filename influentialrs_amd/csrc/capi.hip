@@ -221,6 +221,18 @@ extern "C" int irs_finalize_weights(irs_ctx *ctx, void *arena, size_t bytes, voi
     if ((rc = irs_launch_cross_const(ctx, s))) return rc;
     if ((rc = irs_launch_pack_small(ctx, s))) return rc;
     if ((rc = irs_launch_pack_x6(ctx, s))) return rc;
+    // float16 planes (IRS_GEMM_H3, the V planes of the attention) need every operand below 65504: bound them from the weights,
+    // keep half the range as margin; a model outside it runs the split-bf16 kernels (no range limit) -- the one host
+    // synchronisation of finalisation
+    ctx->h3_ok = true, ctx->h3_bound = 0.f;
+    if (ctx->w_x6) {
+        float *st = ctx->wnorm_max + 8, hst[8];
+        if ((rc = irs_launch_h3_range(ctx, st, s))) return rc;
+        IRS_CHECK_HIP(ctx, hipMemcpyAsync(hst, st, sizeof(hst), hipMemcpyDeviceToHost, s));
+        IRS_CHECK_HIP(ctx, hipStreamSynchronize(s));
+        ctx->h3_bound = irs_h3_operand_bound(ctx, hst);
+        ctx->h3_ok = ctx->h3_bound < 32752.f; // (a NaN or infinite statistic fails the comparison)
+    }
     ctx->finalized = true;
     ctx->proj_stale = false;
     if (ctx->sh_graph) {
@@ -414,7 +426,12 @@ extern "C" int irs_set_decoder_gemm(irs_ctx *ctx, int32_t mode) {
     return IRS_OK;
 }
 
-extern "C" int irs_get_decoder_gemm(const irs_ctx *ctx) { return ctx ? ctx->use_x6 : IRS_E_INVALID; }
+// (what runs: a model whose weights fail finalisation's float16 range bound runs IRS_GEMM_X6 where IRS_GEMM_H3 is selected)
+extern "C" int irs_get_decoder_gemm(const irs_ctx *ctx) {
+    if (!ctx) return IRS_E_INVALID;
+    return (ctx->use_x6 == IRS_GEMM_H3 && ctx->finalized && !ctx->h3_ok) ? IRS_GEMM_X6 : ctx->use_x6;
+}
+extern "C" float irs_h3_range_bound(const irs_ctx *ctx) { return ctx && ctx->finalized ? ctx->h3_bound : -1.f; }
 
 static int ready(irs_ctx *ctx) {
     if (!ctx) return IRS_E_INVALID;

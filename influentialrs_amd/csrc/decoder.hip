@@ -5365,6 +5365,68 @@ int irs_launch_pack_x6(irs_ctx *ctx, hipStream_t s) {
     IRS_CHECK_HIP(ctx, hipGetLastError());
     return IRS_OK;
 }
+// ---- float16 range bounds for IRS_GEMM_H3 and the float16 V planes (finalisation).  Float16 planes overflow at 65504; the
+// operands are weights, embedded tokens, LayerNorm outputs (+ c_l), the FFN's hidden activations and the attention output / V
+// rows.  Seven statistics of the bound weights give a bound for each (LayerNorm output: |z_i| <= sqrt(d) per normalised
+// component, so |y_i| <= sqrt(d) max|gamma| + max|beta|, ||y|| <= sqrt(d) times that; a product row: ||in|| ||W_row|| + |b|).
+// Non-negative floats order like their bit patterns: atomicMax on the bits.
+__global__ void __launch_bounds__(256) k_absmax(const float *__restrict__ p, size_t n, unsigned int *__restrict__ out) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(p[i]));
+    if (!(m == m)) m = INFINITY; // a NaN weight fails the bound
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+__global__ void __launch_bounds__(256) k_rownorm_max(const float *__restrict__ W, int rows, int cols, unsigned int *__restrict__ out) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    float q = 0.f;
+    for (int c = lane; c < cols; c += 64) q = __fmaf_rn(W[(size_t)r * cols + c], W[(size_t)r * cols + c], q);
+    for (int o = 32; o; o >>= 1) q += __shfl_xor(q, o);
+    q = sqrtf(q);
+    if (!(q == q)) q = INFINITY;
+    if (lane == 0) atomicMax(out, __float_as_uint(q));
+}
+// statistics -> stats[0..7] (device, zeroed here): max|E|, max|pe|, max LayerNorm |gamma|, max LayerNorm |beta|, max|c_l|,
+// max row norm of W1 and of the V rows of W_in, max of every other |weight| and |bias| that becomes or feeds an operand
+int irs_launch_h3_range(irs_ctx *ctx, float *stats, hipStream_t s) {
+    const irs_dims &D = ctx->dims;
+    const int d = D.d, F = D.ffn_dim, nl = D.n_layers;
+    unsigned int *u = reinterpret_cast<unsigned int *>(stats);
+    IRS_CHECK_HIP(ctx, hipMemsetAsync(stats, 0, 8 * sizeof(float), s));
+    auto amax = [&](const float *p, size_t n, int slot) {
+        if (!p || !n) return;
+        const int grid = (int)std::min<size_t>((n + 4095) / 4096, 2048);
+        hipLaunchKernelGGL(k_absmax, dim3(grid), dim3(256), 0, s, p, n, u + slot);
+    };
+    auto rmax = [&](const float *W, int rows, int cols, int slot) {
+        if (W) hipLaunchKernelGGL(k_rownorm_max, dim3((rows + 3) / 4), dim3(256), 0, s, W, rows, cols, u + slot);
+    };
+    amax(ctx->item_emb, (size_t)(D.n_item + 1) * d, 0);
+    amax(ctx->pe, (size_t)D.max_len * d, 1);
+    amax(ctx->c_l, (size_t)nl * d, 4);
+    for (int l = 0; l < nl; ++l) {
+        const irs_layer_w &w = ctx->layer[l];
+        amax(w.n1_w, d, 2), amax(w.n2_w, d, 2), amax(w.n3_w, d, 2);
+        amax(w.n1_b, d, 3), amax(w.n2_b, d, 3), amax(w.n3_b, d, 3);
+        rmax(w.l1_w, F, d, 5);
+        rmax(w.sa_in_w + (size_t)2 * d * d, d, d, 6);
+        amax(w.sa_out_w, (size_t)d * d, 7), amax(w.l1_w, (size_t)F * d, 7), amax(w.l2_w, (size_t)d * F, 7), amax(w.sa_in_w, (size_t)3 * d * d, 7);
+        amax(w.l1_b, F, 7), amax(w.sa_in_b, (size_t)3 * d, 7);
+    }
+    IRS_CHECK_HIP(ctx, hipGetLastError());
+    return IRS_OK;
+}
+// the largest operand magnitude the statistics allow (host)
+float irs_h3_operand_bound(const irs_ctx *ctx, const float *st) {
+    const float sd = sqrtf((float)ctx->dims.d);
+    const float a0 = st[0] * sd + st[1];                 // embedded token
+    const float ln = sd * st[2] + st[3] + st[4];         // a LayerNorm output (+ c_l)
+    const float xin = sd * fmaxf(a0, ln);                // norm of a layer's input row
+    const float v = xin * st[6] + st[7];                 // a V row (and the attention output, a convex combination of V rows)
+    const float h = sd * ln * st[5] + st[7];             // a hidden activation
+    return fmaxf(fmaxf(fmaxf(a0, ln), fmaxf(v, h)), st[7]);
+}
 static constexpr int X6_LDS_BYTES = x6_lds_bytes(4);
 // one launcher for every instantiation of the fused layer kernel: QP0 (k | v-only tail), EMBED, NT (4: d = 128, 8: d = 256),
 // NPL (3: bf16 six-product, 2: float16 three-product), NW (4; 1 = the lab's one-wave workgroups at NT = 8, bf16 only)
@@ -5479,7 +5541,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                      attn16_ok(ctx, ctx->act_qkv, ctx->act_yf);
     const bool x6d_small = x6d && rows < 32768;
     // the split-precision layer kernels hand K / V to the attention as float16 plane pairs (k_attn16h) unless switched off
-    const bool kv_planes = ctx->use_attn_h3 && ctx->use_x6 && ctx->w_x6 && (d == 128 || x6d) && F == 256 && ctx->dims.n_layers > 1 &&
+    const bool kv_planes = ctx->use_attn_h3 && ctx->h3_ok && ctx->use_x6 && ctx->w_x6 && (d == 128 || x6d) && F == 256 && ctx->dims.n_layers > 1 &&
                            !x6d_small && rows * (long long)ctx->dims.n_heads > 64 * (long long)L; // (not the z-split latency grid)
     // d = 256 below the throughput regime (C5's 32 beam windows, single users): the 16-token fused layer kernel for wide
     // models (k_block_small_wide) instead of ~8 per-GEMM launches per layer
@@ -5523,7 +5585,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
         if (ctx->use_x6 && ctx->w_x6) { // the same kernel on split-bf16 MFMAs: k_block_x6's q | k | v steps behind an embed prologue
             BlockX6Args xa{};
-            const int npl = (ctx->use_x6 == IRS_GEMM_H3 && !x6d_small) ? 2 : 3;
+            const int npl = (ctx->use_x6 == IRS_GEMM_H3 && ctx->h3_ok && !x6d_small) ? 2 : 3;
             xa.Wx = x6_stream(ctx, npl, ctx->dims.n_layers - 1);
             xa.bin = ctx->layer[0].sa_in_b, xa.Xf = xf, xa.QKV = ctx->act_qkv, xa.M = rows, xa.m_dev = m_dev;
             xa.seq = seq, xa.E = ctx->item_emb, xa.pe = ctx->pe, xa.tok_row = tok, xa.L = L, xa.sqrtd = sqrtf((float)d), xa.n_item = ctx->dims.n_item;
@@ -5686,7 +5748,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                 irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
                 if (tail) irs_prof_begin(ctx, IRS_PROF_LAYER, s); // (one family is enabled at a time)
                 if (tail && ctx->use_x6 && ctx->w_x6) { // the same layer tail on split-bf16 MFMAs
-                    const int npl = (ctx->use_x6 == IRS_GEMM_H3 && !x6d_small) ? 2 : 3;
+                    const int npl = (ctx->use_x6 == IRS_GEMM_H3 && ctx->h3_ok && !x6d_small) ? 2 : 3;
                     BlockX6Args xa{yf, xf, x6_stream(ctx, npl, l), w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b,
                                    w.l1_b, w.l2_b, w.n3_w, w.n3_b, ctx->layer[l + 1].sa_in_b, xf, ctx->act_qkv, rows, m_dev, kv_only ? 1 : 0};
                     xa.kv_planes = kv_planes ? 1 : 0;

@@ -86,6 +86,8 @@ struct irs_ctx {
     float *w_frag16;  // fragment-packed layer weights of the 16-token latency kernel (d = 128, F = 256), or null
     uint4 *w_x6;      // split-bf16 step streams of the fused layer kernel k_block_x6 ([n_layers - 1] x 768 KB), or null
     int use_x6;       // decoder GEMMs of the throughput path on split-bf16 MFMAs (IRS_DECODER_GEMM=x6|f32)
+    bool h3_ok;       // finalisation's float16 range bound holds (else IRS_GEMM_H3 runs as IRS_GEMM_X6 and V stays float32)
+    float h3_bound;   // the largest operand magnitude the bound weights allow (irs_h3_operand_bound)
     int use_attn_x6;  // head-dim-32 attention of the throughput path on split-bf16 MFMAs (IRS_ATTN_GEMM=x6; default off: slower)
     int use_attn_h3;  // throughput attention on split-float16 MFMAs over K / V planes written by the layer kernel (default on; IRS_ATTN_GEMM=f32 off)
     int attn_persist; // packed throughput attention as a resident grid over a length-sorted work list (IRS_ATTN_PERSIST=1; default off:
@@ -195,6 +197,8 @@ size_t irs_small_frag_floats(const irs_ctx *ctx);
 int irs_launch_pack_small(irs_ctx *ctx, hipStream_t s);
 size_t irs_x6_bytes(const irs_ctx *ctx);
 int irs_launch_pack_x6(irs_ctx *ctx, hipStream_t s);
+int irs_launch_h3_range(irs_ctx *ctx, float *stats, hipStream_t s);
+float irs_h3_operand_bound(const irs_ctx *ctx, const float *stats);
 
 // ---- score.hip ----
 int irs_launch_pack_w(irs_ctx *ctx, hipStream_t s);

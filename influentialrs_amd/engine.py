@@ -453,6 +453,12 @@ class Engine:
     def decoder_gemm(self, mode: int):
         self._check(self.lib.irs_set_decoder_gemm(self.h, int(mode)))
 
+    @property
+    def h3_range_bound(self) -> float:
+        """Largest operand magnitude the bound weights allow in the float16-plane kernels (irs_h3_range_bound; -1 before the
+        weights are finalised).  At 32752 or more IRS_GEMM_H3 runs as IRS_GEMM_X6 and `decoder_gemm` reports that."""
+        return float(self.lib.irs_h3_range_bound(self.h))
+
     # ------------------------------------------------------------------ measurement
     def prof_enable(self, family: int):
         with torch.cuda.device(self.device):

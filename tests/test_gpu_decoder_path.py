@@ -756,3 +756,39 @@ def test_float16_plane_attention_equals_float32_attention(monkeypatch):
         assert torch.equal(torch.isnan(ra), torch.isnan(rb))
         ok = ~torch.isnan(ra)
         assert float((ra[ok] - rb[ok]).abs().max()) < 1e-5, over
+
+
+
+@pytest.mark.gpu
+def test_float16_planes_fall_back_outside_their_range():
+    """IRS_GEMM_H3 multiplies on float16 planes (|operand| < 65504).  irs_finalize_weights bounds every operand from the bound
+    weights; a model whose bound reaches half the float16 range must run the split-bf16 kernels instead (no range limit) and say
+    so through irs_get_decoder_gemm -- here: feed-forward weights scaled so that hidden activations reach ~1e5 (the second
+    linear layer scaled back, so the rows stay finite and comparable).  The rows must equal the float32-MFMA kernels' within
+    the split-bf16 tolerance relative to their magnitude, with no inf / NaN that the float32 form does not have."""
+    from influentialrs_amd._lib import IRS_GEMM_F32, IRS_GEMM_H3, IRS_GEMM_X6
+    cfg = synth.make_config("c2")
+    L, B = cfg.max_len, 300
+    sd = synth.irn_state_dict(cfg, 790)
+    base = make_engine(cfg, sd, max_rows=B, max_seqs=B)
+    assert base.decoder_gemm == IRS_GEMM_H3 and 0 < base.h3_range_bound < 32752       # a model of ordinary scale
+    big = dict(sd)
+    for l in range(cfg.n_layers):
+        big[f"decoder.layers.{l}.linear1.weight"] = sd[f"decoder.layers.{l}.linear1.weight"] * 4096.0
+        big[f"decoder.layers.{l}.linear1.bias"] = sd[f"decoder.layers.{l}.linear1.bias"] * 4096.0
+        big[f"decoder.layers.{l}.linear2.weight"] = sd[f"decoder.layers.{l}.linear2.weight"] / 4096.0
+    hists = synth.user_histories(B, cfg.n_item, seed=61)
+    rows = synth.eval_rows(hists, cfg.n_item, seed=62)
+    _, seqs, users, _, _ = synth.collate_eval_irs(rows, L, gap_len=0)
+    seq, u = torch.from_numpy(seqs).cuda(), torch.from_numpy(users).cuda()
+    pos = torch.full((B,), L - 2, dtype=torch.int32, device="cuda")
+    eng = make_engine(cfg, big, max_rows=B, max_seqs=B)
+    assert eng.h3_range_bound >= 32752 and eng.decoder_gemm == IRS_GEMM_X6, (eng.h3_range_bound, eng.decoder_gemm)
+    ra = eng.decode(seq, u, want_x=False, pos=pos)[1].clone()
+    eng.decoder_gemm = IRS_GEMM_F32
+    rb = eng.decode(seq, u, want_x=False, pos=pos)[1]
+    assert torch.isfinite(ra).all() and torch.isfinite(rb).all()
+    assert float((ra - rb).abs().max()) < X_TOL_X6
+    # (the scaled model computes what the unscaled one does: relu is positively homogeneous)
+    r0 = base.decode(seq, u, want_x=False, pos=pos)[1]
+    assert float((r0 - rb).abs().max()) < 2 * X_TOL_X6
