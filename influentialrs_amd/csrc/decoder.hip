@@ -1422,6 +1422,14 @@ __device__ __forceinline__ x6_u32x4 x6_rd(unsigned int base) {
     return v;
 }
 
+// a 16-byte global load the compiler does not track (its wait is a counted vmcnt in inline asm: see RESID_LATE)
+template <int OFF>
+__device__ __forceinline__ x6_u32x4 x6_gld(const void *p) {
+    x6_u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "i"(OFF) : "memory");
+    return v;
+}
+
 // the same read with its wait inside the statement: the value is valid when the statement ends, whatever the register
 // allocator does next (at NT = 8 the prologue runs at ~270 live registers and the compiler parked the four first fragments
 // in AGPRs right behind their reads -- copies of registers whose data had not landed: rows wrong by ~1e-4, found by scanning
@@ -1547,7 +1555,8 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
     f32x16 acc[NT];
     f32x16 at[NT]; // attention output tiles (B operand source of the out-projection): all requested here, so that
                    // the steps carry no plain global load (its wait would be a vmcnt(0) behind the DMA pieces)
-    f32x16 res[RESID_LATE ? NT : 1]; // (RESID_LATE) the residual, added in front of LayerNorm 1
+    x6_u32x4 resq[RESID_LATE ? NT : 1][4]; // (RESID_LATE) the residual as its 16-byte loads, added in front of LayerNorm 1
+    x6_u32x4 atq[RESID_LATE ? NT : 1][4]; // (RESID_LATE) the attention tiles as their four 16-byte loads
     if constexpr (!EMBED) {
         const float4 *rfrag = reinterpret_cast<const float4 *>(a.Rf) + fbase;
         const float4 *afrag = reinterpret_cast<const float4 *>(a.Af) + fbase;
@@ -1566,13 +1575,23 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
                     acc[tn][4 * g + 0] = t4.x, acc[tn][4 * g + 1] = t4.y, acc[tn][4 * g + 2] = t4.z, acc[tn][4 * g + 3] = t4.w;
                 }
         }
+        if constexpr (RESID_LATE) {
+            // inline-asm loads, tile by tile in order, waited for by COUNTED waits in front of each tile's step: a load the
+            // compiler sees gets vmcnt(0) in front of its first use here (every tile and every DMA piece), whatever the order
+            x6_static_for<0, NT>([&](auto tc) __attribute__((always_inline)) {
+                constexpr int tn = decltype(tc)::value;
+                const float4 *tp = afrag + tn * 4 * 64;
+                atq[tn][0] = x6_gld<0>(tp), atq[tn][1] = x6_gld<1024>(tp), atq[tn][2] = x6_gld<2048>(tp), atq[tn][3] = x6_gld<3072>(tp);
+            });
+        } else {
 #pragma unroll
-        for (int tn = 0; tn < NT; ++tn)
+            for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 t4 = afrag[(tn * 4 + g) * 64];
-                at[tn][4 * g + 0] = t4.x, at[tn][4 * g + 1] = t4.y, at[tn][4 * g + 2] = t4.z, at[tn][4 * g + 3] = t4.w;
-            }
+                for (int g = 0; g < 4; ++g) {
+                    const float4 t4 = afrag[(tn * 4 + g) * 64];
+                    at[tn][4 * g + 0] = t4.x, at[tn][4 * g + 1] = t4.y, at[tn][4 * g + 2] = t4.z, at[tn][4 * g + 3] = t4.w;
+                }
+        }
         if constexpr (RESID_LATE) {
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn)
@@ -1606,13 +1625,11 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
     auto load_res = [&]() __attribute__((always_inline)) {
         if constexpr (RESID_LATE) {
             const float4 *rfrag = reinterpret_cast<const float4 *>(a.Rf) + fbase;
-#pragma unroll
-            for (int tn = 0; tn < NT; ++tn)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 t4 = rfrag[(tn * 4 + g) * 64];
-                    res[tn][4 * g + 0] = t4.x, res[tn][4 * g + 1] = t4.y, res[tn][4 * g + 2] = t4.z, res[tn][4 * g + 3] = t4.w;
-                }
+            x6_static_for<0, NT>([&](auto tc) __attribute__((always_inline)) {
+                constexpr int tn = decltype(tc)::value;
+                const float4 *tp = rfrag + tn * 4 * 64;
+                resq[tn][0] = x6_gld<0>(tp), resq[tn][1] = x6_gld<1024>(tp), resq[tn][2] = x6_gld<2048>(tp), resq[tn][3] = x6_gld<3072>(tp);
+            });
         }
     };
     if constexpr (RESID_LATE) {
@@ -1737,6 +1754,19 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
     if constexpr (!EMBED) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            // (RESID_LATE: an attention tile "appears" here -- without the statement the compiler splits all four tiles into
+            //  planes right behind their loads, i.e. waits for every input tile and DMA piece before the start barrier)
+            if constexpr (RESID_LATE) {
+                // vector memory operations behind tile t's loads when its step starts: the later tiles, the DMA groups issued
+                // at mid-step (one per finished step: steps 3 ..), the residual's 16 loads (behind step 1's barrier)
+                const int newer_ = 4 * (NT - 1 - t) + PPW * t + (t >= 2 ? NLOAD : 0);
+                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(atq[t][0]), "+v"(atq[t][1]), "+v"(atq[t][2]), "+v"(atq[t][3]) : "n"(newer_));
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 t4 = __builtin_bit_cast(float4, atq[t][g]);
+                    at[t][4 * g + 0] = t4.x, at[t][4 * g + 1] = t4.y, at[t][4 * g + 2] = t4.z, at[t][4 * g + 3] = t4.w;
+                }
+            }
             X6_STEP(t * HT, at[t], acc[0], acc[1], acc[2], acc[3])
             if constexpr (HT == 2) { X6_STEP(t * HT + 1, at[t], acc[4], acc[5], acc[6], acc[7]) }
         }
@@ -1777,8 +1807,8 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
             vec_stream(std::integral_constant<int, 1>{}, vb_c, x6_ic0{}, x6_ic0{}, [&](auto gc, const float4 bb, const float4, const float4) __attribute__((always_inline)) {
                 constexpr int tn = decltype(gc)::value >> 2, g = decltype(gc)::value & 3;
                 if constexpr (RESID_LATE) {
-                    acc[tn][4 * g + 0] += res[tn][4 * g + 0], acc[tn][4 * g + 1] += res[tn][4 * g + 1];
-                    acc[tn][4 * g + 2] += res[tn][4 * g + 2], acc[tn][4 * g + 3] += res[tn][4 * g + 3];
+                    const float4 rs = __builtin_bit_cast(float4, resq[tn][g]);
+                    acc[tn][4 * g + 0] += rs.x, acc[tn][4 * g + 1] += rs.y, acc[tn][4 * g + 2] += rs.z, acc[tn][4 * g + 3] += rs.w;
                 }
                 acc[tn][4 * g + 0] += bb.x, acc[tn][4 * g + 1] += bb.y, acc[tn][4 * g + 2] += bb.z, acc[tn][4 * g + 3] += bb.w;
                 sum += (acc[tn][4 * g + 0] + acc[tn][4 * g + 1]) + (acc[tn][4 * g + 2] + acc[tn][4 * g + 3]);
@@ -1841,6 +1871,14 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
     X6_T(st_p[1])
     if constexpr (!EMBED) {
         using x6_icn = std::integral_constant<int, -1>;
+        if constexpr (RESID_LATE) { // the residual has landed once only the two DMA groups issued since are in flight
+            static_assert(NT == 4, "sixteen operands");
+            asm volatile("s_waitcnt vmcnt(%16)"
+                         : "+v"(resq[0][0]), "+v"(resq[0][1]), "+v"(resq[0][2]), "+v"(resq[0][3]), "+v"(resq[1][0]), "+v"(resq[1][1]),
+                           "+v"(resq[1][2]), "+v"(resq[1][3]), "+v"(resq[2][0]), "+v"(resq[2][1]), "+v"(resq[2][2]), "+v"(resq[2][3]),
+                           "+v"(resq[3][0]), "+v"(resq[3][1]), "+v"(resq[3][2]), "+v"(resq[3][3])
+                         : "n"(2 * PPW));
+        }
         layer_norm(std::integral_constant<int, V_O + 0 * D>{}, std::integral_constant<int, V_O + 1 * D>{},
                    std::integral_constant<int, V_O + 2 * D>{}, std::integral_constant<int, V_O + 3 * D>{});
         if (a.c) layer_norm(x6_icn{}, std::integral_constant<int, V_O + 4 * D>{}, std::integral_constant<int, V_O + 5 * D>{}, x6_icn{});

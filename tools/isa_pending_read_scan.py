@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Scan a kernel's ISA for uses of registers whose inline-asm LDS read has not been waited for.
+"""Scan a kernel's ISA for uses of registers whose inline-asm LDS read (or global load) has not been waited for.
 
 The fused layer kernels issue their fragment reads as inline-asm `ds_read_b128` and wait for them with hand-counted
 `s_waitcnt lgkmcnt(N)` statements (csrc/decoder.hip: k_block_x6, csrc/score.hip: the ring sweeps).  The compiler does not
@@ -36,29 +36,50 @@ def kernel_lines(lines, prefix):
     return out
 
 
+VMEM = ("global_load", "global_store", "global_atomic", "buffer_load", "buffer_store", "buffer_atomic", "scratch_load",
+        "scratch_store", "flat_load", "flat_store", "flat_atomic")
+
+
 def scan(lines, limit=40):
-    pending, flags = [], 0
+    """pending: LDS reads not yet retired by an lgkmcnt wait; vpending: vector memory operations (in issue order, every
+    kind: they share vmcnt and retire in order) not yet retired by a vmcnt wait -- an entry carries the destination
+    registers of a load into registers, or an empty set (stores, LDS-DMA loads).  Round 4: the layer kernel requests its
+    attention tiles by inline-asm global loads with hand-counted vmcnt waits, the same hazard class as the fragment reads."""
+    pending, vpending, flags, in_asm = [], [], 0, False
     for i, l in enumerate(lines):
         t = l.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif t.startswith(";;#ASMEND"):
+            in_asm = False
         if not t or t[0] in ";.":
             continue
         parts = t.split(None, 1)
         op, ops = parts[0], parts[1] if len(parts) > 1 else ""
         if op.startswith("ds_read") or op.startswith("ds_load"):
-            pending.append((regs_of(ops.split(",")[0]), i, t))
+            # (only inline-asm reads carry destinations: the compiler waits for its own reads, and a linear walk over a kernel
+            #  with branches would pair a read with the other arm's writes)
+            pending.append((regs_of(ops.split(",")[0]) if in_asm else set(), i, t))
             continue
         if op == "s_waitcnt":
             m = re.search(r"lgkmcnt\((\d+)\)", t)
             if m:
                 n = int(m.group(1))
                 pending = pending[len(pending) - n:] if n > 0 else []
+            m = re.search(r"vmcnt\((\d+)\)", t)
+            if m:
+                n = int(m.group(1))
+                vpending = vpending[len(vpending) - n:] if n > 0 else []
             continue
         used = regs_of(ops)
-        for r, ln, tt in pending:
+        for r, ln, tt in pending + vpending:
             if used & r:
                 flags += 1
                 if flags <= limit:
                     print(f"  line {i}: {t}    <-- register of the pending read at line {ln}: {tt}")
+        if op.startswith(VMEM):
+            is_load = "_load" in op and "_lds_" not in op and " lds" not in t
+            vpending.append((regs_of(ops.split(",")[0]) if is_load and in_asm else set(), i, t))
     return flags
 
 
