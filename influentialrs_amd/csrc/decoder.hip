@@ -1454,7 +1454,7 @@ __device__ __forceinline__ x6_u32x4 x6_rd_sync(unsigned int base) {
 // NT = 8 (d = 256, round 4): 8 accumulator tiles per token -- 128 registers of accumulators, 192 of cached planes -- so ONE
 // wave per SIMD (512 registers per lane), one workgroup per CU; the step stream has 96 steps (x6_nstep).
 template <int QP0, int NW, bool EMBED, int NT = 4, int NPL = 3>
-__global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Args a) {
+__global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block_x6(BlockX6Args a) {
     constexpr int NP = 8 * NPL, STEP_B = x6_step_b(NPL); // pieces (fragments) and bytes of a step
     using x6_plane = typename std::conditional<NPL == 2, x6_f16x8, x6_bf16x8>::type;
     constexpr int D = 32 * NT, F = 256, NSLOT = x6_nslot(NPL), LEAD = NSLOT - 1, PPW = NP / NW, HT = NT / 4;
@@ -1465,7 +1465,7 @@ __global__ void __launch_bounds__(64 * NW, NT == 8 ? 1 : 2) k_block_x6(BlockX6Ar
     // operations retire in order, so "all but the newest 8 + 16" is exactly that, and the first four steps' counted waits
     // allow one tile set beside the newest DMA group; the compiler's own waits bring each attention tile in when its step
     // splits it.  (tools/x6_lab stamps: the start was 16.8 K of a wave's 100 K cycles.)
-    constexpr bool RESID_LATE = X6_RESID_LATE && NPL == 2 && NT == 4 && !EMBED && NSLOT == 4 && NW == 4;
+    constexpr bool RESID_LATE = X6_RESID_LATE && NPL == 2 && NT == 4 && !EMBED && NSLOT == 4 && (NW == 4 || NW == 8);
     constexpr int NLOAD = 4 * NT; // plain global loads of one set of a wave's input tiles (attention output; residual)
     constexpr int NPRE = x6_npre(NT), NOUT = NT * HT;
     constexpr int S0 = EMBED ? NPRE : 0; // first step of the sequence
