@@ -2948,11 +2948,12 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
     const int UBh = (sweep == IRS_SWEEP_BF16) ? ub_bf16(ctx->KS) : ub_f32(ctx->KS);
     const int nub = (a.UT + UBh - 1) / UBh;
 
-    // pre-pass over a strided sample of item tiles: >= 1024 tiles (32768 items) or 1/8 of the shard; 1/16 from 4M items up
-    // (round 4: the threshold is then the ceil(3k/16) = 19th largest of >= 8192 sampled tile maxima per row instead of the 38th
-    // of twice as many -- the emitted count per row stays ~3k +- 25 %, far above the k that k_refine needs -- and the pre-pass
-    // over a 10M x 256 catalog costs 0.25 instead of 0.5 ms)
-    int nt0 = nt >= 131072 ? nt / 16 : nt / 8;
+    // pre-pass over a strided sample of item tiles: >= 1024 tiles (32768 items) or 1/8 of the shard; 1/16 where that still is
+    // >= 1024 tiles (shards of 524288 items and more; round 4).  The threshold is then the ceil(3k/16) = 19th largest sampled
+    // group maximum per row instead of the 38th of twice as many: the emitted count per row stays ~3k (for fewer than k items
+    // to lie above it, 19 of the first k catalog items in threshold order would have to fall into the 1/16 sample: 5 sigma),
+    // and the pre-pass costs half (10M x 256: 0.5 -> 0.25 ms)
+    int nt0 = nt >= 16 * 1024 ? nt / 16 : nt / 8;
     if (nt0 < 1024) nt0 = 1024;
     if (nt0 > nt) nt0 = nt;
     const int stride = nt / nt0; // >= 1; sampled tiles 0, stride, 2 stride, ...
