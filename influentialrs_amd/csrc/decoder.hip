@@ -1480,8 +1480,40 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     X6_T(st_p[0])
     const int m0 = blockIdx.x * (32 * NW);
     const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M;
+    // (RESID_LATE) the twelve parameter values of this thread in ONE batch of unconditional loads.  (The conditional form --
+    // "b_o if present", "c_l if present", the halves of the workgroup that hold 128-wide vectors -- compiled to six dependent
+    // memory round trips in front of the first DMA issue.  Stores behind the DMA issue would be better still, but any wait the
+    // compiler inserts while LDS-DMA pieces are pending is vmcnt(0), whatever it waits for.)
+    float pv[RESID_LATE ? 13 : 1];
+    if constexpr (RESID_LATE) {
+        const int td = tid & (D - 1);
+        const float *pbo = a.bo ? a.bo : a.b2, *pc = a.c ? a.c : a.b2, *pg2 = a.c ? a.g2 : a.b2, *pb2n = a.c ? a.b2n : a.b2;
+        pv[0] = a.b1[tid], pv[1] = a.bin[tid], pv[2] = a.bin[256 + td], pv[3] = a.b2[td], pv[4] = a.g[td], pv[5] = a.b[td];
+        pv[6] = pbo[td], pv[7] = a.g1[td], pv[8] = a.b1n[td], pv[9] = pc[td], pv[10] = pg2[td], pv[11] = pb2n[td];
+        pv[12] = 0.f;
+    }
     if (m0 >= M) return;
-    if constexpr (NT == 4) {
+    if constexpr (RESID_LATE) {
+        static_assert(NW == 4 || NW == 8, "every thread index below 256 exists");
+        // (every value "used" here, by every wave: a load still pending in the waves that skip a store below would cost a
+        //  vmcnt(0) in the middle of the DMA issue, where the compiler reuses its register)
+        asm volatile("" ::"v"(pv[0]), "v"(pv[1]), "v"(pv[2]), "v"(pv[3]), "v"(pv[4]), "v"(pv[5]), "v"(pv[6]), "v"(pv[7]), "v"(pv[8]),
+                     "v"(pv[9]), "v"(pv[10]), "v"(pv[11]));
+        if (tid < 256) {
+            vecs[V_B1 + tid] = pv[0];
+            vecs[V_BIN + tid] = pv[1];
+        }
+        if (tid < D) {
+            vecs[V_BIN + 256 + tid] = pv[2];
+            vecs[V_B2 + tid] = pv[3], vecs[V_G + tid] = pv[4], vecs[V_B + tid] = pv[5];
+            vecs[V_O + 0 * D + tid] = a.bo ? pv[6] : 0.f;
+            vecs[V_O + 1 * D + tid] = pv[7];
+            vecs[V_O + 2 * D + tid] = pv[8];
+            vecs[V_O + 3 * D + tid] = a.c ? pv[9] : 0.f;
+            vecs[V_O + 4 * D + tid] = a.c ? pv[10] : 0.f;
+            vecs[V_O + 5 * D + tid] = a.c ? pv[11] : 0.f;
+        }
+    } else if constexpr (NT == 4) {
         if (tid < 256) {
             if (!EMBED) vecs[V_B1 + tid] = a.b1[tid];
             vecs[V_BIN + tid] = a.bin[tid];
