@@ -4645,7 +4645,24 @@ __global__ void __launch_bounds__(64 * NW, 3) k_attn16h(const float *__restrict_
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     constexpr int HD = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int L = cnt ? cnt[blockIdx.y] : Lmax;
+    // every per-sequence scalar of the kernel in ONE batch of loads (packed form: all the pointers exist).  The form that read
+    // each where it was first used -- "cnt if present", "off if present", the pad index in front of the mask words, r_u and the
+    // target id behind the fill barrier -- was five dependent scalar round trips per wave, two of them behind the barrier.
+    const bool irn = (mask_mode == IRS_MASK_IRN);
+    int L_, pq_ = -1;
+    int64_t base_;
+    float ru_ = 0.f;
+    const int64_t last_id = seq[(int64_t)blockIdx.y * Lmax + Lmax - 1];
+    if constexpr (FAST) {
+        L_ = cnt[blockIdx.y], base_ = (int64_t)off[blockIdx.y], pq_ = padq[blockIdx.y];
+        ru_ = (irn ? r_u : reinterpret_cast<const float *>(cnt))[blockIdx.y];
+    } else {
+        L_ = cnt ? cnt[blockIdx.y] : Lmax;
+        base_ = off ? (int64_t)off[blockIdx.y] : (int64_t)blockIdx.y * Lmax;
+        if (padq) pq_ = padq[blockIdx.y];
+        if (irn) ru_ = r_u[blockIdx.y];
+    }
+    const int L = L_;
     const int L16max = (Lmax + 15) & ~15;
     const int PL = L16max * 64;                 // bytes of one plane image
     char *Vp = smem;                            // V: [2 planes][L16][64 B]
@@ -4654,9 +4671,8 @@ __global__ void __launch_bounds__(64 * NW, 3) k_attn16h(const float *__restrict_
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 15, gq = lane >> 4;
-    const int64_t base = off ? (int64_t)off[b] : (int64_t)b * Lmax;
+    const int64_t base = base_;
     const int ld = 3 * d;
-    const bool irn = (mask_mode == IRS_MASK_IRN);
     const int L16 = (L + 15) & ~15, NB16 = L16 >> 4;
     if (L <= 0) return;
     // Fill by LDS-DMA.  K: float32 rows, 8 key rows x 128 B per instruction, chunk p of key j from source chunk p ^ (j & 7) ^
@@ -4710,7 +4726,7 @@ __global__ void __launch_bounds__(64 * NW, 3) k_attn16h(const float *__restrict_
     float4 qn0 = make_float4(0.f, 0.f, 0.f, 0.f), qn1 = qn0;
     int qb_next = mine ? 31 - __builtin_clz(mine) : -1;
     if (qb_next >= 0) load_q(qb_next, qn0, qn1);
-    const int pq = padq ? padq[b] : -1;
+    const int pq = pq_;
     for (int kb = wave; kb < (L + 31) / 32; kb += NW) {
         const int j = kb * 32 + (lane & 31);
         bool masked = (j >= L) || (irn && j == L - 1);
@@ -4722,9 +4738,9 @@ __global__ void __launch_bounds__(64 * NW, 3) k_attn16h(const float *__restrict_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's DMA pieces have landed (the barrier publishes them)
     __syncthreads();
     const float LOG2E = 1.4426950408889634f;
-    const float tgt_add = irn ? (1.0f - r_u[b]) * LOG2E : 0.f;
+    const float tgt_add = irn ? (1.0f - ru_) * LOG2E : 0.f;
     const float scale = LOG2E / sqrtf((float)HD);
-    const bool tgt_ok = irn && (seq[(int64_t)b * Lmax + Lmax - 1] != 0);
+    const bool tgt_ok = irn && (last_id != 0);
     // this lane's addresses: K row read (key = 16 kt + lq, chunk gq), V transposed read (block row (lane & 15) >> 2, columns
     // 16 ct + 4 (lane & 3) ..)
     const int tq = (lane & 15) >> 2, tp = lane & 3;
