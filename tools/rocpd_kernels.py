@@ -15,5 +15,8 @@ tot = sum(r[3] for r in rows)
 for r in rows[:24]:
     print(f"{r[0][:64]:64s} n={r[1]:7d} avg={r[2]:9.2f} us  {100 * r[3] / tot:5.1f}%")
 if len(sys.argv) > 2:
-    n = [r[1] for r in rows if sys.argv[2] in r[0]][0]
-    print(f"kernel time per {sys.argv[2]}: {tot / n:.1f} us")
+    hit = [r[1] for r in rows if sys.argv[2] in r[0]]
+    if hit:
+        print(f"kernel time per {sys.argv[2]}: {tot / hit[0]:.1f} us")
+    else:
+        print(f"(no kernel named *{sys.argv[2]}* in this trace: no per-step figure)")
