@@ -4700,23 +4700,12 @@ __global__ void __launch_bounds__(64 * NW, 3) k_attn16h(const float *__restrict_
                                                  (attn_lds_void *)(Vp + p * PL + i * 1024), 16, 0, 0);
         }
     }
-    // longest-first assignment of the 16-query blocks (block qb costs qb + 1 key tiles) to the NW waves
-    unsigned int mine = 0;
-    {
-        int load[NW];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) load[w] = 0;
-        for (int qb = NB16 - 1; qb >= 0; --qb) {
-            int w = 0;
-#pragma unroll
-            for (int v = 1; v < NW; ++v)
-                if (load[v] < load[w]) w = v;
-#pragma unroll
-            for (int v = 0; v < NW; ++v)
-                if (v == w) load[v] += qb + 1;
-            if (w == wave) mine |= 1u << qb;
-        }
-    }
+    // longest-first assignment of the 16-query blocks (block qb costs qb + 1 key tiles) to the four waves.  With costs n, n - 1,
+    // .. the greedy rule (next block to the least loaded wave, ties to the lowest wave) deals the blocks 0 1 2 3 3 2 1 0 0 1 ..
+    // in descending order: the i-th largest block goes to wave i & 7 (< 4) or 7 - (i & 7) -- a constant bit pattern over i,
+    // reversed into block order (the loop form was ~150 instructions per wave; tests/test_host_logic.py checks the identity).
+    static_assert(NW == 4, "the closed form of the longest-first deal");
+    unsigned int mine = __builtin_bitreverse32((0x01010101u << wave) | (0x01010101u << (7 - wave))) >> (32 - NB16);
     auto load_q = [&](int qb, float4 &t0, float4 &t1) {
         const int qi = qb * 16 + lq;
         const float *qrow = qkv + (base + (qi < L ? qi : L - 1)) * ld + h * HD + 8 * gq;

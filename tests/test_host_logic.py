@@ -160,3 +160,26 @@ def test_bench_windows_are_zipf_without_repeats():
         assert nz[0] == L - len(v), "pads must sit in front (pre-padded window)"
     counts = np.bincount(s[:, :-1].ravel(), minlength=N + 1)[1:]
     assert counts[:10].sum() > 20 * max(counts[1000:1010].sum(), 1) / 10, "head items must dominate (Zipf)"
+
+
+def test_attention_block_deal_closed_form_equals_the_greedy_longest_first_rule():
+    """k_attn16h deals its 16-query blocks (block qb costs qb + 1 key tiles) to four waves longest-first.  The kernel uses the
+    closed form of that greedy rule -- the i-th largest block goes to wave i & 7 if that is below 4, else 7 - (i & 7): a
+    constant bit pattern reversed into block order (decoder.hip) -- this is the identity it rests on, for every block count."""
+    def greedy(nb, nw=4):
+        load, mine = [0] * nw, [0] * nw
+        for qb in range(nb - 1, -1, -1):
+            w = 0
+            for v in range(1, nw):
+                if load[v] < load[w]:
+                    w = v
+            load[w] += qb + 1
+            mine[w] |= 1 << qb
+        return mine
+
+    def closed(nb, wave):
+        m = ((0x01010101 << wave) | (0x01010101 << (7 - wave))) & 0xFFFFFFFF
+        return int("{:032b}".format(m)[::-1], 2) >> (32 - nb)
+
+    for nb in range(1, 17):
+        assert greedy(nb) == [closed(nb, w) for w in range(4)], nb
