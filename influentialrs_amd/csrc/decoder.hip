@@ -3977,6 +3977,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) k_attn16(const float
     else if (!PERSIST && gridDim.z > 1) {
         const int v = 4 * zsplit + wave;
         if (v < NB16) mine = 1u << (NB16 - 1 - v);
+    } else if constexpr (NW == 4) { // the closed form of the greedy deal below (k_attn16h; tests/test_host_logic.py holds the identity)
+        mine = __builtin_bitreverse32((0x01010101u << wave) | (0x01010101u << (7 - wave))) >> (32 - NB16);
     } else {
         int load[NW];
 #pragma unroll
