@@ -2975,9 +2975,13 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
     // score above it).  With a 1/stride sample, r ~ 3k/stride targets ~3k emitted items per row instead of
     // ~k*stride; k_refine validates that >= k items really lie above it and otherwise hands the row to the
     // exhaustive kernel, so the speculation can cost time but never correctness.
+    // (A row falls back when fewer than k items lie above the threshold, i.e. when r_sel of the catalog's k - 1 best items
+    //  landed in the 1/stride sample: Binomial(k - 1, 1/stride) >= r_sel.  k = 100: 6e-11 per row at stride 8 with r = 38;
+    //  1.1e-5 at stride 16 with r = 19 -- one row in 100 000, seen in the soak run -- so the 1/16 sample targets 4k emitted
+    //  items, r = 25: 1.5e-9.)
     int r_sel = k;
     if (stride > 1) {
-        r_sel = (3 * k + stride - 1) / stride;
+        r_sel = ((stride >= 16 ? 4 : 3) * k + stride - 1) / stride;
         if (r_sel < 8) r_sel = 8;
         if (r_sel > k) r_sel = k;
     }
