@@ -371,11 +371,18 @@ class Job:
                                        use_graph=SHARDED_GRAPH and self.comm.is_rccl, paths=self.paths, status=self.status)
 
 
+VERIFY_JOB_HOW = ("4 rows of the last step: ring-sweep top-100 == float32-sweep top-100 (ids and value bits); 4 users of the last step "
+                  "re-decoded 4 per call on the small-batch float32-chain kernels (pinned to the reference goldens irn_c2 / irn_c3 / "
+                  "irn_c4d by tests/test_gpu_decoder_path.py): rows within 7.5e-5 of the throughput kernels'")
+VERIFY_ROW_TOL = 7.5e-5  # decoder rows through the split-precision throughput kernels vs the small-batch float32 kernels (d = 256 bound of tests/test_gpu_decoder_path.py)
+
+
 def verify_job(job, n=4):
     """Self-check of a catalog-scale leg: the rows of the windows as the timed loop left them go through the SAME
     irs_score_topk call the loop ran (>= 256 rows: the LDS-DMA ring sweep), and `n` of them are re-scored with the
-    float32 sweep (another kernel family, the exact chain end to end): ids and value bits must be equal.  Sharded:
-    every rank checks its own shard's lists; the flag is the AND over ranks."""
+    float32 sweep (another kernel family, the exact chain end to end): ids and value bits must be equal; `n` users are decoded
+    again on the small-batch float32-chain kernels and their rows must agree within VERIFY_ROW_TOL.  Sharded: every rank checks
+    its own shard's lists and its own users; the flag is the AND over ranks."""
     import torch
     from influentialrs_amd._lib import IRS_SWEEP_F32
     eng = job.eng
@@ -386,8 +393,22 @@ def verify_job(job, n=4):
     v, i, st = eng.score_topk(rows, job.k, job.sweep)
     sel = torch.linspace(0, rows.shape[0] - 1, n, device=rows.device).long()
     vf, i_f, _ = eng.score_topk(rows[sel].contiguous(), job.k, IRS_SWEEP_F32)
+    # the decoder that produced the rows (round 5): `n` of this rank's users decoded again, n per call in IRS_GEMM_F32 -- at
+    # that size irs_decode takes the small-batch float32-chain kernels (d = 256: k_block_small_wide + the float32 attention),
+    # the ones tests/test_gpu_decoder_path.py pins to the reference's irn_c2 / irn_c3 / irn_c4d goldens user by user
+    from influentialrs_amd._lib import IRS_GEMM_F32
+    sel_d = torch.linspace(0, job.B - 1, min(n, job.B), device=rows.device).long()
+    mode = eng.decoder_gemm
+    eng.decoder_gemm = IRS_GEMM_F32
+    try:
+        _, xr_s, _ = eng.decode(job.seqs[sel_d].contiguous(), job.users[sel_d].contiguous(), want_x=False, pos=job.hep[sel_d].contiguous())
+        xr_s = xr_s.clone()
+    finally:
+        eng.decoder_gemm = mode
     torch.cuda.synchronize()
-    ok = bool(torch.equal(i[sel], i_f) and torch.equal(v[sel].view(torch.int32), vf.view(torch.int32)))
+    row_err = float((xr[sel_d] - xr_s).abs().max().item())
+    job.verify_row_diff = row_err
+    ok = bool(torch.equal(i[sel], i_f) and torch.equal(v[sel].view(torch.int32), vf.view(torch.int32)) and row_err < VERIFY_ROW_TOL)
     if job.world > 1:
         import torch.distributed as dist
         t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=job.device)
@@ -702,7 +723,7 @@ def main():
         if bad:
             head_how = dict(head_how, failed_ranks=bad)
     layer = fam.pop("layer")
-    gemm_mode = job.eng.decoder_gemm
+    gemm_mode = job.eng.decoder_gemm_effective
     x6 = gemm_mode in (IRS_GEMM_X6, IRS_GEMM_H3)  # a split-precision mode of the fused layer kernel
     nprod = 3.0 if gemm_mode == IRS_GEMM_H3 else 6.0  # matrix instructions' products per float32 product
 
@@ -852,7 +873,7 @@ def main():
                           "(packed rows), results identical",
                "packed_row_fraction": fam["linear"]["packed_fraction"],
                "sweep": args.sweep + (" filter + exact f32 re-score" if args.sweep == "bf16" else ""),
-               "decoder_gemm": (("h3: float32 operands split into two float16 planes (22 of 24 significand bits), three plane products per "
+               "decoder_gemm": (("h3: float32 operands split into two float16 planes (22 of 24 significand bits; weight planes pre-scaled by 2^8 out of the float16 subnormal range), three plane products per "
                                  "float32 product on v_mfma_f32_32x32x16_f16" if gemm_mode == IRS_GEMM_H3 else
                                  "x6: float32 operands split exactly into three bf16 planes, six plane products per float32 product on "
                                  "v_mfma_f32_32x32x16_bf16") + ", float32 accumulation (fused layer kernel and embed + layer-0 q|k|v); attention "
@@ -950,7 +971,7 @@ def main():
                   "scaling": args.scaling, "users_per_gpu": j3.B, "items_per_gpu": j3.eng.n_local,
                   "workload": f"c3: n_item={j3.cfg.n_item}, d={j3.cfg.emb_dim}, L={j3.cfg.max_len}, H={j3.cfg.n_heads}; one greedy "
                               f"path-search step, top-100",
-                  "verified": ok3, "verified_how": "4 rows of the last step: ring-sweep top-100 == float32-sweep top-100 (ids and value bits)",
+                  "verified": ok3, "verified_how": VERIFY_JOB_HOW, "max_row_diff": getattr(j3, "verify_row_diff", None),
                   "fallback_rows": fb3, "phase_ms_rank0": phase_times(j3)}
             del j3
             torch.cuda.empty_cache()
@@ -973,7 +994,8 @@ def main():
                                  f"item shards of {j4.eng.n_local} rows x {world}; per step: all-gather of {u4} x {j4.cfg.emb_dim} f32 rows, "
                                  f"one all_to_all of {u4} x 100 packed 64-bit keys per rank, merge"}
             c4["verified"] = ok4
-            c4["verified_how"] = "4 rows of the last step: ring-sweep top-100 == float32-sweep top-100 (ids and value bits)"
+            c4["verified_how"] = VERIFY_JOB_HOW
+            c4["max_row_diff"] = getattr(j4, "verify_row_diff", None)
             c4["fallback_rows"] = fb4
             ph = phase_times(j4)  # every rank runs it (the collectives inside need all of them); rank 0 reports
             c4["phase_ms_rank0"] = ph
@@ -1039,6 +1061,13 @@ def main():
         X["err"] = f"{X['stage']}: {type(e).__name__}: {e}"
         print("bench.py: extra leg failed: " + X["err"], file=sys.stderr, flush=True)
     emit()
+    unverified = [nm for nm, ok_ in (("headline", head_ok), ("c3", (X["c3"] or {}).get("verified", True)),
+                                     ("c4", (X["c4"] or {}).get("verified", True))) if ok_ is False]
+    if unverified and not X["err"]:
+        # a failed self-check must not read as success to a `|| exit 1` chain (the line above still carries the numbers)
+        print("bench.py: self-check failed (verified = false): " + ", ".join(unverified), file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(4)
     if X["err"]:
         sys.stdout.flush()
         os._exit(3)  # (N > 1: the other ranks may sit in a collective of the failed leg; their own watchdogs end them, non-zero too)

@@ -372,7 +372,8 @@ int irs_sharded_graph_state(const irs_ctx *ctx);
  *                leading products hh, hm, mh, hl, lh, mm are summed on v_mfma_f32_32x32x16_bf16: float32-grade products
  *                at 6/16 of the float32-MFMA instruction time;
  *   IRS_GEMM_F32 v_mfma_f32_32x32x2f32.
- * The initial mode is IRS_GEMM_H3 unless the environment holds IRS_DECODER_GEMM=x6 or =f32 when the context is created.
+ * The initial mode is IRS_GEMM_H3 unless the environment holds IRS_DECODER_GEMM=x6 or =f32 when the context is created
+ * (any other value than h3 / x6 / f32 fails irs_create; the same holds for IRS_ATTN_GEMM).
  * Changing the mode drops the context's captured steps (they are re-captured on the next graph call).
  * Attention of the throughput path at head dim 32 behind a split-precision layer kernel (environment IRS_ATTN_GEMM, read at
  * creation): default "h3" -- scores on the float32 matrix chain, O^T += V^T P^T on float16 plane pairs, the V section of a
@@ -381,16 +382,21 @@ int irs_sharded_graph_state(const irs_ctx *ctx);
  * slower, kept for comparison).  The q | k | v buffer is internal to irs_decode: no caller sees the plane format. */
 #define IRS_GEMM_F32 0
 #define IRS_GEMM_X6 1
-/* IRS_GEMM_H3 (round 4): two FLOAT16 planes per float32 operand (h = f16(x), l = f16(x - h): 22 significand bits) and the three
- * leading products hh, hl, lh on v_mfma_f32_32x32x16_f16 -- half the matrix instructions of IRS_GEMM_X6, what is dropped is
- * 2^-22 relative (the class of the float32 accumulation's own rounding).  Needs |weights|, |activations| < 65504 (float16). */
+/* IRS_GEMM_H3 (round 4): two FLOAT16 planes per float32 operand (h = f16(x), l = f16(x - h)) and the three leading products hh,
+ * hl, lh on v_mfma_f32_32x32x16_f16 -- half the matrix instructions of IRS_GEMM_X6.  Error model (round 5): a value's two planes
+ * carry it to 2^-22 RELATIVE while l is a normal float16 (|x| >= 2^-3) and to 2^-25 ABSOLUTE below that (l subnormal).  The weight
+ * operands -- O(0.05) in a trained model -- are therefore packed times 2^8 (exact; the epilogues fold the 2^-8 into their bias
+ * multiply-add), which puts their absolute floor at 2^-33; the activation operands are O(1) LayerNorm outputs, hidden units and
+ * attention outputs, where 2^-25 absolute is 2^-25 of the sum they enter.  Needs 2^8 |weights|, |activations| < 65504 (float16):
+ * checked at finalisation, see irs_h3_range_bound. */
 #define IRS_GEMM_H3 2
 int irs_set_decoder_gemm(irs_ctx *ctx, int32_t mode);
-int irs_get_decoder_gemm(const irs_ctx *ctx);
+int irs_get_decoder_gemm(const irs_ctx *ctx);           /* the selected mode (a get / set round trip restores it) */
+int irs_get_decoder_gemm_effective(const irs_ctx *ctx); /* the mode that runs (IRS_GEMM_X6 where IRS_GEMM_H3 fails its range bound) */
 /* Float16 planes overflow at 65504.  irs_finalize_weights bounds every operand of the float16-plane kernels from the bound
  * weights (embedded tokens, LayerNorm outputs, hidden activations, V rows, the weights themselves) and keeps half the range as
  * margin: a model whose bound is 32752 or more runs IRS_GEMM_X6 (no range limit) wherever IRS_GEMM_H3 is selected, with float32
- * V rows -- irs_get_decoder_gemm reports the mode that RUNS.  irs_h3_range_bound returns the bound (-1 before finalisation).
+ * V rows -- irs_get_decoder_gemm_effective reports the mode that RUNS (irs_get_decoder_gemm the selected one).  irs_h3_range_bound returns the bound (-1 before finalisation).
  * (The reference has no counterpart: model/influentialRS.py:67-74 multiplies in float32 throughout.) */
 float irs_h3_range_bound(const irs_ctx *ctx);
 

@@ -49,6 +49,11 @@ extern "C" int irs_create(irs_ctx **out, const irs_dims *dims, const irs_shard *
     }
     if (sh.item_lo < 0 || sh.item_hi > D.n_item || sh.item_lo >= sh.item_hi) BAD("bad item shard [%lld, %lld)", (long long)sh.item_lo, (long long)sh.item_hi);
     if (sh.item_hi - sh.item_lo > 0x7FFFFFE0LL) BAD("shard too large");
+    {   // the launchers' per-device caches (MaxDynamicSharedMemorySize attributes, occupancy) are keyed by device ordinal
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && (dev < 0 || dev >= IRS_MAX_DEVICES))
+            BAD("device ordinal %d: contexts are supported on devices 0 .. %d", dev, IRS_MAX_DEVICES - 1);
+    }
 #undef BAD
     irs_ctx *c = new (std::nothrow) irs_ctx();
     if (!c) {
@@ -70,9 +75,20 @@ extern "C" int irs_create(irs_ctx **out, const irs_dims *dims, const irs_shard *
     c->lse_slots = 2048;
     {   // decoder GEMMs of the throughput path: split-bf16 MFMAs (k_block_x6, the default) or float32 MFMAs (k_block);
         // the environment variable sets the initial mode, irs_set_decoder_gemm() changes it on a live context
+        // (an unrecognised value is an error, not a silent default: a typo would otherwise select another arithmetic)
         const char *e = getenv("IRS_DECODER_GEMM");
+        if (e && strcmp(e, "f32") && strcmp(e, "x6") && strcmp(e, "h3")) {
+            snprintf(g_create_err, sizeof(g_create_err), "IRS_DECODER_GEMM=%s (expected h3, x6 or f32)", e);
+            delete c;
+            return IRS_E_INVALID;
+        }
         c->use_x6 = e ? (strcmp(e, "f32") == 0 ? IRS_GEMM_F32 : strcmp(e, "x6") == 0 ? IRS_GEMM_X6 : IRS_GEMM_H3) : IRS_GEMM_H3;
         const char *ea = getenv("IRS_ATTN_GEMM");
+        if (ea && strcmp(ea, "f32") && strcmp(ea, "x6") && strcmp(ea, "h3")) {
+            snprintf(g_create_err, sizeof(g_create_err), "IRS_ATTN_GEMM=%s (expected h3, x6 or f32)", ea);
+            delete c;
+            return IRS_E_INVALID;
+        }
         c->use_attn_x6 = ea ? (strcmp(ea, "x6") == 0) : 0;
         c->use_attn_h3 = ea ? (strcmp(ea, "h3") == 0) : 1; // (IRS_ATTN_GEMM=f32: float32 K / V rows and the float32-MFMA attention)
         const char *ep = getenv("IRS_ATTN_PERSIST");
@@ -426,8 +442,14 @@ extern "C" int irs_set_decoder_gemm(irs_ctx *ctx, int32_t mode) {
     return IRS_OK;
 }
 
-// (what runs: a model whose weights fail finalisation's float16 range bound runs IRS_GEMM_X6 where IRS_GEMM_H3 is selected)
+// the SELECTED mode (what irs_set_decoder_gemm stored: a get / set round trip restores it) ...
 extern "C" int irs_get_decoder_gemm(const irs_ctx *ctx) {
+    if (!ctx) return IRS_E_INVALID;
+    return ctx->use_x6;
+}
+// ... and the mode that RUNS: a model whose weights fail finalisation's float16 range bound runs IRS_GEMM_X6 where
+// IRS_GEMM_H3 is selected
+extern "C" int irs_get_decoder_gemm_effective(const irs_ctx *ctx) {
     if (!ctx) return IRS_E_INVALID;
     return (ctx->use_x6 == IRS_GEMM_H3 && ctx->finalized && !ctx->h3_ok) ? IRS_GEMM_X6 : ctx->use_x6;
 }

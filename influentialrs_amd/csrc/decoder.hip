@@ -1257,13 +1257,23 @@ typedef __attribute__((ext_vector_type(4))) unsigned int x6_u32x4;
 __host__ __device__ constexpr int x6_npre(int NT) { return NT * (NT / 4) + 16 * (NT / 4); } // steps in front of the q | k | v region
 __host__ __device__ constexpr int x6_nstep(int NT) { return x6_npre(NT) + 3 * NT * (NT / 4); }
 // NPL = planes per float32 operand.  3 (round 3): bf16 planes h + m + l = the value exactly, six plane products per float32
-// product.  2 (round 4, "h3"): FLOAT16 planes h = f16(x), l = f16(x - h) -- 22 of the 24 significand bits (f16 carries 11),
+// product.  2 (round 4, "h3"): FLOAT16 planes h = f16(x), l = f16(x - h) -- 22 of the 24 significand bits (f16 carries 11)
+// while l is a normal float16, 2^-25 absolute below (see X6_H3_WSHIFT for what that means for the weights) --,
 // three plane products (hh, hl, lh; what is dropped is 2^-22 relative: the float32 accumulation's own rounding class) on
 // v_mfma_f32_32x32x16_f16, same shapes and lane maps: HALF the matrix instructions, 2/3 of the weight stream, a cheaper split
 // (v_cvt_pk_f16_f32: 3 vector instructions per value instead of 5.5).  Float16's range is the price: |operand| < 65504 (weights
 // are O(0.1), activations behind a LayerNorm O(10), embedded tokens |E| sqrt(d) + 1); tiny values fall into f16 subnormals,
 // whose ABSOLUTE spacing 2^-24 is what matters for a sum of products.  A step is 8 groups x NPL planes = 8 NPL KB.
 __host__ __device__ constexpr int x6_step_b(int NPL) { return 8 * NPL * 1024; }
+// Round 5: the float16-plane WEIGHT operands are packed times 2^8.  Weights are O(0.05): their low plane l = f16(w - f16(w)) is
+// a float16 SUBNORMAL (|l| <= 2^-16 < 2^-14), whose absolute spacing 2^-24 left only ~19-20 significand bits on typical weights
+// ("22 bits" held for |x| >= 2^-3 only).  Scaled by a power of two -- exact, commutes with every rounding -- the absolute floor
+// of a weight's two-plane value is 2^-33 instead of 2^-25; the accumulators then hold 2^8 times the product and every epilogue
+// folds the 2^-8 into the multiply-add that adds its bias (one fma instead of one add: no extra instruction).  Activations
+// (LayerNorm outputs, hidden units, attention outputs: O(1)) keep their scale: 2^-25 absolute on an O(1) operand is 2^-25
+// relative to the sum it enters.  Bf16 planes (IRS_GEMM_X6) carry float32's exponent range and are not scaled.
+#define X6_H3_WSHIFT 8
+__host__ __device__ constexpr float x6_wscale(int NPL) { return NPL == 2 ? (float)(1 << X6_H3_WSHIFT) : 1.0f; }
 __host__ __device__ constexpr size_t x6_layer_bytes(int NT, int NPL = 3) { return (size_t)x6_nstep(NT) * x6_step_b(NPL); }
 // ring slots (X6_NSLOT2 for float16 planes: their steps are 16 KB, so four fit twice per CU -- two steps of DMA in flight
 // behind the one being multiplied)
@@ -1328,7 +1338,8 @@ __global__ void __launch_bounds__(256) k_pack_x6(const float *__restrict__ Wo, c
                 bits = u >> 16;
                 v -= __uint_as_float(bits << 16);
             }
-        } else { // float16 planes: h = f16(v), l = f16(v - h), round to nearest even (the conversion instruction's mode)
+        } else { // float16 planes of 2^8 v: h = f16(v), l = f16(v - h), round to nearest even (the conversion instruction's mode)
+            v *= x6_wscale(2);
             _Float16 hv = (_Float16)v;
             if (p == 1) hv = (_Float16)(v - (float)hv);
             bits = (unsigned int)__builtin_bit_cast(unsigned short, hv);
@@ -1458,6 +1469,8 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     constexpr int NP = 8 * NPL, STEP_B = x6_step_b(NPL); // pieces (fragments) and bytes of a step
     using x6_plane = typename std::conditional<NPL == 2, x6_f16x8, x6_bf16x8>::type;
     constexpr int D = 32 * NT, F = 256, NSLOT = x6_nslot(NPL), LEAD = NSLOT - 1, PPW = NP / NW, HT = NT / 4;
+    // the weight planes hold WS x the weights (x6_wscale): an accumulator of plane products holds WS x the product, IWS folds back
+    constexpr float WS = x6_wscale(NPL), IWS = 1.0f / WS;
     // RESID_LATE (round 4, d = 128 with float16 planes): the workgroup's start no longer waits for its 128 KB of inputs.  The
     // first three steps' DMA goes out FIRST, then the attention tiles; the residual goes to its OWN tiles, requested behind the
     // second step's barrier (when two attention tiles are dead: all three sets at once spill) and added with b_o in front of
@@ -1603,8 +1616,8 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 t4 = rfrag[(tn * 4 + g) * 64];
-                    acc[tn][4 * g + 0] = t4.x, acc[tn][4 * g + 1] = t4.y, acc[tn][4 * g + 2] = t4.z, acc[tn][4 * g + 3] = t4.w;
+                    const float4 t4 = rfrag[(tn * 4 + g) * 64]; // (the out-projection accumulates WS x its product onto it)
+                    acc[tn][4 * g + 0] = t4.x * WS, acc[tn][4 * g + 1] = t4.y * WS, acc[tn][4 * g + 2] = t4.z * WS, acc[tn][4 * g + 3] = t4.w * WS;
                 }
         }
         if constexpr (RESID_LATE) {
@@ -1838,11 +1851,16 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
         if constexpr (ASM_VECS && vb >= 0) {
             vec_stream(std::integral_constant<int, 1>{}, vb_c, x6_ic0{}, x6_ic0{}, [&](auto gc, const float4 bb, const float4, const float4) __attribute__((always_inline)) {
                 constexpr int tn = decltype(gc)::value >> 2, g = decltype(gc)::value & 3;
+                // (vb >= 0 = the out-projection's epilogue: the accumulators hold WS x (product [+ residual]))
                 if constexpr (RESID_LATE) {
                     const float4 rs = __builtin_bit_cast(float4, resq[tn][g]);
-                    acc[tn][4 * g + 0] += rs.x, acc[tn][4 * g + 1] += rs.y, acc[tn][4 * g + 2] += rs.z, acc[tn][4 * g + 3] += rs.w;
+                    acc[tn][4 * g + 0] = __builtin_fmaf(acc[tn][4 * g + 0], IWS, rs.x), acc[tn][4 * g + 1] = __builtin_fmaf(acc[tn][4 * g + 1], IWS, rs.y);
+                    acc[tn][4 * g + 2] = __builtin_fmaf(acc[tn][4 * g + 2], IWS, rs.z), acc[tn][4 * g + 3] = __builtin_fmaf(acc[tn][4 * g + 3], IWS, rs.w);
+                    acc[tn][4 * g + 0] += bb.x, acc[tn][4 * g + 1] += bb.y, acc[tn][4 * g + 2] += bb.z, acc[tn][4 * g + 3] += bb.w;
+                } else {
+                    acc[tn][4 * g + 0] = __builtin_fmaf(acc[tn][4 * g + 0], IWS, bb.x), acc[tn][4 * g + 1] = __builtin_fmaf(acc[tn][4 * g + 1], IWS, bb.y);
+                    acc[tn][4 * g + 2] = __builtin_fmaf(acc[tn][4 * g + 2], IWS, bb.z), acc[tn][4 * g + 3] = __builtin_fmaf(acc[tn][4 * g + 3], IWS, bb.w);
                 }
-                acc[tn][4 * g + 0] += bb.x, acc[tn][4 * g + 1] += bb.y, acc[tn][4 * g + 2] += bb.z, acc[tn][4 * g + 3] += bb.w;
                 sum += (acc[tn][4 * g + 0] + acc[tn][4 * g + 1]) + (acc[tn][4 * g + 2] + acc[tn][4 * g + 3]);
             });
         } else {
@@ -1852,7 +1870,8 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
                 for (int g = 0; g < 4; ++g) {
                     if constexpr (vb >= 0) {
                         const float4 bb = *reinterpret_cast<const float4 *>(vecs + vb + tn * 32 + 8 * g + 4 * lk);
-                        acc[tn][4 * g + 0] += bb.x, acc[tn][4 * g + 1] += bb.y, acc[tn][4 * g + 2] += bb.z, acc[tn][4 * g + 3] += bb.w;
+                        acc[tn][4 * g + 0] = __builtin_fmaf(acc[tn][4 * g + 0], IWS, bb.x), acc[tn][4 * g + 1] = __builtin_fmaf(acc[tn][4 * g + 1], IWS, bb.y);
+                        acc[tn][4 * g + 2] = __builtin_fmaf(acc[tn][4 * g + 2], IWS, bb.z), acc[tn][4 * g + 3] = __builtin_fmaf(acc[tn][4 * g + 3], IWS, bb.w);
                     }
                     sum += (acc[tn][4 * g + 0] + acc[tn][4 * g + 1]) + (acc[tn][4 * g + 2] + acc[tn][4 * g + 3]);
                     if constexpr (!ASM_VECS) __builtin_amdgcn_sched_barrier(0); // (the scheduler otherwise hoists every parameter read of the phase: ~480 registers)
@@ -1931,6 +1950,12 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
                 x6_split(acc[tn], s2, Yp[tn][s2]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        if constexpr (NPL == 2) { // FFN-2 accumulates WS x its product onto y in place: y goes on as WS y (exact)
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tn][r] *= WS;
+        }
     }
     // a 32-value bias tile (vecs offset vo) into an accumulator tile: asm reads (a compiler-visible LDS read here would wait
     // for the DMA issued half a step ago); the wait drains the fragment read-aheads with it, which only makes the next
@@ -2023,7 +2048,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             if constexpr (HT == 2) { X6_STEP1(NOUT + 4 * ft + 1, (&Yp[4]), hft) }
             bias_tile(bt, V_B1 + ft * 32);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hft[r] = fmaxf(hft[r] + bt[r], 0.f);
+            for (int r = 0; r < 16; ++r) hft[r] = fmaxf(__builtin_fmaf(hft[r], IWS, bt[r]), 0.f);
             X6_STEP(NOUT + 2 * HT * ft + HT, hft, acc[0], acc[1], acc[2], acc[3])
             if constexpr (HT == 2) { X6_STEP(NOUT + 4 * ft + 3, hft, acc[4], acc[5], acc[6], acc[7]) }
         }
@@ -2036,8 +2061,9 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
         if constexpr (ASM_VECS) {
             vec_stream(std::integral_constant<int, 1>{}, std::integral_constant<int, V_B2>{}, x6_ic0{}, x6_ic0{},
                        [&](auto gc, const float4 bb, const float4, const float4) __attribute__((always_inline)) {
-                constexpr int tn = decltype(gc)::value >> 2, g = decltype(gc)::value & 3;
-                acc[tn][4 * g + 0] += bb.x, acc[tn][4 * g + 1] += bb.y, acc[tn][4 * g + 2] += bb.z, acc[tn][4 * g + 3] += bb.w;
+                constexpr int tn = decltype(gc)::value >> 2, g = decltype(gc)::value & 3; // (acc = WS (y + h W2^T))
+                acc[tn][4 * g + 0] = __builtin_fmaf(acc[tn][4 * g + 0], IWS, bb.x), acc[tn][4 * g + 1] = __builtin_fmaf(acc[tn][4 * g + 1], IWS, bb.y);
+                acc[tn][4 * g + 2] = __builtin_fmaf(acc[tn][4 * g + 2], IWS, bb.z), acc[tn][4 * g + 3] = __builtin_fmaf(acc[tn][4 * g + 3], IWS, bb.w);
                 sum += (acc[tn][4 * g + 0] + acc[tn][4 * g + 1]) + (acc[tn][4 * g + 2] + acc[tn][4 * g + 3]);
             });
         } else {
@@ -2046,7 +2072,8 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 bb = *reinterpret_cast<const float4 *>(vecs + V_B2 + tn * 32 + 8 * g + 4 * lk);
-                acc[tn][4 * g + 0] += bb.x, acc[tn][4 * g + 1] += bb.y, acc[tn][4 * g + 2] += bb.z, acc[tn][4 * g + 3] += bb.w;
+                acc[tn][4 * g + 0] = __builtin_fmaf(acc[tn][4 * g + 0], IWS, bb.x), acc[tn][4 * g + 1] = __builtin_fmaf(acc[tn][4 * g + 1], IWS, bb.y);
+                acc[tn][4 * g + 2] = __builtin_fmaf(acc[tn][4 * g + 2], IWS, bb.z), acc[tn][4 * g + 3] = __builtin_fmaf(acc[tn][4 * g + 3], IWS, bb.w);
                 sum += (acc[tn][4 * g + 0] + acc[tn][4 * g + 1]) + (acc[tn][4 * g + 2] + acc[tn][4 * g + 3]);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -2124,7 +2151,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
                         f16x4 hp, lp;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float v = qt[4 * g + e] + bt[4 * g + e];
+                            const float v = __builtin_fmaf(qt[4 * g + e], IWS, bt[4 * g + e]);
                             const _Float16 hv = (_Float16)v;
                             hp[e] = hv;
                             lp[e] = (_Float16)(v - (float)hv);
@@ -2135,8 +2162,9 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
                 } else {
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<float4 *>(qrow + 8 * g) = make_float4(qt[4 * g + 0] + bt[4 * g + 0], qt[4 * g + 1] + bt[4 * g + 1],
-                                                                                qt[4 * g + 2] + bt[4 * g + 2], qt[4 * g + 3] + bt[4 * g + 3]);
+                        *reinterpret_cast<float4 *>(qrow + 8 * g) =
+                            make_float4(__builtin_fmaf(qt[4 * g + 0], IWS, bt[4 * g + 0]), __builtin_fmaf(qt[4 * g + 1], IWS, bt[4 * g + 1]),
+                                        __builtin_fmaf(qt[4 * g + 2], IWS, bt[4 * g + 2]), __builtin_fmaf(qt[4 * g + 3], IWS, bt[4 * g + 3]));
                 }
             }
             X6_T(st_q1)
@@ -5502,7 +5530,7 @@ float irs_h3_operand_bound(const irs_ctx *ctx, const float *st) {
     const float xin = sd * fmaxf(a0, ln);                // norm of a layer's input row
     const float v = xin * st[6] + st[7];                 // a V row (and the attention output, a convex combination of V rows)
     const float h = sd * ln * st[5] + st[7];             // a hidden activation
-    return fmaxf(fmaxf(fmaxf(a0, ln), fmaxf(v, h)), st[7]);
+    return fmaxf(fmaxf(fmaxf(a0, ln), fmaxf(v, h)), st[7] * x6_wscale(2)); // (the weight planes hold 2^8 x the weights)
 }
 static constexpr int X6_LDS_BYTES = x6_lds_bytes(4);
 // one launcher for every instantiation of the fused layer kernel: QP0 (k | v-only tail), EMBED, NT (4: d = 128, 8: d = 256),
@@ -5618,13 +5646,17 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                      attn16_ok(ctx, ctx->act_qkv, ctx->act_yf);
     const bool x6d_small = x6d && rows < 32768;
     // the split-precision layer kernels hand K / V to the attention as float16 plane pairs (k_attn16h) unless switched off
-    const bool kv_planes = ctx->use_attn_h3 && ctx->h3_ok && ctx->use_x6 && ctx->w_x6 && (d == 128 || x6d) && F == 256 && ctx->dims.n_layers > 1 &&
+    // ONE predicate for the writers (embed kernel, layer kernel tail) and the reader (launch_attn: k_attn16h): it includes the
+    // layer loop's own condition for the fused block + 16-query attention (fragment-major activations, head dim 32, L <= 256,
+    // 16-byte aligned workspace), so a V section is never written as planes for an attention kernel that reads float32
+    const bool frag = (d <= LIN_BN && d % 32 == 0 && rows > 2048 && !small_cfg && !any_cfg) || x6d;
+    const bool fuse_block_cfg = frag && (d == 128 || x6d) && F == 256 && attn16_ok(ctx, ctx->act_qkv, ctx->act_yf);
+    const bool kv_planes = fuse_block_cfg && ctx->use_attn_h3 && ctx->h3_ok && ctx->use_x6 && ctx->w_x6 && ctx->dims.n_layers > 1 &&
                            !x6d_small && rows * (long long)ctx->dims.n_heads > 64 * (long long)L; // (not the z-split latency grid)
     // d = 256 below the throughput regime (C5's 32 beam windows, single users): the 16-token fused layer kernel for wide
     // models (k_block_small_wide) instead of ~8 per-GEMM launches per layer
     const bool wide_cfg = small_wide_shape(d, F) && ctx->w_frag16 && !x6d && rows < 32768;
     const size_t wide_lf = small_wide_layer_floats(d, F); // one wave (32 tokens) per workgroup: a few thousand tokens still reach every CU
-    const bool frag = (d <= LIN_BN && d % 32 == 0 && rows > 2048 && !small_cfg && !any_cfg) || x6d;
     // one sequence (the reference IRN's own regime, and the latency metric's): self-attention runs inside the layer
     // kernel; q | k | v alternate between two buffers so that the last (rows-only) layer reads ctx->act_qkv
     const bool att_fused = small_cfg && rows_only && B == 1 && ctx->dims.n_heads == 4 && L <= 256 && ctx->act_qkv_b1 &&
@@ -5801,7 +5833,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         }
         // d = 128, F = 256, head dim 32: attention writes its output fragment-major and ONE kernel does the rest of
         // the layer (out-projection + LN1/LN2, feed-forward + LN3, the next layer's QKV) with y, h, x' in registers
-        const bool fuse_block = frag && (d == 128 || x6d) && F == 256 && attn16_ok(ctx, ctx->act_qkv, yf);
+        const bool fuse_block = fuse_block_cfg;
         if (!att_fused &&
             (rc = launch_attn(ctx, ctx->act_qkv, seq, ctx->act_ru, fuse_block ? yf : ctx->act_ao, B, s, off, cnt, tok, fuse_block,
                               rows_only && !small_plan ? l : -1, kv_planes && fuse_block && ctx->use_x6 && ctx->w_x6)))

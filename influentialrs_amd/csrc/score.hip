@@ -2949,10 +2949,10 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
     const int nub = (a.UT + UBh - 1) / UBh;
 
     // pre-pass over a strided sample of item tiles: >= 1024 tiles (32768 items) or 1/8 of the shard; 1/16 where that still is
-    // >= 1024 tiles (shards of 524288 items and more; round 4).  The threshold is then the ceil(3k/16) = 19th largest sampled
-    // group maximum per row instead of the 38th of twice as many: the emitted count per row stays ~3k (for fewer than k items
-    // to lie above it, 19 of the first k catalog items in threshold order would have to fall into the 1/16 sample: 5 sigma),
-    // and the pre-pass costs half (10M x 256: 0.5 -> 0.25 ms)
+    // >= 1024 tiles (shards of 524288 items and more; round 4).  The threshold is then the ceil(4k/16) = 25th largest sampled
+    // group maximum per row (r_sel below) instead of the 38th of twice as many: ~4k emitted items per row instead of ~3k (a third
+    // more refine work), for a fallback probability of 1.5e-9 per row -- 25 of the first k - 1 catalog items in threshold order
+    // would have to fall into the 1/16 sample -- and the pre-pass costs half (10M x 256: 0.5 -> 0.25 ms)
     int nt0 = nt >= 16 * 1024 ? nt / 16 : nt / 8;
     if (nt0 < 1024) nt0 = 1024;
     if (nt0 > nt) nt0 = nt;

@@ -446,8 +446,13 @@ class Engine:
     @property
     def decoder_gemm(self) -> int:
         """IRS_GEMM_H3 (split-float16 MFMAs, the default), IRS_GEMM_X6 (split-bf16 MFMAs) or IRS_GEMM_F32 (float32 MFMAs):
-        include/irs_hip.h."""
+        include/irs_hip.h.  The SELECTED mode (get / set round trips restore it); `decoder_gemm_effective` is what runs."""
         return int(self.lib.irs_get_decoder_gemm(self.h))
+
+    @property
+    def decoder_gemm_effective(self) -> int:
+        """The arithmetic that runs: IRS_GEMM_X6 where IRS_GEMM_H3 is selected and the weights fail the float16 range bound."""
+        return int(self.lib.irs_get_decoder_gemm_effective(self.h))
 
     @decoder_gemm.setter
     def decoder_gemm(self, mode: int):
@@ -456,7 +461,7 @@ class Engine:
     @property
     def h3_range_bound(self) -> float:
         """Largest operand magnitude the bound weights allow in the float16-plane kernels (irs_h3_range_bound; -1 before the
-        weights are finalised).  At 32752 or more IRS_GEMM_H3 runs as IRS_GEMM_X6 and `decoder_gemm` reports that."""
+        weights are finalised).  At 32752 or more IRS_GEMM_H3 runs as IRS_GEMM_X6 and `decoder_gemm_effective` reports that."""
         return float(self.lib.irs_h3_range_bound(self.h))
 
     # ------------------------------------------------------------------ measurement

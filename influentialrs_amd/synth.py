@@ -30,6 +30,9 @@ CONFIGS = {
     "c2": dict(n_user=6040, n_item=3415, emb_dim=128, max_len=200, n_heads=4, n_layers=6, ffn_dim=256, u_emb_dim=10),
     "c3": dict(n_user=100_000, n_item=1_000_000, emb_dim=128, max_len=200, n_heads=4, n_layers=6, ffn_dim=256, u_emb_dim=10),
     "c4": dict(n_user=100_000, n_item=10_000_000, emb_dim=256, max_len=200, n_heads=8, n_layers=6, ffn_dim=256, u_emb_dim=10),
+    # C4 / C5's decoder shape (d = 256, 8 heads) on an ml-1m-sized catalog: small enough for the reference to run
+    # on the CPU in seconds per user, so the d = 256 kernels get a reference-run golden of their own (irn_c4d)
+    "c4d": dict(n_user=6040, n_item=3415, emb_dim=256, max_len=200, n_heads=8, n_layers=6, ffn_dim=256, u_emb_dim=10),
     # evaluator (SampleNet) defaults, model_params.py:116-126
     "eval_default": dict(n_user=6040, n_item=3415, emb_dim=30, max_len=60, n_heads=6, n_layers=6, ffn_dim=120, u_emb_dim=10),
     "eval_tiny": dict(n_user=64, n_item=257, emb_dim=16, max_len=12, n_heads=2, n_layers=2, ffn_dim=24, u_emb_dim=10),

@@ -418,6 +418,7 @@ CASES = {
     "irn_c1": lambda: irn_case("irn_c1", "c1", 32),
     "irn_c2": lambda: irn_case("irn_c2", "c2", 32),
     "irn_c3": lambda: irn_case("irn_c3", "c3", 8, max_path_len=4),
+    "irn_c4d": lambda: irn_case("irn_c4d", "c4d", 32),
     "eval_tiny": lambda: eval_case("eval_tiny", "eval_tiny", 8),
     "eval_default": lambda: eval_case("eval_default", "eval_default", 6),
     "contract": contract_case,

@@ -22,10 +22,12 @@ def _setup(cfgname, n):
     return cfg, sd, seqs, users, targets
 
 
+@pytest.mark.parametrize("gname,cfgname", [("irn_default", "default"), ("irn_c4d", "c4d")])
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_beam1_equals_greedy_and_reference(golden, use_graph):
-    g = golden("irn_default")
-    cfg = synth.make_config("default")
+def test_beam1_equals_greedy_and_reference(golden, use_graph, gname, cfgname):
+    """(irn_c4d, round 5: C5's decoder shape -- the beam loop's decodes of 32 windows run k_block_small_wide<256>.)"""
+    g = golden(gname)
+    cfg = synth.make_config(cfgname)
     sd = synth.irn_state_dict(cfg, 1234)
     B, L = g["seqs"].shape
     eng = make_engine(cfg, sd, max_rows=B, max_seqs=B)

@@ -25,7 +25,9 @@ X_TOL = 2e-5
 # mean 1.0e-6 / 1.2e-6).  The north star's bar is 1e-3 relative on the logits.
 X_TOL_X6 = 5e-5
 TAU = 2e-5  # two reference scores closer than this may swap (decoder tolerance propagated to the logits)
-GOLDENS = [("irn_tiny", "tiny"), ("irn_default", "default"), ("irn_c1", "c1"), ("irn_c2", "c2"), ("irn_c3", "c3")]
+# irn_c4d (round 5): C4 / C5's decoder shape (d = 256, 8 heads, L = 200) run by the unmodified reference on an ml-1m-sized
+# catalog -- 32 windows per call = the small-batch d = 256 kernels (k_block_small_wide, per-GEMM float32 kernels for full decodes)
+GOLDENS = [("irn_tiny", "tiny"), ("irn_default", "default"), ("irn_c1", "c1"), ("irn_c2", "c2"), ("irn_c3", "c3"), ("irn_c4d", "c4d")]
 _ENG = {}
 
 
@@ -85,7 +87,7 @@ def test_decoder_rows_vs_golden_and_oracle(oracle, golden, name, cfgname):
 STRICT = {}
 # golden users whose top-100 ids differ from the reference's inside a run of reference gaps < TAU; every other user must be
 # identical id for id (an exact count, like tests/test_oracle_golden.py:18; observed sets in profiles/r04/parity_counts.json)
-NEAR_TIE_USERS = {"irn_tiny": [], "irn_default": [], "irn_c1": [], "irn_c2": [20], "irn_c3": []}
+NEAR_TIE_USERS = {"irn_tiny": [], "irn_default": [], "irn_c1": [], "irn_c2": [20], "irn_c3": [], "irn_c4d": []}
 
 
 @pytest.mark.parametrize("name,cfgname", GOLDENS)
@@ -763,7 +765,7 @@ def test_float16_plane_attention_equals_float32_attention(monkeypatch):
 def test_float16_planes_fall_back_outside_their_range():
     """IRS_GEMM_H3 multiplies on float16 planes (|operand| < 65504).  irs_finalize_weights bounds every operand from the bound
     weights; a model whose bound reaches half the float16 range must run the split-bf16 kernels instead (no range limit) and say
-    so through irs_get_decoder_gemm -- here: feed-forward weights scaled so that hidden activations reach ~1e5 (the second
+    so through irs_get_decoder_gemm_effective (the selected mode stays IRS_GEMM_H3, so a get / set round trip restores it) -- here: feed-forward weights scaled so that hidden activations reach ~1e5 (the second
     linear layer scaled back, so the rows stay finite and comparable).  The rows must equal the float32-MFMA kernels' within
     the split-bf16 tolerance relative to their magnitude, with no inf / NaN that the float32 form does not have."""
     from influentialrs_amd._lib import IRS_GEMM_F32, IRS_GEMM_H3, IRS_GEMM_X6
@@ -771,7 +773,7 @@ def test_float16_planes_fall_back_outside_their_range():
     L, B = cfg.max_len, 300
     sd = synth.irn_state_dict(cfg, 790)
     base = make_engine(cfg, sd, max_rows=B, max_seqs=B)
-    assert base.decoder_gemm == IRS_GEMM_H3 and 0 < base.h3_range_bound < 32752       # a model of ordinary scale
+    assert base.decoder_gemm == IRS_GEMM_H3 == base.decoder_gemm_effective and 0 < base.h3_range_bound < 32752  # a model of ordinary scale
     big = dict(sd)
     for l in range(cfg.n_layers):
         big[f"decoder.layers.{l}.linear1.weight"] = sd[f"decoder.layers.{l}.linear1.weight"] * 4096.0
@@ -783,7 +785,8 @@ def test_float16_planes_fall_back_outside_their_range():
     seq, u = torch.from_numpy(seqs).cuda(), torch.from_numpy(users).cuda()
     pos = torch.full((B,), L - 2, dtype=torch.int32, device="cuda")
     eng = make_engine(cfg, big, max_rows=B, max_seqs=B)
-    assert eng.h3_range_bound >= 32752 and eng.decoder_gemm == IRS_GEMM_X6, (eng.h3_range_bound, eng.decoder_gemm)
+    assert eng.h3_range_bound >= 32752 and eng.decoder_gemm_effective == IRS_GEMM_X6 and eng.decoder_gemm == IRS_GEMM_H3, \
+        (eng.h3_range_bound, eng.decoder_gemm, eng.decoder_gemm_effective)
     ra = eng.decode(seq, u, want_x=False, pos=pos)[1].clone()
     eng.decoder_gemm = IRS_GEMM_F32
     rb = eng.decode(seq, u, want_x=False, pos=pos)[1]

@@ -3,7 +3,8 @@ layer kernel k_block_x6 / k_block, the packed-sequence attention) pinned DIRECTL
 
 tests/test_gpu_decoder_path.py runs the goldens' 32 (c2) / 8 (c3) users per call, i.e. 6400 / 1600 token rows: below the
 32768-row switch of irs_launch_decode, so those tests exercise the small-batch kernels.  Here the golden users are tiled
-(c2 x 6 = 192 windows = 38400 token rows; c3 x 24 = 192 windows), shuffled, and sent through irs_decode +
+(c2 x 6 = 192 windows = 38400 token rows; c3 x 24 = 192 windows; round 5: c4d x 6 -- d = 256, 8 heads, the decoder of
+BASELINE configs[3] / [4] on k_block_x6<.., NT = 8>), shuffled, and sent through irs_decode +
 irs_score_topk + irs_generate_paths (stream and hipGraph) in ALL decoder arithmetic modes (IRS_GEMM_H3, the default,
 IRS_GEMM_X6 and IRS_GEMM_F32): decoder rows, ranked top-100 ids, 20-step paths and the early-success count are compared with what the
 unmodified reference produced for those users (reference model/influentialRS.py:412-450, 340-390).
@@ -18,7 +19,7 @@ import torch
 from influentialrs_amd import synth
 from influentialrs_amd._lib import IRS_GEMM_F32, IRS_GEMM_H3, IRS_GEMM_X6, IRS_SWEEP_BF16
 from gpu_util import make_engine
-from parity_record import check_exact
+from parity_record import check_exact, record
 from rank_check import check_ranked
 
 pytestmark = pytest.mark.gpu
@@ -31,7 +32,10 @@ MODES = {"h3": IRS_GEMM_H3, "x6": IRS_GEMM_X6, "f32": IRS_GEMM_F32}
 NEAR_TIE_USERS = {
     ("irn_c2", "h3"): [], ("irn_c2", "x6"): [20], ("irn_c2", "f32"): [],
     ("irn_c3", "h3"): [], ("irn_c3", "x6"): [], ("irn_c3", "f32"): [],
+    ("irn_c4d", "h3"): [], ("irn_c4d", "x6"): [], ("irn_c4d", "f32"): [],
 }
+# d = 256 (irn_c4d, round 5): K = 256 contractions accumulate twice as long on the truncating 16-bit pipe
+X_TOL_D256 = {IRS_GEMM_F32: 2e-5, IRS_GEMM_X6: 6e-5, IRS_GEMM_H3: 6e-5}
 _ENG = {}
 
 
@@ -54,7 +58,7 @@ def _trim_after_target(paths, targets):
     return out, n
 
 
-@pytest.mark.parametrize("name,cfgname,reps", [("irn_c2", "c2", 6), ("irn_c3", "c3", 24)])
+@pytest.mark.parametrize("name,cfgname,reps", [("irn_c2", "c2", 6), ("irn_c3", "c3", 24), ("irn_c4d", "c4d", 6)])
 @pytest.mark.parametrize("mode", ["h3", "x6", "f32"])
 def test_throughput_kernels_reproduce_reference_goldens(golden, name, cfgname, reps, mode):
     g = golden(name)
@@ -63,6 +67,7 @@ def test_throughput_kernels_reproduce_reference_goldens(golden, name, cfgname, r
     assert B * L > 32768, "must be above the switch to the throughput kernels"
     cfg, eng = _engine(cfgname, B)
     eng.decoder_gemm = MODES[mode]
+    tol = (X_TOL_D256 if cfg.emb_dim == 256 else X_TOL)[MODES[mode]]
     try:
         rng = np.random.default_rng(20261004)
         src = rng.permutation(np.tile(np.arange(B0), reps))
@@ -76,9 +81,10 @@ def test_throughput_kernels_reproduce_reference_goldens(golden, name, cfgname, r
         xr_h, ru_h = xr.cpu().numpy(), ru.cpu().numpy()
         assert np.abs(ru_h - g["r_u"][src]).max() < 1e-6
         err = np.abs(xr_h - g["x_hep"][src]).max()
-        assert err < X_TOL[MODES[mode]], (name, mode, err)
+        assert err < tol, (name, mode, err)
         err_full = np.abs(xr_full.cpu().numpy() - g["x_hep"][src]).max()
-        assert err_full < X_TOL[MODES[mode]], (name, mode, err_full)
+        assert err_full < tol, (name, mode, err_full)
+        record(f"throughput_rows/{name}/{mode}", B0, B0, [], {"max_abs_row_error_vs_reference": float(err), "full_decode": float(err_full)})
         # copies of one user decode to the same bits wherever they sit in the batch
         first = np.array([np.nonzero(src == u)[0][0] for u in range(B0)])
         assert np.array_equal(xr_h, xr_h[first][src])

@@ -2,7 +2,7 @@
 importing the unmodified reference (tests/golden/make_golden.py).
 Tolerances: float32 vs float32 with different accumulation orders, absolute on O(1) decoder
 rows / logits, PER CONFIG: 5e-6 at tiny / default / c1 (observed over their 76 golden users:
-<= 1.5e-6), 2e-5 at c2 / c3 only (the 6-layer x 200-token d = 128 decoder: 1.04e-5 on one c2 user, 7.1e-6 at c3); ranked ids
+<= 1.5e-6), 2e-5 at c2 / c3 only (the 6-layer x 200-token d = 128 decoder: 1.04e-5 on one c2 user, 7.1e-6 at c3) and c4d (d = 256: 8.5e-6); ranked ids
 order-exact except inside runs of reference scores closer than TAU (rank_check.py), and the
 number of users that are id for id identical to the reference is asserted EXACTLY: all of them
 except the recorded near-tie users (NEAR_TIE_USERS: c2 user 20, one swap across a 2.4e-7 gap of
@@ -14,9 +14,10 @@ from influentialrs_amd import synth
 from rank_check import check_ranked
 
 TAU = 1e-5  # reference near-tie width for id comparisons
-TOLS = {"tiny": 5e-6, "default": 5e-6, "c1": 5e-6, "c2": 2e-5, "c3": 2e-5}  # decoder rows / logits, absolute
+TOLS = {"tiny": 5e-6, "default": 5e-6, "c1": 5e-6, "c2": 2e-5, "c3": 2e-5, "c4d": 2e-5}  # decoder rows / logits, absolute
 NEAR_TIE_USERS = {"irn_c2": {20}}  # users whose top-100 differs from the reference's inside a run of gaps < TAU
-IRN = [("irn_tiny", "tiny"), ("irn_default", "default"), ("irn_c1", "c1"), ("irn_c2", "c2")]
+# irn_c4d (round 5): C4 / C5's decoder shape -- d = 256, 8 heads, L = 200 -- on an ml-1m-sized catalog (observed 8.5e-6 over 32 users)
+IRN = [("irn_tiny", "tiny"), ("irn_default", "default"), ("irn_c1", "c1"), ("irn_c2", "c2"), ("irn_c4d", "c4d")]
 
 
 def _inputs(g):
