@@ -30,12 +30,15 @@ MODES = {"h3": IRS_GEMM_H3, "x6": IRS_GEMM_X6, "f32": IRS_GEMM_F32}
 # golden users whose top-100 ids differ from the reference's inside a run of reference gaps < TAU (everything else is
 # identical id for id); filled from a recording run (IRS_RECORD_PARITY=1), see profiles/r04/parity_counts.json
 NEAR_TIE_USERS = {
-    ("irn_c2", "h3"): [], ("irn_c2", "x6"): [20], ("irn_c2", "f32"): [],
+    # (round 5: with the weight planes out of the float16 subnormal range h3 lands on the oracle's side of c2 user 20's 2.4e-7
+    #  gap, like x6, the small-batch kernels and the CPU oracle; the float32-MFMA kernels on the reference's side)
+    ("irn_c2", "h3"): [20], ("irn_c2", "x6"): [20], ("irn_c2", "f32"): [],
     ("irn_c3", "h3"): [], ("irn_c3", "x6"): [], ("irn_c3", "f32"): [],
     ("irn_c4d", "h3"): [], ("irn_c4d", "x6"): [], ("irn_c4d", "f32"): [],
 }
 # d = 256 (irn_c4d, round 5): K = 256 contractions accumulate twice as long on the truncating 16-bit pipe
-X_TOL_D256 = {IRS_GEMM_F32: 2e-5, IRS_GEMM_X6: 6e-5, IRS_GEMM_H3: 6e-5}
+# (observed against the reference's rows, profiles/r05/parity_counts.json: f32 1.1e-5, x6 1.7e-5, h3 2.6e-5)
+X_TOL_D256 = {IRS_GEMM_F32: 2e-5, IRS_GEMM_X6: 4e-5, IRS_GEMM_H3: 4e-5}
 _ENG = {}
 
 
