@@ -1643,29 +1643,60 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[tn][r] = 0.f;
         }
-    } else { // this lane's token, columns 32 tn + 8 g + 4 lk + e (k_embed_frag's arithmetic: the bits k_embed_qkv writes)
-        const bool live = mt < M;
-        const int orig = live ? (a.tok_row ? a.tok_row[mt] : mt) : 0;
-        int64_t id = live ? a.seq[orig] : 0;
-        if (id < 0) id = 0;
-        if (id > a.n_item) id = a.n_item;
-        const float *e = a.E + id * (int64_t)D;
-        const float *pp_ = a.pe + (int64_t)(orig % a.L) * D;
+    } else {
+        // EMBED: x[token] = item_emb[seq[token]] * sqrt(d) + pe[position], k_embed_frag's arithmetic bit for bit.
+        // Round 5: the gather is COALESCED.  The accumulator layout wants lane = token, i.e. 64 lanes reading 32-byte pieces of 32
+        // different table rows per instruction, each 128-byte line being touched by four instructions with the whole CU's 256 KB
+        // of rows in between (the kernel spent ~140 us of its 313 in front of its first matrix instruction).  Now a wave
+        // reads WHOLE rows -- lanes 0-31 the 512 bytes of row 2 i, lanes 32-63 of row 2 i + 1 (D = 256: in two halves) --,
+        // scales and adds the position row in that layout, and transposes through LDS: the ring's slots are idle until the
+        // first DMA, a wave's 32 x 128 tile is 16 KB of them; 16-byte chunk c of row r sits at chunk c ^ (r & 31), so the row
+        // writes (one row = 32 distinct chunks) and the transposed reads (16 lanes = rows r .. r + 15, chunk c ^ r: 16
+        // distinct 16-byte slots of the 256-byte bank window) are both conflict-free.
+        const int l31 = lane & 31, lhi = lane >> 5;
+        char *scr = smem + wave * 16384;
         float4 *xo = reinterpret_cast<float4 *>(a.Xf) + fbase;
+        int64_t rid[16];
+        int rpos[16];
 #pragma unroll
-        for (int tn = 0; tn < NT; ++tn)
+        for (int i = 0; i < 16; ++i) { // token 2 i + lhi of this wave's tile (every lane of a half reads the same words)
+            const int mr = m0 + wave * 32 + 2 * i + lhi;
+            const int orig = mr < M ? (a.tok_row ? a.tok_row[mr] : mr) : 0;
+            int64_t id = mr < M ? a.seq[orig] : 0;
+            if (id < 0) id = 0;
+            if (id > a.n_item) id = a.n_item;
+            rid[i] = id, rpos[i] = orig % a.L;
+        }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = tn * 32 + 8 * g + 4 * lk;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (live) {
-                    const float4 ev = *reinterpret_cast<const float4 *>(e + n), pv = *reinterpret_cast<const float4 *>(pp_ + n);
-                    v = make_float4(__fadd_rn(__fmul_rn(ev.x, a.sqrtd), pv.x), __fadd_rn(__fmul_rn(ev.y, a.sqrtd), pv.y),
-                                    __fadd_rn(__fmul_rn(ev.z, a.sqrtd), pv.z), __fadd_rn(__fmul_rn(ev.w, a.sqrtd), pv.w));
-                }
-                xo[(tn * 4 + g) * 64] = v;
-                acc[tn][4 * g + 0] = v.x, acc[tn][4 * g + 1] = v.y, acc[tn][4 * g + 2] = v.z, acc[tn][4 * g + 3] = v.w;
+        for (int hf = 0; hf < NT / 4; ++hf) { // 128 columns at a time
+            float4 ev[16], pv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                ev[i] = *reinterpret_cast<const float4 *>(a.E + rid[i] * (int64_t)D + 128 * hf + 4 * l31);
+                pv[i] = *reinterpret_cast<const float4 *>(a.pe + (int64_t)rpos[i] * D + 128 * hf + 4 * l31);
             }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = 2 * i + lhi;
+                const bool live = m0 + wave * 32 + r < M;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live)
+                    v = make_float4(__fadd_rn(__fmul_rn(ev[i].x, a.sqrtd), pv[i].x), __fadd_rn(__fmul_rn(ev[i].y, a.sqrtd), pv[i].y),
+                                    __fadd_rn(__fmul_rn(ev[i].z, a.sqrtd), pv[i].z), __fadd_rn(__fmul_rn(ev[i].w, a.sqrtd), pv[i].w));
+                *reinterpret_cast<float4 *>(scr + r * 512 + ((l31 ^ r) << 4)) = v;
+            }
+            // (wave-private scratch: a wave's LDS operations execute in order, no barrier)
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int tn = 4 * hf + t4, c = 8 * t4 + 2 * g + lk; // columns 32 tn + 8 g + 4 lk .. + 3 of token li
+                    const float4 v = *reinterpret_cast<const float4 *>(scr + li * 512 + ((c ^ li) << 4));
+                    xo[(tn * 4 + g) * 64] = v;
+                    acc[tn][4 * g + 0] = v.x, acc[tn][4 * g + 1] = v.y, acc[tn][4 * g + 2] = v.z, acc[tn][4 * g + 3] = v.w;
+                }
+        }
+        __syncthreads(); // the scratch is the ring: every wave has read its tile before the first DMA piece lands
     }
     auto load_res = [&]() __attribute__((always_inline)) {
         if constexpr (RESID_LATE) {
