@@ -776,6 +776,10 @@ def main():
             floor_hbm_ms = alg_bytes / (PEAK_HBM_GBS * 1e9) * 1e3
             floor_mfma_ms = flops_launch / (peak * 1e12) * 1e3
             roof["floor_ms"] = {"hbm": floor_hbm_ms, "mfma": floor_mfma_ms}
+            # both roofs side by side, whatever `bound` says (round 5): algorithmic bytes resp. flops per launch / launch time / peak
+            if per_launch_ms > 0:
+                roof["frac_hbm"] = floor_hbm_ms / per_launch_ms
+                roof["frac_mfma"] = floor_mfma_ms / per_launch_ms
             if floor_hbm_ms > floor_mfma_ms and per_launch_ms > 0:
                 mfma_side = {k: roof[k] for k in ("achieved", "peak", "unit", "frac", "peak_basis", "executed_mfma_tflops",
                                                   "float32_equivalent_vs_f32_matrix_peak")}
@@ -803,7 +807,10 @@ def main():
         # per-launch mean of the committed rocprofv3 passes of this same command (FETCH_SIZE doubled per the gfx950
         # note + WRITE_SIZE, separate --pmc passes), valid for the default workload only.  It is reported together with
         # the packed row count it was measured at; `algorithmic_bytes_per_launch` is quoted at that SAME row count.
-        pmc_file = os.path.join(REPO, "profiles", "r04", "c2_b4096_pmc.json")
+        pmc_file = os.path.join(REPO, "profiles", "r05", "c2_b4096_pmc.json")
+        if not os.path.exists(pmc_file):
+            pmc_file = os.path.join(REPO, "profiles", "r04", "c2_b4096_pmc.json")
+        pmc_rel = os.path.relpath(pmc_file, REPO)
         if dom == "linear" and world == 1 and args.workload == "c2" and args.batch == 4096 and not args.n_item and os.path.exists(pmc_file):
             try:
                 with open(pmc_file) as fh:
@@ -811,7 +818,7 @@ def main():
                 kb = pm["kernels"]["k_block_x6" if x6 and "k_block_x6" in pm["kernels"] else "k_block"]
                 roof["traffic"] = float(kb["hbm_bytes_per_launch"])
                 roof["traffic_measured_at_packed_rows"] = float(pm["packed_rows_mean"])
-                roof["traffic_source"] = ("profiles/r04/c2_b4096_pmc.json (tools/r04_measure.sh: this round's binary, `bench.py "
+                roof["traffic_source"] = (pmc_rel + " (tools/r05_measure.sh: `bench.py "
                                           "--pmc-run` under rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in separate passes, "
                                           "2 x FETCH_SIZE + WRITE_SIZE per the gfx950 note): the fused layer kernel, at "
                                           "that run's own mean packed row count")
@@ -819,7 +826,7 @@ def main():
                 roof["mfma_busy_pmc"] = kb.get("mfma_busy")
                 roof["packed_rows_this_run"] = fam[dom]["packed_fraction"] * job.B * cfg.max_len
             except Exception as e:  # a malformed profile file must not cost the bench line
-                roof["traffic_source"] = f"profiles/r04/c2_b4096_pmc.json unreadable: {e}"
+                roof["traffic_source"] = f"{pmc_rel} unreadable: {e}"
         roof["flops_counted"] = "executed (dense-shape flops x packed non-pad row fraction %.3f)" % fam[dom].get("packed_fraction", 1.0)
         roof["time_basis"] = ("HIP events around every launch of the family (a second pass over the SAME K steps: the windows are "
                               "reset to their state at the start of the timed region), scaled by %.4f so that the four families "
@@ -828,6 +835,54 @@ def main():
         roof["launches_per_step"] = f["launches"] / args.steps
         roof["family_ms_per_step"] = {k: v["ms"] / args.steps for k, v in fam.items()}
         roof["family_ms_per_step_instrumented"] = {k: v["ms_instrumented"] / args.steps for k, v in fam.items()}
+
+    # ---- the whole step against what its arithmetic and its compulsory bytes allow (round 5): algorithmic flops of ONE step on the
+    # step's own windows, priced per pipe (split-precision GEMMs at the 16-bit dense peak / products per float32 product; attention
+    # scores on the float32 matrix pipe; P.V and the bf16 catalog filter on the 16-bit pipe), and the bytes that MUST cross HBM
+    # whatever the decomposition: the embedding rows in, the catalog once, the weights once, one row and one top-100 list per user
+    # out.  Every q | k | v / attention-output / x round trip between the kernels is decomposition traffic and is NOT in the floor.
+    step_roof = None
+    kernels = None
+    if rank == 0:
+        d_, F_, L_, nl_ = cfg.emb_dim, cfg.ffn_dim, cfg.max_len, cfg.n_layers
+        valid = (job.seqs != 0)
+        valid[torch.arange(job.B, device=device), job.hep.long()] = True
+        nseq = valid.sum(dim=1).double()
+        tok = float(nseq.sum().item())
+        sq_sum = float((nseq * nseq).sum().item())
+        Bn = float(job.B)
+        gemm_flops = tok * (nl_ - 1) * (8.0 * d_ * d_ + 4.0 * d_ * F_) - tok * 2.0 * d_ * d_ \
+            + Bn * (8.0 * d_ * d_ + 4.0 * d_ * F_)                       # full layers (the last one's q for B rows only) + the last layer's B rows
+        score_flops = (nl_ - 1) * sq_sum * d_ + 2.0 * tok * d_             # causal q.k: n^2 / 2 pairs x 2 d; last layer: one query per sequence
+        pv_flops = score_flops
+        sweep_flops = 2.0 * d_ * Bn * cfg.n_item
+        gemm_peak = (PEAK_BF16_TFLOPS / nprod if x6 else PEAK_F32_MATRIX_TFLOPS) * 1e12
+        floor_mfma_ms = (gemm_flops / gemm_peak + score_flops / (PEAK_F32_MATRIX_TFLOPS * 1e12) + pv_flops / (PEAK_BF16_TFLOPS / 3.0 * 1e12)
+                         + sweep_flops / (PEAK_BF16_TFLOPS * 1e12)) * 1e3
+        w_bytes = (nl_ * (4.0 * d_ * d_ + 2.0 * d_ * F_) + L_ * d_) * 4.0
+        comp_bytes = tok * d_ * 4.0 + job.eng.n_local * d_ * (2.0 + 4.0 * 100.0 / max(job.eng.n_local, 1)) + w_bytes + Bn * (d_ * 4.0 + 100.0 * 12.0)
+        floor_hbm_ms = comp_bytes / (PEAK_HBM_GBS * 1e9) * 1e3
+        ms_step_ = dt / args.steps * 1e3
+        step_roof = {"packed_token_rows": tok, "algorithmic_gflop": {"decoder_gemms": gemm_flops / 1e9, "attention_scores": score_flops / 1e9,
+                                                                       "attention_pv": pv_flops / 1e9, "catalog_sweep": sweep_flops / 1e9},
+                     "compulsory_hbm_gb": comp_bytes / 1e9, "floor_ms_mfma": floor_mfma_ms, "floor_ms_hbm": floor_hbm_ms,
+                     "ms_per_step": ms_step_, "ms_per_step_over_floor": ms_step_ / max(floor_mfma_ms, floor_hbm_ms),
+                     "pricing": "GEMMs at %s, attention scores at the float32 matrix peak %.1f TFLOP/s, P.V at 2500 / 3, catalog sweep at 2500 TFLOP/s; "
+                                "HBM 8 TB/s" % (("2500 / %d TFLOP/s" % int(nprod)) if x6 else "the float32 matrix peak", PEAK_F32_MATRIX_TFLOPS)}
+        # per-kernel numbers of the committed PMC passes of this same command (tools/r05_measure.sh -> tools/r05_pmc.py)
+        pmc5 = os.path.join(REPO, "profiles", "r05", "c2_b4096_pmc.json")
+        if world == 1 and args.workload == "c2" and args.batch == 4096 and not args.n_item and os.path.exists(pmc5):
+            try:
+                with open(pmc5) as fh:
+                    pm5 = json.load(fh)
+                kernels = [{"kernel": lab, "launches_per_step": k_.get("launches_per_step"), "us": k_["median_us"], "mfma_busy": k_.get("mfma_busy"),
+                            "hbm_gb": k_["hbm_bytes_per_launch"] / 1e9, "algorithmic_gb": k_["algorithmic_bytes_per_launch"] / 1e9,
+                            "algorithmic_gbs": k_.get("algorithmic_gbs"), "frac_hbm": k_.get("frac_hbm_peak")}
+                           for lab, k_ in pm5["kernels"].items() if lab != "k_block_x6"]
+                step_roof["decoder_hbm_gb_per_step_pmc"] = pm5.get("decoder_hbm_bytes_per_step", 0.0) / 1e9
+                step_roof["pmc_source"] = "profiles/r05/c2_b4096_pmc.json at %d packed rows" % int(pm5["packed_rows_mean"])
+            except Exception as e:  # noqa: BLE001
+                kernels = [{"error": f"profiles/r05/c2_b4096_pmc.json unreadable: {e}"}]
 
     lat = lat128 = lat1024 = lat_tokens = None
     if rank == 0 and not args.no_latency and world == 1:
@@ -917,14 +972,18 @@ def main():
             "data": "synthetic",
             "config": out_cfg,
             "verified": head_ok,
-            "verified_how": dict(head_how, what="sampled users of the timed loop's last windows: full-batch throughput kernels vs the "
-                                 "same users 8 per call on the float32-MFMA small-batch kernels (the ones the reference goldens pin "
-                                 "user by user): rows < 5e-5, top-100 values < 5e-5, ids equal outside near-ties < 5e-5, same greedy item"),
+            "verified_how": dict(head_how, what="a comparison INSIDE this library (no oracle, no reference on the GPU box): sampled users of "
+                                 "the timed loop's last windows, full-batch throughput kernels vs the same users 8 per call on the "
+                                 "float32-MFMA small-batch kernels: rows < 5e-5, top-100 values < 5e-5, ids equal outside near-ties < 5e-5, same "
+                                 "greedy item.  It is sound because tests/test_gpu_throughput_goldens.py and tests/test_gpu_decoder_path.py pin "
+                                 "BOTH sides to the unmodified reference's goldens (irn_c2, irn_c3, irn_c4d)"),
             "path_gen_p50_ms_b1": lat,
             "path_gen_b1_window_tokens": lat_tokens,
             "path_gen_ms_per_user_b128": lat128,
             "path_gen_ms_per_user_b1024": lat1024,
             "roofline": roof,
+            "step_roofline": step_roof,
+            "kernels": kernels,
             "scoring": X["scoring"],
             "c3_1M_items": X["c3"],
             "c4_item_sharded": X["c4"],
@@ -938,6 +997,35 @@ def main():
         }
         if X["err"]:
             out["extras_error"] = X["err"]
+        flat = {}
+        if roof:
+            fm = roof.get("family_ms_per_step") or {}
+            flat.update(layer_frac_hbm=roof.get("frac_hbm"), layer_frac_mfma=roof.get("frac_mfma"), layer_launch_ms=roof.get("avg_launch_ms"),
+                        linear_ms_per_step=fm.get("linear"), attn_ms_per_step=fm.get("attn"), sweep_ms_per_step=fm.get("sweep"),
+                        refine_ms_per_step=fm.get("refine"))
+        if step_roof:
+            flat.update(step_floor_ms_mfma=step_roof["floor_ms_mfma"], step_floor_ms_hbm=step_roof["floor_ms_hbm"],
+                        step_ms_over_floor=step_roof["ms_per_step_over_floor"], decoder_hbm_gb_per_step_pmc=step_roof.get("decoder_hbm_gb_per_step_pmc"))
+        for k_ in (kernels or []):
+            if k_.get("kernel") == "embed_qkv0":
+                flat["k1_embed_gather_algorithmic_gbs"] = k_.get("algorithmic_gbs")
+                flat["k1_embed_gather_us"] = k_.get("us")
+        sc_ = X["scoring"] or {}
+        for shape, tag in (("1Mx128", "1Mx128"), ("1.25Mx256", "1p25Mx256")):
+            leg = sc_.get(shape) or {}
+            m1024, m32 = leg.get("M=1024") or {}, leg.get("M=32") or {}
+            flat[f"emit_sweep_frac_bf16_peak_{tag}"] = m1024.get("emit_sweep_frac_bf16_peak")
+            flat[f"score_topk_frac_bf16_peak_{tag}"] = m1024.get("score_topk_frac_bf16_peak")
+            flat[f"score_topk_frac_hbm_m32_{tag}"] = m32.get("score_topk_frac_hbm")
+        if X["c3"]:
+            flat["c3_ms_per_step"] = X["c3"]["ms_per_step"]
+        if X["c4"]:
+            flat["c4_ms_per_step"] = X["c4"]["ms_per_step"]
+            ph_ = X["c4"].get("phase_ms_rank0") or {}
+            flat["c4_decode_ms"], flat["c4_score_topk_ms"] = ph_.get("decode"), ph_.get("score_topk")
+            c5_ = X["c4"].get("c5_beam32") or {}
+            flat["c5_step_p50_ms"] = c5_.get("step_p50_ms_stream")
+        out.update({k_: v_ for k_, v_ in flat.items() if v_ is not None})
         print(json.dumps(out), flush=True)
 
     def watchdog():
@@ -1001,7 +1089,7 @@ def main():
             c4["phase_ms_rank0"] = ph
             X["c4"] = c4
             X["stage"] = "c5"
-            if not args.no_latency and 32 % world == 0:
+            if not args.no_latency:
                 # BASELINE configs[4] (C5), D1 (ii): beam-width-32 persuasion-path search over the 10M-item catalog for ONE
                 # user -- 32 windows decoded, scored (top-100 + exact log-sum-exp over the catalog) and re-ranked per step,
                 # 20 steps; p50 over 10 repetitions after 2 warm-ups, stream launches and the captured two-step hipGraph.

@@ -378,8 +378,10 @@ int irs_sharded_graph_state(const irs_ctx *ctx);
  * Attention of the throughput path at head dim 32 behind a split-precision layer kernel (environment IRS_ATTN_GEMM, read at
  * creation): default "h3" -- scores on the float32 matrix chain, O^T += V^T P^T on float16 plane pairs, the V section of a
  * q | k | v row being WRITTEN as [32 f16 h | 32 f16 l] per (token, head) by the layer kernel (same 128 bytes; rows within 6e-6
- * of the float32 attention's); "f32": the float32-MFMA attention on float32 q | k | v rows; "x6": split-bf16 attention (measured
- * slower, kept for comparison).  The q | k | v buffer is internal to irs_decode: no caller sees the plane format. */
+ * of the float32 attention's); "f32": the float32-MFMA attention on float32 q | k | v rows.  (Round 5 removed the variants that
+ * lost twice -- split-bf16 attention "x6", the persistent work-list attention IRS_ATTN_PERSIST, the one-wave d = 256 layer kernel
+ * IRS_X6D_MIN_ROWS: their records are under profiles/r03, profiles/r04 and in HISTORY.md.)  The q | k | v buffer is internal to
+ * irs_decode: no caller sees the plane format. */
 #define IRS_GEMM_F32 0
 #define IRS_GEMM_X6 1
 /* IRS_GEMM_H3 (round 4): two FLOAT16 planes per float32 operand (h = f16(x), l = f16(x - h)) and the three leading products hh,

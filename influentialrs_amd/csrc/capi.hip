@@ -84,15 +84,12 @@ extern "C" int irs_create(irs_ctx **out, const irs_dims *dims, const irs_shard *
         }
         c->use_x6 = e ? (strcmp(e, "f32") == 0 ? IRS_GEMM_F32 : strcmp(e, "x6") == 0 ? IRS_GEMM_X6 : IRS_GEMM_H3) : IRS_GEMM_H3;
         const char *ea = getenv("IRS_ATTN_GEMM");
-        if (ea && strcmp(ea, "f32") && strcmp(ea, "x6") && strcmp(ea, "h3")) {
-            snprintf(g_create_err, sizeof(g_create_err), "IRS_ATTN_GEMM=%s (expected h3, x6 or f32)", ea);
+        if (ea && strcmp(ea, "f32") && strcmp(ea, "h3")) {
+            snprintf(g_create_err, sizeof(g_create_err), "IRS_ATTN_GEMM=%s (expected h3 or f32)", ea);
             delete c;
             return IRS_E_INVALID;
         }
-        c->use_attn_x6 = ea ? (strcmp(ea, "x6") == 0) : 0;
         c->use_attn_h3 = ea ? (strcmp(ea, "h3") == 0) : 1; // (IRS_ATTN_GEMM=f32: float32 K / V rows and the float32-MFMA attention)
-        const char *ep = getenv("IRS_ATTN_PERSIST");
-        c->attn_persist = ep ? (atoi(ep) != 0) : 0;
         const char *er = getenv("IRS_LSE_RING");
         c->lse_no_ring = er ? (strcmp(er, "0") == 0) : 0;
     }
@@ -269,7 +266,7 @@ extern "C" int irs_finalize_weights(irs_ctx *ctx, void *arena, size_t bytes, voi
 // ------------------------------------------------------------------ workspace
 struct ws_plan {
     size_t x, y, xf, yf, qkv, qkv_b1, ao, h, ru, xb, eps, thr, gm, cnt, cand, lse, ref, xrows, tval, tids, status, step, pos;
-    size_t bseq[2], bhep[2], bcum[2], bpaths[2], buser, lmax, lsum, tokrow, scnt, soff, sqrow, spadq, aorder, atab, mdev, xlocal, ksend, krecv, gmax, fbcount, fblist, exhkeys, total;
+    size_t bseq[2], bhep[2], bcum[2], bpaths[2], buser, lmax, lsum, tokrow, scnt, soff, sqrow, spadq, mdev, xlocal, ksend, krecv, gmax, fbcount, fblist, exhkeys, total;
 };
 
 static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
@@ -324,8 +321,6 @@ static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
     p->soff = take((size_t)ctx->max_seqs * 4);
     p->sqrow = take((size_t)ctx->max_seqs * 4);
     p->spadq = take((size_t)ctx->max_seqs * 4);
-    p->aorder = take((size_t)ctx->max_seqs * 4);
-    p->atab = take(512);
     p->mdev = take(256);
     p->xlocal = take((size_t)ctx->max_seqs * D.d * 4);
     p->ksend = take((size_t)ctx->max_rows * D.max_k * 8); // exchange buffers of the item-sharded loops (comm.hip)
@@ -391,8 +386,6 @@ extern "C" int irs_bind_workspace(irs_ctx *ctx, void *ws, size_t bytes) {
     ctx->seq_off = (int32_t *)(b + p.soff);
     ctx->seq_qrow = (int32_t *)(b + p.sqrow);
     ctx->seq_padq = (int32_t *)(b + p.spadq);
-    ctx->att_order = (int32_t *)(b + p.aorder);
-    ctx->att_tab = (int32_t *)(b + p.atab);
     ctx->m_dev = (int32_t *)(b + p.mdev);
     ctx->x_local = (float *)(b + p.xlocal);
     ctx->keys_send = (uint64_t *)(b + p.ksend);

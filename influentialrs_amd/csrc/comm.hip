@@ -408,7 +408,12 @@ extern "C" int irs_beam_search_sharded(irs_ctx *ctx, irs_comm *comm, const int64
     const int rows_all = split_decode ? R : R * world; // rows every rank sweeps
     if (R > ctx->max_seqs || (int64_t)R * world > ctx->max_rows) // (split_decode: the gathered key lists are world x R x k)
         IRS_FAIL(ctx, IRS_E_INVALID, "irs_beam_search_sharded: B*W=%d needs max_seqs >= %d and max_rows >= %d", R, R, R * world);
-    if (split_decode && R % world) IRS_FAIL(ctx, IRS_E_INVALID, "irs_beam_search_sharded: split_decode needs B*W (%d) divisible by world (%d)", R, world);
+    // split_decode: rank r decodes beam rows [r per, min((r + 1) per, R)), per = ceil(R / world) -- any world size (round 5: 32
+    // beams over 3, 5 or 6 ranks; the last ranks' slices are short or empty).  The row all-gather moves `per` rows per rank, so
+    // gathered position g holds beam row g for every g < R and the positions from R on are never read.
+    const int per_split = (R + world - 1) / world;
+    if (split_decode && (int64_t)per_split * world > ctx->max_rows)
+        IRS_FAIL(ctx, IRS_E_INVALID, "irs_beam_search_sharded: split_decode gathers %d rows, max_rows is %d", per_split * world, ctx->max_rows);
     hipStream_t s = (hipStream_t)stream;
     IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->step_ctr, 0, 2 * sizeof(int32_t), s));
     IRS_CHECK_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t) * B, s));
@@ -421,9 +426,10 @@ extern "C" int irs_beam_search_sharded(irs_ctx *ctx, irs_comm *comm, const int64
         int r;
         const float *lmax = nullptr, *lsum = nullptr;
         if (split_decode) {
-            const int per = R / world, r0 = comm->rank * per; // this rank's slice of the (replicated) beam windows
-            if ((r = irs_launch_decode(ctx, ctx->bm_seq[in] + (size_t)r0 * L, ctx->bm_user + r0, per, nullptr, ctx->bm_hep[in] + r0,
-                                       ctx->x_local, nullptr, q)))
+            const int per = per_split, r0 = comm->rank * per; // this rank's slice of the (replicated) beam windows
+            const int mine = R - r0 < per ? (R - r0 > 0 ? R - r0 : 0) : per;
+            if (mine > 0 && (r = irs_launch_decode(ctx, ctx->bm_seq[in] + (size_t)r0 * L, ctx->bm_user + r0, mine, nullptr, ctx->bm_hep[in] + r0,
+                                                   ctx->x_local, nullptr, q)))
                 return r;
             if ((r = comm_allgather(ctx, comm, ctx->x_local, ctx->xrows, (size_t)per * d * sizeof(float), q))) return r;
         } else {

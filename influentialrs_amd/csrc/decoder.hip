@@ -114,51 +114,6 @@ __global__ void __launch_bounds__(1024) k_plan_scan(const int32_t *__restrict__ 
     if (tid == 0) m_dev[0] = s_base;
 }
 
-// Work list of the persistent attention kernel (k_attn16<.., PERSIST>): the sequences sorted by their number of 16-token
-// tiles, LONGEST FIRST (a counting sort over the 16 classes; the order inside a class is whatever the atomics give --
-// it only decides which workgroup takes which item, every item is computed independently), and per class where its
-// sequences and its work items start.  A sequence is H items, one per head; a short one -- four padded sequences fit the
-// LDS images of one workgroup -- is H / 4 items, each a group of four heads (wave = head).
-//   tab[0] = number of items; tab[1 + j], tab[18 + j] (j = 0 .. 16): first sequence rank / first item of class nb16 = 16 - j
-//   (j = 16: the totals); tab[40 + l]: the work counter of layer l's launch (zeroed here, once per decode).
-#define ATT_TAB_WORDS 64
-__device__ __forceinline__ bool attn_share_class(int nb16, int Lcap16, int H) { return (H & 3) == 0 && 4 * 16 * nb16 <= Lcap16; }
-__global__ void __launch_bounds__(1024) k_plan_attn_order(const int32_t *__restrict__ cnt, int B, int Lcap16, int H,
-                                                          int32_t *__restrict__ order, int32_t *__restrict__ tab) {
-    __shared__ int s_hist[17], s_start[18], s_fill[17];
-    const int tid = threadIdx.x;
-    if (tid < 17) s_hist[tid] = 0, s_fill[tid] = 0;
-    __syncthreads();
-    for (int b = tid; b < B; b += 1024) {
-        int nb = (cnt[b] + 15) >> 4;
-        nb = nb < 1 ? 1 : (nb > 16 ? 16 : nb);
-        atomicAdd(&s_hist[nb], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int rank = 0, item = 0;
-        for (int j = 0; j < 16; ++j) { // class nb16 = 16 - j
-            const int nb = 16 - j;
-            s_start[j] = rank;
-            tab[1 + j] = rank;
-            tab[18 + j] = item;
-            rank += s_hist[nb];
-            item += s_hist[nb] * (attn_share_class(nb, Lcap16, H) ? H / 4 : H);
-        }
-        s_start[16] = rank;
-        tab[1 + 16] = rank;
-        tab[18 + 16] = item;
-        tab[0] = item;
-    }
-    if (tid < IRS_MAX_LAYERS) tab[40 + tid] = 0;
-    __syncthreads();
-    for (int b = tid; b < B; b += 1024) {
-        int nb = (cnt[b] + 15) >> 4;
-        nb = nb < 1 ? 1 : (nb > 16 ? 16 : nb);
-        order[s_start[16 - nb] + atomicAdd(&s_fill[nb], 1)] = b;
-    }
-}
-
 __global__ void __launch_bounds__(256) k_plan_fill(const int64_t *__restrict__ seq, const int32_t *__restrict__ pos, int B,
                                                    int L, const int32_t *__restrict__ off, int32_t *__restrict__ qrow,
                                                    int32_t *__restrict__ tok_row, int32_t *__restrict__ padq) {
@@ -3929,23 +3884,13 @@ typedef const __attribute__((address_space(1))) void attn_glb_void;
 // the rate at which workgroups are DISPATCHED (~8 ns per workgroup chip-wide: 16384 workgroups = 129 us whatever they do), and
 // workgroups that return at once are dispatched all the same.  What that regime needs is fewer dispatches: a persistent
 // grid over a work list built by the plan kernel (profiles/r04/README.md).
-// PERSIST (round 4; packed sequences of a throughput batch): a grid of RESIDENT workgroups (three per CU) walks the work
-// list of k_plan_attn_order -- sequences longest first, one item per (sequence, head), or per (sequence, group of four heads)
-// when the sequence is short enough for four padded copies of its K / V images to share the workgroup's LDS (then wave =
-// head) -- taking items off an atomic counter whose next value is requested while the current item is computed.  What it
-// buys over one workgroup per (sequence, head): (1) no dispatch bound -- 16384 workgroups cost ~8 ns each to dispatch
-// chip-wide, which alone is the run time of a batch of short sequences; (2) longest-first dynamic balance instead of
-// dispatch order; (3) a short sequence pays one fill latency for four heads.  (The earlier attempt at (3) with one
-// workgroup per group and three workgroups returning at once was SLOWER: returning workgroups are dispatched all the same.)
-template <int MAXT, bool FAST, bool DMA = false, int NW = 4, bool PERSIST = false>
+template <int MAXT, bool FAST, bool DMA = false, int NW = 4>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) k_attn16(const float *__restrict__ qkv, const int64_t *__restrict__ seq,
                                                 const float *__restrict__ r_u, float *__restrict__ out, int Lmax, int d,
                                                 int mask_mode, const int32_t *__restrict__ off,
                                                 const int32_t *__restrict__ cnt, const int32_t *__restrict__ padq,
-                                                int out_frag, int H, const int32_t *__restrict__ order = nullptr,
-                                                int32_t *__restrict__ tab = nullptr, int layer = 0) {
+                                                int out_frag, int H) {
     static_assert(NW == 4 || DMA, "the register-staged fill is written for four waves");
-    static_assert(!PERSIST || (DMA && FAST && NW == 4), "the persistent form is the packed LDS-DMA kernel");
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     constexpr int HD = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -3958,48 +3903,23 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) k_attn16(const float
     const int lq = lane & 15, gq = lane >> 4;
     const int ld = 3 * d;
     const bool irn = (mask_mode == IRS_MASK_IRN);
-    // Static assignment, no work counter: the list is sorted longest first, and workgroup w takes items w, 2G - 1 - w, 2G + w,
-    // 4G - 1 - w, ... (G = grid size) -- a boustrophedon walk, so every workgroup gets one item out of each stretch of G
-    // similar lengths, alternately from its long and its short end.  (A shared atomic counter was measured first: ~16K
-    // returning atomics on one address cost more than the balance they buy -- 387 vs 348 us on the bench's mix.)
-    const int n_items = PERSIST ? tab[0] : 0;
-    for (int trip = 0;; ++trip) { // PERSIST: one trip per work item; otherwise exactly one trip
-    int h = blockIdx.x, b = blockIdx.y;
-    bool share = false;
-    if constexpr (PERSIST) {
-        const int G = gridDim.x;
-        const int item = trip * G + ((trip & 1) ? G - 1 - (int)blockIdx.x : (int)blockIdx.x);
-        if (item >= n_items) break; // (its later trips lie further out still: (trip + 1) G > trip G + G - 1 - w)
-        if (trip) __syncthreads(); // every wave is past the previous item's LDS reads
-        int j = 0;
-        while (j < 15 && item >= tab[18 + j + 1]) ++j; // class nb16 = 16 - j (longest first)
-        share = attn_share_class(16 - j, Lcap16, H);
-        const int ipc = share ? H / 4 : H, rel = item - tab[18 + j];
-        b = order[tab[1 + j] + rel / ipc];
-        h = share ? 4 * (rel % ipc) + wave : rel % ipc;
-    }
+    const int h = blockIdx.x, b = blockIdx.y;
+    {
     const int L = cnt ? cnt[b] : Lmax;
     const int64_t base = off ? (int64_t)off[b] : (int64_t)b * Lmax;
     const int L16 = (L + 15) & ~15, NB16 = L16 >> 4;
     float *Vt = Vt0, *Ks = Ks0;
-    if (share) Vt += wave * L16 * HD, Ks += wave * L16 * HD; // wave = head: its own quarter of the images
-    if constexpr (PERSIST) {
-        if (L <= 0) continue; // (never: the consumed row always counts)
-    }
-    (void)layer;
     // gridDim.z > 1 (few sequences, the latency path): the query blocks of a (sequence, head) are dealt one per wave
     // over 4 gridDim.z waves, largest first -- a wave's dependent chain is then one block instead of three, on
     // three times as many CUs.  Workgroup z owns blocks NB16-1-4z .. NB16-4-4z; each stages the whole K / V of the
     // (sequence, head) -- the loads of a fill are all in flight together, and the IRN target column needs key L-1.
     const int zsplit = blockIdx.z;
-    if constexpr (!PERSIST) {
-        if (gridDim.z > 1 && 4 * zsplit >= NB16) return;
-        if (L <= 0) return; // (a plan never yields an empty sequence: the consumed row always counts)
-    }
+    if (gridDim.z > 1 && 4 * zsplit >= NB16) return;
+    if (L <= 0) return; // (a plan never yields an empty sequence: the consumed row always counts)
     ATTN_T(0);
     if constexpr (DMA) {
         const int jl = lane >> 3, p = lane & 7;
-        for (int i = share ? 0 : wave; i < (L16 >> 3); i += share ? 1 : NW) { // 8 key rows per instruction; the LDS destination is wave-uniform
+        for (int i = wave; i < (L16 >> 3); i += NW) { // 8 key rows per instruction; the LDS destination is wave-uniform
             const int j = 8 * i + jl;
             const float *row = qkv + (base + (j < L ? j : L - 1)) * ld + h * HD;
             const int swk = (j & 7) ^ ((j >> 3) & 1), swv = ((j >> 2) & 1) << 2;
@@ -4032,8 +3952,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) k_attn16(const float
     // (the assignment below and the first Q request run while the K / V rows are in flight)
     // longest-first assignment of the 16-query blocks (block qb costs qb + 1 key tiles) to the 4 waves
     unsigned int mine = 0;
-    if (share) mine = (1u << NB16) - 1u; // wave = head: every block of this head
-    else if (!PERSIST && gridDim.z > 1) {
+    if (gridDim.z > 1) {
         const int v = 4 * zsplit + wave;
         if (v < NB16) mine = 1u << (NB16 - 1 - v);
     } else if constexpr (NW == 4) { // the closed form of the greedy deal below (k_attn16h; tests/test_host_logic.py holds the identity)
@@ -4310,368 +4229,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) k_attn16(const float
         }
     }
     ATTN_T(4);
-    if constexpr (!PERSIST) break;
     } // work items
-}
-
-// ------------------------------------------------------------------ attention, head dim 32, split-bf16 MFMAs
-// k_attn16 on the bf16 matrix pipe (IRS_GEMM_X6): the same masks, the same two-pass softmax, the same query-block
-// assignment and register layouts; the float32 operands are split exactly into three bf16 planes (h + m + l) and each
-// product is the six leading plane products on v_mfma_f32_16x16x32_bf16, small ones first into the zero-started
-// accumulator (the pipe truncates when it adds):
-//   S^T tile (16 keys x 16 queries, K = head dim 32: ONE MFMA per plane product): A = K planes, one ds_read_b128 each
-//     from the [plane][key][32] images; B = the query block's planes (split once per block);
-//   O^T (32 columns x 16 queries) per PAIR of key tiles (K = 32 keys): B = the planes of p = exp2(s - m), the two
-//     accumulator tiles of the pair side by side -- k slot 8 gq + j is key 4 gq + j of the first tile (j < 4), of the
-//     second (j >= 4), no shuffle; A = V^T planes, read from the row-major [plane][key][32] V images by the transposing
-//     ds_read_b64_tr_b16 (two reads per operand: the pair's two 4-key blocks of this lane group).
-// LDS: 384 B per key (float32 images: 256 B), V in front of K so that the pair partner of an odd last tile reads
-// finite values (times p = 0).  16-byte chunks are XOR-swizzled per key row: K by (-(key >> 2)) & 3 (conflict-free for
-// the four 16-lane groups of ds_read_b128), V by ((key >> 2) & 1) << 1 (conflict-free for the 32-lane halves of the
-// transposed read).  NW waves per workgroup share the images.
-typedef __attribute__((ext_vector_type(4))) short attn_s16x4;
-__device__ __forceinline__ void attn_split8(const float (&v)[8], x6_bf16x8 (&P)[3]) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)v[j];
-        const float r1 = v[j] - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const float r2 = r1 - (float)m;
-        P[0][j] = h, P[1][j] = m, P[2][j] = (__bf16)r2;
-    }
-}
-__device__ __forceinline__ void attn_split4(const float4 &v, uint2 (&P)[3]) {
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-    const float f[4] = {v.x, v.y, v.z, v.w};
-    bf16x4 q[3];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const __bf16 h = (__bf16)f[j];
-        const float r1 = f[j] - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const float r2 = r1 - (float)m;
-        q[0][j] = h, q[1][j] = m, q[2][j] = (__bf16)r2;
-    }
-#pragma unroll
-    for (int p = 0; p < 3; ++p) P[p] = __builtin_bit_cast(uint2, q[p]);
-}
-__device__ __forceinline__ float attn_bf16_hi(unsigned int w) { return __uint_as_float(w & 0xFFFF0000u); }
-__device__ __forceinline__ float attn_bf16_lo(unsigned int w) { return __uint_as_float(w << 16); }
-
-template <int MAXT, bool FAST, int NW>
-__global__ void __launch_bounds__(64 * NW, NW / 2) k_attn16x( // (two workgroups per CU: the LDS images allow no more at L = 200)
-const float *__restrict__ qkv, const int64_t *__restrict__ seq,
-                                                       const float *__restrict__ r_u, float *__restrict__ out, int Lmax, int d,
-                                                       int mask_mode, const int32_t *__restrict__ off,
-                                                       const int32_t *__restrict__ cnt, const int32_t *__restrict__ padq,
-                                                       int out_frag) {
-    typedef __attribute__((ext_vector_type(4))) float f32x4;
-    constexpr int HD = 32, RPI = NW * 8, NIT = (MAXT * 16 + RPI - 1) / RPI; // key rows per fill iteration, iterations
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int L = cnt ? cnt[blockIdx.y] : Lmax;
-    const int L16max = (Lmax + 15) & ~15;
-    const int PL = L16max * 64;                 // bytes of one plane image
-    char *Vp = smem, *Kp = smem + 3 * PL;       // [3][L16][64 B]
-    unsigned int *padbits = reinterpret_cast<unsigned int *>(smem + 6 * PL); // [ceil(L/32)]
-    const int h = blockIdx.x, b = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lq = lane & 15, gq = lane >> 4;
-    const int64_t base = off ? (int64_t)off[b] : (int64_t)b * Lmax;
-    const int ld = 3 * d;
-    const bool irn = (mask_mode == IRS_MASK_IRN);
-    const int L16 = (L + 15) & ~15, NB16 = L16 >> 4;
-    // K / V of this (sequence, head): 8 consecutive lanes take the 8 16-byte chunks of one key row; all loads first
-    float4 kv[NIT], vv[NIT];
-    {
-        const int jl = tid >> 3, c4 = tid & 7;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int j = jl + RPI * it;
-            kv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            vv[it] = kv[it];
-            if (j < L) {
-                const float *row = qkv + (base + j) * ld + h * HD + 4 * c4;
-                kv[it] = *reinterpret_cast<const float4 *>(row + d);
-                vv[it] = *reinterpret_cast<const float4 *>(row + 2 * d);
-            }
-        }
-    }
-    // longest-first assignment of the 16-query blocks (block qb costs qb + 1 key tiles) to the NW waves
-    unsigned int mine = 0;
-    {
-        int load[NW];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) load[w] = 0;
-        for (int qb = NB16 - 1; qb >= 0; --qb) {
-            int w = 0;
-#pragma unroll
-            for (int v = 1; v < NW; ++v)
-                if (load[v] < load[w]) w = v;
-#pragma unroll
-            for (int v = 0; v < NW; ++v)
-                if (v == w) load[v] += qb + 1;
-            if (w == wave) mine |= 1u << qb;
-        }
-    }
-    auto load_q = [&](int qb, float4 &t0, float4 &t1) {
-        const int qi = qb * 16 + lq;
-        const float *qrow = qkv + (base + (qi < L ? qi : L - 1)) * ld + h * HD + 8 * gq;
-        t0 = *reinterpret_cast<const float4 *>(qrow);
-        t1 = *reinterpret_cast<const float4 *>(qrow + 4);
-    };
-    float4 qn0 = make_float4(0.f, 0.f, 0.f, 0.f), qn1 = qn0;
-    int qb_next = mine ? 31 - __builtin_clz(mine) : -1;
-    if (qb_next >= 0) load_q(qb_next, qn0, qn1);
-    const int pq = padq ? padq[b] : -1;
-    for (int kb = wave; kb < (L + 31) / 32; kb += NW) {
-        const int j = kb * 32 + (lane & 31);
-        bool masked = (j >= L) || (irn && j == L - 1);
-        if (padq) masked = masked || (j == pq);
-        else masked = masked || (seq[base + (j < L ? j : L - 1)] == 0);
-        const unsigned long long bal = __ballot(masked);
-        if (lane == 0) padbits[kb] = (unsigned int)bal;
-    }
-    {
-        const int jl = tid >> 3, c4 = tid & 7;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int j = jl + RPI * it;
-            // V rows up to one tile past L16 are written (zeros): an odd last tile's pair partner reads them (times p = 0;
-            // stale LDS could hold NaN patterns); past the allocation the partner aliases K rows of this sequence: finite
-            if (j < L16 + 16 && j < L16max) {
-                uint2 kp[3], vp[3];
-                attn_split4(kv[it], kp);
-                attn_split4(vv[it], vp);
-                const int ko = j * 64 + ((((c4 >> 1) ^ ((-(j >> 2)) & 3))) << 4) + 8 * (c4 & 1);
-                const int vo = j * 64 + ((((c4 >> 1) ^ (((j >> 2) & 1) << 1))) << 4) + 8 * (c4 & 1);
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    if (j < L16) *reinterpret_cast<uint2 *>(Kp + p * PL + ko) = kp[p];
-                    *reinterpret_cast<uint2 *>(Vp + p * PL + vo) = vp[p];
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const float LOG2E = 1.4426950408889634f;
-    const float tgt_add = irn ? (1.0f - r_u[b]) * LOG2E : 0.f;
-    const float scale = LOG2E / sqrtf((float)HD);
-    const bool tgt_ok = irn && (seq[(int64_t)b * Lmax + Lmax - 1] != 0);
-    // this lane's addresses: K row read (key = 16 kt + lq, chunk gq), V transposed read (block row (lane & 15) >> 2, columns
-    // 16 ct + 4 (lane & 3) ..)
-    const int tq = (lane & 15) >> 2, tp = lane & 3;
-
-    while (qb_next >= 0) {
-        const int qb = qb_next;
-        mine &= ~(1u << qb);
-        const int qi = qb * 16 + lq;
-        x6_bf16x8 Q[3];
-        float qf[8];
-        {
-            const float4 t0 = qn0, t1 = qn1;
-            qb_next = mine ? 31 - __builtin_clz(mine) : -1;
-            if (qb_next >= 0) load_q(qb_next, qn0, qn1);
-            const float sc = qi < L ? scale : 0.f;
-            qf[0] = t0.x * sc, qf[1] = t0.y * sc, qf[2] = t0.z * sc, qf[3] = t0.w * sc;
-            qf[4] = t1.x * sc, qf[5] = t1.y * sc, qf[6] = t1.z * sc, qf[7] = t1.w * sc;
-            attn_split8(qf, Q);
-        }
-        f32x4 sacc[MAXT];
-        float mx = -INFINITY;
-        auto score_tile = [&](int kt, f32x4 &sa) __attribute__((always_inline)) {
-            const int key = kt * 16 + lq;
-            const char *kr = Kp + key * 64 + ((gq ^ ((-(key >> 2)) & 3)) << 4);
-            const x6_bf16x8 kh = *reinterpret_cast<const x6_bf16x8 *>(kr);
-            const x6_bf16x8 km = *reinterpret_cast<const x6_bf16x8 *>(kr + PL);
-            const x6_bf16x8 kl = *reinterpret_cast<const x6_bf16x8 *>(kr + 2 * PL);
-            sa = {0.f, 0.f, 0.f, 0.f};
-            sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, Q[2], sa, 0, 0, 0);
-            sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, Q[0], sa, 0, 0, 0);
-            sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(km, Q[1], sa, 0, 0, 0);
-            sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, Q[1], sa, 0, 0, 0);
-            sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(km, Q[0], sa, 0, 0, 0);
-            sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, Q[0], sa, 0, 0, 0);
-        };
-        auto mask_tile = [&](int kt, unsigned int pm, f32x4 &sa) __attribute__((always_inline)) {
-            if (pm == 0u && kt < qb) {
-                mx = fmaxf(fmaxf(mx, sa[0]), fmaxf(sa[1], fmaxf(sa[2], sa[3])));
-            } else {
-                const unsigned int pmk = pm >> (4 * gq);
-                const int qlim = (kt < qb) ? 64 : lq - 4 * gq;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = !((pmk >> r) & 1u) && (r <= qlim);
-                    const float v = ok ? sa[r] : -INFINITY;
-                    sa[r] = v;
-                    mx = fmaxf(mx, v);
-                }
-            }
-        };
-        unsigned int live = 0;
-        if (FAST) {
-            const int pq_pair = pq >= 0 ? pq >> 5 : -1;
-            auto pad_fix = [&](int kt, f32x4 &sa) __attribute__((always_inline)) {
-                if ((pq >> 4) == kt) {
-                    const bool mine_ = ((pq >> 2) & 3) == gq;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sa[r] = (mine_ && (pq & 3) == r) ? -INFINITY : sa[r];
-                }
-            };
-            const unsigned int pm_diag = (padbits[qb >> 1] >> (16 * (qb & 1))) & 0xFFFFu;
-#pragma unroll
-            for (int kg = 0; kg < MAXT / 4; ++kg) {
-                if (4 * kg <= qb) {
-#pragma unroll
-                    for (int kp = 2 * kg; kp < 2 * kg + 2; ++kp) {
-                        const int k0t = 2 * kp, k1t = 2 * kp + 1;
-                        if (k1t <= qb) {
-                            score_tile(k0t, sacc[k0t]);
-                            score_tile(k1t, sacc[k1t]);
-                            if (kp == pq_pair) {
-                                pad_fix(k0t, sacc[k0t]);
-                                if (k1t < qb) pad_fix(k1t, sacc[k1t]);
-                            }
-                            mx = fmaxf(fmaxf(mx, sacc[k0t][0]), fmaxf(sacc[k0t][1], fmaxf(sacc[k0t][2], sacc[k0t][3])));
-                            if (k1t < qb) mx = fmaxf(fmaxf(mx, sacc[k1t][0]), fmaxf(sacc[k1t][1], fmaxf(sacc[k1t][2], sacc[k1t][3])));
-                            else mask_tile(k1t, pm_diag, sacc[k1t]);
-                        } else if (k0t == qb) {
-                            score_tile(k0t, sacc[k0t]);
-                            mask_tile(k0t, pm_diag, sacc[k0t]);
-                        }
-                    }
-                }
-            }
-            live = (2u << qb) - 1u;
-        } else {
-#pragma unroll
-            for (int kp = 0; kp < MAXT / 2; ++kp) {
-                const int k0t = 2 * kp, k1t = 2 * kp + 1;
-                const unsigned int pw = (k0t <= qb) ? padbits[kp] : 0xFFFFFFFFu;
-                const unsigned int pm0 = pw & 0xFFFFu, pm1 = pw >> 16;
-                const bool do0 = pm0 != 0xFFFFu, do1 = (k1t <= qb) && pm1 != 0xFFFFu;
-                if (do0) {
-                    score_tile(k0t, sacc[k0t]);
-                    mask_tile(k0t, pm0, sacc[k0t]);
-                    live |= 1u << k0t;
-                }
-                if (do1) {
-                    score_tile(k1t, sacc[k1t]);
-                    mask_tile(k1t, pm1, sacc[k1t]);
-                    live |= 2u << k0t;
-                }
-            }
-        }
-        // ---- the IRN target column (key L-1, +1.0, visible to every query): float32 arithmetic on the summed planes
-        float st = -INFINITY;
-        float vt[8]; // V[L-1][16 ct + 4 gq + r], ct = 0, 1
-        if (tgt_ok) {
-            const int jt = L - 1;
-            const char *kr = Kp + jt * 64 + ((gq ^ ((-(jt >> 2)) & 3)) << 4);
-            const uint4 a0 = *reinterpret_cast<const uint4 *>(kr), a1 = *reinterpret_cast<const uint4 *>(kr + PL),
-                        a2 = *reinterpret_cast<const uint4 *>(kr + 2 * PL);
-            const unsigned int w0[4] = {a0.x, a0.y, a0.z, a0.w}, w1[4] = {a1.x, a1.y, a1.z, a1.w}, w2[4] = {a2.x, a2.y, a2.z, a2.w};
-            float part = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float klo = (attn_bf16_lo(w0[e]) + attn_bf16_lo(w1[e])) + attn_bf16_lo(w2[e]); // = the float32 K value exactly
-                const float khi = (attn_bf16_hi(w0[e]) + attn_bf16_hi(w1[e])) + attn_bf16_hi(w2[e]);
-                part = __fmaf_rn(qf[2 * e], klo, part);
-                part = __fmaf_rn(qf[2 * e + 1], khi, part);
-            }
-            st = quad16_sum(part) + tgt_add;
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) { // columns 16 ct + 4 gq .. + 3: chunk 2 ct + (gq >> 1), half gq & 1
-                const char *vr = Vp + jt * 64 + ((((2 * ct + (gq >> 1)) ^ (((jt >> 2) & 1) << 1))) << 4) + 8 * (gq & 1);
-                const uint2 b0 = *reinterpret_cast<const uint2 *>(vr), b1 = *reinterpret_cast<const uint2 *>(vr + PL),
-                            b2 = *reinterpret_cast<const uint2 *>(vr + 2 * PL);
-                vt[4 * ct + 0] = (attn_bf16_lo(b0.x) + attn_bf16_lo(b1.x)) + attn_bf16_lo(b2.x);
-                vt[4 * ct + 1] = (attn_bf16_hi(b0.x) + attn_bf16_hi(b1.x)) + attn_bf16_hi(b2.x);
-                vt[4 * ct + 2] = (attn_bf16_lo(b0.y) + attn_bf16_lo(b1.y)) + attn_bf16_lo(b2.y);
-                vt[4 * ct + 3] = (attn_bf16_hi(b0.y) + attn_bf16_hi(b1.y)) + attn_bf16_hi(b2.y);
-            }
-        }
-        mx = quad16_max(mx);
-        float m = fmaxf(mx, st);
-        if (m == -INFINITY) m = 0.f;
-        // ---- pass 2: p = exp2(s - m); O^T += V^T P^T, one 32-key MFMA step per pair of tiles
-        float l = 0.f;
-        f32x4 o[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[i][ct][r] = 0.f;
-        float ot[8]; // the target column's contribution (float32, added at the end)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ot[e] = 0.f;
-        if (tgt_ok) {
-            const float pt = __builtin_amdgcn_exp2f(st - m);
-            l = (gq == 0) ? pt : 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ot[e] = pt * vt[e];
-        }
-#pragma unroll
-        for (int kp = 0; kp < MAXT / 2; ++kp) {
-            const int k0t = 2 * kp, k1t = 2 * kp + 1;
-            const bool on0 = FAST ? (k0t <= qb) : (((live >> k0t) & 1u) != 0u);
-            const bool on1 = FAST ? (k1t <= qb) : (((live >> k1t) & 1u) != 0u);
-            if (on0 || on1) { // wave-uniform
-                float pa[8];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pa[r] = on0 ? __builtin_amdgcn_exp2f(sacc[k0t][r] - m) : 0.f;
-                    pa[4 + r] = on1 ? __builtin_amdgcn_exp2f(sacc[k1t][r] - m) : 0.f;
-                    l += pa[r] + pa[4 + r];
-                }
-                x6_bf16x8 P[3];
-                attn_split8(pa, P);
-                const int r0 = k0t * 16 + 4 * gq + tq, r1 = r0 + 16;
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    const int o0 = r0 * 64 + ((((2 * ct + (tp >> 1)) ^ (((r0 >> 2) & 1) << 1))) << 4) + 8 * (tp & 1);
-                    const int o1 = r1 * 64 + ((((2 * ct + (tp >> 1)) ^ (((r1 >> 2) & 1) << 1))) << 4) + 8 * (tp & 1);
-                    x6_bf16x8 V[3];
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        const attn_s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) attn_s16x4 *)(Vp + p * PL + o0));
-                        const attn_s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) attn_s16x4 *)(Vp + p * PL + o1));
-                        typedef __attribute__((ext_vector_type(8))) short s16x8;
-                        const s16x8 both = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                        V[p] = __builtin_bit_cast(x6_bf16x8, both);
-                    }
-                    f32x4 oo = o[kp & 1][ct];
-                    oo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(V[0], P[2], oo, 0, 0, 0);
-                    oo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(V[2], P[0], oo, 0, 0, 0);
-                    oo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(V[1], P[1], oo, 0, 0, 0);
-                    oo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(V[0], P[1], oo, 0, 0, 0);
-                    oo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(V[1], P[0], oo, 0, 0, 0);
-                    oo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(V[0], P[0], oo, 0, 0, 0);
-                    o[kp & 1][ct] = oo;
-                }
-            }
-        }
-        const float lt = quad16_sum(l);
-        const float inv = 1.0f / lt;
-        if (qi < L) {
-            if (out_frag) {
-                const int64_t tk = base + qi;
-                float4 *of = reinterpret_cast<float4 *>(out) + ((size_t)(tk >> 5) * gridDim.x + h) * 4 * 64 + (gq & 1) * 32 + (tk & 31);
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-                    of[(2 * ct + (gq >> 1)) * 64] =
-                        make_float4(((o[0][ct][0] + o[1][ct][0]) + ot[4 * ct + 0]) * inv, ((o[0][ct][1] + o[1][ct][1]) + ot[4 * ct + 1]) * inv,
-                                    ((o[0][ct][2] + o[1][ct][2]) + ot[4 * ct + 2]) * inv, ((o[0][ct][3] + o[1][ct][3]) + ot[4 * ct + 3]) * inv);
-            } else {
-                float *orow = out + (base + qi) * d + h * HD + 4 * gq;
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-                    *reinterpret_cast<float4 *>(orow + 16 * ct) =
-                        make_float4(((o[0][ct][0] + o[1][ct][0]) + ot[4 * ct + 0]) * inv, ((o[0][ct][1] + o[1][ct][1]) + ot[4 * ct + 1]) * inv,
-                                    ((o[0][ct][2] + o[1][ct][2]) + ot[4 * ct + 2]) * inv, ((o[0][ct][3] + o[1][ct][3]) + ot[4 * ct + 3]) * inv);
-            }
-        }
-    }
 }
 
 // ------------------------------------------------------------------ attention, head dim 32, split-float16 MFMAs (round 4)
@@ -4689,6 +4247,7 @@ const float *__restrict__ qkv, const int64_t *__restrict__ seq,
 //   * p = exp2(s - m) is split into two planes (3 vector instructions per value: v_cvt_pk_f16_f32, back, subtract, again).
 // Everything else is k_attn16x's structure: [plane][key][64 B] images, V in front of K, V^T operands by the transposing
 // ds_read_b64_tr_b16, the two score tiles of a pair side by side as the 32-key B operand, two-pass softmax, LPT blocks.
+typedef __attribute__((ext_vector_type(4))) short attn_s16x4; // operand type of the transposing LDS read
 __device__ __forceinline__ void attn_split8h(const float (&v)[8], x6_f16x8 (&P)[2]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -5332,9 +4891,6 @@ static int launch_linear(irs_ctx *ctx, const float *X, const float *W, const flo
     return IRS_OK;
 }
 
-#ifndef ATTN16X_NW
-#define ATTN16X_NW 4 // waves per workgroup of k_attn16x (8: 128 registers per lane at 4 waves per SIMD, 28-41 spilled: 3.0 vs 2.2 ms per C2 step)
-#endif
 static int g_attn16 = 1; // 16-query-block attention kernel for head dim 32 (0: k_attn_mfma everywhere)
 
 // attn16 is the only attention kernel that can write the fragment-major image the fused block kernel consumes
@@ -5343,16 +4899,9 @@ static bool attn16_ok(const irs_ctx *ctx, const float *qkv, const float *out) {
     return g_attn16 && d % H == 0 && d / H == 32 && L <= 256 && d % 4 == 0 && ((((uintptr_t)qkv) | ((uintptr_t)out)) & 15) == 0;
 }
 
-// the persistent attention needs the plan's work list: packed rows-only decodes planned by k_plan_count / scan / fill (more
-// than 64 sequences), head dim 32, L <= 256, and enough (sequence, head) pairs to be worth a resident grid
-static bool attn_persist_ok(const irs_ctx *ctx, int B) {
-    const int L = ctx->dims.max_len, d = ctx->dims.d, H = ctx->dims.n_heads;
-    return ctx->attn_persist && B > 64 && d % H == 0 && d / H == 32 && L <= 256 && ctx->dims.n_layers <= IRS_MAX_LAYERS && (long long)B * H >= 1024;
-}
-static int g_attn_persist = 1; // (lab switch; the context's attn_persist decides in the product)
 static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const float *r_u, float *out, int B,
                        hipStream_t s, const int32_t *off = nullptr, const int32_t *cnt = nullptr,
-                       const int32_t *tok_row = nullptr, bool frag_out = false, int layer = -1, bool kv_planes = false) {
+                       const int32_t *tok_row = nullptr, bool frag_out = false, bool kv_planes = false) {
     const int L = ctx->dims.max_len, d = ctx->dims.d, H = ctx->dims.n_heads, hd = d / H;
     const int HDP = hd <= 8 ? 8 : hd <= 16 ? 16 : hd <= 32 ? 32 : 64;
     const int Lp = ((L + 31) / 32) * 32, VW = HDP < 32 ? 32 : HDP;
@@ -5368,10 +4917,6 @@ static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const
         const size_t lds16 = (size_t)32 * S16 * 4 + (size_t)((L + 15) & ~15) * 32 * 4 + 64;
         const size_t lds16d = (size_t)2 * ((L + 15) & ~15) * 32 * 4 + 64; // LDS-DMA form: V row-major like K
         if (H * B <= 64) grid.z = (((L + 15) / 16) + 3) / 4; // latency path: one query block per wave
-        const size_t lds16x = (size_t)6 * ((L + 15) & ~15) * 64 + 64;
-        // The same kernel on split-bf16 MFMAs: measured SLOWER than the float32-MFMA kernel on C2 (2.24 vs 1.92 ms of attention
-        // per step: the plane splits of p and of K / V make it VALU-bound, 14 % MFMA busy, and its LDS images allow two
-        // workgroups per CU instead of three), so it runs only on request (IRS_ATTN_GEMM=x6 when the context is created).
         if (kv_planes) { // K / V arrive as float16 plane pairs (k_block_x6's tail): the split-float16 attention
             if (grid.z != 1) IRS_FAIL(ctx, IRS_E_STATE, "plane-format K / V on the latency path");
             if (tok_row)
@@ -5380,17 +4925,6 @@ static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const
             else
                 hipLaunchKernelGGL((k_attn16h<16, false, 4>), grid, dim3(256), lds16d, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
                                    nullptr, frag_out ? 1 : 0);
-        } else if (ctx->use_attn_x6 && grid.z == 1 && lds16x <= 160 * 1024) {
-            IRS_ONCE_PER_DEVICE({
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn16x<16, true, ATTN16X_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn16x<16, false, ATTN16X_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            });
-            if (tok_row)
-                hipLaunchKernelGGL((k_attn16x<16, true, ATTN16X_NW>), grid, dim3(64 * ATTN16X_NW), lds16x, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
-                                   ctx->seq_padq, frag_out ? 1 : 0);
-            else
-                hipLaunchKernelGGL((k_attn16x<16, false, ATTN16X_NW>), grid, dim3(64 * ATTN16X_NW), lds16x, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
-                                   nullptr, frag_out ? 1 : 0);
         } else if (g_attn16 == 2) { // (lab A/B: the register-staged fill with the transposed V^T image)
             if (tok_row)
                 hipLaunchKernelGGL((k_attn16<16, true, false>), grid, dim3(256), lds16, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
@@ -5398,21 +4932,6 @@ static int launch_attn(irs_ctx *ctx, const float *qkv, const int64_t *seq, const
             else
                 hipLaunchKernelGGL((k_attn16<16, false, false>), grid, dim3(256), lds16, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
                                    nullptr, frag_out ? 1 : 0, H);
-        } else if (tok_row && layer >= 0 && g_attn_persist && attn_persist_ok(ctx, B)) {
-            // resident grid over the plan's work list (k_plan_attn_order ran with this decode's plan)
-            static std::atomic<int> slots_dev[IRS_MAX_DEVICES];
-            const int dev_ = irs_cur_dev();
-            int slots = slots_dev[dev_].load(std::memory_order_acquire);
-            if (!slots) {
-                int ncu = 256;
-                hipDeviceProp_t prop;
-                if (hipGetDeviceProperties(&prop, dev_) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-                slots = 3 * ncu; // three workgroups per CU (53 KB of LDS each)
-                slots_dev[dev_].store(slots, std::memory_order_release);
-            }
-            const int nwg = H * B < slots ? H * B : slots;
-            hipLaunchKernelGGL((k_attn16<16, true, true, 4, true>), dim3(nwg), dim3(256), lds16d, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
-                               ctx->seq_padq, frag_out ? 1 : 0, H, ctx->att_order, ctx->att_tab, layer);
         } else if (tok_row)
             hipLaunchKernelGGL((k_attn16<16, true, true>), grid, dim3(256), lds16d, s, qkv, seq, r_u, out, L, d, mm, off, cnt,
                                ctx->seq_padq, frag_out ? 1 : 0, H);
@@ -5573,10 +5092,9 @@ static void x6_launch_one(int rows, const BlockX6Args &xa, hipStream_t s) {
     IRS_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(kern, dim3((rows + 32 * NW - 1) / (32 * NW)), dim3(64 * NW), lds, s, xa);
 }
-static void x6_launch(int qp0, bool embed, int nt, int npl, bool one_wave, int rows, const BlockX6Args &xa, hipStream_t s) {
+static void x6_launch(int qp0, bool embed, int nt, int npl, int rows, const BlockX6Args &xa, hipStream_t s) {
 #define X6_L(Q_, E_) do {                                                                                                 \
-        if (nt == 8 && one_wave) x6_launch_one<Q_, 1, E_, 8, 3>(rows, xa, s);                                             \
-        else if (nt == 8 && npl == 2) x6_launch_one<Q_, 4, E_, 8, 2>(rows, xa, s);                                        \
+        if (nt == 8 && npl == 2) x6_launch_one<Q_, 4, E_, 8, 2>(rows, xa, s);                                             \
         else if (nt == 8) x6_launch_one<Q_, 4, E_, 8, 3>(rows, xa, s);                                                    \
         else if (npl == 2) x6_launch_one<Q_, 4, E_, 4, 2>(rows, xa, s);                                                   \
         else x6_launch_one<Q_, X6_NW, E_, 4, 3>(rows, xa, s);                                                             \
@@ -5672,10 +5190,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     // d = 256 (C4's decoder), rows-only decode of a throughput batch: the split-bf16 fused layer kernel at 8 accumulator tiles
     // per token (k_block_x6<.., NT = 8>) with fragment-major activations, like d = 128.  Everything else at d = 256 (full
     // decodes, small batches, IRS_GEMM_F32) keeps the per-GEMM float32 kernels.
-    static const int x6d_min_rows = [] { const char *e = getenv("IRS_X6D_MIN_ROWS"); return e ? atoi(e) : 32768; }(); // (lab: crossover probe)
-    const bool x6d = d == 256 && F == 256 && ctx->use_x6 && ctx->w_x6 && rows_only && rows >= x6d_min_rows && ctx->dims.n_layers > 1 &&
+    const bool x6d = d == 256 && F == 256 && ctx->use_x6 && ctx->w_x6 && rows_only && rows >= 32768 && ctx->dims.n_layers > 1 &&
                      attn16_ok(ctx, ctx->act_qkv, ctx->act_yf);
-    const bool x6d_small = x6d && rows < 32768;
     // the split-precision layer kernels hand K / V to the attention as float16 plane pairs (k_attn16h) unless switched off
     // ONE predicate for the writers (embed kernel, layer kernel tail) and the reader (launch_attn: k_attn16h): it includes the
     // layer loop's own condition for the fused block + 16-query attention (fragment-major activations, head dim 32, L <= 256,
@@ -5683,7 +5199,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     const bool frag = (d <= LIN_BN && d % 32 == 0 && rows > 2048 && !small_cfg && !any_cfg) || x6d;
     const bool fuse_block_cfg = frag && (d == 128 || x6d) && F == 256 && attn16_ok(ctx, ctx->act_qkv, ctx->act_yf);
     const bool kv_planes = fuse_block_cfg && ctx->use_attn_h3 && ctx->h3_ok && ctx->use_x6 && ctx->w_x6 && ctx->dims.n_layers > 1 &&
-                           !x6d_small && rows * (long long)ctx->dims.n_heads > 64 * (long long)L; // (not the z-split latency grid)
+                           rows * (long long)ctx->dims.n_heads > 64 * (long long)L; // (not the z-split latency grid)
     // d = 256 below the throughput regime (C5's 32 beam windows, single users): the 16-token fused layer kernel for wide
     // models (k_block_small_wide) instead of ~8 per-GEMM launches per layer
     const bool wide_cfg = small_wide_shape(d, F) && ctx->w_frag16 && !x6d && rows < 32768;
@@ -5708,9 +5224,6 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, s, ctx->seq_cnt, B, ctx->seq_off, ctx->m_dev);
             hipLaunchKernelGGL(k_plan_fill, dim3((B + 3) / 4), dim3(256), 0, s, seq, pos, B, L, ctx->seq_off, ctx->seq_qrow,
                                ctx->tok_row, ctx->seq_padq);
-            if (g_attn_persist && attn_persist_ok(ctx, B))
-                hipLaunchKernelGGL(k_plan_attn_order, dim3(1), dim3(1024), 0, s, ctx->seq_cnt, B, (L + 15) & ~15, ctx->dims.n_heads,
-                                   ctx->att_order, ctx->att_tab);
         }
         off = ctx->seq_off;
         cnt = ctx->seq_cnt;
@@ -5725,12 +5238,12 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
         if (ctx->use_x6 && ctx->w_x6) { // the same kernel on split-bf16 MFMAs: k_block_x6's q | k | v steps behind an embed prologue
             BlockX6Args xa{};
-            const int npl = (ctx->use_x6 == IRS_GEMM_H3 && ctx->h3_ok && !x6d_small) ? 2 : 3;
+            const int npl = (ctx->use_x6 == IRS_GEMM_H3 && ctx->h3_ok) ? 2 : 3;
             xa.Wx = x6_stream(ctx, npl, ctx->dims.n_layers - 1);
             xa.bin = ctx->layer[0].sa_in_b, xa.Xf = xf, xa.QKV = ctx->act_qkv, xa.M = rows, xa.m_dev = m_dev;
             xa.seq = seq, xa.E = ctx->item_emb, xa.pe = ctx->pe, xa.tok_row = tok, xa.L = L, xa.sqrtd = sqrtf((float)d), xa.n_item = ctx->dims.n_item;
             xa.kv_planes = kv_planes ? 1 : 0;
-            x6_launch(0, true, x6d ? 8 : 4, npl, x6d_small, rows, xa, s);
+            x6_launch(0, true, x6d ? 8 : 4, npl, rows, xa, s);
         } else
         hipLaunchKernelGGL(k_embed_qkv, dim3((rows + 127) / 128), dim3(256), 0, s, ea);
         irs_prof_end(ctx, IRS_PROF_LINEAR, s, 6.0 * rows * (double)d * d, 4.0 * 4.0 * rows * (double)d);
@@ -5867,7 +5380,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         const bool fuse_block = fuse_block_cfg;
         if (!att_fused &&
             (rc = launch_attn(ctx, ctx->act_qkv, seq, ctx->act_ru, fuse_block ? yf : ctx->act_ao, B, s, off, cnt, tok, fuse_block,
-                              rows_only && !small_plan ? l : -1, kv_planes && fuse_block && ctx->use_x6 && ctx->w_x6)))
+                              kv_planes)))
             return rc;
         if (frag) {
             const bool last = l + 1 == ctx->dims.n_layers;
@@ -5888,11 +5401,11 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                 irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
                 if (tail) irs_prof_begin(ctx, IRS_PROF_LAYER, s); // (one family is enabled at a time)
                 if (tail && ctx->use_x6 && ctx->w_x6) { // the same layer tail on split-bf16 MFMAs
-                    const int npl = (ctx->use_x6 == IRS_GEMM_H3 && ctx->h3_ok && !x6d_small) ? 2 : 3;
+                    const int npl = (ctx->use_x6 == IRS_GEMM_H3 && ctx->h3_ok) ? 2 : 3;
                     BlockX6Args xa{yf, xf, x6_stream(ctx, npl, l), w.sa_out_b, w.n1_w, w.n1_b, cl, w.n2_w, w.n2_b,
                                    w.l1_b, w.l2_b, w.n3_w, w.n3_b, ctx->layer[l + 1].sa_in_b, xf, ctx->act_qkv, rows, m_dev, kv_only ? 1 : 0};
                     xa.kv_planes = kv_planes ? 1 : 0;
-                    x6_launch(kv_only ? 1 : 0, false, x6d ? 8 : 4, npl, x6d_small, rows, xa, s);
+                    x6_launch(kv_only ? 1 : 0, false, x6d ? 8 : 4, npl, rows, xa, s);
                 } else if (x6d) IRS_FAIL(ctx, IRS_E_STATE, "d = 256 fused layer kernel without a successor layer");
                 else if (tail) hipLaunchKernelGGL((k_block<true, true>), dim3((rows + 127) / 128), dim3(256), 0, s, ba);
                 else hipLaunchKernelGGL((k_block<true, false>), dim3((rows + 127) / 128), dim3(256), 0, s, ba);

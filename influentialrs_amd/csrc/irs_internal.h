@@ -15,7 +15,7 @@
 // influentialrs_amd/build.py never defines (and tests/test_cabi.py checks that it does not).
 #if !defined(IRS_LAB) && (defined(X6_DUMP) || defined(X6_STAMP) || defined(X6_NO_SPLIT) || defined(X6_STAGGER) ||            \
                           defined(X6_NO_MFMA) || defined(X6_NO_READS) || defined(X6_NO_DMA) || defined(X6_NO_BARRIER) ||       \
-                          defined(X6_NW) || defined(ATTN16X_NW) || defined(ATTN_STAMP) || defined(ATTNP_STAMP) ||               \
+                          defined(X6_NW) || defined(ATTN_STAMP) || defined(ATTNP_STAMP) ||               \
                           defined(IRS_SMALL_TIMING) || defined(IRS_DIRECT_TIMING) || defined(SWEEP_LAB) || defined(X6D_STAMP) ||              \
                           defined(X6_NO_QKV_STORE) || defined(X6_NSLOT2) || defined(X6_RESID_LATE) || defined(X6_RING4) ||      \
                           defined(X6_SPLIT_ACC4))
@@ -88,10 +88,7 @@ struct irs_ctx {
     int use_x6;       // decoder GEMMs of the throughput path on split-bf16 MFMAs (IRS_DECODER_GEMM=x6|f32)
     bool h3_ok;       // finalisation's float16 range bound holds (else IRS_GEMM_H3 runs as IRS_GEMM_X6 and V stays float32)
     float h3_bound;   // the largest operand magnitude the bound weights allow (irs_h3_operand_bound)
-    int use_attn_x6;  // head-dim-32 attention of the throughput path on split-bf16 MFMAs (IRS_ATTN_GEMM=x6; default off: slower)
     int use_attn_h3;  // throughput attention on split-float16 MFMAs over K / V planes written by the layer kernel (default on; IRS_ATTN_GEMM=f32 off)
-    int attn_persist; // packed throughput attention as a resident grid over a length-sorted work list (IRS_ATTN_PERSIST=1; default off:
-                      // faster on short sequences only -- 94 vs 116 us at 40 tokens, 352 vs 285 at 110 -- profiles/r04/README.md)
     int lse_no_ring;  // IRS_LSE_RING=0: the register-fragment log-sum-exp kernel at <= 32 rows too (A/B measurements, tests)
     bool finalized;
     bool proj_stale;  // a training entry point ran since irs_finalize_weights: wp / wnorm_max may lag project.*
@@ -107,8 +104,6 @@ struct irs_ctx {
     int32_t *tok_row;  // [max_seqs * L] packed index -> b*L + t
     int32_t *seq_cnt, *seq_off, *seq_qrow; // [max_seqs]
     int32_t *seq_padq; // [max_seqs] index within the packed sequence of the one pad token it may hold (pos), or -1
-    int32_t *att_order; // [max_seqs] sequences sorted by length, longest first: the persistent attention kernel's work order
-    int32_t *att_tab;   // class starts, item count and per-layer work counters of that kernel (decoder.hip: k_plan_attn_order)
     int32_t *m_dev;    // [1] number of packed rows
     // scoring
     uint4 *xb;          // packed bf16 rows [m_pad/32][KS][64] x 16 B

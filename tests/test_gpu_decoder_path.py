@@ -576,39 +576,6 @@ def test_split_bf16_layer_kernel_equals_float32_mfma_kernel(oracle, B, kv_only):
     eng.decoder_gemm = IRS_GEMM_H3
 
 
-def test_split_bf16_attention_kernel_on_request(oracle, monkeypatch):
-    """IRS_ATTN_GEMM=x6 (read when a context is created) runs the head-dim-32 attention of the throughput path on
-    split-bf16 MFMAs (k_attn16x: K / V / p as three bf16 planes, six plane products, V^T through the transposing LDS
-    read).  It is off by default because it measured slower than the float32-MFMA kernel (profiles/r03/README.md); its
-    rows must agree with the default kernel's and with the oracle like every other pair of decoder kernels."""
-    cfg = synth.make_config("c2")
-    L, B = cfg.max_len, 176
-    sd = synth.irn_state_dict(cfg, 778)
-    hists = synth.user_histories(B, cfg.n_item, seed=45)
-    rows = synth.eval_rows(hists, cfg.n_item, seed=47)
-    _, seqs, users, _, _ = synth.collate_eval_irs(rows, L, gap_len=1)
-    seqs[1, :] = 0
-    seqs[1, -1] = 5              # an all-pad window with a target
-    seqs[2, seqs[2] == 0] = 3    # a full window
-    seq, u = torch.from_numpy(seqs).cuda(), torch.from_numpy(users).cuda()
-    pos = torch.full((B,), L - 2, dtype=torch.int32, device="cuda")
-    base = make_engine(cfg, sd, max_rows=B, max_seqs=B)
-    xa, ra, _ = base.decode(seq, u, want_x=True, pos=pos)
-    _, rpa, _ = base.decode(seq, u, want_x=False, pos=pos)  # packed rows: the FAST instantiation
-    monkeypatch.setenv("IRS_ATTN_GEMM", "x6")
-    eng = make_engine(cfg, sd, max_rows=B, max_seqs=B)
-    monkeypatch.delenv("IRS_ATTN_GEMM")
-    xb, rb, _ = eng.decode(seq, u, want_x=True, pos=pos)
-    _, rpb, _ = eng.decode(seq, u, want_x=False, pos=pos)
-    assert not torch.equal(ra, rb), "the request must change the code path"
-    ok = torch.isfinite(xa) & torch.isfinite(xb)
-    assert torch.equal(torch.isnan(xa), torch.isnan(xb)) and (xa - xb)[ok].abs().max().item() < X_TOL_X6
-    assert (rpa - rpb).abs().max().item() < X_TOL_X6
-    for b in (0, 2, 9):
-        ref = oracle.decode(sd, cfg, seqs[b], int(users[b]))[0][L - 2]
-        assert np.abs(ref - rpb[b].cpu().numpy()).max() < X_TOL_X6
-
-
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_split_bf16_kernels_random_batches(seed):
     """Randomly drawn batch sizes, history lengths (pads in front, a few all-pad and a few full windows), consumed
@@ -700,34 +667,21 @@ def test_split_bf16_layer_kernel_d256(oracle, B):
     assert torch.equal(pg, ps)
 
 
-def test_persistent_attention_on_request(monkeypatch):
-    """IRS_ATTN_PERSIST=1 (read when a context is created) runs the packed throughput attention as a resident grid over the
-    plan's length-sorted work list (k_plan_attn_order; short sequences as groups of four heads per workgroup).  Off by
-    default: it measured faster on short sequences only (profiles/r04/README.md).  Same MFMA chains on the same operands:
-    the consumed rows must equal the default kernel's BIT FOR BIT, at d = 128 (4 heads) and d = 256 (8 heads: two groups)."""
-    monkeypatch.setenv("IRS_ATTN_GEMM", "f32")  # (the persistent grid is a form of the float32 attention kernel)
-    for over in ({}, {"emb_dim": 256, "n_heads": 8}):
-        cfg = synth.make_config("c2", **over)
-        L, B = cfg.max_len, 300
-        sd = synth.irn_state_dict(cfg, 780)
-        hists = synth.user_histories(B, cfg.n_item, seed=55)
-        rows = synth.eval_rows(hists, cfg.n_item, seed=57)
-        _, seqs, users, targets, _ = synth.collate_eval_irs(rows, L, gap_len=0)
-        seqs[1, :] = 0
-        seqs[1, -1] = targets[1]              # an all-pad window
-        seqs[2, seqs[2] == 0] = 3             # a full window
-        seqs[3, : L - 20] = 0                 # short windows: the four-heads-per-workgroup items
-        seqs[4, : L - 40] = 0
-        seq, u = torch.from_numpy(seqs).cuda(), torch.from_numpy(users).cuda()
-        pos = torch.full((B,), L - 2, dtype=torch.int32, device="cuda")
-        base = make_engine(cfg, sd, max_rows=B, max_seqs=B)
-        ra = base.decode(seq, u, want_x=False, pos=pos)[1].clone()
-        monkeypatch.setenv("IRS_ATTN_PERSIST", "1")
-        eng = make_engine(cfg, sd, max_rows=B, max_seqs=B)
-        monkeypatch.delenv("IRS_ATTN_PERSIST")
-        rb = eng.decode(seq, u, want_x=False, pos=pos)[1]
-        assert torch.equal(torch.isnan(ra), torch.isnan(rb))
-        assert torch.equal(ra.view(torch.int32), rb.view(torch.int32)), over
+def test_unknown_arithmetic_requests_are_rejected(monkeypatch):
+    """IRS_DECODER_GEMM / IRS_ATTN_GEMM are read when a context is created; a value that names no arithmetic (a typo, or the
+    split-bf16 attention "x6" that round 5 removed) fails irs_create with a message instead of silently selecting a default."""
+    from influentialrs_amd.engine import IrsError
+    cfg = synth.make_config("tiny")
+    sd = synth.irn_state_dict(cfg, 5)
+    for var, val in (("IRS_ATTN_GEMM", "x6"), ("IRS_ATTN_GEMM", "F32"), ("IRS_DECODER_GEMM", "bf16")):
+        monkeypatch.setenv(var, val)
+        with pytest.raises(IrsError, match=var):
+            make_engine(cfg, sd, max_rows=4)
+        monkeypatch.delenv(var)
+    for var, val in (("IRS_ATTN_GEMM", "f32"), ("IRS_DECODER_GEMM", "x6")):
+        monkeypatch.setenv(var, val)
+        make_engine(cfg, sd, max_rows=4)
+        monkeypatch.delenv(var)
 
 
 @pytest.mark.gpu

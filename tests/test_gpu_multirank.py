@@ -195,7 +195,7 @@ def _worker_catalog(rank, world, port, ret):
         torch.cuda.set_device(dev)
         cfg = synth.make_config("c3")
         B, W, P = 8, 32, 3
-        rows = world * W  # split_decode: the world's B * W beam rows pass through every shard's sweep
+        rows = world * max(W, B)  # split_decode: the world's B * W beam rows pass through every shard's sweep
 
         def engine(r, w):
             lo, hi = shard_bounds(cfg.n_item, w, r)
@@ -235,11 +235,12 @@ def _worker_catalog(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_in_library_sharded_loops_world4_million_items():
+@pytest.mark.parametrize("world", [4, 3])
+def test_in_library_sharded_loops_million_items(world):
     """irs_generate_paths_sharded and irs_beam_search_sharded(split_decode) with FOUR ranks at a 1M-item catalog (world 2
-    above runs them at 3415 items).  Four, not eight: the GPU box admits at most 6 processes on its card (this test
-    runner is one of them), and the beam-32 split needs a divisor of 32."""
-    world = 4
+    above runs them at 3415 items), and with THREE: 32 beam windows over 3 ranks is the uneven split of the decode (11 / 11 /
+    10 rows; round 5 -- 8 ranks is a divisor of 32, 3, 5 or 6 are not).  Not more: the GPU box admits at most 6 processes on
+    its card and this test runner is one of them."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

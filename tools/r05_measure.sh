@@ -18,6 +18,6 @@ python3 tools/rocpd_kernels.py $(ls gpurun_out/prof_bench/*/*.db | head -1) k_pa
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d gpurun_out/pmc_c2_sq -- python3 bench.py --pmc-run --steps 5 --warmup 2 > gpurun_out/pmc_c2_rows.json 2> gpurun_out/pmc_c2_sq.err || { tail -5 gpurun_out/pmc_c2_sq.err; exit 1; }
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_c2_fetch -- python3 bench.py --pmc-run --steps 5 --warmup 2 > gpurun_out/pmc_c2_fetch.log 2>&1 || { tail -5 gpurun_out/pmc_c2_fetch.log; exit 1; }
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_c2_write -- python3 bench.py --pmc-run --steps 5 --warmup 2 > gpurun_out/pmc_c2_write.log 2>&1 || { tail -5 gpurun_out/pmc_c2_write.log; exit 1; }
-python3 tools/r04_pmc.py gpurun_out/pmc_c2_sq gpurun_out/pmc_c2_fetch gpurun_out/pmc_c2_write gpurun_out/pmc_c2_rows.json gpurun_out/c2_b4096_pmc_${V}.json || exit 1
+python3 tools/r05_pmc.py gpurun_out/pmc_c2_sq gpurun_out/pmc_c2_fetch gpurun_out/pmc_c2_write gpurun_out/pmc_c2_rows.json gpurun_out/c2_b4096_pmc_${V}.json || exit 1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d gpurun_out/pmc_sweep3 -- python3 tools/sweep_bench.py --shapes 1000000,128,1024 1250000,256,1024 --reps 3 > gpurun_out/pmc_run.log 2>&1 || { tail -5 gpurun_out/pmc_run.log; exit 1; }
 python3 tools/pmc_summary.py gpurun_out/pmc_sweep3 k_sweep k_select k_refine k_prep > gpurun_out/sweep_pmc_${V}.txt; cat gpurun_out/sweep_pmc_${V}.txt
