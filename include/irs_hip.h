@@ -395,6 +395,18 @@ int irs_sharded_graph_state(const irs_ctx *ctx);
 int irs_set_decoder_gemm(irs_ctx *ctx, int32_t mode);
 int irs_get_decoder_gemm(const irs_ctx *ctx);           /* the selected mode (a get / set round trip restores it) */
 int irs_get_decoder_gemm_effective(const irs_ctx *ctx); /* the mode that runs (IRS_GEMM_X6 where IRS_GEMM_H3 fails its range bound) */
+/* Sequence-resident decoder layers (round 5; reference model/influentialRS.py:183-193 is ONE nn.TransformerDecoder call): with
+ * IRS_GEMM_H3 at d = 128, 4 heads, ffn 256, L <= 256, rows-only decodes of a throughput batch run every layer but the last as ONE
+ * launch -- q | k | v from x, K / V of a head in LDS, attention, out-projection, feed-forward, layer norms -- on whole sequences
+ * per workgroup (k_block_x6<.., SEQ>), instead of a layer kernel + an attention kernel exchanging q | k | v rows through HBM.
+ * Same arithmetic as the default kernels (rows within the float16-plane tolerance).  Off by default; environment
+ * IRS_DECODER_SEQ=1 at creation or this call. */
+int irs_set_decoder_seq(irs_ctx *ctx, int32_t on);
+int irs_get_decoder_seq(const irs_ctx *ctx);
+/* (tests / lab) device address of a decoder workspace buffer: 0 x (fragment-major), 1 attention output (fragment-major), 2 / 3 the
+ * sequence-resident plan's tile -> sequence / tile index, 4 image row of a sequence, 5 tile-order consumed row, 6 workgroup count,
+ * 7 / 8 packed offset / count per sequence, 9 q | k | v rows, 10 packed consumed row.  Null for an unknown index. */
+void *irs_debug_ptr(const irs_ctx *ctx, int32_t which);
 /* Float16 planes overflow at 65504.  irs_finalize_weights bounds every operand of the float16-plane kernels from the bound
  * weights (embedded tokens, LayerNorm outputs, hidden activations, V rows, the weights themselves) and keeps half the range as
  * margin: a model whose bound is 32752 or more runs IRS_GEMM_X6 (no range limit) wherever IRS_GEMM_H3 is selected, with float32

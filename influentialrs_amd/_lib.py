@@ -84,6 +84,9 @@ SIGNATURES = {
     "irs_set_decoder_gemm": (c_int32, [c_void_p, c_int32]),
     "irs_get_decoder_gemm": (c_int32, [c_void_p]),
     "irs_get_decoder_gemm_effective": (c_int32, [c_void_p]),
+    "irs_set_decoder_seq": (c_int32, [c_void_p, c_int32]),
+    "irs_get_decoder_seq": (c_int32, [c_void_p]),
+    "irs_debug_ptr": (c_void_p, [c_void_p, c_int32]),
     "irs_h3_range_bound": (c_float, [c_void_p]),
     "irs_prof_enable": (c_int32, [c_void_p, c_int32]),
     "irs_prof_read": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),

@@ -90,6 +90,8 @@ extern "C" int irs_create(irs_ctx **out, const irs_dims *dims, const irs_shard *
             return IRS_E_INVALID;
         }
         c->use_attn_h3 = ea ? (strcmp(ea, "h3") == 0) : 1; // (IRS_ATTN_GEMM=f32: float32 K / V rows and the float32-MFMA attention)
+        const char *es = getenv("IRS_DECODER_SEQ");
+        c->use_seq = es ? (atoi(es) != 0) : 0;
         const char *er = getenv("IRS_LSE_RING");
         c->lse_no_ring = er ? (strcmp(er, "0") == 0) : 0;
     }
@@ -266,7 +268,7 @@ extern "C" int irs_finalize_weights(irs_ctx *ctx, void *arena, size_t bytes, voi
 // ------------------------------------------------------------------ workspace
 struct ws_plan {
     size_t x, y, xf, yf, qkv, qkv_b1, ao, h, ru, xb, eps, thr, gm, cnt, cand, lse, ref, xrows, tval, tids, status, step, pos;
-    size_t bseq[2], bhep[2], bcum[2], bpaths[2], buser, lmax, lsum, tokrow, scnt, soff, sqrow, spadq, mdev, xlocal, ksend, krecv, gmax, fbcount, fblist, exhkeys, total;
+    size_t bseq[2], bhep[2], bcum[2], bpaths[2], buser, lmax, lsum, tokrow, scnt, soff, sqrow, spadq, mdev, tseq, tidx, srow0, qtile, sorder, sbin, nwg, xlocal, ksend, krecv, gmax, fbcount, fblist, exhkeys, total;
 };
 
 static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
@@ -281,7 +283,11 @@ static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
     };
     p->x = take(RL * D.d * 4);
     p->y = take(RL * D.d * 4);
-    const size_t RLf = ((RL + 127) / 128) * 128; // 128-token tiles x 128 padded columns
+    // (the sequence-resident layer kernel pads every sequence to whole 32-token tiles and every workgroup to 8 tiles: up to 256 rows
+    //  per sequence in the fragment-major images)
+    const bool seq_shape = D.d == 128 && D.ffn_dim == 256 && D.n_heads == 4 && D.max_len <= 256 && D.n_layers > 1;
+    const size_t RLs = seq_shape ? (size_t)ctx->max_seqs * 256 : RL;
+    const size_t RLf = (((RLs > RL ? RLs : RL) + 127) / 128) * 128; // 128-token tiles x 128 padded columns
     const size_t fcols = D.d > 128 ? (size_t)((D.d + 31) / 32) * 32 : 128; // (d = 256: eight column tiles per token tile)
     p->xf = take(RLf * fcols * 4);
     p->yf = take(RLf * fcols * 4);
@@ -322,6 +328,13 @@ static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
     p->sqrow = take((size_t)ctx->max_seqs * 4);
     p->spadq = take((size_t)ctx->max_seqs * 4);
     p->mdev = take(256);
+    p->tseq = seq_shape ? take((size_t)ctx->max_seqs * 8 * 4) : 0;
+    p->tidx = seq_shape ? take((size_t)ctx->max_seqs * 8 * 4) : 0;
+    p->srow0 = seq_shape ? take((size_t)ctx->max_seqs * 4) : 0;
+    p->qtile = seq_shape ? take((size_t)ctx->max_seqs * 4) : 0;
+    p->sorder = seq_shape ? take((size_t)ctx->max_seqs * 4) : 0;
+    p->sbin = seq_shape ? take((size_t)ctx->max_seqs * 8) : 0;
+    p->nwg = seq_shape ? take(256) : 0;
     p->xlocal = take((size_t)ctx->max_seqs * D.d * 4);
     p->ksend = take((size_t)ctx->max_rows * D.max_k * 8); // exchange buffers of the item-sharded loops (comm.hip)
     p->krecv = take((size_t)ctx->max_rows * D.max_k * 8);
@@ -387,6 +400,17 @@ extern "C" int irs_bind_workspace(irs_ctx *ctx, void *ws, size_t bytes) {
     ctx->seq_qrow = (int32_t *)(b + p.sqrow);
     ctx->seq_padq = (int32_t *)(b + p.spadq);
     ctx->m_dev = (int32_t *)(b + p.mdev);
+    {
+        const irs_dims &D_ = ctx->dims;
+        const bool seq_shape = D_.d == 128 && D_.ffn_dim == 256 && D_.n_heads == 4 && D_.max_len <= 256 && D_.n_layers > 1;
+        ctx->tile_seq = seq_shape ? (int32_t *)(b + p.tseq) : nullptr;
+        ctx->tile_idx = seq_shape ? (int32_t *)(b + p.tidx) : nullptr;
+        ctx->seq_row0 = seq_shape ? (int32_t *)(b + p.srow0) : nullptr;
+        ctx->qrow_tile = seq_shape ? (int32_t *)(b + p.qtile) : nullptr;
+        ctx->seq_order = seq_shape ? (int32_t *)(b + p.sorder) : nullptr;
+        ctx->seq_bin = seq_shape ? (int32_t *)(b + p.sbin) : nullptr;
+        ctx->n_wg_dev = seq_shape ? (int32_t *)(b + p.nwg) : nullptr;
+    }
     ctx->x_local = (float *)(b + p.xlocal);
     ctx->keys_send = (uint64_t *)(b + p.ksend);
     ctx->keys_recv = (uint64_t *)(b + p.krecv);
@@ -433,6 +457,34 @@ extern "C" int irs_set_decoder_gemm(irs_ctx *ctx, int32_t mode) {
         drop_graphs(ctx);
     }
     return IRS_OK;
+}
+
+extern "C" int irs_set_decoder_seq(irs_ctx *ctx, int32_t on) {
+    if (!ctx) return IRS_E_INVALID;
+    if ((ctx->use_seq != 0) != (on != 0)) {
+        ctx->use_seq = on != 0;
+        drop_graphs(ctx);
+    }
+    return IRS_OK;
+}
+extern "C" int irs_get_decoder_seq(const irs_ctx *ctx) { return ctx ? ctx->use_seq : IRS_E_INVALID; }
+// (lab / tests: device addresses of decoder workspace buffers, so that a test can look at what a decode left behind)
+extern "C" void *irs_debug_ptr(const irs_ctx *ctx, int32_t which) {
+    if (!ctx) return nullptr;
+    switch (which) {
+    case 0: return ctx->act_xf;
+    case 1: return ctx->act_yf;
+    case 2: return ctx->tile_seq;
+    case 3: return ctx->tile_idx;
+    case 4: return ctx->seq_row0;
+    case 5: return ctx->qrow_tile;
+    case 6: return ctx->n_wg_dev;
+    case 7: return ctx->seq_off;
+    case 8: return ctx->seq_cnt;
+    case 9: return ctx->act_qkv;
+    case 10: return ctx->seq_qrow;
+    default: return nullptr;
+    }
 }
 
 // the SELECTED mode (what irs_set_decoder_gemm stored: a get / set round trip restores it) ...

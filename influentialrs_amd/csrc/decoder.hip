@@ -139,6 +139,176 @@ __global__ void __launch_bounds__(256) k_plan_fill(const int64_t *__restrict__ s
     }
 }
 
+// ------------------------------------------------------------------ plan of the sequence-resident layer kernel (round 5)
+// k_block_x6<.., SEQ> wants every sequence inside ONE workgroup of SEQ_WG_TILES wave tiles; a tile is two mirrored 16-token
+// blocks of the sequence, so sequence b takes T_b = ceil(blocks / 2) consecutive tiles.  Packing = best fit, largest first, done
+// class by class (T = 8 .. 1) with the open workgroups kept as pools per free-tile count f: the items of a class fill the
+// pools' free tiles smallest f first (a workgroup with f free tiles takes floor(f / T) of them), the rest opens new workgroups
+// (floor(8 / T) items each).  Workgroups are created as contiguous id ranges and move between pools a prefix at a time, so a
+// pool is a short list of ranges and item i of a class finds its (workgroup, first tile) by arithmetic: every thread places
+// its own items, one thread does the O(pools) bookkeeping between classes (the first version walked the 4096 sequences in
+// one thread: 1.7 ms).  tools/seq_pack_sim.py: 0.84 lane efficiency on the bench's windows against 0.68 in window order.
+//   tile_seq[t] / tile_idx[t]: the sequence (-1: none) and its tile index for grid tile t = 8 workgroup + wave;
+//   seq_row0[b]: first row of the sequence in its workgroup's K / V images; qrow_tile[b]: tile-order row of the consumed token;
+//   n_wg[0]: workgroups in use.
+#define SEQ_WG_TILES 8
+#define SEQ_RMAX 48
+__global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ cnt, const int32_t *__restrict__ off,
+                                                   const int32_t *__restrict__ qrow, int B, int32_t *__restrict__ order,
+                                                   int32_t *__restrict__ bin_slot, int32_t *__restrict__ tile_seq,
+                                                   int32_t *__restrict__ tile_idx, int32_t *__restrict__ seq_row0,
+                                                   int32_t *__restrict__ qrow_tile, int32_t *__restrict__ n_wg, int tiles_cap) {
+    __shared__ int s_hist[SEQ_WG_TILES + 1], s_start[SEQ_WG_TILES + 2], s_fill[SEQ_WG_TILES + 1];
+    __shared__ int p_n[SEQ_WG_TILES], p_s[SEQ_WG_TILES][SEQ_RMAX], p_l[SEQ_WG_TILES][SEQ_RMAX]; // pool f = 1 .. 7: ranges of workgroup ids
+    __shared__ int c_cum[SEQ_WG_TILES + 1], c_q[SEQ_WG_TILES], c_exist, c_newbase, s_nwg;
+    const int tid = threadIdx.x;
+    if (tid <= SEQ_WG_TILES) s_hist[tid] = 0, s_fill[tid] = 0;
+    if (tid < SEQ_WG_TILES) p_n[tid] = 0;
+    if (tid == 0) s_nwg = 0;
+    for (int t = tid; t < tiles_cap; t += 1024) tile_seq[t] = -1;
+    __syncthreads();
+    auto tiles_of = [&](int b) { // a tile = two mirrored 16-token blocks (k_block_x6<.., SEQ>): ceil(blocks / 2)
+        int T = (((cnt[b] + 15) >> 4) + 1) >> 1;
+        return T < 1 ? 1 : (T > SEQ_WG_TILES ? SEQ_WG_TILES : T);
+    };
+    for (int b = tid; b < B; b += 1024) atomicAdd(&s_hist[tiles_of(b)], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int T = SEQ_WG_TILES; T >= 1; --T) { // largest first
+            s_start[T] = run;
+            run += s_hist[T];
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < B; b += 1024) {
+        const int T = tiles_of(b);
+        order[s_start[T] + atomicAdd(&s_fill[T], 1)] = b;
+    }
+    __syncthreads();
+    auto pool_bins = [&](int f) {
+        int n = 0;
+        for (int r = 0; r < p_n[f]; ++r) n += p_l[f][r];
+        return n;
+    };
+    auto append = [&](int f, int start, int len) { // (thread 0) `len` workgroups from `start` on now have f free tiles
+        if (f < 1 || len < 1) return;
+        if (p_n[f] > 0 && p_s[f][p_n[f] - 1] + p_l[f][p_n[f] - 1] == start) p_l[f][p_n[f] - 1] += len;
+        else if (p_n[f] < SEQ_RMAX) p_s[f][p_n[f]] = start, p_l[f][p_n[f]] = len, ++p_n[f];
+        // (a full list drops the range: those workgroups stay as filled as they are -- packing quality, never correctness)
+    };
+    auto take_prefix = [&](int f, int m, int dest) { // (thread 0) the first m workgroups of pool f move to pool dest
+        for (int r = 0; r < p_n[f] && m > 0; ++r) {
+            const int t = m < p_l[f][r] ? m : p_l[f][r];
+            append(dest, p_s[f][r], t);
+            p_s[f][r] += t, p_l[f][r] -= t, m -= t;
+        }
+        int w = 0;
+        for (int r = 0; r < p_n[f]; ++r)
+            if (p_l[f][r] > 0) p_s[f][w] = p_s[f][r], p_l[f][w] = p_l[f][r], ++w;
+        p_n[f] = w;
+    };
+    for (int T = SEQ_WG_TILES; T >= 1; --T) {
+        const int n = s_hist[T], base = s_start[T], qnew = SEQ_WG_TILES / T;
+        if (n == 0) continue; // (uniform: s_hist is shared)
+        if (tid == 0) {
+            int tot = 0;
+            for (int f = T; f < SEQ_WG_TILES; ++f) {
+                c_cum[f] = tot, c_q[f] = f / T;
+                tot += pool_bins(f) * c_q[f];
+            }
+            c_cum[SEQ_WG_TILES] = tot;
+            c_exist = n < tot ? n : tot;
+            c_newbase = s_nwg;
+            s_nwg += (n - c_exist + qnew - 1) / qnew;
+        }
+        __syncthreads();
+        const int exist = c_exist;
+        for (int i = tid; i < n; i += 1024) {
+            const int b = order[base + i];
+            int w, slot;
+            if (i < exist) {
+                int f = T;
+                while (f < SEQ_WG_TILES - 1 && i >= c_cum[f + 1]) ++f;
+                const int s_ = i - c_cum[f];
+                int bl = s_ / c_q[f];
+                const int k = s_ % c_q[f];
+                int r = 0;
+                while (r < p_n[f] - 1 && bl >= p_l[f][r]) bl -= p_l[f][r], ++r;
+                w = p_s[f][r] + bl;
+                slot = (SEQ_WG_TILES - f) + k * T;
+            } else {
+                const int j_ = i - exist;
+                w = c_newbase + j_ / qnew;
+                slot = (j_ % qnew) * T;
+            }
+            bin_slot[b] = w * SEQ_WG_TILES + slot;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int left = exist;
+            for (int f = T; f < SEQ_WG_TILES && left > 0; ++f) {
+                const int q = c_q[f], cap = pool_bins(f) * q;
+                const int used = left < cap ? left : cap;
+                left -= used;
+                const int full = used / q, part = used % q;
+                take_prefix(f, full, f - T * q);
+                if (part) take_prefix(f, 1, f - T * part);
+            }
+            const int nnew = n - exist, fullnew = nnew / qnew, partnew = nnew % qnew;
+            append(SEQ_WG_TILES - T * qnew, c_newbase, fullnew);
+            if (partnew) append(SEQ_WG_TILES - T * partnew, c_newbase + fullnew, 1);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) n_wg[0] = s_nwg;
+    for (int b = tid; b < B; b += 1024) {
+        const int T = tiles_of(b), t0 = bin_slot[b];
+        for (int t = 0; t < T; ++t)
+            if (t0 + t < tiles_cap) tile_seq[t0 + t] = b, tile_idx[t0 + t] = t;
+        seq_row0[b] = 32 * (t0 % SEQ_WG_TILES);
+        const int p = qrow[b] - off[b], pb = p >> 4, nb = (cnt[b] + 15) >> 4; // the consumed token: block pb, in its tile's first or second half
+        qrow_tile[b] = (pb <= nb - 1 - pb) ? 32 * (t0 + pb) + (p & 15) : 32 * (t0 + nb - 1 - pb) + 16 + (p & 15);
+    }
+}
+// x = item_emb[seq] * sqrt(d) + pe[position] into the fragment-major image in TILE order (k_embed_frag's arithmetic)
+__global__ void __launch_bounds__(256) k_embed_seq(const int64_t *__restrict__ seq, const float *__restrict__ E,
+                                                   const float *__restrict__ pe, float *__restrict__ xf,
+                                                   const int32_t *__restrict__ tok_row, const int32_t *__restrict__ tile_seq,
+                                                   const int32_t *__restrict__ tile_idx, const int32_t *__restrict__ seq_off,
+                                                   const int32_t *__restrict__ seq_cnt, const int32_t *__restrict__ n_wg, int L, int d,
+                                                   float sqrtd, int64_t n_item) {
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5;
+    if (tile >= n_wg[0] * SEQ_WG_TILES) return;
+    const int b = tile_seq[tile];
+    int j = 0x3FFFFFFF;
+    if (b >= 0) { // lanes 0-15: block ti; lanes 16-31: its mirror image nb - 1 - ti (k_block_x6<.., SEQ>)
+        const int ti = tile_idx[tile], nb = (seq_cnt[b] + 15) >> 4, qb1 = nb - 1 - ti;
+        j = li < 16 ? 16 * ti + li : (qb1 > ti ? 16 * qb1 + (li - 16) : 0x3FFFFFFF);
+    }
+    const bool live = b >= 0 && j < seq_cnt[b];
+    const int orig = live ? tok_row[seq_off[b] + j] : 0;
+    int64_t id = live ? seq[orig] : 0;
+    if (id < 0) id = 0;
+    if (id > n_item) id = n_item;
+    const float *e = E + id * (int64_t)d;
+    const float *p = pe + (int64_t)(orig % L) * d;
+    float4 *o = reinterpret_cast<float4 *>(xf) + (size_t)tile * 16 * 64 + lane;
+#pragma unroll 4
+    for (int c = 0; c < 16; ++c) { // c = tn * 4 + g
+        const int n = (c >> 2) * 32 + (c & 3) * 8 + 4 * lk;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            v.x = __fadd_rn(__fmul_rn(e[n + 0], sqrtd), p[n + 0]);
+            v.y = __fadd_rn(__fmul_rn(e[n + 1], sqrtd), p[n + 1]);
+            v.z = __fadd_rn(__fmul_rn(e[n + 2], sqrtd), p[n + 2]);
+            v.w = __fadd_rn(__fmul_rn(e[n + 3], sqrtd), p[n + 3]);
+        }
+        o[c * 64] = v;
+    }
+}
+
 // Few sequences (the latency path): count, scan and fill in ONE workgroup of 16 waves, together with the
 // personalised impressionability factor r_u (k_pif) and, inside a hipGraph path loop, the hand-over of the step
 // counter -- five launches of ~4.5 us each become one.
@@ -1325,6 +1495,16 @@ struct BlockX6Args {
     // of k_attn16h; the q and k sections stay float32.  (The k | v-only tail that feeds the rows-only last layer keeps float32:
     // k_attn_row32 reads it.)
     int kv_planes;
+    // SEQ instantiation (round 5, k_block_x6<.., SEQ = true>: the sequence-resident layer kernel).  A workgroup of eight waves owns
+    // WHOLE sequences (tile t of the grid = 32 consecutive tokens of sequence tile_seq[t], its tile_idx[t]-th; k_plan_seq), computes
+    // this layer's q | k | v from x itself, keeps K / V of one head at a time in LDS, runs the attention of its own queries and
+    // goes on with the layer body: no q | k | v row ever reaches HBM.  Rf = x (fragment-major, TILE order), Af = scratch for the
+    // attention output in the same order (written and read back by the same wave), Xf = x'.
+    const uint4 *Wq;       // the stream whose q | k | v region holds THIS layer's in-projection (the previous layer's stream)
+    const float *bq;       // this layer's in-projection bias [3 d]
+    const int32_t *tile_seq, *tile_idx, *seq_off, *seq_cnt, *seq_padq, *seq_row0, *n_wg_dev;
+    const float *r_u;
+    int mask_mode;
 #ifdef X6_DUMP
     uint4 *dbg;            // (lab) the fragments workgroup 0 / wave 0 consumed, [step][fragment][lane]
 #endif
@@ -1407,7 +1587,20 @@ __device__ __forceinline__ x6_u32x4 x6_rd_sync(unsigned int base) {
     return v;
 }
 
-// QP0 = 0: the tail computes q | k | v; 1: k | v only (feeding the rows-only last layer)
+// one 16-query block of the sequence-resident kernel's attention (defined behind k_attn16h, whose mathematics it shares)
+__device__ __forceinline__ void seq_attn_block(const float *Ks, const char *Vp, int PL, int L, int qb, bool irn, float tgt_add, bool tgt_ok,
+                                               int pq, const float *qscr, float4 *of, bool store);
+#ifndef SEQ_EXP
+#define SEQ_EXP 0 // (lab, tools/seq_lab.sh: 1 = no attention compute, 2 = asynchronous tail reads: timing experiments, results wrong)
+#endif
+// SEQ layout of the dynamic LDS behind the ring and the parameter vectors (x6_seq_lds_bytes)
+#define X6_SEQ_VECS (256 + 12 * 32 * 4 + 384)   // floats: the parameter vectors + this layer's in-projection bias
+#define X6_SEQ_KIMG (3 * 16384 + X6_SEQ_VECS * 4)  // K image of ONE head: 256 token rows x 32 float32, chunk-swizzled (k_attn16h's)
+#define X6_SEQ_VIMG (X6_SEQ_KIMG + 32768)        // V image: 2 float16 planes x 256 rows x 64 B
+#define X6_SEQ_SCR (X6_SEQ_VIMG + 32768)         // per wave: the q tile as [32 tokens][36] float32
+#define X6_SEQ_SCR_B 4608
+__host__ __device__ constexpr int x6_seq_lds_bytes() { return X6_SEQ_SCR + 8 * X6_SEQ_SCR_B; }
+// QP0 = 0: the tail computes q | k | v; 1: k | v only (feeding the rows-only last layer); 3 (SEQ): no tail
 #ifdef X6_STAMP
 #define X6_T(v_) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); v_ = t_; }
 #else
@@ -1419,11 +1612,14 @@ __device__ __forceinline__ x6_u32x4 x6_rd_sync(unsigned int base) {
 // blocks are unused) run: the same ring, the same step code.
 // NT = 8 (d = 256, round 4): 8 accumulator tiles per token -- 128 registers of accumulators, 192 of cached planes -- so ONE
 // wave per SIMD (512 registers per lane), one workgroup per CU; the step stream has 96 steps (x6_nstep).
-template <int QP0, int NW, bool EMBED, int NT = 4, int NPL = 3>
+template <int QP0, int NW, bool EMBED, int NT = 4, int NPL = 3, bool SEQ = false>
 __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block_x6(BlockX6Args a) {
+    static_assert(!SEQ || (NT == 4 && NPL == 2 && NW == 8 && !EMBED && (QP0 == 1 || QP0 == 3)), "the sequence-resident form: d = 128, float16 planes, eight waves");
     constexpr int NP = 8 * NPL, STEP_B = x6_step_b(NPL); // pieces (fragments) and bytes of a step
     using x6_plane = typename std::conditional<NPL == 2, x6_f16x8, x6_bf16x8>::type;
-    constexpr int D = 32 * NT, F = 256, NSLOT = x6_nslot(NPL), LEAD = NSLOT - 1, PPW = NP / NW, HT = NT / 4;
+    // (SEQ: three ring slots -- the K / V images and the q scratch take the rest of the CU's LDS)
+    constexpr int D = 32 * NT, F = 256, NSLOT = SEQ ? 3 : x6_nslot(NPL), LEAD = NSLOT - 1, PPW = NP / NW, HT = NT / 4;
+    constexpr int NFRONT = SEQ ? 3 * NT : 0; // SEQ: the q | k | v steps of THIS layer run in front (head-major: q_h, k_h, v_h)
     // the weight planes hold WS x the weights (x6_wscale): an accumulator of plane products holds WS x the product, IWS folds back
     constexpr float WS = x6_wscale(NPL), IWS = 1.0f / WS;
     // RESID_LATE (round 4, d = 128 with float16 planes): the workgroup's start no longer waits for its 128 KB of inputs.  The
@@ -1434,10 +1630,13 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     // allow one tile set beside the newest DMA group; the compiler's own waits bring each attention tile in when its step
     // splits it.  (tools/x6_lab stamps: the start was 16.8 K of a wave's 100 K cycles.)
     constexpr bool RESID_LATE = X6_RESID_LATE && NPL == 2 && NT == 4 && !EMBED && NSLOT == 4 && (NW == 4 || NW == 8);
+    // (SEQ keeps the residual apart the same way -- out-projection from zero, residual added with b_o -- without the counted start)
+    constexpr bool RESID_SEP = RESID_LATE || SEQ;
     constexpr int NLOAD = 4 * NT; // plain global loads of one set of a wave's input tiles (attention output; residual)
     constexpr int NPRE = x6_npre(NT), NOUT = NT * HT;
     constexpr int S0 = EMBED ? NPRE : 0; // first step of the sequence
     constexpr int V_B1 = 0, V_B2 = F, V_G = F + D, V_B = F + 2 * D, V_BIN = F + 3 * D, V_O = F + 3 * D + 3 * D;
+    constexpr int V_BQ = V_O + 6 * D; // (SEQ) this layer's in-projection bias
     static_assert(NT == 4 || NT == 8, "d = 128 or 256");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *vecs = reinterpret_cast<float *>(smem + NSLOT * STEP_B); // b1[256], b2, g, b, b_in[384], b_o, g1, b1n, c, g2, b2n
@@ -1447,7 +1646,25 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     unsigned long long st_p[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // (lab) phase boundaries
     X6_T(st_p[0])
     const int m0 = blockIdx.x * (32 * NW);
-    const int M = a.m_dev ? min(a.M, a.m_dev[0]) : a.M;
+    const int M = SEQ ? 0x7FFFFFFF : (a.m_dev ? min(a.M, a.m_dev[0]) : a.M);
+    // SEQ: this wave's tile = 32 consecutive tokens of ONE sequence (or nothing: s_b < 0 -- the wave still takes part in every
+    // step and barrier); lane li is token s_j of the sequence, packed row s_off + s_j while s_j < s_cnt
+    int s_b = -1, s_ti = 0, s_off = 0, s_cnt = 0, s_pq = -1, s_row0 = 0;
+    float s_ru = 0.f;
+    bool s_tgt = false;
+    if constexpr (SEQ) {
+        if ((int)blockIdx.x >= a.n_wg_dev[0]) return;
+        const int tg_ = blockIdx.x * NW + wave;
+        s_b = __builtin_amdgcn_readfirstlane(a.tile_seq[tg_]);
+        if (s_b >= 0) {
+            s_ti = __builtin_amdgcn_readfirstlane(a.tile_idx[tg_]);
+            s_off = __builtin_amdgcn_readfirstlane(a.seq_off[s_b]), s_cnt = __builtin_amdgcn_readfirstlane(a.seq_cnt[s_b]);
+            s_pq = __builtin_amdgcn_readfirstlane(a.seq_padq[s_b]), s_row0 = __builtin_amdgcn_readfirstlane(a.seq_row0[s_b]);
+            const bool irn_ = a.mask_mode == IRS_MASK_IRN;
+            s_ru = irn_ ? a.r_u[s_b] : 0.f;
+            s_tgt = irn_ && a.seq[(int64_t)s_b * a.L + a.L - 1] != 0;
+        }
+    }
     // (RESID_LATE) the twelve parameter values of this thread in ONE batch of unconditional loads.  (The conditional form --
     // "b_o if present", "c_l if present", the halves of the workgroup that hold 128-wide vectors -- compiled to six dependent
     // memory round trips in front of the first DMA issue.  Stores behind the DMA issue would be better still, but any wait the
@@ -1460,7 +1677,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
         pv[6] = pbo[td], pv[7] = a.g1[td], pv[8] = a.b1n[td], pv[9] = pc[td], pv[10] = pg2[td], pv[11] = pb2n[td];
         pv[12] = 0.f;
     }
-    if (m0 >= M) return;
+    if (!SEQ && m0 >= M) return;
     if constexpr (RESID_LATE) {
         static_assert(NW == 4 || NW == 8, "every thread index below 256 exists");
         // (every value "used" here, by every wave: a load still pending in the waves that skip a store below would cost a
@@ -1482,6 +1699,9 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             vecs[V_O + 5 * D + tid] = a.c ? pv[11] : 0.f;
         }
     } else if constexpr (NT == 4) {
+        if constexpr (SEQ) {
+            if (tid < 3 * D) vecs[V_BQ + tid] = a.bq[tid];
+        }
         if (tid < 256) {
             if (!EMBED) vecs[V_B1 + tid] = a.b1[tid];
             vecs[V_BIN + tid] = a.bin[tid];
@@ -1521,14 +1741,20 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     if (blockIdx.x >= 256 && blockIdx.x < 512)
         for (int i = 0; i < X6_STAGGER; ++i) __builtin_amdgcn_s_sleep(127); // (lab) second resident workgroup of a CU starts ~4 us x N late
 #endif
-    const int mtile = (m0 >> 5) + wave;
-    const int mt = m0 + wave * 32 + li;
+    const int mtile = SEQ ? (int)blockIdx.x * NW + wave : (m0 >> 5) + wave;
+    // (SEQ) this lane's token of its sequence.  A wave's tile is TWO 16-token blocks of the sequence, block s_ti in lanes 0-15 and
+    // its mirror image s_nb - 1 - s_ti in lanes 16-31 (causal attention: block qb costs qb + 1 key tiles, so every wave of a
+    // sequence gets s_nb + 1 of them; consecutive blocks per wave left the last waves with 1.8 x the mean).  An odd middle
+    // block stands alone: the second half of its tile is dead.
+    const int s_nb = (s_cnt + 15) >> 4, s_qb1 = s_nb - 1 - s_ti;
+    const int s_j = li < 16 ? 16 * s_ti + li : (s_qb1 > s_ti ? 16 * s_qb1 + (li - 16) : 0x3FFFFFFF);
+    const int mt = SEQ ? ((s_b >= 0 && s_j < s_cnt) ? s_off + s_j : 0x7FFFFFFF) : m0 + wave * 32 + li; // packed row (SEQ: dead lanes never store)
     const size_t fbase = (size_t)mtile * (4 * NT) * 64 + lane;
     const unsigned int lds0 = (unsigned int)(size_t)(__attribute__((address_space(3))) char *)smem;
     const unsigned int fr_addr = lds0 + lane * 16; // + slot * X6_STEP_B + piece * 1024
     const unsigned int vecs_addr = lds0 + NSLOT * STEP_B + 16 * lk; // this lane's float4 of a 32-value tile's group g: + 32 g bytes
     constexpr int qoff = NOUT * QP0;                // the q tiles' steps (NT tiles x HT) are skipped when QP0
-    constexpr int nsteps = x6_nstep(NT) - qoff;     // executed steps; step i of the sequence is stream block i (+ qoff past the FFN)
+    constexpr int nsteps = NFRONT + x6_nstep(NT) - qoff; // executed steps; step i of the sequence is stream block i (+ qoff past the FFN)
     // DMA of sequence step i into slot i % NSLOT: this wave's pieces PPW wave .. PPW wave + PPW - 1.  The slot holds the
     // step's block in stream order, and the instruction's immediate offset moves the global source AND the LDS destination
     // (tools/dma_probe.hip), so the pieces share one address register pair and one M0: base = the middle piece, offsets
@@ -1538,11 +1764,16 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     constexpr int PPG = PPW <= 6 ? PPW : (PPW % 6 == 0 ? 6 : 4), NGRP = PPW / PPG;
     static_assert(PPW * NW == NP && PPG * NGRP == PPW, "a step's pieces divide over the waves and their issue groups");
     const uint4 *dma_src = a.Wx + (PPW * wave + PPG / 2) * 64 + lane;
+    const uint4 *dma_src_q = SEQ ? a.Wq + (PPW * wave + PPG / 2) * 64 + lane : dma_src;
     auto issue = [&](int i) __attribute__((always_inline)) {
-        const int blk = i < NPRE ? i : i + qoff;
+        // SEQ: front step i = 3 h + c (c = 0 q, 1 k, 2 v of head h) is q | k | v tile NT c + h of the OTHER stream's tail region;
+        // body step i is block i - NFRONT of this layer's stream
+        const int ib = i - NFRONT;
+        const int blk = (SEQ && i < NFRONT) ? NPRE + NT * (i % 3) + i / 3 : (ib < NPRE ? ib : ib + qoff);
+        const uint4 *dsrc = (SEQ && i < NFRONT) ? dma_src_q : dma_src;
         x6_static_for<0, NGRP>([&](auto gc) __attribute__((always_inline)) {
             constexpr int grp = decltype(gc)::value;
-            const uint4 *src = dma_src + (size_t)blk * (STEP_B / 16) + grp * PPG * 64;
+            const uint4 *src = dsrc + (size_t)blk * (STEP_B / 16) + grp * PPG * 64;
             char *dst = smem + (i % NSLOT) * STEP_B + (PPW * wave + grp * PPG + PPG / 2) * 1024;
             x6_static_for<0, PPG>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int off = (decltype(jc)::value - PPG / 2) * 1024;
@@ -1555,8 +1786,8 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     f32x16 acc[NT];
     f32x16 at[NT]; // attention output tiles (B operand source of the out-projection): all requested here, so that
                    // the steps carry no plain global load (its wait would be a vmcnt(0) behind the DMA pieces)
-    x6_u32x4 resq[RESID_LATE ? NT : 1][4]; // (RESID_LATE) the residual as its 16-byte loads, added in front of LayerNorm 1
-    x6_u32x4 atq[RESID_LATE ? NT : 1][4]; // (RESID_LATE) the attention tiles as their four 16-byte loads
+    x6_u32x4 resq[RESID_SEP ? NT : 1][4]; // (RESID_LATE, SEQ) the residual as its 16-byte loads, added in front of LayerNorm 1
+    x6_u32x4 atq[RESID_SEP ? NT : 1][4]; // (RESID_LATE, SEQ) the attention tiles as their four 16-byte loads
     if constexpr (!EMBED) {
         const float4 *rfrag = reinterpret_cast<const float4 *>(a.Rf) + fbase;
         const float4 *afrag = reinterpret_cast<const float4 *>(a.Af) + fbase;
@@ -1566,7 +1797,15 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             x6_static_for<0, LEAD>([&](auto ic) __attribute__((always_inline)) { issue(S0 + decltype(ic)::value); });
             asm volatile("" ::: "memory");
         }
-        if constexpr (!RESID_LATE) {
+        if constexpr (SEQ) { // x itself: the B operand of this layer's q | k | v steps (split into planes below)
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 t4 = rfrag[(tn * 4 + g) * 64];
+                    acc[tn][4 * g + 0] = t4.x, acc[tn][4 * g + 1] = t4.y, acc[tn][4 * g + 2] = t4.z, acc[tn][4 * g + 3] = t4.w;
+                }
+        } else if constexpr (!RESID_LATE) {
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
@@ -1583,7 +1822,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
                 const float4 *tp = afrag + tn * 4 * 64;
                 atq[tn][0] = x6_gld<0>(tp), atq[tn][1] = x6_gld<1024>(tp), atq[tn][2] = x6_gld<2048>(tp), atq[tn][3] = x6_gld<3072>(tp);
             });
-        } else {
+        } else if constexpr (!SEQ) { // (SEQ: the attention tiles do not exist yet)
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
@@ -1654,7 +1893,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
         __syncthreads(); // the scratch is the ring: every wave has read its tile before the first DMA piece lands
     }
     auto load_res = [&]() __attribute__((always_inline)) {
-        if constexpr (RESID_LATE) {
+        if constexpr (RESID_SEP) {
             const float4 *rfrag = reinterpret_cast<const float4 *>(a.Rf) + fbase;
             x6_static_for<0, NT>([&](auto tc) __attribute__((always_inline)) {
                 constexpr int tn = decltype(tc)::value;
@@ -1698,6 +1937,13 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     });
     if constexpr (NT != 8) landed_all();
 
+    // SEQ: the steps whose read-ahead of the NEXT step's head stays pending across compiler-written code with spills in it (the
+    // attention region behind a v step, LayerNorm 1 behind the last out-projection step, LayerNorm 3 behind the last FFN-2
+    // step): there the reads wait inside their own asm statement.  (The first version spilled three pending fragments in front
+    // of LayerNorm 1 -- a tenth of the tiles came out wrong; tools/isa_pending_read_scan.py finds such uses in the ISA.)
+    auto seq_sync_tail = [&](int i) __attribute__((always_inline)) {
+        return (i < NFRONT && i % 3 == 2) || i == NFRONT + NOUT - 1 || i == NFRONT + NPRE - 1;
+    };
     const float invn = 1.0f / (float)D;
     x6_plane X[NPL];
     unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_wait = 0, st_bar = 0, st_iss = 0, st_0 = 0, st_1 = 0, st_steps = 0;
@@ -1722,6 +1968,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
 #else
 #define X6_READ_AHEAD(f_)                                                                                                \
     if constexpr ((f_) + RA < NP) af[((f_) + RA) & RA] = x6_rd<((f_) + RA) * 1024>(sb_);                                 \
+    else if (SEQ && !(SEQ_EXP & 2) && seq_sync_tail(step_)) af[((f_) + RA) & RA] = x6_rd_sync<((f_) + RA - NP) * 1024>(sn_); /* (SEQ: a read that stays pending across a compiler-written phase may be spilled before it lands) */ \
     else af[((f_) + RA) & RA] = x6_rd<((f_) + RA - NP) * 1024>(sn_); /* next step's head (behind this step's barrier) */ \
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af[(f_) & RA]) : "i"(RA));                                               \
     X6_DUMP_FRAG(step_, f_)
@@ -1747,7 +1994,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
         X6_T(st_b)                                                                                                       \
         __builtin_amdgcn_s_barrier();                                                                                    \
         X6_T(st_c)                                                                                                       \
-        if ((I_) + LEAD < nsteps) X6_ISSUE((I_) + LEAD);                                                                 \
+        if ((I_) + LEAD < nsteps && !(SEQ && (I_) < NFRONT && (I_) % 3 == 2)) X6_ISSUE((I_) + LEAD); /* (SEQ: see the front phase) */ \
         if constexpr (RESID_LATE) { if ((I_) == 1) load_res(); }                                                         \
         X6_T(st_d)                                                                                                       \
         st_wait += st_b - st_a, st_bar += st_c - st_b, st_iss += st_d - st_c;                                            \
@@ -1781,27 +2028,6 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     // (reads past the last step of the sequence fetch a stale slot and are never multiplied: the counted waits assume
     // every read of the schedule is in flight)
 
-    // ---- out-projection: acc += W_o . ao^T, k tile t, output half oh: step t HT + oh
-    if constexpr (!EMBED) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            // (RESID_LATE: an attention tile "appears" here -- without the statement the compiler splits all four tiles into
-            //  planes right behind their loads, i.e. waits for every input tile and DMA piece before the start barrier)
-            if constexpr (RESID_LATE) {
-                // vector memory operations behind tile t's loads when its step starts: the later tiles, the DMA groups issued
-                // at mid-step (one per finished step: steps 3 ..), the residual's 16 loads (behind step 1's barrier)
-                const int newer_ = 4 * (NT - 1 - t) + PPW * t + (t >= 2 ? NLOAD : 0);
-                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(atq[t][0]), "+v"(atq[t][1]), "+v"(atq[t][2]), "+v"(atq[t][3]) : "n"(newer_));
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 t4 = __builtin_bit_cast(float4, atq[t][g]);
-                    at[t][4 * g + 0] = t4.x, at[t][4 * g + 1] = t4.y, at[t][4 * g + 2] = t4.z, at[t][4 * g + 3] = t4.w;
-                }
-            }
-            X6_STEP(t * HT, at[t], acc[0], acc[1], acc[2], acc[3])
-            if constexpr (HT == 2) { X6_STEP(t * HT + 1, at[t], acc[4], acc[5], acc[6], acc[7]) }
-        }
-    }
     // ---- the parameter vectors of the LayerNorm phases (d = 128): inline-asm LDS reads at immediate offsets from ONE base
     // register, two or three groups ahead of their use through a small register ring with counted waits.  (Compiler-visible
     // reads: every one waits for the DMA in flight -- the compiler cannot tell the ring from the vectors --, their 48 addresses
@@ -1838,7 +2064,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             vec_stream(std::integral_constant<int, 1>{}, vb_c, x6_ic0{}, x6_ic0{}, [&](auto gc, const float4 bb, const float4, const float4) __attribute__((always_inline)) {
                 constexpr int tn = decltype(gc)::value >> 2, g = decltype(gc)::value & 3;
                 // (vb >= 0 = the out-projection's epilogue: the accumulators hold WS x (product [+ residual]))
-                if constexpr (RESID_LATE) {
+                if constexpr (RESID_SEP) {
                     const float4 rs = __builtin_bit_cast(float4, resq[tn][g]);
                     acc[tn][4 * g + 0] = __builtin_fmaf(acc[tn][4 * g + 0], IWS, rs.x), acc[tn][4 * g + 1] = __builtin_fmaf(acc[tn][4 * g + 1], IWS, rs.y);
                     acc[tn][4 * g + 2] = __builtin_fmaf(acc[tn][4 * g + 2], IWS, rs.z), acc[tn][4 * g + 3] = __builtin_fmaf(acc[tn][4 * g + 3], IWS, rs.w);
@@ -1902,47 +2128,6 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
                 }
         }
     };
-    // (NT = 8: the LayerNorm phases run at full register pressure and the compiler parks the fragments read ahead for the next
-    //  step in AGPRs across them -- copies taken before the data has landed unless the reads are waited for first)
-    if constexpr (NT == 8) landed_all();
-    X6_T(st_p[1])
-    if constexpr (!EMBED) {
-        using x6_icn = std::integral_constant<int, -1>;
-        if constexpr (RESID_LATE) { // the residual has landed once only the two DMA groups issued since are in flight
-            static_assert(NT == 4, "sixteen operands");
-            asm volatile("s_waitcnt vmcnt(%16)"
-                         : "+v"(resq[0][0]), "+v"(resq[0][1]), "+v"(resq[0][2]), "+v"(resq[0][3]), "+v"(resq[1][0]), "+v"(resq[1][1]),
-                           "+v"(resq[1][2]), "+v"(resq[1][3]), "+v"(resq[2][0]), "+v"(resq[2][1]), "+v"(resq[2][2]), "+v"(resq[2][3]),
-                           "+v"(resq[3][0]), "+v"(resq[3][1]), "+v"(resq[3][2]), "+v"(resq[3][3])
-                         : "n"(2 * PPW));
-        }
-        layer_norm(std::integral_constant<int, V_O + 0 * D>{}, std::integral_constant<int, V_O + 1 * D>{},
-                   std::integral_constant<int, V_O + 2 * D>{}, std::integral_constant<int, V_O + 3 * D>{});
-        if (a.c) layer_norm(x6_icn{}, std::integral_constant<int, V_O + 4 * D>{}, std::integral_constant<int, V_O + 5 * D>{}, x6_icn{});
-    }
-    X6_T(st_p[2])
-
-    // ---- feed-forward, one hidden tile (32 units) at a time: FFN-1 step h_ft = W1[32 ft ..] y^T over the whole K = 128
-    //      (B operand: y's bf16 planes, split ONCE and kept -- 96 registers -- while acc itself goes on as the residual
-    //      accumulator), bias + relu on the 16 values, FFN-2 step acc += W2[:, 32 ft ..] h_ft^T.  (The round-2 order --
-    //      all eight hidden tiles, then FFN-2 -- keeps 128 registers of h beside the 64 of y: with the split's
-    //      temporaries that is ~265 of the 256 registers two waves per SIMD have: 173 spilled.)
-    x6_plane Yp[NT][2][NPL];
-    if constexpr (!EMBED) {
-#pragma unroll
-        for (int tn = 0; tn < NT; ++tn)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                x6_split(acc[tn], s2, Yp[tn][s2]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        if constexpr (NPL == 2) { // FFN-2 accumulates WS x its product onto y in place: y goes on as WS y (exact)
-#pragma unroll
-            for (int tn = 0; tn < NT; ++tn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[tn][r] *= WS;
-        }
-    }
     // a 32-value bias tile (vecs offset vo) into an accumulator tile: asm reads (a compiler-visible LDS read here would wait
     // for the DMA issued half a step ago); the wait drains the fragment read-aheads with it, which only makes the next
     // step's counted waits pass early
@@ -1977,6 +2162,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
 #define X6_RD_V(v_)                                                                                                      \
     if constexpr ((v_) < NP) af[(v_) & RA] = x6_rd<(v_) * 1024>(sb_);                                                    \
     else if constexpr ((v_) < NV) af[(v_) & RA] = x6_rd<NPL * ((v_) - NP) * 1024>(sb_);                                  \
+    else if (SEQ && !(SEQ_EXP & 2) && seq_sync_tail(step_)) af[(v_) & RA] = x6_rd_sync<((v_) - NV) * 1024>(sn_);             \
     else af[(v_) & RA] = x6_rd<((v_) - NV) * 1024>(sn_); /* next step's head (behind this step's barrier) */
 #define X6_WAIT_V(v_) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af[(v_) & RA]) : "i"(RA));
 #endif
@@ -2020,13 +2206,188 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
         st_steps += sq_1 - sq_0;                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }
+    x6_plane Yp[NT][2][NPL];
+    if constexpr (SEQ) {
+        // ================= the sequence-resident front (round 5): this layer's q | k | v from x, head by head, K / V of the head
+        // into the workgroup's LDS images, the attention of this wave's own 32 queries, its output to the scratch tiles the
+        // out-projection below reads back.  The three steps of a head run back to back with their result tiles in registers; the
+        // LDS traffic the compiler can see (image writes, the attention's reads) sits in ONE region per head, behind the v step,
+        // and that step leaves its ring refill to the end of the region: a compiler-visible LDS access behind an LDS-DMA issue
+        // gets a vmcnt(0) in front, i.e. it would drain the ring at every step.
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                x6_split(acc[tn], s2, Yp[tn][s2]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        float *Kimg = reinterpret_cast<float *>(smem + X6_SEQ_KIMG);
+        char *Vimg = smem + X6_SEQ_VIMG;
+        float *scr = reinterpret_cast<float *>(smem + X6_SEQ_SCR + wave * X6_SEQ_SCR_B);
+        const int irow = s_row0 + s_j; // this lane's row of the images (rows [L, 32 T) of a sequence hold finite values of dead tokens)
+        const bool irn_ = a.mask_mode == IRS_MASK_IRN;
+        const float tgt_add_ = irn_ ? (1.0f - s_ru) * 1.4426950408889634f : 0.f;
+        float4 *ao4 = reinterpret_cast<float4 *>(const_cast<float *>(a.Af)) + (size_t)mtile * NT * 4 * 64;
+#pragma unroll
+        for (int h = 0; h < NT; ++h) {
+            f32x16 tq, tk, tv, bt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tq[r] = 0.f, tk[r] = 0.f, tv[r] = 0.f;
+            X6_STEP1(3 * h, Yp, tq)
+            X6_STEP1(3 * h + 1, Yp, tk)
+            X6_STEP1(3 * h + 2, Yp, tv) // (no ring refill behind this step: X6_PUBLISH)
+            bias_tile(bt, V_BQ + 32 * h);
+            if (s_b >= 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4 *>(scr + li * 36 + 8 * g + 4 * lk) =
+                        make_float4(__builtin_fmaf(tq[4 * g + 0], IWS, bt[4 * g + 0]), __builtin_fmaf(tq[4 * g + 1], IWS, bt[4 * g + 1]),
+                                    __builtin_fmaf(tq[4 * g + 2], IWS, bt[4 * g + 2]), __builtin_fmaf(tq[4 * g + 3], IWS, bt[4 * g + 3]));
+            }
+            bias_tile(bt, V_BQ + D + 32 * h);
+            if (s_b >= 0 && s_j < 16 * s_nb) { // (rows [cnt, 16 nb) hold finite values of dead tokens: read with p = 0)
+                const int sw = (s_j & 7) ^ ((s_j >> 3) & 1);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4 *>(Kimg + irow * 32 + (((2 * g + lk) ^ sw) << 2)) =
+                        make_float4(__builtin_fmaf(tk[4 * g + 0], IWS, bt[4 * g + 0]), __builtin_fmaf(tk[4 * g + 1], IWS, bt[4 * g + 1]),
+                                    __builtin_fmaf(tk[4 * g + 2], IWS, bt[4 * g + 2]), __builtin_fmaf(tk[4 * g + 3], IWS, bt[4 * g + 3]));
+            }
+            bias_tile(bt, V_BQ + 2 * D + 32 * h);
+            if (s_b >= 0 && s_j < 16 * s_nb) {
+                typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+                const int swv = ((s_j >> 2) & 1) << 1;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f16x4 hp, lp;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = __builtin_fmaf(tv[4 * g + e], IWS, bt[4 * g + e]);
+                        const _Float16 hv = (_Float16)v;
+                        hp[e] = hv;
+                        lp[e] = (_Float16)(v - (float)hv);
+                    }
+                    char *slot = Vimg + irow * 64 + ((g ^ swv) << 4) + 8 * lk;
+                    *reinterpret_cast<f16x4 *>(slot) = hp;
+                    *reinterpret_cast<f16x4 *>(slot + 16384) = lp;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // every wave's rows of head h are in the images
+            asm volatile("" ::: "memory");
+            if (s_b >= 0 && !(SEQ_EXP & 1)) {
+                const float *Ks_ = Kimg + s_row0 * 32;
+                const char *Vp_ = Vimg + s_row0 * 64;
+#pragma unroll 1
+                for (int blk = 0; blk < 2; ++blk) // (a dead half: block index beyond the sequence -> zeros)
+                    seq_attn_block(Ks_, Vp_, 16384, s_cnt, blk == 0 ? s_ti : (s_qb1 > s_ti ? s_qb1 : 16), irn_, tgt_add_, s_tgt, s_pq,
+                                   scr + 16 * blk * 36, ao4 + (size_t)h * 4 * 64 + 16 * blk, true);
+            }
+            asm volatile("" ::: "memory");
+            // (the next head's image writes come three steps -- three workgroup barriers -- later: every wave is past its reads)
+            if (3 * h + 2 + LEAD < nsteps) issue(3 * h + 2 + LEAD); // the refill the v step left out
+        }
+        // ---- the layer body's inputs: the attention tiles this wave wrote and the residual, as loads the compiler does not see (it
+        // would hoist and spread them over the front: registers) with ONE wait; the out-projection accumulates from zero and the
+        // residual is added with b_o in front of LayerNorm 1, as in the RESID_LATE form.
+        // (the same WAVE wrote the tiles it reads back: workgroup scope -- its stores are complete and its L1 holds no older copy.
+        //  An agent-scope fence here is a write-back of the XCD's whole L2 on this chip: the first version spent most of its time in it)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        {
+            const float4 *afrag = reinterpret_cast<const float4 *>(a.Af) + fbase;
+            x6_static_for<0, NT>([&](auto tc) __attribute__((always_inline)) {
+                constexpr int tn = decltype(tc)::value;
+                const float4 *tp = afrag + tn * 4 * 64;
+                atq[tn][0] = x6_gld<0>(tp), atq[tn][1] = x6_gld<1024>(tp), atq[tn][2] = x6_gld<2048>(tp), atq[tn][3] = x6_gld<3072>(tp);
+            });
+            load_res();
+            static_assert(NT == 4, "sixteen operands per statement");
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(atq[0][0]), "+v"(atq[0][1]), "+v"(atq[0][2]), "+v"(atq[0][3]), "+v"(atq[1][0]), "+v"(atq[1][1]), "+v"(atq[1][2]),
+                           "+v"(atq[1][3]), "+v"(atq[2][0]), "+v"(atq[2][1]), "+v"(atq[2][2]), "+v"(atq[2][3]), "+v"(atq[3][0]), "+v"(atq[3][1]),
+                           "+v"(atq[3][2]), "+v"(atq[3][3]));
+            asm volatile("" : "+v"(resq[0][0]), "+v"(resq[0][1]), "+v"(resq[0][2]), "+v"(resq[0][3]), "+v"(resq[1][0]), "+v"(resq[1][1]),
+                              "+v"(resq[1][2]), "+v"(resq[1][3]), "+v"(resq[2][0]), "+v"(resq[2][1]), "+v"(resq[2][2]), "+v"(resq[2][3]),
+                              "+v"(resq[3][0]), "+v"(resq[3][1]), "+v"(resq[3][2]), "+v"(resq[3][3]));
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 u4 = __builtin_bit_cast(float4, atq[tn][g]);
+                    at[tn][4 * g + 0] = u4.x, at[tn][4 * g + 1] = u4.y, at[tn][4 * g + 2] = u4.z, at[tn][4 * g + 3] = u4.w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[tn][4 * g + e] = 0.f;
+                }
+        }
+    }
+    // ---- out-projection: acc += W_o . ao^T, k tile t, output half oh: step t HT + oh
+    if constexpr (!EMBED) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            // (RESID_LATE: an attention tile "appears" here -- without the statement the compiler splits all four tiles into
+            //  planes right behind their loads, i.e. waits for every input tile and DMA piece before the start barrier)
+            if constexpr (RESID_LATE) {
+                // vector memory operations behind tile t's loads when its step starts: the later tiles, the DMA groups issued
+                // at mid-step (one per finished step: steps 3 ..), the residual's 16 loads (behind step 1's barrier)
+                const int newer_ = 4 * (NT - 1 - t) + PPW * t + (t >= 2 ? NLOAD : 0);
+                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(atq[t][0]), "+v"(atq[t][1]), "+v"(atq[t][2]), "+v"(atq[t][3]) : "n"(newer_));
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 t4 = __builtin_bit_cast(float4, atq[t][g]);
+                    at[t][4 * g + 0] = t4.x, at[t][4 * g + 1] = t4.y, at[t][4 * g + 2] = t4.z, at[t][4 * g + 3] = t4.w;
+                }
+            }
+            X6_STEP(NFRONT + t * HT, at[t], acc[0], acc[1], acc[2], acc[3])
+            if constexpr (HT == 2) { X6_STEP(t * HT + 1, at[t], acc[4], acc[5], acc[6], acc[7]) }
+        }
+    }
+    // (NT = 8: the LayerNorm phases run at full register pressure and the compiler parks the fragments read ahead for the next
+    //  step in AGPRs across them -- copies taken before the data has landed unless the reads are waited for first)
+    if constexpr (NT == 8) landed_all();
+    X6_T(st_p[1])
+    if constexpr (!EMBED) {
+        using x6_icn = std::integral_constant<int, -1>;
+        if constexpr (RESID_LATE) { // the residual has landed once only the two DMA groups issued since are in flight
+            static_assert(NT == 4, "sixteen operands");
+            asm volatile("s_waitcnt vmcnt(%16)"
+                         : "+v"(resq[0][0]), "+v"(resq[0][1]), "+v"(resq[0][2]), "+v"(resq[0][3]), "+v"(resq[1][0]), "+v"(resq[1][1]),
+                           "+v"(resq[1][2]), "+v"(resq[1][3]), "+v"(resq[2][0]), "+v"(resq[2][1]), "+v"(resq[2][2]), "+v"(resq[2][3]),
+                           "+v"(resq[3][0]), "+v"(resq[3][1]), "+v"(resq[3][2]), "+v"(resq[3][3])
+                         : "n"(2 * PPW));
+        }
+        layer_norm(std::integral_constant<int, V_O + 0 * D>{}, std::integral_constant<int, V_O + 1 * D>{},
+                   std::integral_constant<int, V_O + 2 * D>{}, std::integral_constant<int, V_O + 3 * D>{});
+        if (a.c) layer_norm(x6_icn{}, std::integral_constant<int, V_O + 4 * D>{}, std::integral_constant<int, V_O + 5 * D>{}, x6_icn{});
+    }
+    X6_T(st_p[2])
+
+    // ---- feed-forward, one hidden tile (32 units) at a time: FFN-1 step h_ft = W1[32 ft ..] y^T over the whole K = 128
+    //      (B operand: y's bf16 planes, split ONCE and kept -- 96 registers -- while acc itself goes on as the residual
+    //      accumulator), bias + relu on the 16 values, FFN-2 step acc += W2[:, 32 ft ..] h_ft^T.  (The round-2 order --
+    //      all eight hidden tiles, then FFN-2 -- keeps 128 registers of h beside the 64 of y: with the split's
+    //      temporaries that is ~265 of the 256 registers two waves per SIMD have: 173 spilled.)
+    if constexpr (!EMBED) {
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                x6_split(acc[tn], s2, Yp[tn][s2]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        if constexpr (NPL == 2) { // FFN-2 accumulates WS x its product onto y in place: y goes on as WS y (exact)
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tn][r] *= WS;
+        }
+    }
     if constexpr (!EMBED) {
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft) {
             f32x16 hft, bt;
 #pragma unroll
             for (int r = 0; r < 16; ++r) hft[r] = 0.f;
-            X6_STEP1(NOUT + 2 * HT * ft, Yp, hft)
+            X6_STEP1(NFRONT + NOUT + 2 * HT * ft, Yp, hft)
             // (k tiles 4 .. 7 go onto the same accumulator.  A zero-started second accumulator + one rounded addition --
             //  the first half's full-size sum then sees no further truncating additions -- was measured: the rows' mean
             //  distance to the float32 kernels 1.33e-6 vs 1.39e-6, but 16 more live registers tip the LayerNorm phases
@@ -2035,7 +2396,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             bias_tile(bt, V_B1 + ft * 32);
 #pragma unroll
             for (int r = 0; r < 16; ++r) hft[r] = fmaxf(__builtin_fmaf(hft[r], IWS, bt[r]), 0.f);
-            X6_STEP(NOUT + 2 * HT * ft + HT, hft, acc[0], acc[1], acc[2], acc[3])
+            X6_STEP(NFRONT + NOUT + 2 * HT * ft + HT, hft, acc[0], acc[1], acc[2], acc[3])
             if constexpr (HT == 2) { X6_STEP(NOUT + 4 * ft + 3, hft, acc[4], acc[5], acc[6], acc[7]) }
         }
     }
@@ -2118,7 +2479,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             f32x16 qt, bt;
 #pragma unroll
             for (int r = 0; r < 16; ++r) qt[r] = 0.f;
-            X6_STEP1(NPRE + HT * (NT * pp + i), Yp, qt)
+            X6_STEP1(NFRONT + NPRE + HT * (NT * pp + i), Yp, qt)
             if constexpr (HT == 2) { X6_STEP1(NPRE + 2 * (NT * pp + i) + 1, (&Yp[4]), qt) }
             bias_tile(bt, V_BIN + c0 + i * 32); // (its wait lands every fragment register too: control flow ahead)
             X6_T(st_q0)
@@ -4563,6 +4924,202 @@ __global__ void __launch_bounds__(64 * NW, 3) k_attn16h(const float *__restrict_
     }
 }
 
+// ------------------------------------------------------------------ one query block of the sequence-resident kernel (round 5)
+// k_attn16h's block body (FAST form: a packed sequence, at most one pad below the diagonal; float32 score chain, two-pass softmax
+// with every score tile of the block in registers, O^T += V^T P^T on float16 plane pairs through the transposing LDS read) on
+// images the layer kernel's own waves wrote: Ks = float32 [key][32] chunk-swizzled, Vp = [2 planes][PL bytes] of [key][64 B], both
+// based at the sequence's first row.  The query rows come from the wave's q scratch ([16 rows][36] float32), the normalised
+// output goes to the fragment-major scratch tile (`of` = the tile's float4 base + 16 blk: lane (lq, gq) writes token column lq);
+// query rows beyond the sequence store zeros (the layer body multiplies whole tiles: they must stay finite).
+__device__ __forceinline__ void seq_attn_block(const float *Ks, const char *Vp, int PL, int L, int qb, bool irn, float tgt_add, bool tgt_ok,
+                                               int pq, const float *qscr, float4 *of, bool store) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    constexpr int HD = 32, MAXT = 16;
+    const int lane = threadIdx.x & 63, lq = lane & 15, gq = lane >> 4;
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    float4 *dst = of + (gq & 1) * 32 + lq;
+    if (16 * qb >= L) { // the whole block lies beyond the sequence
+        if (store) {
+            dst[(gq >> 1) * 64] = make_float4(0.f, 0.f, 0.f, 0.f);
+            dst[(2 + (gq >> 1)) * 64] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+    const float LOG2E = 1.4426950408889634f;
+    const float scale = LOG2E / sqrtf((float)HD);
+    const int qi = qb * 16 + lq;
+    float qf[8];
+    {
+        const float4 t0 = *reinterpret_cast<const float4 *>(qscr + lq * 36 + 8 * gq), t1 = *reinterpret_cast<const float4 *>(qscr + lq * 36 + 8 * gq + 4);
+        const float sc = qi < L ? scale : 0.f;
+        qf[0] = t0.x * sc, qf[1] = t0.y * sc, qf[2] = t0.z * sc, qf[3] = t0.w * sc;
+        qf[4] = t1.x * sc, qf[5] = t1.y * sc, qf[6] = t1.z * sc, qf[7] = t1.w * sc;
+    }
+    f32x4 sacc[MAXT];
+    float mx = -INFINITY;
+    auto score_tile = [&](int kt, f32x4 &sa) __attribute__((always_inline)) {
+        const int key = kt * 16 + lq;
+        const float *kr = Ks + key * HD;
+        const int sw = (key & 7) ^ ((key >> 3) & 1);
+        const float4 k0 = *reinterpret_cast<const float4 *>(kr + (((2 * gq) ^ sw) << 2));
+        const float4 k1 = *reinterpret_cast<const float4 *>(kr + (((2 * gq + 1) ^ sw) << 2));
+        sa = {0.f, 0.f, 0.f, 0.f};
+        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.x, qf[0], sa, 0, 0, 0);
+        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.y, qf[1], sa, 0, 0, 0);
+        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.z, qf[2], sa, 0, 0, 0);
+        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.w, qf[3], sa, 0, 0, 0);
+        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.x, qf[4], sa, 0, 0, 0);
+        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.y, qf[5], sa, 0, 0, 0);
+        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.z, qf[6], sa, 0, 0, 0);
+        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.w, qf[7], sa, 0, 0, 0);
+    };
+    // masked keys of the diagonal tile: beyond the sequence, the IRN target column (added separately), the one pad
+    unsigned int pm_diag = 0;
+    {
+        const int k0_ = 16 * qb;
+        if (L - k0_ < 16) pm_diag = (0xFFFFu << (L - k0_)) & 0xFFFFu;
+        if (irn && L - 1 >= k0_ && L - 1 < k0_ + 16) pm_diag |= 1u << (L - 1 - k0_);
+        if (pq >= k0_ && pq < k0_ + 16) pm_diag |= 1u << (pq - k0_);
+    }
+    auto mask_diag = [&](int kt, f32x4 &sa) __attribute__((always_inline)) {
+        const unsigned int pmk = pm_diag >> (4 * gq);
+        const int qlim = lq - 4 * gq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = !((pmk >> r) & 1u) && (r <= qlim);
+            const float v = ok ? sa[r] : -INFINITY;
+            sa[r] = v;
+            mx = fmaxf(mx, v);
+        }
+    };
+    const int pq_pair = pq >= 0 ? pq >> 5 : -1;
+    auto pad_fix = [&](int kt, f32x4 &sa) __attribute__((always_inline)) {
+        if ((pq >> 4) == kt) {
+            const bool mine_ = ((pq >> 2) & 3) == gq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sa[r] = (mine_ && (pq & 3) == r) ? -INFINITY : sa[r];
+        }
+    };
+#pragma unroll
+    for (int kg = 0; kg < MAXT / 4; ++kg) {
+        if (4 * kg <= qb) {
+#pragma unroll
+            for (int kp = 2 * kg; kp < 2 * kg + 2; ++kp) {
+                const int k0t = 2 * kp, k1t = 2 * kp + 1;
+                if (k1t <= qb) {
+                    score_tile(k0t, sacc[k0t]);
+                    score_tile(k1t, sacc[k1t]);
+                    if (kp == pq_pair) {
+                        pad_fix(k0t, sacc[k0t]);
+                        if (k1t < qb) pad_fix(k1t, sacc[k1t]);
+                    }
+                    mx = fmaxf(fmaxf(mx, sacc[k0t][0]), fmaxf(sacc[k0t][1], fmaxf(sacc[k0t][2], sacc[k0t][3])));
+                    if (k1t < qb) mx = fmaxf(fmaxf(mx, sacc[k1t][0]), fmaxf(sacc[k1t][1], fmaxf(sacc[k1t][2], sacc[k1t][3])));
+                    else mask_diag(k1t, sacc[k1t]);
+                } else if (k0t == qb) {
+                    score_tile(k0t, sacc[k0t]);
+                    mask_diag(k0t, sacc[k0t]);
+                }
+            }
+        }
+    }
+    // ---- the IRN target column (key L - 1, +1.0 where every other visible key carries +r_u, visible to every query)
+    float st = -INFINITY;
+    float vt[8];
+    if (tgt_ok) {
+        const int jt = L - 1;
+        const float *kr = Ks + jt * HD;
+        const int sw = (jt & 7) ^ ((jt >> 3) & 1);
+        const float4 k0 = *reinterpret_cast<const float4 *>(kr + (((2 * gq) ^ sw) << 2));
+        const float4 k1 = *reinterpret_cast<const float4 *>(kr + (((2 * gq + 1) ^ sw) << 2));
+        float part = qf[0] * k0.x;
+        part = __fmaf_rn(qf[1], k0.y, part);
+        part = __fmaf_rn(qf[2], k0.z, part);
+        part = __fmaf_rn(qf[3], k0.w, part);
+        part = __fmaf_rn(qf[4], k1.x, part);
+        part = __fmaf_rn(qf[5], k1.y, part);
+        part = __fmaf_rn(qf[6], k1.z, part);
+        part = __fmaf_rn(qf[7], k1.w, part);
+        st = quad16_sum(part) + tgt_add;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+            const char *vr = Vp + jt * 64 + ((((2 * ct + (gq >> 1)) ^ (((jt >> 2) & 1) << 1))) << 4) + 8 * (gq & 1);
+            const f16x4 b0 = *reinterpret_cast<const f16x4 *>(vr), b1 = *reinterpret_cast<const f16x4 *>(vr + PL);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vt[4 * ct + r] = (float)b0[r] + (float)b1[r];
+        }
+    }
+    mx = quad16_max(mx);
+    float m = fmaxf(mx, st);
+    if (m == -INFINITY) m = 0.f;
+    float l = 0.f;
+    f32x4 o[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[i][ct][r] = 0.f;
+    float ot[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ot[e] = 0.f;
+    if (tgt_ok) {
+        const float pt = __builtin_amdgcn_exp2f(st - m);
+        l = (gq == 0) ? pt : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ot[e] = pt * vt[e];
+    }
+#pragma unroll
+    for (int kp = 0; kp < MAXT / 2; ++kp) {
+        const int k0t = 2 * kp, k1t = 2 * kp + 1;
+        const bool on0 = k0t <= qb, on1 = k1t <= qb;
+        if (on0 || on1) { // wave-uniform
+            float pa[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pa[r] = on0 ? __builtin_amdgcn_exp2f(sacc[k0t][r] - m) : 0.f;
+                pa[4 + r] = on1 ? __builtin_amdgcn_exp2f(sacc[k1t][r] - m) : 0.f;
+                l += pa[r] + pa[4 + r];
+            }
+            x6_f16x8 P[2];
+            attn_split8h(pa, P);
+            const int r0 = k0t * 16 + 4 * gq + tq, r1 = r0 + 16;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int o0 = r0 * 64 + ((((2 * ct + (tp >> 1)) ^ (((r0 >> 2) & 1) << 1))) << 4) + 8 * (tp & 1);
+                const int o1 = r1 * 64 + ((((2 * ct + (tp >> 1)) ^ (((r1 >> 2) & 1) << 1))) << 4) + 8 * (tp & 1);
+                x6_f16x8 V[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const attn_s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) attn_s16x4 *)(Vp + p * PL + o0));
+                    attn_s16x4 a1 = {0, 0, 0, 0};
+                    if (on1) a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) attn_s16x4 *)(Vp + p * PL + o1));
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    const s16x8 both = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    V[p] = __builtin_bit_cast(x6_f16x8, both);
+                }
+                f32x4 oo = o[kp & 1][ct];
+                oo = __builtin_amdgcn_mfma_f32_16x16x32_f16(V[0], P[1], oo, 0, 0, 0);
+                oo = __builtin_amdgcn_mfma_f32_16x16x32_f16(V[1], P[0], oo, 0, 0, 0);
+                oo = __builtin_amdgcn_mfma_f32_16x16x32_f16(V[0], P[0], oo, 0, 0, 0);
+                o[kp & 1][ct] = oo;
+            }
+        }
+    }
+    const float lt = quad16_sum(l);
+    const float inv = qi < L ? 1.0f / lt : 0.f;
+    if (store) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            float4 v = make_float4(((o[0][ct][0] + o[1][ct][0]) + ot[4 * ct + 0]) * inv, ((o[0][ct][1] + o[1][ct][1]) + ot[4 * ct + 1]) * inv,
+                                   ((o[0][ct][2] + o[1][ct][2]) + ot[4 * ct + 2]) * inv, ((o[0][ct][3] + o[1][ct][3]) + ot[4 * ct + 3]) * inv);
+            if (qi >= L) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            dst[(2 * ct + (gq >> 1)) * 64] = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ single-query attention (last layer, rows-only decode)
 // Only row pos[b] of the last layer is consumed by the scoring step (the reference computes all L
 // rows and uses output[index][history_end_pos], influentialRS.py:374,421).  One wave per (sequence,
@@ -5092,6 +5649,14 @@ static void x6_launch_one(int rows, const BlockX6Args &xa, hipStream_t s) {
     IRS_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(kern, dim3((rows + 32 * NW - 1) / (32 * NW)), dim3(64 * NW), lds, s, xa);
 }
+// the sequence-resident form: grid = an upper bound of the plan's workgroups (the kernel reads the count), eight waves, 160 KB of LDS
+template <int QP0>
+static void x6_launch_seq(int wg_cap, const BlockX6Args &xa, hipStream_t s) {
+    auto kern = k_block_x6<QP0, 8, false, 4, 2, true>;
+    constexpr int lds = x6_seq_lds_bytes();
+    IRS_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3(wg_cap), dim3(512), lds, s, xa);
+}
 static void x6_launch(int qp0, bool embed, int nt, int npl, int rows, const BlockX6Args &xa, hipStream_t s) {
 #define X6_L(Q_, E_) do {                                                                                                 \
         if (nt == 8 && npl == 2) x6_launch_one<Q_, 4, E_, 8, 2>(rows, xa, s);                                             \
@@ -5210,6 +5775,11 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                            ctx->dims.n_layers > 1;
     auto qkv_in = [&](int l) { return (!att_fused || ((ctx->dims.n_layers - 1 - l) & 1) == 0) ? ctx->act_qkv : ctx->act_qkv_b1; };
     float *xf = ctx->act_xf, *yf = ctx->act_yf;
+    // the sequence-resident layer kernel (round 5, opt-in: irs_set_decoder_seq / IRS_DECODER_SEQ=1): the throughput shape of
+    // config 2 / 3 on float16 planes; layers 0 .. n_layers - 2 are ONE launch each (q | k | v, attention and the layer body; K / V
+    // stay in LDS), the rows-only last layer runs as before on the k | v rows the last of them writes
+    const bool seq_mode = ctx->use_seq && kv_planes && d == 128 && ctx->dims.n_heads == 4 && L <= 256 && !small_plan && ctx->tile_seq &&
+                          ctx->use_x6 == IRS_GEMM_H3 && ctx->h3_ok;
     if (rows_only) {
         const bool plan_in_embed = small_plan && B == 1 && L <= 256 && ctx->dims.n_layers > 1 && (att_fused || any_cfg);
         if (plan_in_embed) {
@@ -5232,7 +5802,34 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         m_dev = ctx->m_dev;
     }
     bool qkv0_done = false;
-    if (frag && (d == 128 || x6d) && ctx->dims.n_layers > 1) { // embed + layer 0's QKV in one kernel
+    int l_begin = 0;
+    if (seq_mode) {
+        const int nl = ctx->dims.n_layers;
+        hipLaunchKernelGGL(k_plan_seq, dim3(1), dim3(1024), 0, s, ctx->seq_cnt, ctx->seq_off, ctx->seq_qrow, B, ctx->seq_order, ctx->seq_bin,
+                           ctx->tile_seq, ctx->tile_idx, ctx->seq_row0, ctx->qrow_tile, ctx->n_wg_dev, B * SEQ_WG_TILES);
+        hipLaunchKernelGGL(k_embed_seq, dim3(2 * B), dim3(256), 0, s, seq, ctx->item_emb, ctx->pe, xf, tok, ctx->tile_seq, ctx->tile_idx,
+                           ctx->seq_off, ctx->seq_cnt, ctx->n_wg_dev, L, d, sqrtf((float)d), ctx->dims.n_item);
+        for (int l = 0; l + 1 < nl; ++l) {
+            const irs_layer_w &w = ctx->layer[l];
+            const bool kv_tail = l + 2 == nl; // the rows-only last layer reads k | v rows (float32, packed row order)
+            BlockX6Args xa{yf, xf, x6_stream(ctx, 2, l), w.sa_out_b, w.n1_w, w.n1_b, ctx->c_l + (size_t)l * d, w.n2_w, w.n2_b,
+                           w.l1_b, w.l2_b, w.n3_w, w.n3_b, ctx->layer[l + 1].sa_in_b, xf, ctx->act_qkv, rows, m_dev, kv_tail ? 1 : 3};
+            xa.seq = seq, xa.L = L;
+            xa.Wq = x6_stream(ctx, 2, l == 0 ? nl - 1 : l - 1), xa.bq = w.sa_in_b;
+            xa.tile_seq = ctx->tile_seq, xa.tile_idx = ctx->tile_idx, xa.seq_off = ctx->seq_off, xa.seq_cnt = ctx->seq_cnt;
+            xa.seq_padq = ctx->seq_padq, xa.seq_row0 = ctx->seq_row0, xa.n_wg_dev = ctx->n_wg_dev, xa.r_u = ctx->act_ru;
+            xa.mask_mode = ctx->dims.mask_mode;
+            const double fl = rows * (8.0 * d * d + 4.0 * d * F);
+            irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
+            irs_prof_begin(ctx, IRS_PROF_LAYER, s);
+            if (kv_tail) x6_launch_seq<1>(B, xa, s);
+            else x6_launch_seq<3>(B, xa, s);
+            irs_prof_end(ctx, IRS_PROF_LINEAR, s, fl, 3.0 * 4.0 * rows * (double)d);
+            irs_prof_end(ctx, IRS_PROF_LAYER, s, fl, 3.0 * 4.0 * rows * (double)d);
+        }
+        qkv0_done = true;
+        l_begin = nl - 1;
+    } else if (frag && (d == 128 || x6d) && ctx->dims.n_layers > 1) { // embed + layer 0's QKV in one kernel
         EmbedQkvArgs ea{seq, ctx->item_emb, ctx->pe, tok, m_dev, rows, L, sqrtf((float)d), ctx->dims.n_item, xf,
                         ctx->layer[0].sa_in_w, ctx->layer[0].sa_in_b, ctx->act_qkv};
         irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
@@ -5298,8 +5895,9 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                            sqrtf((float)d), ctx->dims.n_item);
     IRS_CHECK_HIP(ctx, hipGetLastError());
     if (r_u_out) IRS_CHECK_HIP(ctx, hipMemcpyAsync(r_u_out, ctx->act_ru, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
-    bool qkv_done = qkv0_done, q_split = false;
-    for (int l = 0; l < ctx->dims.n_layers; ++l) {
+    bool qkv_done = qkv0_done, q_split = seq_mode; // (seq_mode: the last fused layer wrote k | v only)
+    const int32_t *qrow_f = seq_mode ? ctx->qrow_tile : qrow; // the consumed rows in the fragment-major image's own row order
+    for (int l = l_begin; l < ctx->dims.n_layers; ++l) {
         const irs_layer_w &w = ctx->layer[l];
         const bool last_rows = rows_only && (l + 1 == ctx->dims.n_layers);
         // qkv = x W_in^T + b_in (already produced by the previous layer's fused feed-forward kernel where that ran)
@@ -5316,7 +5914,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             float *h_r = ctx->act_h;                   // [B, F]
             const float *q_r = nullptr;
             if (q_split) { // the previous layer's kernel wrote k | v only: queries for the B consumed rows here
-                hipLaunchKernelGGL(k_gather_rows_frag, dim3(B), dim3(64), 0, s, xf, qrow, x_r, d, d > 128 ? d / 32 : 4);
+                hipLaunchKernelGGL(k_gather_rows_frag, dim3(B), dim3(64), 0, s, xf, qrow_f, x_r, d, d > 128 ? d / 32 : 4);
                 if ((rc = launch_linear(ctx, x_r, w.sa_in_w, w.sa_in_b, nullptr, h_r, B, d, d, false, s))) return rc;
                 q_r = h_r;
             }

@@ -18,7 +18,7 @@
                           defined(X6_NW) || defined(ATTN_STAMP) || defined(ATTNP_STAMP) ||               \
                           defined(IRS_SMALL_TIMING) || defined(IRS_DIRECT_TIMING) || defined(SWEEP_LAB) || defined(X6D_STAMP) ||              \
                           defined(X6_NO_QKV_STORE) || defined(X6_NSLOT2) || defined(X6_RESID_LATE) || defined(X6_RING4) ||      \
-                          defined(X6_SPLIT_ACC4))
+                          defined(X6_SPLIT_ACC4) || defined(SEQ_EXP))
 #error "a lab switch (X6_* / ATTN* / IRS_*_TIMING) is defined without IRS_LAB: the product library must be built without them"
 #endif
 
@@ -88,6 +88,7 @@ struct irs_ctx {
     int use_x6;       // decoder GEMMs of the throughput path on split-bf16 MFMAs (IRS_DECODER_GEMM=x6|f32)
     bool h3_ok;       // finalisation's float16 range bound holds (else IRS_GEMM_H3 runs as IRS_GEMM_X6 and V stays float32)
     float h3_bound;   // the largest operand magnitude the bound weights allow (irs_h3_operand_bound)
+    int use_seq;      // sequence-resident layer kernel for the d = 128 throughput shape (irs_set_decoder_seq / IRS_DECODER_SEQ=1; opt-in)
     int use_attn_h3;  // throughput attention on split-float16 MFMAs over K / V planes written by the layer kernel (default on; IRS_ATTN_GEMM=f32 off)
     int lse_no_ring;  // IRS_LSE_RING=0: the register-fragment log-sum-exp kernel at <= 32 rows too (A/B measurements, tests)
     bool finalized;
@@ -105,6 +106,11 @@ struct irs_ctx {
     int32_t *seq_cnt, *seq_off, *seq_qrow; // [max_seqs]
     int32_t *seq_padq; // [max_seqs] index within the packed sequence of the one pad token it may hold (pos), or -1
     int32_t *m_dev;    // [1] number of packed rows
+    // plan of the sequence-resident layer kernel (decoder.hip: k_plan_seq; null unless the shape supports it)
+    int32_t *tile_seq, *tile_idx;   // [8 max_seqs] grid tile -> sequence (-1: none), tile index inside it
+    int32_t *seq_row0, *qrow_tile;  // [max_seqs] first K / V image row in its workgroup; tile-order row of the consumed token
+    int32_t *seq_order, *seq_bin;   // [max_seqs], [2 max_seqs] scratch of the plan (sorted order; workgroup slot + stack links)
+    int32_t *n_wg_dev;              // [1] workgroups in use
     // scoring
     uint4 *xb;          // packed bf16 rows [m_pad/32][KS][64] x 16 B
     float *eps;         // [m_pad]

@@ -458,6 +458,25 @@ class Engine:
     def decoder_gemm(self, mode: int):
         self._check(self.lib.irs_set_decoder_gemm(self.h, int(mode)))
 
+    def debug_buffer(self, which: int, numel: int, dtype: torch.dtype) -> torch.Tensor:
+        """(tests / lab) a view of one of the decoder's workspace buffers (irs_debug_ptr): what the last decode left behind."""
+        p = self.lib.irs_debug_ptr(self.h, int(which))
+        if not p:
+            raise IrsError(f"irs_debug_ptr({which}) is null")
+        off = int(p) - self._ws.data_ptr()
+        nbytes = numel * torch.empty((), dtype=dtype).element_size()
+        assert 0 <= off and off + nbytes <= self._ws.numel()
+        return self._ws[off:off + nbytes].view(dtype)
+
+    @property
+    def decoder_seq(self) -> bool:
+        """Sequence-resident decoder layers (irs_set_decoder_seq, include/irs_hip.h): off by default."""
+        return bool(self.lib.irs_get_decoder_seq(self.h))
+
+    @decoder_seq.setter
+    def decoder_seq(self, on: bool):
+        self._check(self.lib.irs_set_decoder_seq(self.h, int(bool(on))))
+
     @property
     def h3_range_bound(self) -> float:
         """Largest operand magnitude the bound weights allow in the float16-plane kernels (irs_h3_range_bound; -1 before the

@@ -53,7 +53,7 @@ def test_counted_vmcnt_waits_see_the_operations_they_count(decoder_isa):
     front of each barrier, 4 DMA pieces behind it, the 16 residual loads behind the second step's barrier; vmcnt(8) in front
     of LayerNorm 1; then one publish wait (4) and 4 pieces per step."""
     for qp0 in (0, 1):
-        body = _kernel(decoder_isa, f"_Z10k_block_x6ILi{qp0}ELi4ELb0ELi4ELi2EEv11BlockX6Args")
+        body = _kernel(decoder_isa, f"_Z10k_block_x6ILi{qp0}ELi4ELb0ELi4ELi2ELb0EEv11BlockX6Args")
         seq = []
         for l in body:
             t = l.strip()
