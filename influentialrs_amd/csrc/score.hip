@@ -1728,9 +1728,11 @@ __device__ __forceinline__ uint4 pack8_bf16(const float *__restrict__ src, int k
 __global__ void __launch_bounds__(256) k_prep_x(const float *__restrict__ x, int M, int M_pad, int d, int KS,
                                                 uint4 *__restrict__ xb, float *__restrict__ eps,
                                                 const float *__restrict__ wn, float acc_factor,
-                                                unsigned int *__restrict__ cand_cnt, int32_t *__restrict__ status) {
+                                                unsigned int *__restrict__ cand_cnt, int32_t *__restrict__ status,
+                                                unsigned int *__restrict__ fb_count) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
+    if (fb_count && blockIdx.x == 0 && threadIdx.x == 0) *fb_count = 0u; // (the cooperative fallback's row counter: a memset launch less)
     if (row >= M_pad) return;
     // also resets this row's candidate bucket counters and status word (two memset launches less per call)
     cand_cnt[(size_t)row * IRS_CAND_BUCKETS + lane] = 0u; // IRS_CAND_BUCKETS == 64 == wave size
@@ -2934,11 +2936,13 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
     const int nt = ctx->n_tiles;
     int rc;
     static_assert(IRS_CAND_BUCKETS == 64, "k_prep_x resets one bucket counter per lane");
+    // big shards: rows that need the exhaustive path are recorded by k_refine and redone cooperatively (see k_exh_strips)
+    const bool coop_fb = ctx->n_local >= IRS_COOP_FALLBACK_MIN_ITEMS && ctx->exh_keys != nullptr;
     if (sweep == IRS_SWEEP_BF16) {
         // |approx - exact| <= eps[row] for every item of the shard: see k_prep_x
         const float acc_factor = (float)(ctx->d_pad + 8) * 2.384185791015625e-07f; // (d_pad + 8) 2^-22
         hipLaunchKernelGGL(k_prep_x, dim3((M_pad + 3) / 4), dim3(256), 0, s, xrows, M, M_pad, d, ctx->KS,
-                           ctx->xb, ctx->eps, ctx->wnorm_max, acc_factor, ctx->cand_cnt, status);
+                           ctx->xb, ctx->eps, ctx->wnorm_max, acc_factor, ctx->cand_cnt, status, coop_fb ? ctx->fb_count : nullptr);
     } else {
         IRS_CHECK_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t) * M, s));
         IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->cand_cnt, 0, sizeof(unsigned int) * (size_t)M_pad * IRS_CAND_BUCKETS, s));
@@ -3021,8 +3025,8 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
     irs_prof_begin(ctx, IRS_PROF_REFINE, s);
     // big shards: rows that need the exhaustive path are recorded by k_refine and redone cooperatively (see k_exh_strips);
     // on small shards one workgroup walks the shard faster than two more launches cost
-    const bool coop = ctx->n_local >= IRS_COOP_FALLBACK_MIN_ITEMS && ctx->exh_keys != nullptr;
-    if (coop) IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->fb_count, 0, sizeof(unsigned int), s));
+    const bool coop = coop_fb;
+    if (coop && sweep != IRS_SWEEP_BF16) IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->fb_count, 0, sizeof(unsigned int), s)); // (bf16: k_prep_x reset it)
     hipLaunchKernelGGL(k_refine, dim3(M), dim3(256), 0, s, xrows, d, ctx->proj_w, ctx->proj_b, ctx->cand_cnt, ctx->cand,
                        ctx->eps, ctx->ref_tmp, k, ctx->shard.item_lo, ctx->n_local, val, ids0, status,
                        coop ? ctx->fb_count : nullptr, ctx->fb_list);
