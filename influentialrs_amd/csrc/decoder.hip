@@ -5778,7 +5778,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     // the sequence-resident layer kernel (round 5, opt-in: irs_set_decoder_seq / IRS_DECODER_SEQ=1): the throughput shape of
     // config 2 / 3 on float16 planes; layers 0 .. n_layers - 2 are ONE launch each (q | k | v, attention and the layer body; K / V
     // stay in LDS), the rows-only last layer runs as before on the k | v rows the last of them writes
-    const bool seq_mode = ctx->use_seq && kv_planes && d == 128 && ctx->dims.n_heads == 4 && L <= 256 && !small_plan && ctx->tile_seq &&
+    const bool seq_mode = ctx->use_seq && rows_only && kv_planes && d == 128 && ctx->dims.n_heads == 4 && L <= 256 && !small_plan && ctx->tile_seq &&
                           ctx->use_x6 == IRS_GEMM_H3 && ctx->h3_ok;
     if (rows_only) {
         const bool plan_in_embed = small_plan && B == 1 && L <= 256 && ctx->dims.n_layers > 1 && (att_fused || any_cfg);
