@@ -933,6 +933,8 @@ def main():
                                  "x6: float32 operands split exactly into three bf16 planes, six plane products per float32 product on "
                                  "v_mfma_f32_32x32x16_bf16") + ", float32 accumulation (fused layer kernel and embed + layer-0 q|k|v); attention "
                                 "and the last layer's rows on float32 MFMAs" if x6 else "float32 MFMAs"),
+               "decoder_layers": ("sequence-resident (irs_set_decoder_seq / IRS_DECODER_SEQ=1): one launch per layer on whole sequences, K / V in LDS"
+                                  if job.eng.decoder_seq else "layer kernel + packed-sequence attention kernel per layer (default)"),
                "parallelism": "single GPU" if world == 1 else (
                    f"rows data-parallel + item-sharded x{world}: RCCL all-gather of rows, one all_to_all of packed 64-bit top-100 keys "
                    f"(irs_generate_paths_sharded: collectives below the C ABI, "

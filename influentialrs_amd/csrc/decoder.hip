@@ -1500,8 +1500,14 @@ struct BlockX6Args {
     // this layer's q | k | v from x itself, keeps K / V of one head at a time in LDS, runs the attention of its own queries and
     // goes on with the layer body: no q | k | v row ever reaches HBM.  Rf = x (fragment-major, TILE order), Af = scratch for the
     // attention output in the same order (written and read back by the same wave), Xf = x'.
-    const uint4 *Wq;       // the stream whose q | k | v region holds THIS layer's in-projection (the previous layer's stream)
-    const float *bq;       // this layer's in-projection bias [3 d]
+    // ALL of layers 0 .. n_lay - 1 in ONE launch (stage B): x stays in the wave's registers from layer to layer, the weight ring
+    // runs through the layer boundaries (one empty step per layer keeps the slot numbering: 33 = 0 mod 3 steps), the parameter
+    // vectors of the next layer are re-staged into LDS at the boundary from a packed copy.  The last of them also writes the
+    // k | v rows the rows-only last layer reads.
+    const uint4 *Wbase;    // float16-plane stream of layer 0; layer l's stream = Wbase + l * wstride (x6_stream)
+    long long wstride;     // in uint4
+    int n_lay, nl_total;   // layers run here (n_layers - 1); streams in the arena (layer l's q | k | v sits in stream l - 1, layer 0's in stream nl_total - 1)
+    const float *vecpack;  // [n_lay][X6_SEQ_VECS]: every parameter vector of a layer in the kernel's LDS order (k_pack_seqvec)
     const int32_t *tile_seq, *tile_idx, *seq_off, *seq_cnt, *seq_padq, *seq_row0, *n_wg_dev;
     const float *r_u;
     int mask_mode;
@@ -1614,7 +1620,7 @@ __host__ __device__ constexpr int x6_seq_lds_bytes() { return X6_SEQ_SCR + 8 * X
 // wave per SIMD (512 registers per lane), one workgroup per CU; the step stream has 96 steps (x6_nstep).
 template <int QP0, int NW, bool EMBED, int NT = 4, int NPL = 3, bool SEQ = false>
 __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block_x6(BlockX6Args a) {
-    static_assert(!SEQ || (NT == 4 && NPL == 2 && NW == 8 && !EMBED && (QP0 == 1 || QP0 == 3)), "the sequence-resident form: d = 128, float16 planes, eight waves");
+    static_assert(!SEQ || (NT == 4 && NPL == 2 && NW == 8 && !EMBED && QP0 == 1), "the sequence-resident form: d = 128, float16 planes, eight waves, k | v tail behind the last layer");
     constexpr int NP = 8 * NPL, STEP_B = x6_step_b(NPL); // pieces (fragments) and bytes of a step
     using x6_plane = typename std::conditional<NPL == 2, x6_f16x8, x6_bf16x8>::type;
     // (SEQ: three ring slots -- the K / V images and the q scratch take the rest of the CU's LDS)
@@ -1700,15 +1706,17 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
         }
     } else if constexpr (NT == 4) {
         if constexpr (SEQ) {
-            if (tid < 3 * D) vecs[V_BQ + tid] = a.bq[tid];
+#pragma unroll
+            for (int k = 0; k < (X6_SEQ_VECS + 64 * NW - 1) / (64 * NW); ++k)
+                if (tid + 64 * NW * k < X6_SEQ_VECS) vecs[tid + 64 * NW * k] = a.vecpack[tid + 64 * NW * k];
         }
-        if (tid < 256) {
+        if (!SEQ && tid < 256) {
             if (!EMBED) vecs[V_B1 + tid] = a.b1[tid];
             vecs[V_BIN + tid] = a.bin[tid];
         }
         if (EMBED) {
             if (tid < D) vecs[V_BIN + 256 + tid] = a.bin[256 + tid];
-        } else if (tid < D) {
+        } else if (!SEQ && tid < D) {
             vecs[V_B2 + tid] = a.b2[tid];
             vecs[V_G + tid] = a.g[tid];
             vecs[V_B + tid] = a.b[tid];
@@ -1741,7 +1749,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     if (blockIdx.x >= 256 && blockIdx.x < 512)
         for (int i = 0; i < X6_STAGGER; ++i) __builtin_amdgcn_s_sleep(127); // (lab) second resident workgroup of a CU starts ~4 us x N late
 #endif
-    const int mtile = SEQ ? (int)blockIdx.x * NW + wave : (m0 >> 5) + wave;
+    int mtile = SEQ ? (int)blockIdx.x * NW + wave : (m0 >> 5) + wave; // (not const: SEQ launders it per layer, see layer_body)
     // (SEQ) this lane's token of its sequence.  A wave's tile is TWO 16-token blocks of the sequence, block s_ti in lanes 0-15 and
     // its mirror image s_nb - 1 - s_ti in lanes 16-31 (causal attention: block qb costs qb + 1 key tiles, so every wave of a
     // sequence gets s_nb + 1 of them; consecutive blocks per wave left the last waves with 1.8 x the mean).  An odd middle
@@ -1749,12 +1757,22 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     const int s_nb = (s_cnt + 15) >> 4, s_qb1 = s_nb - 1 - s_ti;
     const int s_j = li < 16 ? 16 * s_ti + li : (s_qb1 > s_ti ? 16 * s_qb1 + (li - 16) : 0x3FFFFFFF);
     const int mt = SEQ ? ((s_b >= 0 && s_j < s_cnt) ? s_off + s_j : 0x7FFFFFFF) : m0 + wave * 32 + li; // packed row (SEQ: dead lanes never store)
-    const size_t fbase = (size_t)mtile * (4 * NT) * 64 + lane;
+    size_t fbase = (size_t)mtile * (4 * NT) * 64 + lane;
     const unsigned int lds0 = (unsigned int)(size_t)(__attribute__((address_space(3))) char *)smem;
-    const unsigned int fr_addr = lds0 + lane * 16; // + slot * X6_STEP_B + piece * 1024
-    const unsigned int vecs_addr = lds0 + NSLOT * STEP_B + 16 * lk; // this lane's float4 of a 32-value tile's group g: + 32 g bytes
+    unsigned int fr_addr = lds0 + lane * 16; // + slot * X6_STEP_B + piece * 1024
+    unsigned int vecs_addr = lds0 + NSLOT * STEP_B + 16 * lk; // this lane's float4 of a 32-value tile's group g: + 32 g bytes
     constexpr int qoff = NOUT * QP0;                // the q tiles' steps (NT tiles x HT) are skipped when QP0
-    constexpr int nsteps = NFRONT + x6_nstep(NT) - qoff; // executed steps; step i of the sequence is stream block i (+ qoff past the FFN)
+    constexpr int nsteps_c = NFRONT + x6_nstep(NT) - qoff; // executed steps; step i of the sequence is stream block i (+ qoff past the FFN)
+    // SEQ: per layer NFRONT + NPRE = 32 steps + ONE empty step (33 = 0 mod NSLOT: the ring's slot numbering repeats from layer
+    // to layer); the last layer has its k | v tail (8 steps) in place of the empty step.  `nsteps` only bounds the ring refills:
+    // behind a layer that is not the last one the refills go on into the next layer's stream.
+    constexpr int SEQ_LSTEPS = NFRONT + NPRE + 1;
+    static_assert(!SEQ || SEQ_LSTEPS % NSLOT == 0, "slot numbering repeats per layer");
+    // (the non-SEQ kernels see compile-time constants here: `nsteps` and `last` are macros over a constexpr condition)
+    int ly = 0, nsteps_rt = nsteps_c;
+    bool last_rt = true;
+#define nsteps (SEQ ? nsteps_rt : nsteps_c)
+#define last (!SEQ || last_rt)
     // DMA of sequence step i into slot i % NSLOT: this wave's pieces PPW wave .. PPW wave + PPW - 1.  The slot holds the
     // step's block in stream order, and the instruction's immediate offset moves the global source AND the LDS destination
     // (tools/dma_probe.hip), so the pieces share one address register pair and one M0: base = the middle piece, offsets
@@ -1763,14 +1781,24 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     //  groups of six, one base per group)
     constexpr int PPG = PPW <= 6 ? PPW : (PPW % 6 == 0 ? 6 : 4), NGRP = PPW / PPG;
     static_assert(PPW * NW == NP && PPG * NGRP == PPW, "a step's pieces divide over the waves and their issue groups");
-    const uint4 *dma_src = a.Wx + (PPW * wave + PPG / 2) * 64 + lane;
-    const uint4 *dma_src_q = SEQ ? a.Wq + (PPW * wave + PPG / 2) * 64 + lane : dma_src;
+    // (SEQ: layer l's out-projection / FFN / next q | k | v = stream l; ITS q | k | v = the tail region of stream l - 1, layer 0's of
+    //  stream nl_total - 1.  dma_src / dma_src_q / dma_src_qn = this layer's, this layer's q | k | v, the NEXT layer's q | k | v.)
+    const uint4 *dma_src = (SEQ ? a.Wbase : a.Wx) + (PPW * wave + PPG / 2) * 64 + lane;
+    const uint4 *dma_src_q = SEQ ? a.Wbase + (long long)(a.nl_total - 1) * a.wstride + (PPW * wave + PPG / 2) * 64 + lane : dma_src;
+    const uint4 *dma_src_qn = dma_src; // (layer l + 1's q | k | v sits in stream l)
     auto issue = [&](int i) __attribute__((always_inline)) {
         // SEQ: front step i = 3 h + c (c = 0 q, 1 k, 2 v of head h) is q | k | v tile NT c + h of the OTHER stream's tail region;
-        // body step i is block i - NFRONT of this layer's stream
+        // body step i is block i - NFRONT of this layer's stream; behind the body: the last layer's k | v tail, else the empty
+        // step (nothing to fetch) and then the NEXT layer's front steps
         const int ib = i - NFRONT;
-        const int blk = (SEQ && i < NFRONT) ? NPRE + NT * (i % 3) + i / 3 : (ib < NPRE ? ib : ib + qoff);
+        int blk = (SEQ && i < NFRONT) ? NPRE + NT * (i % 3) + i / 3 : (ib < NPRE ? ib : ib + qoff);
         const uint4 *dsrc = (SEQ && i < NFRONT) ? dma_src_q : dma_src;
+        if (SEQ && ib >= NPRE && !last) {
+            if (i == SEQ_LSTEPS - 1) return; // the empty step
+            const int j = i - SEQ_LSTEPS;
+            blk = NPRE + NT * (j % 3) + j / 3;
+            dsrc = dma_src_qn;
+        }
         x6_static_for<0, NGRP>([&](auto gc) __attribute__((always_inline)) {
             constexpr int grp = decltype(gc)::value;
             const uint4 *src = dsrc + (size_t)blk * (STEP_B / 16) + grp * PPG * 64;
@@ -2207,13 +2235,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }
     x6_plane Yp[NT][2][NPL];
-    if constexpr (SEQ) {
-        // ================= the sequence-resident front (round 5): this layer's q | k | v from x, head by head, K / V of the head
-        // into the workgroup's LDS images, the attention of this wave's own 32 queries, its output to the scratch tiles the
-        // out-projection below reads back.  The three steps of a head run back to back with their result tiles in registers; the
-        // LDS traffic the compiler can see (image writes, the attention's reads) sits in ONE region per head, behind the v step,
-        // and that step leaves its ring refill to the end of the region: a compiler-visible LDS access behind an LDS-DMA issue
-        // gets a vmcnt(0) in front, i.e. it would drain the ring at every step.
+    if constexpr (SEQ) { // the planes of layer 0's x (every later layer finds them where LayerNorm 3's split left them)
 #pragma unroll
         for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
@@ -2221,10 +2243,38 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
                 x6_split(acc[tn], s2, Yp[tn][s2]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+    }
+    float nv[SEQ ? (X6_SEQ_VECS + 64 * NW - 1) / (64 * NW) : 1]; // (SEQ) the next layer's parameter vectors on their way into LDS
+    unsigned long long st_q0 = 0, st_q1 = 0, st_qst = 0;
+    auto layer_body = [&]() __attribute__((always_inline)) { // (SEQ: once per layer of this launch; otherwise once)
+    if constexpr (SEQ) {
+        // Launder what every address of the body is computed from: with the layers in a loop the compiler hoists each of the
+        // ~70 loop-invariant addresses (bias tiles, x' stores, attention-tile stores, image rows) out of it and then spills
+        // them -- 130 spilled registers, a scratch reload in every step.  Behind these statements the addresses are values of
+        // THIS trip and are recomputed where they are used (a few hundred vector instructions per layer).
+        {
+            unsigned int fb_lo = (unsigned int)fbase, fb_hi = (unsigned int)(fbase >> 32);
+            asm volatile("" : "+v"(vecs_addr), "+v"(fr_addr), "+v"(mtile), "+v"(fb_lo), "+v"(fb_hi));
+            fbase = ((size_t)fb_hi << 32) | fb_lo;
+        }
+        last_rt = ly + 1 == a.n_lay;
+        nsteps_rt = last_rt ? NFRONT + x6_nstep(NT) - qoff : (1 << 20);
+        dma_src = a.Wbase + (long long)ly * a.wstride + (PPW * wave + PPG / 2) * 64 + lane;
+        dma_src_q = a.Wbase + (long long)(ly == 0 ? a.nl_total - 1 : ly - 1) * a.wstride + (PPW * wave + PPG / 2) * 64 + lane;
+        dma_src_qn = dma_src;
+    }
+    if constexpr (SEQ) {
+        // ================= the sequence-resident front (round 5): this layer's q | k | v from x, head by head, K / V of the head
+        // into the workgroup's LDS images, the attention of this wave's own 32 queries, its output to the scratch tiles the
+        // out-projection below reads back.  The three steps of a head run back to back with their result tiles in registers; the
+        // LDS traffic the compiler can see (image writes, the attention's reads) sits in ONE region per head, behind the v step,
+        // and that step leaves its ring refill to the end of the region: a compiler-visible LDS access behind an LDS-DMA issue
+        // gets a vmcnt(0) in front, i.e. it would drain the ring at every step.
         float *Kimg = reinterpret_cast<float *>(smem + X6_SEQ_KIMG);
         char *Vimg = smem + X6_SEQ_VIMG;
         float *scr = reinterpret_cast<float *>(smem + X6_SEQ_SCR + wave * X6_SEQ_SCR_B);
-        const int irow = s_row0 + s_j; // this lane's row of the images (rows [L, 32 T) of a sequence hold finite values of dead tokens)
+        int irow = s_row0 + s_j, li_l = li; // this lane's row of the images (rows [L, 32 T) of a sequence hold finite values of dead tokens)
+        asm volatile("" : "+v"(irow), "+v"(li_l)); // (laundered like the addresses above)
         const bool irn_ = a.mask_mode == IRS_MASK_IRN;
         const float tgt_add_ = irn_ ? (1.0f - s_ru) * 1.4426950408889634f : 0.f;
         float4 *ao4 = reinterpret_cast<float4 *>(const_cast<float *>(a.Af)) + (size_t)mtile * NT * 4 * 64;
@@ -2240,7 +2290,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             if (s_b >= 0) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4 *>(scr + li * 36 + 8 * g + 4 * lk) =
+                    *reinterpret_cast<float4 *>(scr + li_l * 36 + 8 * g + 4 * lk) =
                         make_float4(__builtin_fmaf(tq[4 * g + 0], IWS, bt[4 * g + 0]), __builtin_fmaf(tq[4 * g + 1], IWS, bt[4 * g + 1]),
                                     __builtin_fmaf(tq[4 * g + 2], IWS, bt[4 * g + 2]), __builtin_fmaf(tq[4 * g + 3], IWS, bt[4 * g + 3]));
             }
@@ -2374,6 +2424,13 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
                 x6_split(acc[tn], s2, Yp[tn][s2]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        if constexpr (SEQ) {
+            if (!last) {
+#pragma unroll
+                for (int k = 0; k < (X6_SEQ_VECS + 64 * NW - 1) / (64 * NW); ++k)
+                    nv[k] = (tid + 64 * NW * k < X6_SEQ_VECS) ? a.vecpack[(size_t)(ly + 1) * X6_SEQ_VECS + tid + 64 * NW * k] : 0.f;
+            }
+        }
         if constexpr (NPL == 2) { // FFN-2 accumulates WS x its product onto y in place: y goes on as WS y (exact)
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn)
@@ -2468,7 +2525,22 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             __builtin_amdgcn_sched_barrier(0);
         }
     X6_T(st_p[4])
-    unsigned long long st_q0 = 0, st_q1 = 0, st_qst = 0;
+    if (SEQ && !last) {
+        // ---- the empty step between two layers: publishes the next layer's first step (fetched at mid-step 31), frees step
+        // 31's slot for its second one, re-stages the parameter vectors (every wave is past LayerNorm 3: nothing reads the old
+        // ones) BEFORE the refill goes out (a compiler-visible LDS store behind a DMA issue would wait for it), and reads the next
+        // step's head inside its own asm statement (compiler code follows)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < (X6_SEQ_VECS + 64 * NW - 1) / (64 * NW); ++k)
+            if (tid + 64 * NW * k < X6_SEQ_VECS) vecs[tid + 64 * NW * k] = nv[k];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (visible to the others behind the next step's barrier)
+        issue(SEQ_LSTEPS - 1 + LEAD);
+        af[0] = x6_rd_sync<0>(fr_addr), af[1] = x6_rd_sync<1024>(fr_addr), af[2] = x6_rd_sync<2048>(fr_addr); // step 0's slot is slot 0
+        return;
+    }
     // ---- the next layer's QKV: passes of d output columns (NT tiles); sequence steps NPRE ..
 #pragma unroll
     for (int pp = 0; pp < 3; ++pp) {
@@ -2518,6 +2590,12 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             st_qst += st_q1 - st_q0;
         }
     }
+    }; // (layer_body)
+    if constexpr (SEQ) {
+#pragma unroll 1
+        for (ly = 0; ly < a.n_lay; ++ly) layer_body();
+    } else
+        layer_body();
     landed_all(); // the reads issued past the last step
 #ifdef X6_STAMP
     X6_T(st_1)
@@ -2531,6 +2609,8 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
 #endif
     (void)st_p, (void)st_q0, (void)st_q1, (void)st_qst;
     (void)st_a, (void)st_b, (void)st_c, (void)st_d, (void)st_wait, (void)st_bar, (void)st_iss, (void)st_0, (void)st_1, (void)st_steps;
+#undef nsteps
+#undef last
 #undef X6_STEP
 #undef X6_STEP1
 #undef X6_RD_V
@@ -4935,7 +5015,11 @@ __device__ __forceinline__ void seq_attn_block(const float *Ks, const char *Vp, 
                                                int pq, const float *qscr, float4 *of, bool store) {
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     constexpr int HD = 32, MAXT = 16;
-    const int lane = threadIdx.x & 63, lq = lane & 15, gq = lane >> 4;
+    int lane = threadIdx.x & 63;
+    // (laundered: the lane-derived masks, offsets and predicates below are the same for every head and layer; hoisted out of the
+    //  caller's loops they cost ~50 registers held -- spilled -- for the whole kernel instead of ~30 instructions per call)
+    asm volatile("" : "+v"(lane));
+    const int lq = lane & 15, gq = lane >> 4;
     const int tq = (lane & 15) >> 2, tp = lane & 3;
     float4 *dst = of + (gq & 1) * 32 + lq;
     if (16 * qb >= L) { // the whole block lies beyond the sequence
@@ -5554,8 +5638,39 @@ static const uint4 *x6_stream(const irs_ctx *ctx, int npl, int layer) {
 }
 // streams 0 .. n_layers - 2: layer l's out-projection / FFN and layer l + 1's q | k | v; stream n_layers - 1: layer 0's
 // q | k | v alone (the embed kernel's; its other blocks are zero and never fetched)
+static bool seq_shape(const irs_ctx *ctx) {
+    const irs_dims &D = ctx->dims;
+    return D.d == 128 && D.ffn_dim == 256 && D.n_heads == 4 && D.max_len <= 256 && D.n_layers > 1;
+}
+static size_t x6_streams_bytes(const irs_ctx *ctx) { return (size_t)ctx->dims.n_layers * (x6_layer_b(ctx, 3) + x6_layer_b(ctx, 2)); }
+// (+ the sequence-resident kernel's packed parameter vectors: [n_layers][X6_SEQ_VECS] floats behind the streams)
 size_t irs_x6_bytes(const irs_ctx *ctx) {
-    return x6_shape(ctx) ? (size_t)ctx->dims.n_layers * (x6_layer_b(ctx, 3) + x6_layer_b(ctx, 2)) : 0;
+    return x6_shape(ctx) ? x6_streams_bytes(ctx) + (seq_shape(ctx) ? (size_t)ctx->dims.n_layers * X6_SEQ_VECS * 4 : 0) : 0;
+}
+static const float *seq_vecpack(const irs_ctx *ctx) {
+    return reinterpret_cast<const float *>(reinterpret_cast<const char *>(ctx->w_x6) + x6_streams_bytes(ctx));
+}
+// layer l's parameter vectors in k_block_x6's LDS order: b1[256] b2 g3 b3 b_in(l + 1)[384] b_o g1 b1n c_l g2 b2n b_in(l)[384]
+__global__ void __launch_bounds__(256) k_pack_seqvec(const float *b1, const float *b2, const float *g3, const float *b3,
+                                                     const float *bin_next, const float *bo, const float *g1, const float *b1n,
+                                                     const float *c, const float *g2, const float *b2n, const float *bq,
+                                                     float *__restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= X6_SEQ_VECS) return;
+    float v;
+    if (e < 256) v = b1[e];
+    else if (e < 384) v = b2[e - 256];
+    else if (e < 512) v = g3[e - 384];
+    else if (e < 640) v = b3[e - 512];
+    else if (e < 1024) v = bin_next ? bin_next[e - 640] : 0.f;
+    else if (e < 1152) v = bo ? bo[e - 1024] : 0.f;
+    else if (e < 1280) v = g1[e - 1152];
+    else if (e < 1408) v = b1n[e - 1280];
+    else if (e < 1536) v = c[e - 1408];
+    else if (e < 1664) v = g2[e - 1536];
+    else if (e < 1792) v = b2n[e - 1664];
+    else v = bq[e - 1792];
+    out[e] = v;
 }
 int irs_launch_pack_x6(irs_ctx *ctx, hipStream_t s) {
     if (!ctx->w_x6) return IRS_OK;
@@ -5573,6 +5688,14 @@ int irs_launch_pack_x6(irs_ctx *ctx, hipStream_t s) {
             pack(w.sa_out_w, w.l1_w, w.l2_w, ctx->layer[l + 1].sa_in_w, const_cast<uint4 *>(x6_stream(ctx, npl, l)));
         }
         pack(nullptr, nullptr, nullptr, ctx->layer[0].sa_in_w, const_cast<uint4 *>(x6_stream(ctx, npl, nl - 1)));
+    }
+    if (seq_shape(ctx)) { // (behind irs_launch_cross_const: c_l exists)
+        for (int l = 0; l < nl; ++l) {
+            const irs_layer_w &w = ctx->layer[l];
+            hipLaunchKernelGGL(k_pack_seqvec, dim3((X6_SEQ_VECS + 255) / 256), dim3(256), 0, s, w.l1_b, w.l2_b, w.n3_w, w.n3_b,
+                               l + 1 < nl ? ctx->layer[l + 1].sa_in_b : nullptr, w.sa_out_b, w.n1_w, w.n1_b, ctx->c_l + (size_t)l * ctx->dims.d,
+                               w.n2_w, w.n2_b, w.sa_in_b, const_cast<float *>(seq_vecpack(ctx)) + (size_t)l * X6_SEQ_VECS);
+        }
     }
     IRS_CHECK_HIP(ctx, hipGetLastError());
     return IRS_OK;
@@ -5650,9 +5773,8 @@ static void x6_launch_one(int rows, const BlockX6Args &xa, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((rows + 32 * NW - 1) / (32 * NW)), dim3(64 * NW), lds, s, xa);
 }
 // the sequence-resident form: grid = an upper bound of the plan's workgroups (the kernel reads the count), eight waves, 160 KB of LDS
-template <int QP0>
 static void x6_launch_seq(int wg_cap, const BlockX6Args &xa, hipStream_t s) {
-    auto kern = k_block_x6<QP0, 8, false, 4, 2, true>;
+    auto kern = k_block_x6<1, 8, false, 4, 2, true>;
     constexpr int lds = x6_seq_lds_bytes();
     IRS_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(kern, dim3(wg_cap), dim3(512), lds, s, xa);
@@ -5809,23 +5931,22 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                            ctx->tile_seq, ctx->tile_idx, ctx->seq_row0, ctx->qrow_tile, ctx->n_wg_dev, B * SEQ_WG_TILES);
         hipLaunchKernelGGL(k_embed_seq, dim3(2 * B), dim3(256), 0, s, seq, ctx->item_emb, ctx->pe, xf, tok, ctx->tile_seq, ctx->tile_idx,
                            ctx->seq_off, ctx->seq_cnt, ctx->n_wg_dev, L, d, sqrtf((float)d), ctx->dims.n_item);
-        for (int l = 0; l + 1 < nl; ++l) {
-            const irs_layer_w &w = ctx->layer[l];
-            const bool kv_tail = l + 2 == nl; // the rows-only last layer reads k | v rows (float32, packed row order)
-            BlockX6Args xa{yf, xf, x6_stream(ctx, 2, l), w.sa_out_b, w.n1_w, w.n1_b, ctx->c_l + (size_t)l * d, w.n2_w, w.n2_b,
-                           w.l1_b, w.l2_b, w.n3_w, w.n3_b, ctx->layer[l + 1].sa_in_b, xf, ctx->act_qkv, rows, m_dev, kv_tail ? 1 : 3};
+        {   // layers 0 .. nl - 2 in ONE launch (x resident in registers from layer to layer); the last of them writes the k | v rows
+            BlockX6Args xa{};
+            xa.Af = yf, xa.Rf = xf, xa.Xf = xf, xa.QKV = ctx->act_qkv, xa.M = rows, xa.m_dev = m_dev, xa.qkv_pass0 = 1;
             xa.seq = seq, xa.L = L;
-            xa.Wq = x6_stream(ctx, 2, l == 0 ? nl - 1 : l - 1), xa.bq = w.sa_in_b;
+            xa.Wbase = x6_stream(ctx, 2, 0), xa.wstride = (long long)(x6_layer_b(ctx, 2) / 16), xa.n_lay = nl - 1, xa.nl_total = nl;
+            xa.vecpack = seq_vecpack(ctx);
+            xa.c = ctx->c_l; // (non-null: the second LayerNorm always runs)
             xa.tile_seq = ctx->tile_seq, xa.tile_idx = ctx->tile_idx, xa.seq_off = ctx->seq_off, xa.seq_cnt = ctx->seq_cnt;
             xa.seq_padq = ctx->seq_padq, xa.seq_row0 = ctx->seq_row0, xa.n_wg_dev = ctx->n_wg_dev, xa.r_u = ctx->act_ru;
             xa.mask_mode = ctx->dims.mask_mode;
-            const double fl = rows * (8.0 * d * d + 4.0 * d * F);
+            const double fl = (double)(nl - 1) * rows * (8.0 * d * d + 4.0 * d * F);
             irs_prof_begin(ctx, IRS_PROF_LINEAR, s);
             irs_prof_begin(ctx, IRS_PROF_LAYER, s);
-            if (kv_tail) x6_launch_seq<1>(B, xa, s);
-            else x6_launch_seq<3>(B, xa, s);
-            irs_prof_end(ctx, IRS_PROF_LINEAR, s, fl, 3.0 * 4.0 * rows * (double)d);
-            irs_prof_end(ctx, IRS_PROF_LAYER, s, fl, 3.0 * 4.0 * rows * (double)d);
+            x6_launch_seq(B, xa, s);
+            irs_prof_end(ctx, IRS_PROF_LINEAR, s, fl, (double)(nl - 1) * 3.0 * 4.0 * rows * (double)d);
+            irs_prof_end(ctx, IRS_PROF_LAYER, s, fl, (double)(nl - 1) * 3.0 * 4.0 * rows * (double)d);
         }
         qkv0_done = true;
         l_begin = nl - 1;
