@@ -1507,7 +1507,11 @@ struct BlockX6Args {
     const uint4 *Wbase;    // float16-plane stream of layer 0; layer l's stream = Wbase + l * wstride (x6_stream)
     long long wstride;     // in uint4
     int n_lay, nl_total;   // layers run here (n_layers - 1); streams in the arena (layer l's q | k | v sits in stream l - 1, layer 0's in stream nl_total - 1)
-    const float *vecpack;  // [n_lay][X6_SEQ_VECS]: every parameter vector of a layer in the kernel's LDS order (k_pack_seqvec)
+    const float *vecpack;  // [n_lay + 1][X6_SEQ_VECS]: every parameter vector of a layer in the kernel's LDS order (k_pack_seqvec)
+    // Behind layer n_lay - 1 the kernel runs the FRONT of layer n_lay too (the model's last layer, of which the handlers consume one
+    // row per sequence): q | k | v of every token, K / V images, and the attention of the ONE 16-query block that holds the consumed
+    // token seq_qrow[b] -- its output row is gathered from the attention tiles by the host side; no k | v row reaches HBM.
+    const int32_t *seq_qrow;
     const int32_t *tile_seq, *tile_idx, *seq_off, *seq_cnt, *seq_padq, *seq_row0, *n_wg_dev;
     const float *r_u;
     int mask_mode;
@@ -1620,7 +1624,7 @@ __host__ __device__ constexpr int x6_seq_lds_bytes() { return X6_SEQ_SCR + 8 * X
 // wave per SIMD (512 registers per lane), one workgroup per CU; the step stream has 96 steps (x6_nstep).
 template <int QP0, int NW, bool EMBED, int NT = 4, int NPL = 3, bool SEQ = false>
 __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block_x6(BlockX6Args a) {
-    static_assert(!SEQ || (NT == 4 && NPL == 2 && NW == 8 && !EMBED && QP0 == 1), "the sequence-resident form: d = 128, float16 planes, eight waves, k | v tail behind the last layer");
+    static_assert(!SEQ || (NT == 4 && NPL == 2 && NW == 8 && !EMBED && QP0 == 3), "the sequence-resident form: d = 128, float16 planes, eight waves, no q | k | v tail");
     constexpr int NP = 8 * NPL, STEP_B = x6_step_b(NPL); // pieces (fragments) and bytes of a step
     using x6_plane = typename std::conditional<NPL == 2, x6_f16x8, x6_bf16x8>::type;
     // (SEQ: three ring slots -- the K / V images and the q scratch take the rest of the CU's LDS)
@@ -1655,7 +1659,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     const int M = SEQ ? 0x7FFFFFFF : (a.m_dev ? min(a.M, a.m_dev[0]) : a.M);
     // SEQ: this wave's tile = 32 consecutive tokens of ONE sequence (or nothing: s_b < 0 -- the wave still takes part in every
     // step and barrier); lane li is token s_j of the sequence, packed row s_off + s_j while s_j < s_cnt
-    int s_b = -1, s_ti = 0, s_off = 0, s_cnt = 0, s_pq = -1, s_row0 = 0;
+    int s_b = -1, s_ti = 0, s_off = 0, s_cnt = 0, s_pq = -1, s_row0 = 0, s_pb = -1;
     float s_ru = 0.f;
     bool s_tgt = false;
     if constexpr (SEQ) {
@@ -1669,6 +1673,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             const bool irn_ = a.mask_mode == IRS_MASK_IRN;
             s_ru = irn_ ? a.r_u[s_b] : 0.f;
             s_tgt = irn_ && a.seq[(int64_t)s_b * a.L + a.L - 1] != 0;
+            s_pb = (__builtin_amdgcn_readfirstlane(a.seq_qrow[s_b]) - s_off) >> 4;
         }
     }
     // (RESID_LATE) the twelve parameter values of this thread in ONE batch of unconditional loads.  (The conditional form --
@@ -2257,8 +2262,8 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             asm volatile("" : "+v"(vecs_addr), "+v"(fr_addr), "+v"(mtile), "+v"(fb_lo), "+v"(fb_hi));
             fbase = ((size_t)fb_hi << 32) | fb_lo;
         }
-        last_rt = ly + 1 == a.n_lay;
-        nsteps_rt = last_rt ? NFRONT + x6_nstep(NT) - qoff : (1 << 20);
+        last_rt = ly == a.n_lay; // the extra trip: only the front of the model's last layer, the ring ends behind its 12 steps
+        nsteps_rt = last_rt ? NFRONT : (1 << 20);
         dma_src = a.Wbase + (long long)ly * a.wstride + (PPW * wave + PPG / 2) * 64 + lane;
         dma_src_q = a.Wbase + (long long)(ly == 0 ? a.nl_total - 1 : ly - 1) * a.wstride + (PPW * wave + PPG / 2) * 64 + lane;
         dma_src_qn = dma_src;
@@ -2329,14 +2334,18 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
                 const float *Ks_ = Kimg + s_row0 * 32;
                 const char *Vp_ = Vimg + s_row0 * 64;
 #pragma unroll 1
-                for (int blk = 0; blk < 2; ++blk) // (a dead half: block index beyond the sequence -> zeros)
-                    seq_attn_block(Ks_, Vp_, 16384, s_cnt, blk == 0 ? s_ti : (s_qb1 > s_ti ? s_qb1 : 16), irn_, tgt_add_, s_tgt, s_pq,
-                                   scr + 16 * blk * 36, ao4 + (size_t)h * 4 * 64 + 16 * blk, true);
+                for (int blk = 0; blk < 2; ++blk) { // (a dead half: block index beyond the sequence -> zeros)
+                    const int qb_ = blk == 0 ? s_ti : (s_qb1 > s_ti ? s_qb1 : 16);
+                    if (last_rt && qb_ != s_pb) continue; // (the model's last layer: only the block of the consumed token)
+                    seq_attn_block(Ks_, Vp_, 16384, s_cnt, qb_, irn_, tgt_add_, s_tgt, s_pq, scr + 16 * blk * 36,
+                                   ao4 + (size_t)h * 4 * 64 + 16 * blk, true);
+                }
             }
             asm volatile("" ::: "memory");
             // (the next head's image writes come three steps -- three workgroup barriers -- later: every wave is past its reads)
             if (3 * h + 2 + LEAD < nsteps) issue(3 * h + 2 + LEAD); // the refill the v step left out
         }
+        if (last_rt) return; // (the model's last layer goes on, for one row per sequence, in the small-batch kernels)
         // ---- the layer body's inputs: the attention tiles this wave wrote and the residual, as loads the compiler does not see (it
         // would hoist and spread them over the front: registers) with ONE wait; the out-projection accumulates from zero and the
         // residual is added with b_o in front of LayerNorm 1, as in the RESID_LATE form.
@@ -2593,7 +2602,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     }; // (layer_body)
     if constexpr (SEQ) {
 #pragma unroll 1
-        for (ly = 0; ly < a.n_lay; ++ly) layer_body();
+        for (ly = 0; ly <= a.n_lay; ++ly) layer_body();
     } else
         layer_body();
     landed_all(); // the reads issued past the last step
@@ -5774,7 +5783,7 @@ static void x6_launch_one(int rows, const BlockX6Args &xa, hipStream_t s) {
 }
 // the sequence-resident form: grid = an upper bound of the plan's workgroups (the kernel reads the count), eight waves, 160 KB of LDS
 static void x6_launch_seq(int wg_cap, const BlockX6Args &xa, hipStream_t s) {
-    auto kern = k_block_x6<1, 8, false, 4, 2, true>;
+    auto kern = k_block_x6<3, 8, false, 4, 2, true>;
     constexpr int lds = x6_seq_lds_bytes();
     IRS_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(kern, dim3(wg_cap), dim3(512), lds, s, xa);
@@ -5933,7 +5942,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                            ctx->seq_off, ctx->seq_cnt, ctx->n_wg_dev, L, d, sqrtf((float)d), ctx->dims.n_item);
         {   // layers 0 .. nl - 2 in ONE launch (x resident in registers from layer to layer); the last of them writes the k | v rows
             BlockX6Args xa{};
-            xa.Af = yf, xa.Rf = xf, xa.Xf = xf, xa.QKV = ctx->act_qkv, xa.M = rows, xa.m_dev = m_dev, xa.qkv_pass0 = 1;
+            xa.Af = yf, xa.Rf = xf, xa.Xf = xf, xa.QKV = ctx->act_qkv, xa.M = rows, xa.m_dev = m_dev, xa.qkv_pass0 = 3;
+            xa.seq_qrow = ctx->seq_qrow;
             xa.seq = seq, xa.L = L;
             xa.Wbase = x6_stream(ctx, 2, 0), xa.wstride = (long long)(x6_layer_b(ctx, 2) / 16), xa.n_lay = nl - 1, xa.nl_total = nl;
             xa.vecpack = seq_vecpack(ctx);
@@ -6034,13 +6044,19 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             float *y_r = ctx->act_ao + (size_t)2 * B * d;
             float *h_r = ctx->act_h;                   // [B, F]
             const float *q_r = nullptr;
-            if (q_split) { // the previous layer's kernel wrote k | v only: queries for the B consumed rows here
+            if (seq_mode) {
+                // the sequence-resident launch ran this layer's q | k | v and the attention of every consumed token's block: the
+                // residual row and the attention row come out of the fragment-major images by the tile-order row index
+                hipLaunchKernelGGL(k_gather_rows_frag, dim3(B), dim3(64), 0, s, xf, qrow_f, x_r, d, 4);
+                hipLaunchKernelGGL(k_gather_rows_frag, dim3(B), dim3(64), 0, s, yf, qrow_f, ao_r, d, 4);
+            } else if (q_split) { // the previous layer's kernel wrote k | v only: queries for the B consumed rows here
                 hipLaunchKernelGGL(k_gather_rows_frag, dim3(B), dim3(64), 0, s, xf, qrow_f, x_r, d, d > 128 ? d / 32 : 4);
                 if ((rc = launch_linear(ctx, x_r, w.sa_in_w, w.sa_in_b, nullptr, h_r, B, d, d, false, s))) return rc;
                 q_r = h_r;
             }
             irs_prof_begin(ctx, IRS_PROF_ATTN, s);
-            if (d / ctx->dims.n_heads == 32 && L <= 256 && d % 4 == 0 && (((uintptr_t)ctx->act_qkv | (uintptr_t)q_r) & 15) == 0)
+            if (seq_mode) {
+            } else if (d / ctx->dims.n_heads == 32 && L <= 256 && d % 4 == 0 && (((uintptr_t)ctx->act_qkv | (uintptr_t)q_r) & 15) == 0)
                 hipLaunchKernelGGL(k_attn_row32, dim3(ctx->dims.n_heads, B), dim3(256), 0, s, ctx->act_qkv, seq, ctx->act_ru,
                                    ao_r, L, d, ctx->dims.mask_mode, off, cnt, qrow, q_r, ctx->seq_padq);
             else
