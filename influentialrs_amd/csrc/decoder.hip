@@ -140,49 +140,57 @@ __global__ void __launch_bounds__(256) k_plan_fill(const int64_t *__restrict__ s
 }
 
 // ------------------------------------------------------------------ plan of the sequence-resident layer kernel (round 5)
-// k_block_x6<.., SEQ> wants every sequence inside ONE workgroup of SEQ_WG_TILES wave tiles; a tile is two mirrored 16-token
-// blocks of the sequence, so sequence b takes T_b = ceil(blocks / 2) consecutive tiles.  Packing = best fit, largest first, done
-// class by class (T = 8 .. 1) with the open workgroups kept as pools per free-tile count f: the items of a class fill the
-// pools' free tiles smallest f first (a workgroup with f free tiles takes floor(f / T) of them), the rest opens new workgroups
-// (floor(8 / T) items each).  Workgroups are created as contiguous id ranges and move between pools a prefix at a time, so a
-// pool is a short list of ranges and item i of a class finds its (workgroup, first tile) by arithmetic: every thread places
-// its own items, one thread does the O(pools) bookkeeping between classes (the first version walked the 4096 sequences in
-// one thread: 1.7 ms).  tools/seq_pack_sim.py: 0.84 lane efficiency on the bench's windows against 0.68 in window order.
-//   tile_seq[t] / tile_idx[t]: the sequence (-1: none) and its tile index for grid tile t = 8 workgroup + wave;
-//   seq_row0[b]: first row of the sequence in its workgroup's K / V images; qrow_tile[b]: tile-order row of the consumed token;
-//   n_wg[0]: workgroups in use.
+// k_block_x6<.., SEQ> wants every sequence inside ONE workgroup of 8 wave tiles = 16 half tiles of 16 tokens.  A sequence of nb
+// 16-token blocks needs nb half tiles: its mirrored block pairs (i, nb - 1 - i) each fill one tile, and an odd middle block takes
+// ONE half -- which it may share with the middle block of another odd sequence of the workgroup (the first version gave every
+// sequence whole tiles: 0.84 lane efficiency on the bench's windows; in blocks: 0.915, tools/seq_pack_sim.py).  Any set of
+// sequences with <= 16 blocks fits (pairs first, odd blocks two per tile), so the packing is one-dimensional, best fit, largest
+// first, done class by class (nb = 16 .. 1) with the open workgroups kept as pools per free-block count f: the items of a class
+// fill the pools' free blocks smallest f first (a workgroup with f free blocks takes floor(f / nb) of them), the rest opens new
+// workgroups.  Workgroups are created as contiguous id ranges and move between pools a prefix at a time, so a pool is a short
+// list of ranges and item i of a class finds its (workgroup, first block) by arithmetic: every thread places its own items, one
+// thread does the O(pools) bookkeeping between classes (a one-thread walk over 4096 sequences took 1.7 ms).  Then the layout
+// inside each workgroup: a sequence's pairs go to tiles [pairs of the sequences placed before it ..), its odd block to half
+// (odd rank) of the tiles behind all pairs.
+//   tile_seq[2 t + h] / tile_qb[2 t + h]: sequence (-1: none) and block index in lanes 16 h .. 16 h + 15 of grid tile t = 8 wg + wave;
+//   seq_row0[b]: first row of the sequence in its workgroup's K / V images (16 x its first block slot); qrow_tile[b]: tile-order
+//   row of the consumed token; n_wg[0]: workgroups in use.
 #define SEQ_WG_TILES 8
+#define SEQ_WG_BLOCKS 16
 #define SEQ_RMAX 48
 __global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ cnt, const int32_t *__restrict__ off,
                                                    const int32_t *__restrict__ qrow, int B, int32_t *__restrict__ order,
                                                    int32_t *__restrict__ bin_slot, int32_t *__restrict__ tile_seq,
-                                                   int32_t *__restrict__ tile_idx, int32_t *__restrict__ seq_row0,
-                                                   int32_t *__restrict__ qrow_tile, int32_t *__restrict__ n_wg, int tiles_cap) {
-    __shared__ int s_hist[SEQ_WG_TILES + 1], s_start[SEQ_WG_TILES + 2], s_fill[SEQ_WG_TILES + 1];
-    __shared__ int p_n[SEQ_WG_TILES], p_s[SEQ_WG_TILES][SEQ_RMAX], p_l[SEQ_WG_TILES][SEQ_RMAX]; // pool f = 1 .. 7: ranges of workgroup ids
-    __shared__ int c_cum[SEQ_WG_TILES + 1], c_q[SEQ_WG_TILES], c_exist, c_newbase, s_nwg;
+                                                   int32_t *__restrict__ tile_qb, int32_t *__restrict__ seq_row0,
+                                                   int32_t *__restrict__ qrow_tile, int32_t *__restrict__ n_wg,
+                                                   int32_t *__restrict__ wg_members, int tiles_cap) {
+    constexpr int C = SEQ_WG_BLOCKS;
+    __shared__ int s_hist[C + 1], s_start[C + 2], s_fill[C + 1];
+    __shared__ int p_n[C], p_s[C][SEQ_RMAX], p_l[C][SEQ_RMAX]; // pool f = 1 .. 15: ranges of workgroup ids with f free blocks
+    __shared__ int c_cum[C + 1], c_q[C], c_exist, c_newbase, s_nwg;
     const int tid = threadIdx.x;
-    if (tid <= SEQ_WG_TILES) s_hist[tid] = 0, s_fill[tid] = 0;
-    if (tid < SEQ_WG_TILES) p_n[tid] = 0;
+    if (tid <= C) s_hist[tid] = 0, s_fill[tid] = 0;
+    if (tid < C) p_n[tid] = 0;
     if (tid == 0) s_nwg = 0;
-    for (int t = tid; t < tiles_cap; t += 1024) tile_seq[t] = -1;
+    for (int t = tid; t < 2 * tiles_cap; t += 1024) tile_seq[t] = -1;
+    for (int t = tid; t < (tiles_cap / SEQ_WG_TILES) * (C + 1); t += 1024) wg_members[t] = 0; // [wg][0] = count
     __syncthreads();
-    auto tiles_of = [&](int b) { // a tile = two mirrored 16-token blocks (k_block_x6<.., SEQ>): ceil(blocks / 2)
-        int T = (((cnt[b] + 15) >> 4) + 1) >> 1;
-        return T < 1 ? 1 : (T > SEQ_WG_TILES ? SEQ_WG_TILES : T);
+    auto blocks_of = [&](int b) {
+        int nb = (cnt[b] + 15) >> 4;
+        return nb < 1 ? 1 : (nb > C ? C : nb);
     };
-    for (int b = tid; b < B; b += 1024) atomicAdd(&s_hist[tiles_of(b)], 1);
+    for (int b = tid; b < B; b += 1024) atomicAdd(&s_hist[blocks_of(b)], 1);
     __syncthreads();
     if (tid == 0) {
         int run = 0;
-        for (int T = SEQ_WG_TILES; T >= 1; --T) { // largest first
+        for (int T = C; T >= 1; --T) { // largest first
             s_start[T] = run;
             run += s_hist[T];
         }
     }
     __syncthreads();
     for (int b = tid; b < B; b += 1024) {
-        const int T = tiles_of(b);
+        const int T = blocks_of(b);
         order[s_start[T] + atomicAdd(&s_fill[T], 1)] = b;
     }
     __syncthreads();
@@ -191,7 +199,7 @@ __global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ c
         for (int r = 0; r < p_n[f]; ++r) n += p_l[f][r];
         return n;
     };
-    auto append = [&](int f, int start, int len) { // (thread 0) `len` workgroups from `start` on now have f free tiles
+    auto append = [&](int f, int start, int len) { // (thread 0) `len` workgroups from `start` on now have f free blocks
         if (f < 1 || len < 1) return;
         if (p_n[f] > 0 && p_s[f][p_n[f] - 1] + p_l[f][p_n[f] - 1] == start) p_l[f][p_n[f] - 1] += len;
         else if (p_n[f] < SEQ_RMAX) p_s[f][p_n[f]] = start, p_l[f][p_n[f]] = len, ++p_n[f];
@@ -208,16 +216,16 @@ __global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ c
             if (p_l[f][r] > 0) p_s[f][w] = p_s[f][r], p_l[f][w] = p_l[f][r], ++w;
         p_n[f] = w;
     };
-    for (int T = SEQ_WG_TILES; T >= 1; --T) {
-        const int n = s_hist[T], base = s_start[T], qnew = SEQ_WG_TILES / T;
+    for (int T = C; T >= 1; --T) {
+        const int n = s_hist[T], base = s_start[T], qnew = C / T;
         if (n == 0) continue; // (uniform: s_hist is shared)
         if (tid == 0) {
             int tot = 0;
-            for (int f = T; f < SEQ_WG_TILES; ++f) {
+            for (int f = T; f < C; ++f) {
                 c_cum[f] = tot, c_q[f] = f / T;
                 tot += pool_bins(f) * c_q[f];
             }
-            c_cum[SEQ_WG_TILES] = tot;
+            c_cum[C] = tot;
             c_exist = n < tot ? n : tot;
             c_newbase = s_nwg;
             s_nwg += (n - c_exist + qnew - 1) / qnew;
@@ -229,25 +237,29 @@ __global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ c
             int w, slot;
             if (i < exist) {
                 int f = T;
-                while (f < SEQ_WG_TILES - 1 && i >= c_cum[f + 1]) ++f;
+                while (f < C - 1 && i >= c_cum[f + 1]) ++f;
                 const int s_ = i - c_cum[f];
                 int bl = s_ / c_q[f];
                 const int k = s_ % c_q[f];
                 int r = 0;
                 while (r < p_n[f] - 1 && bl >= p_l[f][r]) bl -= p_l[f][r], ++r;
                 w = p_s[f][r] + bl;
-                slot = (SEQ_WG_TILES - f) + k * T;
+                slot = (C - f) + k * T;
             } else {
                 const int j_ = i - exist;
                 w = c_newbase + j_ / qnew;
                 slot = (j_ % qnew) * T;
             }
-            bin_slot[b] = w * SEQ_WG_TILES + slot;
+            bin_slot[b] = w * C + slot;
+            if (w * SEQ_WG_TILES < tiles_cap) { // the workgroup's member list (for the layout pass)
+                const int m = atomicAdd(&wg_members[w * (C + 1)], 1);
+                if (m < C) wg_members[w * (C + 1) + 1 + m] = b;
+            }
         }
         __syncthreads();
         if (tid == 0) {
             int left = exist;
-            for (int f = T; f < SEQ_WG_TILES && left > 0; ++f) {
+            for (int f = T; f < C && left > 0; ++f) {
                 const int q = c_q[f], cap = pool_bins(f) * q;
                 const int used = left < cap ? left : cap;
                 left -= used;
@@ -256,37 +268,56 @@ __global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ c
                 if (part) take_prefix(f, 1, f - T * part);
             }
             const int nnew = n - exist, fullnew = nnew / qnew, partnew = nnew % qnew;
-            append(SEQ_WG_TILES - T * qnew, c_newbase, fullnew);
-            if (partnew) append(SEQ_WG_TILES - T * partnew, c_newbase + fullnew, 1);
+            append(C - T * qnew, c_newbase, fullnew);
+            if (partnew) append(C - T * partnew, c_newbase + fullnew, 1);
         }
         __syncthreads();
     }
     if (tid == 0) n_wg[0] = s_nwg;
+    __threadfence_block();
+    __syncthreads();
+    // layout inside the workgroups: pairs of the sequences in block-slot order, then the odd blocks two per tile
     for (int b = tid; b < B; b += 1024) {
-        const int T = tiles_of(b), t0 = bin_slot[b];
-        for (int t = 0; t < T; ++t)
-            if (t0 + t < tiles_cap) tile_seq[t0 + t] = b, tile_idx[t0 + t] = t;
-        seq_row0[b] = 32 * (t0 % SEQ_WG_TILES);
-        const int p = qrow[b] - off[b], pb = p >> 4, nb = (cnt[b] + 15) >> 4; // the consumed token: block pb, in its tile's first or second half
-        qrow_tile[b] = (pb <= nb - 1 - pb) ? 32 * (t0 + pb) + (p & 15) : 32 * (t0 + nb - 1 - pb) + 16 + (p & 15);
+        const int w = bin_slot[b] / C, p = bin_slot[b] % C, nb = blocks_of(b);
+        if (w * SEQ_WG_TILES >= tiles_cap) continue;
+        const int nm = wg_members[w * (C + 1)] < C ? wg_members[w * (C + 1)] : C;
+        int pairs_before = 0, odd_rank = 0, pairs_total = 0;
+        for (int m = 0; m < nm; ++m) {
+            const int o = wg_members[w * (C + 1) + 1 + m], po = bin_slot[o] % C, nbo = blocks_of(o);
+            pairs_total += nbo >> 1;
+            if (po < p) pairs_before += nbo >> 1, odd_rank += nbo & 1;
+        }
+        const int t0 = w * SEQ_WG_TILES;
+        for (int i = 0; i < (nb >> 1); ++i) {
+            const int t = t0 + pairs_before + i;
+            tile_seq[2 * t] = b, tile_qb[2 * t] = i;
+            tile_seq[2 * t + 1] = b, tile_qb[2 * t + 1] = nb - 1 - i;
+        }
+        if (nb & 1) {
+            const int t = t0 + pairs_total + (odd_rank >> 1);
+            tile_seq[2 * t + (odd_rank & 1)] = b, tile_qb[2 * t + (odd_rank & 1)] = nb >> 1;
+        }
+        seq_row0[b] = 16 * p;
+        const int pt = qrow[b] - off[b], pb = pt >> 4; // the consumed token: block pb
+        int t, h;
+        if ((nb & 1) && pb == (nb >> 1)) t = t0 + pairs_total + (odd_rank >> 1), h = odd_rank & 1;
+        else if (pb < nb - 1 - pb) t = t0 + pairs_before + pb, h = 0;
+        else t = t0 + pairs_before + (nb - 1 - pb), h = 1;
+        qrow_tile[b] = 32 * t + 16 * h + (pt & 15);
     }
 }
 // x = item_emb[seq] * sqrt(d) + pe[position] into the fragment-major image in TILE order (k_embed_frag's arithmetic)
 __global__ void __launch_bounds__(256) k_embed_seq(const int64_t *__restrict__ seq, const float *__restrict__ E,
                                                    const float *__restrict__ pe, float *__restrict__ xf,
                                                    const int32_t *__restrict__ tok_row, const int32_t *__restrict__ tile_seq,
-                                                   const int32_t *__restrict__ tile_idx, const int32_t *__restrict__ seq_off,
+                                                   const int32_t *__restrict__ tile_qb, const int32_t *__restrict__ seq_off,
                                                    const int32_t *__restrict__ seq_cnt, const int32_t *__restrict__ n_wg, int L, int d,
                                                    float sqrtd, int64_t n_item) {
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5;
     if (tile >= n_wg[0] * SEQ_WG_TILES) return;
-    const int b = tile_seq[tile];
-    int j = 0x3FFFFFFF;
-    if (b >= 0) { // lanes 0-15: block ti; lanes 16-31: its mirror image nb - 1 - ti (k_block_x6<.., SEQ>)
-        const int ti = tile_idx[tile], nb = (seq_cnt[b] + 15) >> 4, qb1 = nb - 1 - ti;
-        j = li < 16 ? 16 * ti + li : (qb1 > ti ? 16 * qb1 + (li - 16) : 0x3FFFFFFF);
-    }
+    const int b = tile_seq[2 * tile + (li >> 4)]; // lanes 0-15 / 16-31: one 16-token block of a sequence each (k_plan_seq)
+    const int j = b >= 0 ? 16 * tile_qb[2 * tile + (li >> 4)] + (li & 15) : 0x3FFFFFFF;
     const bool live = b >= 0 && j < seq_cnt[b];
     const int orig = live ? tok_row[seq_off[b] + j] : 0;
     int64_t id = live ? seq[orig] : 0;
@@ -1512,7 +1543,7 @@ struct BlockX6Args {
     // row per sequence): q | k | v of every token, K / V images, and the attention of the ONE 16-query block that holds the consumed
     // token seq_qrow[b] -- its output row is gathered from the attention tiles by the host side; no k | v row reaches HBM.
     const int32_t *seq_qrow;
-    const int32_t *tile_seq, *tile_idx, *seq_off, *seq_cnt, *seq_padq, *seq_row0, *n_wg_dev;
+    const int32_t *tile_seq, *tile_qb, *seq_off, *seq_cnt, *seq_padq, *seq_row0, *n_wg_dev;
     const float *r_u;
     int mask_mode;
 #ifdef X6_DUMP
@@ -1657,23 +1688,30 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     X6_T(st_p[0])
     const int m0 = blockIdx.x * (32 * NW);
     const int M = SEQ ? 0x7FFFFFFF : (a.m_dev ? min(a.M, a.m_dev[0]) : a.M);
-    // SEQ: this wave's tile = 32 consecutive tokens of ONE sequence (or nothing: s_b < 0 -- the wave still takes part in every
-    // step and barrier); lane li is token s_j of the sequence, packed row s_off + s_j while s_j < s_cnt
-    int s_b = -1, s_ti = 0, s_off = 0, s_cnt = 0, s_pq = -1, s_row0 = 0, s_pb = -1;
-    float s_ru = 0.f;
-    bool s_tgt = false;
+    // SEQ: this wave's tile = TWO 16-token blocks, one per half h (lanes 16 h .. 16 h + 15 of li): block sh_qb[h] of sequence
+    // sh_b[h] (-1: nothing there; a wave with two empty halves still takes part in every step and barrier).  Normally the two are
+    // mirror images of ONE sequence (blocks i and nb - 1 - i: causal attention costs qb + 1 key tiles for block qb, so every
+    // wave of a sequence gets nb + 1 of them); the odd middle blocks of two sequences may share a tile (k_plan_seq).
+    int sh_b[2] = {-1, -1}, sh_qb[2] = {0, 0}, sh_cnt[2] = {0, 0}, sh_pq[2] = {-1, -1}, sh_row0[2] = {0, 0}, sh_pb[2] = {-1, -1};
+    float sh_ru[2] = {0.f, 0.f};
+    bool sh_tgt[2] = {false, false};
     if constexpr (SEQ) {
         if ((int)blockIdx.x >= a.n_wg_dev[0]) return;
         const int tg_ = blockIdx.x * NW + wave;
-        s_b = __builtin_amdgcn_readfirstlane(a.tile_seq[tg_]);
-        if (s_b >= 0) {
-            s_ti = __builtin_amdgcn_readfirstlane(a.tile_idx[tg_]);
-            s_off = __builtin_amdgcn_readfirstlane(a.seq_off[s_b]), s_cnt = __builtin_amdgcn_readfirstlane(a.seq_cnt[s_b]);
-            s_pq = __builtin_amdgcn_readfirstlane(a.seq_padq[s_b]), s_row0 = __builtin_amdgcn_readfirstlane(a.seq_row0[s_b]);
-            const bool irn_ = a.mask_mode == IRS_MASK_IRN;
-            s_ru = irn_ ? a.r_u[s_b] : 0.f;
-            s_tgt = irn_ && a.seq[(int64_t)s_b * a.L + a.L - 1] != 0;
-            s_pb = (__builtin_amdgcn_readfirstlane(a.seq_qrow[s_b]) - s_off) >> 4;
+        const bool irn_ = a.mask_mode == IRS_MASK_IRN;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int b_ = __builtin_amdgcn_readfirstlane(a.tile_seq[2 * tg_ + h]);
+            sh_b[h] = b_;
+            if (b_ >= 0) {
+                sh_qb[h] = __builtin_amdgcn_readfirstlane(a.tile_qb[2 * tg_ + h]);
+                const int off_ = __builtin_amdgcn_readfirstlane(a.seq_off[b_]);
+                sh_cnt[h] = __builtin_amdgcn_readfirstlane(a.seq_cnt[b_]);
+                sh_pq[h] = __builtin_amdgcn_readfirstlane(a.seq_padq[b_]), sh_row0[h] = __builtin_amdgcn_readfirstlane(a.seq_row0[b_]);
+                sh_ru[h] = irn_ ? a.r_u[b_] : 0.f;
+                sh_tgt[h] = irn_ && a.seq[(int64_t)b_ * a.L + a.L - 1] != 0;
+                sh_pb[h] = (__builtin_amdgcn_readfirstlane(a.seq_qrow[b_]) - off_) >> 4;
+            }
         }
     }
     // (RESID_LATE) the twelve parameter values of this thread in ONE batch of unconditional loads.  (The conditional form --
@@ -1755,13 +1793,12 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
         for (int i = 0; i < X6_STAGGER; ++i) __builtin_amdgcn_s_sleep(127); // (lab) second resident workgroup of a CU starts ~4 us x N late
 #endif
     int mtile = SEQ ? (int)blockIdx.x * NW + wave : (m0 >> 5) + wave; // (not const: SEQ launders it per layer, see layer_body)
-    // (SEQ) this lane's token of its sequence.  A wave's tile is TWO 16-token blocks of the sequence, block s_ti in lanes 0-15 and
-    // its mirror image s_nb - 1 - s_ti in lanes 16-31 (causal attention: block qb costs qb + 1 key tiles, so every wave of a
-    // sequence gets s_nb + 1 of them; consecutive blocks per wave left the last waves with 1.8 x the mean).  An odd middle
-    // block stands alone: the second half of its tile is dead.
-    const int s_nb = (s_cnt + 15) >> 4, s_qb1 = s_nb - 1 - s_ti;
-    const int s_j = li < 16 ? 16 * s_ti + li : (s_qb1 > s_ti ? 16 * s_qb1 + (li - 16) : 0x3FFFFFFF);
-    const int mt = SEQ ? ((s_b >= 0 && s_j < s_cnt) ? s_off + s_j : 0x7FFFFFFF) : m0 + wave * 32 + li; // packed row (SEQ: dead lanes never store)
+    // (SEQ) this lane's half, its sequence's image row of its token
+    const bool l_h1 = li >= 16;
+    const int l_b = l_h1 ? sh_b[1] : sh_b[0];
+    const int s_j = l_b >= 0 ? 16 * (l_h1 ? sh_qb[1] : sh_qb[0]) + (li & 15) : 0x3FFFFFFF;
+    const int l_row0 = l_h1 ? sh_row0[1] : sh_row0[0];
+    const int mt = SEQ ? 0x7FFFFFFF : m0 + wave * 32 + li; // packed row (SEQ: no row-major stores)
     size_t fbase = (size_t)mtile * (4 * NT) * 64 + lane;
     const unsigned int lds0 = (unsigned int)(size_t)(__attribute__((address_space(3))) char *)smem;
     unsigned int fr_addr = lds0 + lane * 16; // + slot * X6_STEP_B + piece * 1024
@@ -2278,10 +2315,9 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
         float *Kimg = reinterpret_cast<float *>(smem + X6_SEQ_KIMG);
         char *Vimg = smem + X6_SEQ_VIMG;
         float *scr = reinterpret_cast<float *>(smem + X6_SEQ_SCR + wave * X6_SEQ_SCR_B);
-        int irow = s_row0 + s_j, li_l = li; // this lane's row of the images (rows [L, 32 T) of a sequence hold finite values of dead tokens)
+        int irow = l_row0 + s_j, li_l = li; // this lane's row of the images (rows [L, 32 T) of a sequence hold finite values of dead tokens)
         asm volatile("" : "+v"(irow), "+v"(li_l)); // (laundered like the addresses above)
         const bool irn_ = a.mask_mode == IRS_MASK_IRN;
-        const float tgt_add_ = irn_ ? (1.0f - s_ru) * 1.4426950408889634f : 0.f;
         float4 *ao4 = reinterpret_cast<float4 *>(const_cast<float *>(a.Af)) + (size_t)mtile * NT * 4 * 64;
 #pragma unroll
         for (int h = 0; h < NT; ++h) {
@@ -2292,7 +2328,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             X6_STEP1(3 * h + 1, Yp, tk)
             X6_STEP1(3 * h + 2, Yp, tv) // (no ring refill behind this step: X6_PUBLISH)
             bias_tile(bt, V_BQ + 32 * h);
-            if (s_b >= 0) {
+            {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<float4 *>(scr + li_l * 36 + 8 * g + 4 * lk) =
@@ -2300,7 +2336,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
                                     __builtin_fmaf(tq[4 * g + 2], IWS, bt[4 * g + 2]), __builtin_fmaf(tq[4 * g + 3], IWS, bt[4 * g + 3]));
             }
             bias_tile(bt, V_BQ + D + 32 * h);
-            if (s_b >= 0 && s_j < 16 * s_nb) { // (rows [cnt, 16 nb) hold finite values of dead tokens: read with p = 0)
+            if (l_b >= 0) { // (rows [cnt, 16 nb) hold finite values of dead tokens: read with p = 0)
                 const int sw = (s_j & 7) ^ ((s_j >> 3) & 1);
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -2309,7 +2345,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
                                     __builtin_fmaf(tk[4 * g + 2], IWS, bt[4 * g + 2]), __builtin_fmaf(tk[4 * g + 3], IWS, bt[4 * g + 3]));
             }
             bias_tile(bt, V_BQ + 2 * D + 32 * h);
-            if (s_b >= 0 && s_j < 16 * s_nb) {
+            if (l_b >= 0) {
                 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
                 const int swv = ((s_j >> 2) & 1) << 1;
 #pragma unroll
@@ -2330,15 +2366,15 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier(); // every wave's rows of head h are in the images
             asm volatile("" ::: "memory");
-            if (s_b >= 0 && !(SEQ_EXP & 1)) {
-                const float *Ks_ = Kimg + s_row0 * 32;
-                const char *Vp_ = Vimg + s_row0 * 64;
+            if (!(SEQ_EXP & 1)) {
 #pragma unroll 1
-                for (int blk = 0; blk < 2; ++blk) { // (a dead half: block index beyond the sequence -> zeros)
-                    const int qb_ = blk == 0 ? s_ti : (s_qb1 > s_ti ? s_qb1 : 16);
-                    if (last_rt && qb_ != s_pb) continue; // (the model's last layer: only the block of the consumed token)
-                    seq_attn_block(Ks_, Vp_, 16384, s_cnt, qb_, irn_, tgt_add_, s_tgt, s_pq, scr + 16 * blk * 36,
-                                   ao4 + (size_t)h * 4 * 64 + 16 * blk, true);
+                for (int blk = 0; blk < 2; ++blk) {
+                    const int b_ = blk ? sh_b[1] : sh_b[0], qb_ = blk ? sh_qb[1] : sh_qb[0], row0_ = blk ? sh_row0[1] : sh_row0[0];
+                    if (b_ >= 0 && last_rt && qb_ != (blk ? sh_pb[1] : sh_pb[0])) continue; // (the model's last layer: only the consumed token's block)
+                    // (an empty half: block index beyond a zero-length sequence -> zeros, the layer body multiplies whole tiles)
+                    seq_attn_block(Kimg + row0_ * 32, Vimg + row0_ * 64, 16384, b_ >= 0 ? (blk ? sh_cnt[1] : sh_cnt[0]) : 0, b_ >= 0 ? qb_ : 16, irn_,
+                                   irn_ ? (1.0f - (blk ? sh_ru[1] : sh_ru[0])) * 1.4426950408889634f : 0.f, blk ? sh_tgt[1] : sh_tgt[0],
+                                   blk ? sh_pq[1] : sh_pq[0], scr + 16 * blk * 36, ao4 + (size_t)h * 4 * 64 + 16 * blk, true);
                 }
             }
             asm volatile("" ::: "memory");
@@ -5937,7 +5973,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     if (seq_mode) {
         const int nl = ctx->dims.n_layers;
         hipLaunchKernelGGL(k_plan_seq, dim3(1), dim3(1024), 0, s, ctx->seq_cnt, ctx->seq_off, ctx->seq_qrow, B, ctx->seq_order, ctx->seq_bin,
-                           ctx->tile_seq, ctx->tile_idx, ctx->seq_row0, ctx->qrow_tile, ctx->n_wg_dev, B * SEQ_WG_TILES);
+                           ctx->tile_seq, ctx->tile_idx, ctx->seq_row0, ctx->qrow_tile, ctx->n_wg_dev, ctx->seq_wgmem, B * SEQ_WG_TILES);
         hipLaunchKernelGGL(k_embed_seq, dim3(2 * B), dim3(256), 0, s, seq, ctx->item_emb, ctx->pe, xf, tok, ctx->tile_seq, ctx->tile_idx,
                            ctx->seq_off, ctx->seq_cnt, ctx->n_wg_dev, L, d, sqrtf((float)d), ctx->dims.n_item);
         {   // layers 0 .. nl - 2 in ONE launch (x resident in registers from layer to layer); the last of them writes the k | v rows
@@ -5948,7 +5984,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
             xa.Wbase = x6_stream(ctx, 2, 0), xa.wstride = (long long)(x6_layer_b(ctx, 2) / 16), xa.n_lay = nl - 1, xa.nl_total = nl;
             xa.vecpack = seq_vecpack(ctx);
             xa.c = ctx->c_l; // (non-null: the second LayerNorm always runs)
-            xa.tile_seq = ctx->tile_seq, xa.tile_idx = ctx->tile_idx, xa.seq_off = ctx->seq_off, xa.seq_cnt = ctx->seq_cnt;
+            xa.tile_seq = ctx->tile_seq, xa.tile_qb = ctx->tile_idx, xa.seq_off = ctx->seq_off, xa.seq_cnt = ctx->seq_cnt;
             xa.seq_padq = ctx->seq_padq, xa.seq_row0 = ctx->seq_row0, xa.n_wg_dev = ctx->n_wg_dev, xa.r_u = ctx->act_ru;
             xa.mask_mode = ctx->dims.mask_mode;
             const double fl = (double)(nl - 1) * rows * (8.0 * d * d + 4.0 * d * F);
