@@ -869,6 +869,27 @@ def main():
                      "ms_per_step": ms_step_, "ms_per_step_over_floor": ms_step_ / max(floor_mfma_ms, floor_hbm_ms),
                      "pricing": "GEMMs at %s, attention scores at the float32 matrix peak %.1f TFLOP/s, P.V at 2500 / 3, catalog sweep at 2500 TFLOP/s; "
                                 "HBM 8 TB/s" % (("2500 / %d TFLOP/s" % int(nprod)) if x6 else "the float32 matrix peak", PEAK_F32_MATRIX_TFLOPS)}
+        if job.eng.decoder_seq_last and layer["launches"] > 0:
+            # the sequence-resident decoder: ONE launch per step holds layers 0 .. n - 2 AND the attention (and the last layer's
+            # q | k | v + attention for the consumed tokens); it is the dominant kernel, and what bounds it is the matrix side --
+            # its arithmetic priced per pipe (GEMMs and P.V on the 16-bit pipe at 3 products per float32 product, attention scores
+            # on the float32 pipe) against its launch time; the bytes it MUST move are the embedded rows in and x of the last fused
+            # layer out (its attention tiles and x' round trips are scratch traffic of this decomposition, counted by `traffic`).
+            lt_ms = layer["ms"] / max(layer["launches"], 1)
+            dec_floor_ms = (gemm_flops / gemm_peak + score_flops / (PEAK_F32_MATRIX_TFLOPS * 1e12) + pv_flops / (PEAK_BF16_TFLOPS / 3.0 * 1e12)) * 1e3
+            alg_b = tok * d_ * 4.0 * 2.0
+            roof = {"kernel": "k_block_x6<.., SEQ> (sequence-resident decoder: layers 0 .. n-2 with their attention, and the last layer's "
+                              "q|k|v + attention of the consumed tokens, in ONE launch; split-float16 MFMA GEMMs, float32-MFMA attention scores)",
+                    "bound": "mfma", "achieved": (gemm_flops + score_flops + pv_flops) / (lt_ms * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS / nprod,
+                    "unit": "TFLOP/s", "frac": dec_floor_ms / lt_ms, "frac_mfma": dec_floor_ms / lt_ms,
+                    "frac_hbm": alg_b / (lt_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                    "peak_basis": "frac = (GEMM flops / (2500 / 3) + attention-score flops / 157.3 + P.V flops / (2500 / 3) TFLOP/s) / launch time: the "
+                                  "fraction of the launch its arithmetic needs at each pipe's dense peak; `achieved` = all float32-equivalent flops / time",
+                    "floor_ms": {"mfma": dec_floor_ms, "hbm": alg_b / (PEAK_HBM_GBS * 1e9) * 1e3},
+                    "avg_launch_ms": lt_ms, "launches_per_step": layer["launches"] / args.steps,
+                    "family_ms_per_step": (roof or {}).get("family_ms_per_step"),
+                    "flops_counted": "executed on the step's own windows (packed non-pad tokens; causal attention pairs)",
+                    "time_basis": (roof or {}).get("time_basis")}
         # per-kernel numbers of the committed PMC passes of this same command (tools/r05_measure.sh -> tools/r05_pmc.py)
         pmc5 = os.path.join(REPO, "profiles", "r05", "c2_b4096_pmc.json")
         if world == 1 and args.workload == "c2" and args.batch == 4096 and not args.n_item and os.path.exists(pmc5):
@@ -880,6 +901,12 @@ def main():
                             "algorithmic_gbs": k_.get("algorithmic_gbs"), "frac_hbm": k_.get("frac_hbm_peak")}
                            for lab, k_ in pm5["kernels"].items() if lab != "k_block_x6"]
                 step_roof["decoder_hbm_gb_per_step_pmc"] = pm5.get("decoder_hbm_bytes_per_step", 0.0) / 1e9
+                if job.eng.decoder_seq_last and "seq_decoder" in pm5["kernels"]:
+                    ks_ = pm5["kernels"]["seq_decoder"]
+                    roof["traffic"] = float(ks_["hbm_bytes_per_launch"])
+                    roof["traffic_measured_at_packed_rows"] = float(pm5["packed_rows_mean"])
+                    roof["mfma_busy_pmc"] = ks_.get("mfma_busy")
+                    roof["traffic_source"] = "profiles/r05/c2_b4096_pmc.json (tools/r05_measure.sh: separate --pmc passes of `bench.py --pmc-run`, 2 x FETCH_SIZE + WRITE_SIZE)"
                 step_roof["pmc_source"] = "profiles/r05/c2_b4096_pmc.json at %d packed rows" % int(pm5["packed_rows_mean"])
             except Exception as e:  # noqa: BLE001
                 kernels = [{"error": f"profiles/r05/c2_b4096_pmc.json unreadable: {e}"}]
@@ -933,8 +960,9 @@ def main():
                                  "x6: float32 operands split exactly into three bf16 planes, six plane products per float32 product on "
                                  "v_mfma_f32_32x32x16_bf16") + ", float32 accumulation (fused layer kernel and embed + layer-0 q|k|v); attention "
                                 "and the last layer's rows on float32 MFMAs" if x6 else "float32 MFMAs"),
-               "decoder_layers": ("sequence-resident (irs_set_decoder_seq / IRS_DECODER_SEQ=1): one launch per layer on whole sequences, K / V in LDS"
-                                  if job.eng.decoder_seq else "layer kernel + packed-sequence attention kernel per layer (default)"),
+               "decoder_layers": ("sequence-resident (irs_set_decoder_seq mode %d): layers 0 .. n-2 and the last layer's attention in ONE launch on "
+                                  "whole sequences per workgroup, K / V in LDS, x resident across layers" % job.eng.decoder_seq
+                                  if job.eng.decoder_seq_last else "layer kernel + packed-sequence attention kernel per layer (irs_set_decoder_seq mode %d)" % job.eng.decoder_seq),
                "parallelism": "single GPU" if world == 1 else (
                    f"rows data-parallel + item-sharded x{world}: RCCL all-gather of rows, one all_to_all of packed 64-bit top-100 keys "
                    f"(irs_generate_paths_sharded: collectives below the C ABI, "

@@ -399,10 +399,14 @@ int irs_get_decoder_gemm_effective(const irs_ctx *ctx); /* the mode that runs (I
  * IRS_GEMM_H3 at d = 128, 4 heads, ffn 256, L <= 256, rows-only decodes of a throughput batch run every layer but the last as ONE
  * launch -- q | k | v from x, K / V of a head in LDS, attention, out-projection, feed-forward, layer norms -- on whole sequences
  * per workgroup (k_block_x6<.., SEQ>), instead of a layer kernel + an attention kernel exchanging q | k | v rows through HBM.
- * Same arithmetic as the default kernels (rows within the float16-plane tolerance).  Off by default; environment
- * IRS_DECODER_SEQ=1 at creation or this call. */
-int irs_set_decoder_seq(irs_ctx *ctx, int32_t on);
+ * The launch covers layers 0 .. n - 2 (x stays in registers from layer to layer) and the q | k | v + attention of the last layer
+ * for the consumed token's block: no q | k | v row ever reaches HBM.  Same arithmetic as the default kernels (bit-identical up to
+ * the last layer's attention, rows within 2e-6).  mode: 0 never, 1 whenever the shape allows, 2 (default) from 1024 sequences per
+ * call up, where it measured 4-8 % ahead of the two-kernel path.  Environment IRS_DECODER_SEQ=0 / 1 / auto at creation or this call.
+ * irs_decoder_seq_last: 1 when the last irs_decode took this path. */
+int irs_set_decoder_seq(irs_ctx *ctx, int32_t mode);
 int irs_get_decoder_seq(const irs_ctx *ctx);
+int irs_decoder_seq_last(const irs_ctx *ctx);
 /* (tests / lab) device address of a decoder workspace buffer: 0 x (fragment-major), 1 attention output (fragment-major), 2 / 3 the
  * sequence-resident plan's tile -> sequence / tile index, 4 image row of a sequence, 5 tile-order consumed row, 6 workgroup count,
  * 7 / 8 packed offset / count per sequence, 9 q | k | v rows, 10 packed consumed row.  Null for an unknown index. */

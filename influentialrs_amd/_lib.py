@@ -86,6 +86,7 @@ SIGNATURES = {
     "irs_get_decoder_gemm_effective": (c_int32, [c_void_p]),
     "irs_set_decoder_seq": (c_int32, [c_void_p, c_int32]),
     "irs_get_decoder_seq": (c_int32, [c_void_p]),
+    "irs_decoder_seq_last": (c_int32, [c_void_p]),
     "irs_debug_ptr": (c_void_p, [c_void_p, c_int32]),
     "irs_h3_range_bound": (c_float, [c_void_p]),
     "irs_prof_enable": (c_int32, [c_void_p, c_int32]),

@@ -91,7 +91,7 @@ extern "C" int irs_create(irs_ctx **out, const irs_dims *dims, const irs_shard *
         }
         c->use_attn_h3 = ea ? (strcmp(ea, "h3") == 0) : 1; // (IRS_ATTN_GEMM=f32: float32 K / V rows and the float32-MFMA attention)
         const char *es = getenv("IRS_DECODER_SEQ");
-        c->use_seq = es ? (atoi(es) != 0) : 0;
+        c->use_seq = es ? (strcmp(es, "auto") == 0 ? 2 : (atoi(es) != 0 ? 1 : 0)) : 2;
         const char *er = getenv("IRS_LSE_RING");
         c->lse_no_ring = er ? (strcmp(er, "0") == 0) : 0;
     }
@@ -461,15 +461,17 @@ extern "C" int irs_set_decoder_gemm(irs_ctx *ctx, int32_t mode) {
     return IRS_OK;
 }
 
-extern "C" int irs_set_decoder_seq(irs_ctx *ctx, int32_t on) {
+extern "C" int irs_set_decoder_seq(irs_ctx *ctx, int32_t mode) {
     if (!ctx) return IRS_E_INVALID;
-    if ((ctx->use_seq != 0) != (on != 0)) {
-        ctx->use_seq = on != 0;
+    if (mode < 0 || mode > 2) IRS_FAIL(ctx, IRS_E_INVALID, "decoder seq mode %d (0 off, 1 on, 2 auto)", mode);
+    if (ctx->use_seq != mode) {
+        ctx->use_seq = mode;
         drop_graphs(ctx);
     }
     return IRS_OK;
 }
 extern "C" int irs_get_decoder_seq(const irs_ctx *ctx) { return ctx ? ctx->use_seq : IRS_E_INVALID; }
+extern "C" int irs_decoder_seq_last(const irs_ctx *ctx) { return ctx ? (ctx->seq_last ? 1 : 0) : IRS_E_INVALID; }
 // (lab / tests: device addresses of decoder workspace buffers, so that a test can look at what a decode left behind)
 extern "C" void *irs_debug_ptr(const irs_ctx *ctx, int32_t which) {
     if (!ctx) return nullptr;

@@ -157,6 +157,7 @@ __global__ void __launch_bounds__(256) k_plan_fill(const int64_t *__restrict__ s
 //   row of the consumed token; n_wg[0]: workgroups in use.
 #define SEQ_WG_TILES 8
 #define SEQ_WG_BLOCKS 16
+#define SEQ_AUTO_MIN_SEQS 1024
 #define SEQ_RMAX 48
 __global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ cnt, const int32_t *__restrict__ off,
                                                    const int32_t *__restrict__ qrow, int B, int32_t *__restrict__ order,
@@ -5945,8 +5946,12 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     // the sequence-resident layer kernel (round 5, opt-in: irs_set_decoder_seq / IRS_DECODER_SEQ=1): the throughput shape of
     // config 2 / 3 on float16 planes; layers 0 .. n_layers - 2 are ONE launch each (q | k | v, attention and the layer body; K / V
     // stay in LDS), the rows-only last layer runs as before on the k | v rows the last of them writes
-    const bool seq_mode = ctx->use_seq && rows_only && kv_planes && d == 128 && ctx->dims.n_heads == 4 && L <= 256 && !small_plan && ctx->tile_seq &&
-                          ctx->use_x6 == IRS_GEMM_H3 && ctx->h3_ok;
+    // use_seq: 0 never, 1 whenever the shape allows, 2 (default) where it measured ahead: >= SEQ_AUTO_MIN_SEQS sequences (one
+    // workgroup per CU: below ~4 rounds of workgroups the last, partly filled round costs more than the fusion saves --
+    // profiles/r05/seq_sizes.txt: 6-layer decode 0.98 vs 1.06 ms at 1024 users, 3.83 vs 3.98 at 4096, but 0.89 vs 0.80 at 768)
+    const bool seq_mode = (ctx->use_seq == 1 || (ctx->use_seq == 2 && B >= SEQ_AUTO_MIN_SEQS)) && rows_only && kv_planes && d == 128 &&
+                          ctx->dims.n_heads == 4 && L <= 256 && !small_plan && ctx->tile_seq && ctx->use_x6 == IRS_GEMM_H3 && ctx->h3_ok;
+    ctx->seq_last = seq_mode;
     if (rows_only) {
         const bool plan_in_embed = small_plan && B == 1 && L <= 256 && ctx->dims.n_layers > 1 && (att_fused || any_cfg);
         if (plan_in_embed) {

@@ -88,7 +88,8 @@ struct irs_ctx {
     int use_x6;       // decoder GEMMs of the throughput path on split-bf16 MFMAs (IRS_DECODER_GEMM=x6|f32)
     bool h3_ok;       // finalisation's float16 range bound holds (else IRS_GEMM_H3 runs as IRS_GEMM_X6 and V stays float32)
     float h3_bound;   // the largest operand magnitude the bound weights allow (irs_h3_operand_bound)
-    int use_seq;      // sequence-resident layer kernel for the d = 128 throughput shape (irs_set_decoder_seq / IRS_DECODER_SEQ=1; opt-in)
+    int use_seq;      // sequence-resident decoder for the d = 128 throughput shape: 0 off, 1 on, 2 auto (default: from 1024 sequences up)
+    bool seq_last;    // the last irs_decode took it
     int use_attn_h3;  // throughput attention on split-float16 MFMAs over K / V planes written by the layer kernel (default on; IRS_ATTN_GEMM=f32 off)
     int lse_no_ring;  // IRS_LSE_RING=0: the register-fragment log-sum-exp kernel at <= 32 rows too (A/B measurements, tests)
     bool finalized;

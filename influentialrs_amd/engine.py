@@ -469,13 +469,19 @@ class Engine:
         return self._ws[off:off + nbytes].view(dtype)
 
     @property
-    def decoder_seq(self) -> bool:
-        """Sequence-resident decoder layers (irs_set_decoder_seq, include/irs_hip.h): off by default."""
-        return bool(self.lib.irs_get_decoder_seq(self.h))
+    def decoder_seq(self) -> int:
+        """Sequence-resident decoder (irs_set_decoder_seq, include/irs_hip.h): 0 off, 1 on, 2 auto (default: from 1024 sequences
+        per call up).  The setter takes False / True / None (= auto) or the numbers."""
+        return int(self.lib.irs_get_decoder_seq(self.h))
 
     @decoder_seq.setter
-    def decoder_seq(self, on: bool):
-        self._check(self.lib.irs_set_decoder_seq(self.h, int(bool(on))))
+    def decoder_seq(self, mode):
+        self._check(self.lib.irs_set_decoder_seq(self.h, 2 if mode is None else int(mode)))
+
+    @property
+    def decoder_seq_last(self) -> bool:
+        """True when the last decode took the sequence-resident path."""
+        return bool(self.lib.irs_decoder_seq_last(self.h))
 
     @property
     def h3_range_bound(self) -> float:

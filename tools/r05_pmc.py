@@ -22,9 +22,9 @@ KERNELS = [  # label, regex on the kernel name, algorithmic HBM bytes per packed
     ("embed_qkv0", r"k_block_x6<0, 4, true", 4 * D * 5, "K1: in: embedding row; out: x + layer 0's q | k | v"),
     ("attention", r"k_attn16h<", 4 * D * 4, "in: q | k | v rows; out: attention output (fragment-major)"),
     ("attention_last_row", r"k_attn_row32", 4 * D * 2, "in: k | v rows of every token; out: one row per sequence"),
-    # IRS_DECODER_SEQ=1: the sequence-resident layer kernel (q | k | v + attention + layer body in one launch)
-    ("seq_layer", r"k_block_x6<3, 8, false, 4, 2, true>", 4 * D * 3, "in: x (twice: planes, residual); out: x' (the attention tile goes through L2)"),
-    ("seq_layer_kv_tail", r"k_block_x6<1, 8, false, 4, 2, true>", 4 * D * 5, "the same + the last layer's k | v rows"),
+    # the sequence-resident decoder (irs_set_decoder_seq; default from 1024 sequences up): ONE launch per step
+    ("seq_decoder", r"k_block_x6<3, 8, false, 4, 2, true>", 4 * D * 2, "layers 0 .. n-2 with attention + the last layer's q|k|v and attention: "
+     "in: x (embedded rows); out: x of the last fused layer (attention tiles and x' round trips between the layers are scratch traffic)"),
     ("seq_embed", r"k_embed_seq", 4 * D * 2, "in: embedding row; out: x"),
 ]
 

@@ -29,7 +29,7 @@ if len(sys.argv) > 3:  # every window cut to the same number of tokens (history 
 users = torch.randint(0, cfg.n_user, (B,), device=dev, generator=torch.Generator(device=dev).manual_seed(1))
 pos = torch.full((B,), cfg.max_len - 2, dtype=torch.int32, device=dev)
 out = {}
-for name, on in (("default", False), ("seq", True), ("default", False), ("seq", True)):
+for name, on in (("default", 0), ("seq", 1), ("default", 0), ("seq", 1)):
     eng.decoder_seq = on
     xr = eng.decode(seqs, users, want_x=False, pos=pos)[1].clone()
     torch.cuda.synchronize()
@@ -61,7 +61,7 @@ if nl == 2:
     def frag_rows(buf, rows):  # fragment-major [tile][tn 4][g 4][lk 2][li 32][4] -> [rows][128]
         t = buf[: (rows // 32) * 4096].view(rows // 32, 4, 4, 2, 32, 4)       # tile, tn, g, lk, li, e
         return t.permute(0, 4, 1, 2, 3, 5).reshape(rows, 128)               # row = tile * 32 + li; col = 32 tn + 8 g + 4 lk + e
-    eng.decoder_seq = False
+    eng.decoder_seq = 0
     eng.decode(seqs, users, want_x=False, pos=pos)
     torch.cuda.synchronize()
     off = eng.debug_buffer(7, B, torch.int32).clone().long()
@@ -70,7 +70,7 @@ if nl == 2:
     Mp = (M + 31) // 32 * 32
     x_def = frag_rows(eng.debug_buffer(0, Mp * 128, torch.float32), Mp).clone()
     a_def = frag_rows(eng.debug_buffer(1, Mp * 128, torch.float32), Mp).clone()
-    eng.decoder_seq = True
+    eng.decoder_seq = 1
     eng.decode(seqs, users, want_x=False, pos=pos)
     torch.cuda.synchronize()
     nwg = int(eng.debug_buffer(6, 1, torch.int32)[0])
