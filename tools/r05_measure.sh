@@ -23,7 +23,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_C
 python3 tools/pmc_summary.py /tmp/irs_prof/pmc_sweep3 k_sweep k_select k_refine k_prep > gpurun_out/sweep_pmc_${V}.txt; cat gpurun_out/sweep_pmc_${V}.txt
 # ---- the two-kernel decoder path for comparison (IRS_DECODER_SEQ=0): bench line, kernel trace, the three PMC passes
 export IRS_DECODER_SEQ=0
-timeout -k 10 400 python bench.py --no-scoring --no-c3 --no-c4 --no-latency --no-cpu-baseline > gpurun_out/bench_twokernel_${V}.json 2> gpurun_out/bench_twokernel_${V}.err || { tail -5 gpurun_out/bench_twokernel_${V}.err; exit 1; }
+timeout -k 10 400 python bench.py --no-scoring --no-c4 --no-latency --no-cpu-baseline > gpurun_out/bench_twokernel_${V}.json 2> gpurun_out/bench_twokernel_${V}.err || { tail -5 gpurun_out/bench_twokernel_${V}.err; exit 1; }
 python3 tools/bench_summary.py gpurun_out/bench_twokernel_${V}.json | head -4
 rm -rf /tmp/irs_prof/prof_seq /tmp/irs_prof/pmc_seq_sq /tmp/irs_prof/pmc_seq_fetch /tmp/irs_prof/pmc_seq_write
 rocprofv3 --kernel-trace --stats -d /tmp/irs_prof/prof_seq -- python3 bench.py --pmc-run --steps 5 --warmup 2 > gpurun_out/prof_seq.log 2>&1 || { tail -5 gpurun_out/prof_seq.log; exit 1; }
