@@ -1632,6 +1632,14 @@ __device__ __forceinline__ x6_u32x4 x6_rd_sync(unsigned int base) {
 // one 16-query block of the sequence-resident kernel's attention (defined behind k_attn16h, whose mathematics it shares)
 __device__ __forceinline__ void seq_attn_block(const float *Ks, const char *Vp, int PL, int L, int qb, bool irn, float tgt_add, bool tgt_ok,
                                                int pq, const float *qscr, float4 *of, bool store);
+// k and q of the sequence-resident attention are split into float16 planes as they are.  (Measured, profiles/r05/README.md: planes
+// of 16 k and 16 q -- low planes of elements below 2^-3 are subnormal float16, 2^-25 absolute instead of 2^-22 relative -- change
+// nothing: rows against the two-kernel path max 1.88e-5 / mean 3.98e-7 with the factor, 1.87e-5 / 4.0e-7 without, and four more
+// vector instructions per score tile.)  Range: |k|, |q| < 65504 is the V rows' bound (irs_h3_operand_bound: st[6] covers all of W_in).
+#define SEQ_KQ_SCALE 1.0f
+#ifndef SEQ_ASM_DMA
+#define SEQ_ASM_DMA 1
+#endif
 #ifndef SEQ_EXP
 #define SEQ_EXP 0 // (lab, tools/seq_lab.sh: 1 = no attention compute, 2 = asynchronous tail reads: timing experiments, results wrong)
 #endif
@@ -1645,8 +1653,16 @@ __host__ __device__ constexpr int x6_seq_lds_bytes() { return X6_SEQ_SCR + 8 * X
 // QP0 = 0: the tail computes q | k | v; 1: k | v only (feeding the rows-only last layer); 3 (SEQ): no tail
 #ifdef X6_STAMP
 #define X6_T(v_) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); v_ = t_; }
+#if X6_STAMP + 0 == 2 // (phase stamps only: the per-step stamps cost the sequence-resident form 400 spilled scalar registers)
+#define X6_TI(v_)
+#else
+#define X6_TI(v_) X6_T(v_)
+#endif
+#define X6_PH(i_) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_ph[i_] += t_ - st_prev; st_prev = t_; }
 #else
 #define X6_T(v_)
+#define X6_TI(v_)
+#define X6_PH(i_)
 #endif
 // NW = waves per workgroup (4 or 8), each on its own 32 tokens; the 24 1-KB pieces of a step are fetched 24 / NW per wave
 // EMBED: the kernel in front of layer 0 -- the accumulator tiles are filled with the embedded tokens (k_embed_frag's
@@ -1846,11 +1862,29 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             constexpr int grp = decltype(gc)::value;
             const uint4 *src = dsrc + (size_t)blk * (STEP_B / 16) + grp * PPG * 64;
             char *dst = smem + (i % NSLOT) * STEP_B + (PPW * wave + grp * PPG + PPG / 2) * 1024;
+            if constexpr (SEQ && SEQ_ASM_DMA) {
+                // (the sequence-resident form: the DMA as inline asm.  Behind the builtin the compiler puts s_waitcnt vmcnt(0) in
+                //  front of every LDS access it can see -- the image writes, the attention's reads -- i.e. a refill issued before
+                //  the attention would be WAITED for there; the first version therefore left the v step's refill to the end of the
+                //  head and the next head's first step then waited out the whole DMA latency.  The ring's slots are disjoint from
+                //  everything the compiler reads or writes, and every consumer of a slot sits behind a counted wait + barrier.)
+                const unsigned int m0v = lds0 + (unsigned int)((i % NSLOT) * STEP_B + (PPW * wave + grp * PPG + PPG / 2) * 1024);
+                x6_static_for<0, PPG>([&](auto jc) __attribute__((always_inline)) {
+                    constexpr int off = (decltype(jc)::value - PPG / 2) * 1024;
+                    const uint4 *src_ = src; // (an asm operand does not capture)
+                    const unsigned int m0_ = m0v;
+                    if constexpr (decltype(jc)::value == 0)
+                        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2" :: "v"(src_), "s"(m0_), "n"(off) : "memory", "m0");
+                    else
+                        asm volatile("global_load_lds_dwordx4 %0, off offset:%1" :: "v"(src_), "n"(off) : "memory");
+                });
+            } else {
             x6_static_for<0, PPG>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int off = (decltype(jc)::value - PPG / 2) * 1024;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)dst, 16, off, 0);
             });
+            }
         });
     };
     // accumulators start from the residual x; the attention output tile 0 is requested with it
@@ -2058,24 +2092,26 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     // only make the wait stricter).
 #define X6_PUBLISH(I_)                                                                                                   \
     if ((I_) + 1 < nsteps) {                                                                                             \
-        X6_T(st_a)                                                                                                       \
+        X6_TI(st_a)                                                                                                       \
         if (RESID_LATE && (I_) < 4) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PPW * (LEAD - 2) + NLOAD) : "memory"); /* (one tile set lies between the DMA groups) */ \
         else if (LEAD > 2 && (I_) + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PPW * (LEAD - 2)) : "memory");      \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
-        X6_T(st_b)                                                                                                       \
+        X6_TI(st_b)                                                                                                       \
         __builtin_amdgcn_s_barrier();                                                                                    \
-        X6_T(st_c)                                                                                                       \
-        if ((I_) + LEAD < nsteps && !(SEQ && (I_) < NFRONT && (I_) % 3 == 2)) X6_ISSUE((I_) + LEAD); /* (SEQ: see the front phase) */ \
+        X6_TI(st_c)                                                                                                       \
+        if ((I_) + LEAD < nsteps && !(SEQ && !SEQ_ASM_DMA && (I_) < NFRONT && (I_) % 3 == 2)) X6_ISSUE((I_) + LEAD); /* (SEQ with the builtin DMA: see the front phase) */ \
         if constexpr (RESID_LATE) { if ((I_) == 1) load_res(); }                                                         \
-        X6_T(st_d)                                                                                                       \
+        X6_TI(st_d)                                                                                                       \
         st_wait += st_b - st_a, st_bar += st_c - st_b, st_iss += st_d - st_c;                                            \
+        if (SEQ && (I_) < NFRONT && (I_) % 3 == 0) st_ph[10] += st_c - st_b; /* (the first barrier behind a head's attention) */ \
+        if (SEQ && (I_) == NFRONT) st_ph[11] += st_c - st_b; /* (the first barrier of the layer body) */                 \
     }
 #endif
 #define X6_STEP(I_, SRC, T0, T1, T2, T3)                                                                                \
     {                                                                                                                    \
         const int step_ = (I_);                                                                                          \
         unsigned long long sq_0 = 0, sq_1 = 0;                                                                           \
-        X6_T(sq_0)                                                                                                       \
+        X6_TI(sq_0)                                                                                                       \
         const unsigned int sb_ = fr_addr + (unsigned int)((step_ % NSLOT) * STEP_B);                                     \
         const unsigned int sn_ = fr_addr + (unsigned int)(((step_ + 1) % NSLOT) * STEP_B);                               \
         x6_static_for<0, NP>([&](auto fc_) __attribute__((always_inline)) {                                              \
@@ -2092,7 +2128,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
                 X6_MFMA(af[f_ & RA], NPL - 1 - pl_ - decltype(qc_)::value, T_);                                           \
             });                                                                                                          \
         });                                                                                                              \
-        X6_T(sq_1)                                                                                                       \
+        X6_TI(sq_1)                                                                                                       \
         st_steps += sq_1 - sq_0;                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }
@@ -2241,7 +2277,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     {                                                                                                                    \
         const int step_ = (I_);                                                                                          \
         unsigned long long sq_0 = 0, sq_1 = 0;                                                                           \
-        X6_T(sq_0)                                                                                                       \
+        X6_TI(sq_0)                                                                                                       \
         const unsigned int sb_ = fr_addr + (unsigned int)((step_ % NSLOT) * STEP_B);                                     \
         const unsigned int sn_ = fr_addr + (unsigned int)(((step_ + 1) % NSLOT) * STEP_B);                               \
         f32x16 ts_;                                                                                                      \
@@ -2273,7 +2309,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
         if constexpr (SPLIT_ACC) {                                                                                       \
             _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) T_[r_] += ts_[r_];                                         \
         }                                                                                                                \
-        X6_T(sq_1)                                                                                                       \
+        X6_TI(sq_1)                                                                                                       \
         st_steps += sq_1 - sq_0;                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }
@@ -2289,6 +2325,8 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     }
     float nv[SEQ ? (X6_SEQ_VECS + 64 * NW - 1) / (64 * NW) : 1]; // (SEQ) the next layer's parameter vectors on their way into LDS
     unsigned long long st_q0 = 0, st_q1 = 0, st_qst = 0;
+    unsigned long long st_ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0; // (lab, SEQ) cycles per phase, summed over the layers
+    X6_T(st_prev)
     auto layer_body = [&]() __attribute__((always_inline)) { // (SEQ: once per layer of this launch; otherwise once)
     if constexpr (SEQ) {
         // Launder what every address of the body is computed from: with the layers in a loop the compiler hoists each of the
@@ -2327,7 +2365,8 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             for (int r = 0; r < 16; ++r) tq[r] = 0.f, tk[r] = 0.f, tv[r] = 0.f;
             X6_STEP1(3 * h, Yp, tq)
             X6_STEP1(3 * h + 1, Yp, tk)
-            X6_STEP1(3 * h + 2, Yp, tv) // (no ring refill behind this step: X6_PUBLISH)
+            X6_STEP1(3 * h + 2, Yp, tv) // (builtin DMA: no ring refill behind this step, see X6_PUBLISH)
+            X6_PH(9)
             bias_tile(bt, V_BQ + 32 * h);
             {
 #pragma unroll
@@ -2338,12 +2377,24 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             }
             bias_tile(bt, V_BQ + D + 32 * h);
             if (l_b >= 0) { // (rows [cnt, 16 nb) hold finite values of dead tokens: read with p = 0)
-                const int sw = (s_j & 7) ^ ((s_j >> 3) & 1);
+                // K as two float16 planes (the score products of seq_attn_block): 128 B per key = chunks 0 .. 3 plane h, 4 .. 7
+                // plane l (chunk = 8 channels), chunk index ^ ((key >> 1) & 7): a tile's 16 keys x one chunk = 16 bank groups
+                typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+                const int swk = (s_j >> 1) & 7;
+                char *krow = reinterpret_cast<char *>(Kimg) + irow * 128 + 8 * lk;
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4 *>(Kimg + irow * 32 + (((2 * g + lk) ^ sw) << 2)) =
-                        make_float4(__builtin_fmaf(tk[4 * g + 0], IWS, bt[4 * g + 0]), __builtin_fmaf(tk[4 * g + 1], IWS, bt[4 * g + 1]),
-                                    __builtin_fmaf(tk[4 * g + 2], IWS, bt[4 * g + 2]), __builtin_fmaf(tk[4 * g + 3], IWS, bt[4 * g + 3]));
+                for (int g = 0; g < 4; ++g) {
+                    f16x4 hp, lp;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = __builtin_fmaf(tk[4 * g + e], IWS, bt[4 * g + e]) * SEQ_KQ_SCALE; // (exact)
+                        const _Float16 hv = (_Float16)v;
+                        hp[e] = hv;
+                        lp[e] = (_Float16)(v - (float)hv);
+                    }
+                    *reinterpret_cast<f16x4 *>(krow + ((g ^ swk) << 4)) = hp;
+                    *reinterpret_cast<f16x4 *>(krow + (((4 + g) ^ swk) << 4)) = lp;
+                }
             }
             bias_tile(bt, V_BQ + 2 * D + 32 * h);
             if (l_b >= 0) {
@@ -2365,8 +2416,10 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            X6_PH(0)
             __builtin_amdgcn_s_barrier(); // every wave's rows of head h are in the images
             asm volatile("" ::: "memory");
+            X6_PH(1)
             if (!(SEQ_EXP & 1)) {
 #pragma unroll 1
                 for (int blk = 0; blk < 2; ++blk) {
@@ -2380,7 +2433,8 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             }
             asm volatile("" ::: "memory");
             // (the next head's image writes come three steps -- three workgroup barriers -- later: every wave is past its reads)
-            if (3 * h + 2 + LEAD < nsteps) issue(3 * h + 2 + LEAD); // the refill the v step left out
+            X6_PH(2)
+            if (!SEQ_ASM_DMA && 3 * h + 2 + LEAD < nsteps) issue(3 * h + 2 + LEAD); // (builtin DMA: the refill the v step left out)
         }
         if (last_rt) return; // (the model's last layer goes on, for one row per sequence, in the small-batch kernels)
         // ---- the layer body's inputs: the attention tiles this wave wrote and the residual, as loads the compiler does not see (it
@@ -2415,6 +2469,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
                     for (int e = 0; e < 4; ++e) acc[tn][4 * g + e] = 0.f;
                 }
         }
+        X6_PH(3)
     }
     // ---- out-projection: acc += W_o . ao^T, k tile t, output half oh: step t HT + oh
     if constexpr (!EMBED) {
@@ -2441,6 +2496,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     //  step in AGPRs across them -- copies taken before the data has landed unless the reads are waited for first)
     if constexpr (NT == 8) landed_all();
     X6_T(st_p[1])
+    X6_PH(4)
     if constexpr (!EMBED) {
         using x6_icn = std::integral_constant<int, -1>;
         if constexpr (RESID_LATE) { // the residual has landed once only the two DMA groups issued since are in flight
@@ -2456,6 +2512,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
         if (a.c) layer_norm(x6_icn{}, std::integral_constant<int, V_O + 4 * D>{}, std::integral_constant<int, V_O + 5 * D>{}, x6_icn{});
     }
     X6_T(st_p[2])
+    X6_PH(5)
 
     // ---- feed-forward, one hidden tile (32 units) at a time: FFN-1 step h_ft = W1[32 ft ..] y^T over the whole K = 128
     //      (B operand: y's bf16 planes, split ONCE and kept -- 96 registers -- while acc itself goes on as the residual
@@ -2505,6 +2562,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     }
     if constexpr (NT == 8) landed_all();
     X6_T(st_p[3])
+    X6_PH(6)
     // ---- + b2, LN3 -> x' (fragment-major store), then split ONCE into the plane registers as the QKV tail's B operand
     if constexpr (!EMBED) {
         float sum = 0.f;
@@ -2571,6 +2629,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             __builtin_amdgcn_sched_barrier(0);
         }
     X6_T(st_p[4])
+    X6_PH(7)
     if (SEQ && !last) {
         // ---- the empty step between two layers: publishes the next layer's first step (fetched at mid-step 31), frees step
         // 31's slot for its second one, re-stages the parameter vectors (every wave is past LayerNorm 3: nothing reads the old
@@ -2585,6 +2644,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (visible to the others behind the next step's barrier)
         issue(SEQ_LSTEPS - 1 + LEAD);
         af[0] = x6_rd_sync<0>(fr_addr), af[1] = x6_rd_sync<1024>(fr_addr), af[2] = x6_rd_sync<2048>(fr_addr); // step 0's slot is slot 0
+        X6_PH(8)
         return;
     }
     // ---- the next layer's QKV: passes of d output columns (NT tiles); sequence steps NPRE ..
@@ -2645,14 +2705,19 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     landed_all(); // the reads issued past the last step
 #ifdef X6_STAMP
     X6_T(st_1)
-    if (lane == 0) {
-        unsigned long long *o = a.stamps + (size_t)(blockIdx.x * NW + wave) * 8;
+    if (lane == 0 && a.stamps) {
+        unsigned long long *o = a.stamps + (size_t)(blockIdx.x * NW + wave) * (SEQ ? 24 : 8);
+        if constexpr (SEQ) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) o[8 + i] = st_ph[i];
+        }
         o[0] = st_1 - st_p[0], o[1] = st_wait, o[2] = st_bar, o[3] = st_iss, o[4] = st_steps;
         o[5] = st_0 - st_p[0];                                   // prologue
         o[6] = (st_p[2] - st_p[1]) + (st_p[4] - st_p[3]);         // layer norms + plane splits
         o[7] = st_qst;                                            // q | k | v stores
     }
 #endif
+    (void)st_ph, (void)st_prev;
     (void)st_p, (void)st_q0, (void)st_q1, (void)st_qst;
     (void)st_a, (void)st_b, (void)st_c, (void)st_d, (void)st_wait, (void)st_bar, (void)st_iss, (void)st_0, (void)st_1, (void)st_steps;
 #undef nsteps
@@ -5051,9 +5116,10 @@ __global__ void __launch_bounds__(64 * NW, 3) k_attn16h(const float *__restrict_
 }
 
 // ------------------------------------------------------------------ one query block of the sequence-resident kernel (round 5)
-// k_attn16h's block body (FAST form: a packed sequence, at most one pad below the diagonal; float32 score chain, two-pass softmax
-// with every score tile of the block in registers, O^T += V^T P^T on float16 plane pairs through the transposing LDS read) on
-// images the layer kernel's own waves wrote: Ks = float32 [key][32] chunk-swizzled, Vp = [2 planes][PL bytes] of [key][64 B], both
+// k_attn16h's block body (FAST form: a packed sequence, at most one pad below the diagonal; two-pass softmax with every score
+// tile of the block in registers, O^T += V^T P^T on float16 plane pairs through the transposing LDS read) with the SCORES too on
+// exact float16 plane products (three v_mfma_f32_16x16x32_f16 per tile instead of eight 16x16x4_f32), on images the layer
+// kernel's own waves wrote: Ks = [key][2 planes x 32 float16] chunk-swizzled, Vp = [2 planes][PL bytes] of [key][64 B], both
 // based at the sequence's first row.  The query rows come from the wave's q scratch ([16 rows][36] float32), the normalised
 // output goes to the fragment-major scratch tile (`of` = the tile's float4 base + 16 blk: lane (lq, gq) writes token column lq);
 // query rows beyond the sequence store zeros (the layer body multiplies whole tiles: they must stay finite).
@@ -5081,27 +5147,29 @@ __device__ __forceinline__ void seq_attn_block(const float *Ks, const char *Vp, 
     float qf[8];
     {
         const float4 t0 = *reinterpret_cast<const float4 *>(qscr + lq * 36 + 8 * gq), t1 = *reinterpret_cast<const float4 *>(qscr + lq * 36 + 8 * gq + 4);
-        const float sc = qi < L ? scale : 0.f;
+        const float sc = qi < L ? scale * SEQ_KQ_SCALE : 0.f;
         qf[0] = t0.x * sc, qf[1] = t0.y * sc, qf[2] = t0.z * sc, qf[3] = t0.w * sc;
         qf[4] = t1.x * sc, qf[5] = t1.y * sc, qf[6] = t1.z * sc, qf[7] = t1.w * sc;
     }
     f32x4 sacc[MAXT];
     float mx = -INFINITY;
+    // scores on exact float16 plane products (round 5): K arrives as two planes (the front's epilogue splits each key row
+    // once), q is split here once per block; Kl.qh + Kh.ql + Kh.qh on v_mfma_f32_16x16x32_f16 (the whole head dim in one
+    // instruction: 3 x 16 cycles per tile instead of 8 x 32 on the float32 pipe).  Lane (lq, gq): key 16 kt + lq, channels 8 gq ..
+    x6_f16x8 Q[2];
+    attn_split8h(qf, Q);
+    const char *Kc = reinterpret_cast<const char *>(Ks);
     auto score_tile = [&](int kt, f32x4 &sa) __attribute__((always_inline)) {
         const int key = kt * 16 + lq;
-        const float *kr = Ks + key * HD;
-        const int sw = (key & 7) ^ ((key >> 3) & 1);
-        const float4 k0 = *reinterpret_cast<const float4 *>(kr + (((2 * gq) ^ sw) << 2));
-        const float4 k1 = *reinterpret_cast<const float4 *>(kr + (((2 * gq + 1) ^ sw) << 2));
+        const char *kr = Kc + key * 128;
+        const int sw = (key >> 1) & 7;
+        const x6_f16x8 kh = *reinterpret_cast<const x6_f16x8 *>(kr + ((gq ^ sw) << 4));
+        const x6_f16x8 kl = *reinterpret_cast<const x6_f16x8 *>(kr + (((4 + gq) ^ sw) << 4));
         sa = {0.f, 0.f, 0.f, 0.f};
-        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.x, qf[0], sa, 0, 0, 0);
-        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.y, qf[1], sa, 0, 0, 0);
-        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.z, qf[2], sa, 0, 0, 0);
-        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.w, qf[3], sa, 0, 0, 0);
-        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.x, qf[4], sa, 0, 0, 0);
-        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.y, qf[5], sa, 0, 0, 0);
-        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.z, qf[6], sa, 0, 0, 0);
-        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.w, qf[7], sa, 0, 0, 0);
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, Q[0], sa, 0, 0, 0);
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, Q[1], sa, 0, 0, 0);
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, Q[0], sa, 0, 0, 0);
+        if (SEQ_KQ_SCALE != 1.0f) sa *= 1.0f / (SEQ_KQ_SCALE * SEQ_KQ_SCALE);
     };
     // masked keys of the diagonal tile: beyond the sequence, the IRN target column (added separately), the one pad
     unsigned int pm_diag = 0;
@@ -5158,10 +5226,12 @@ __device__ __forceinline__ void seq_attn_block(const float *Ks, const char *Vp, 
     float vt[8];
     if (tgt_ok) {
         const int jt = L - 1;
-        const float *kr = Ks + jt * HD;
-        const int sw = (jt & 7) ^ ((jt >> 3) & 1);
-        const float4 k0 = *reinterpret_cast<const float4 *>(kr + (((2 * gq) ^ sw) << 2));
-        const float4 k1 = *reinterpret_cast<const float4 *>(kr + (((2 * gq + 1) ^ sw) << 2));
+        const char *kr = Kc + jt * 128;
+        const int sw = (jt >> 1) & 7;
+        const x6_f16x8 th = *reinterpret_cast<const x6_f16x8 *>(kr + ((gq ^ sw) << 4));
+        const x6_f16x8 tl = *reinterpret_cast<const x6_f16x8 *>(kr + (((4 + gq) ^ sw) << 4));
+        const float4 k0 = make_float4((float)th[0] + (float)tl[0], (float)th[1] + (float)tl[1], (float)th[2] + (float)tl[2], (float)th[3] + (float)tl[3]);
+        const float4 k1 = make_float4((float)th[4] + (float)tl[4], (float)th[5] + (float)tl[5], (float)th[6] + (float)tl[6], (float)th[7] + (float)tl[7]);
         float part = qf[0] * k0.x;
         part = __fmaf_rn(qf[1], k0.y, part);
         part = __fmaf_rn(qf[2], k0.z, part);
@@ -5170,7 +5240,7 @@ __device__ __forceinline__ void seq_attn_block(const float *Ks, const char *Vp, 
         part = __fmaf_rn(qf[5], k1.y, part);
         part = __fmaf_rn(qf[6], k1.z, part);
         part = __fmaf_rn(qf[7], k1.w, part);
-        st = quad16_sum(part) + tgt_add;
+        st = quad16_sum(part) * (1.0f / (SEQ_KQ_SCALE * SEQ_KQ_SCALE)) + tgt_add;
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
@@ -5791,7 +5861,8 @@ int irs_launch_h3_range(irs_ctx *ctx, float *stats, hipStream_t s) {
         amax(w.n1_w, d, 2), amax(w.n2_w, d, 2), amax(w.n3_w, d, 2);
         amax(w.n1_b, d, 3), amax(w.n2_b, d, 3), amax(w.n3_b, d, 3);
         rmax(w.l1_w, F, d, 5);
-        rmax(w.sa_in_w + (size_t)2 * d * d, d, d, 6);
+        if (seq_shape(ctx)) rmax(w.sa_in_w, 3 * d, d, 6); // (the sequence-resident attention splits q and k rows too)
+        else rmax(w.sa_in_w + (size_t)2 * d * d, d, d, 6);
         amax(w.sa_out_w, (size_t)d * d, 7), amax(w.l1_w, (size_t)F * d, 7), amax(w.l2_w, (size_t)d * F, 7), amax(w.sa_in_w, (size_t)3 * d * d, 7);
         amax(w.l1_b, F, 7), amax(w.sa_in_b, (size_t)3 * d, 7);
     }
@@ -5804,7 +5875,8 @@ float irs_h3_operand_bound(const irs_ctx *ctx, const float *st) {
     const float a0 = st[0] * sd + st[1];                 // embedded token
     const float ln = sd * st[2] + st[3] + st[4];         // a LayerNorm output (+ c_l)
     const float xin = sd * fmaxf(a0, ln);                // norm of a layer's input row
-    const float v = xin * st[6] + st[7];                 // a V row (and the attention output, a convex combination of V rows)
+    float v = xin * st[6] + st[7];                       // a V row (and the attention output, a convex combination of V rows)
+    if (seq_shape(ctx)) v *= SEQ_KQ_SCALE;               // ... and a q or k row (st[6] then covers all of W_in's rows)
     const float h = sd * ln * st[5] + st[7];             // a hidden activation
     return fmaxf(fmaxf(fmaxf(a0, ln), fmaxf(v, h)), st[7] * x6_wscale(2)); // (the weight planes hold 2^8 x the weights)
 }
@@ -5818,12 +5890,24 @@ static void x6_launch_one(int rows, const BlockX6Args &xa, hipStream_t s) {
     IRS_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(kern, dim3((rows + 32 * NW - 1) / (32 * NW)), dim3(64 * NW), lds, s, xa);
 }
+#ifdef X6_STAMP
+static unsigned long long *g_seq_stamps = nullptr;
+extern "C" void *irs_lab_seq_stamps() { return g_seq_stamps; }
+#endif
 // the sequence-resident form: grid = an upper bound of the plan's workgroups (the kernel reads the count), eight waves, 160 KB of LDS
 static void x6_launch_seq(int wg_cap, const BlockX6Args &xa, hipStream_t s) {
     auto kern = k_block_x6<3, 8, false, 4, 2, true>;
     constexpr int lds = x6_seq_lds_bytes();
     IRS_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#ifdef X6_STAMP
+    BlockX6Args xs = xa; // (lab) 24 counters per wave
+    if (!g_seq_stamps) (void)hipMalloc(&g_seq_stamps, (size_t)8192 * 8 * 24 * 8);
+    (void)hipMemsetAsync(g_seq_stamps, 0, (size_t)8192 * 8 * 24 * 8, s);
+    xs.stamps = g_seq_stamps;
+    hipLaunchKernelGGL(kern, dim3(wg_cap < 8192 ? wg_cap : 8192), dim3(512), lds, s, xs);
+#else
     hipLaunchKernelGGL(kern, dim3(wg_cap), dim3(512), lds, s, xa);
+#endif
 }
 static void x6_launch(int qp0, bool embed, int nt, int npl, int rows, const BlockX6Args &xa, hipStream_t s) {
 #define X6_L(Q_, E_) do {                                                                                                 \

@@ -39,6 +39,16 @@ for name, on in (("default", 0), ("seq", 1), ("default", 0), ("seq", 1)):
     torch.cuda.synchronize()
     print("%-8s %.3f ms per decode of %d users (%d layers)" % (name, (time.perf_counter() - t0) * 100, B, nl), flush=True)
     out[name] = xr
+if os.environ.get("SEQ_PROBE_F32"):  # both against the float32-MFMA kernels (IRS_GEMM_F32, two-kernel path)
+    from influentialrs_amd._lib import IRS_GEMM_F32, IRS_GEMM_H3
+    eng.decoder_seq = 0
+    eng.decoder_gemm = IRS_GEMM_F32
+    ref = eng.decode(seqs, users, want_x=False, pos=pos)[1].clone()
+    eng.decoder_gemm = IRS_GEMM_H3
+    for nm in ("default", "seq"):
+        dd = (out[nm] - ref).abs()
+        print("%-8s vs float32-MFMA kernels: max %.3g  mean %.3g  row-max p50 %.3g p99 %.3g p99.9 %.3g" % (nm, float(dd.max()), float(dd.mean()),
+              float(dd.max(1).values.quantile(0.5)), float(dd.max(1).values.quantile(0.99)), float(dd.max(1).values.quantile(0.999))))
 a, b = out["default"], out["seq"]
 nan_a, nan_b = torch.isnan(a).any(1), torch.isnan(b).any(1)
 print("NaN rows: default %d, seq %d" % (int(nan_a.sum()), int(nan_b.sum())))
