@@ -857,7 +857,10 @@ def main():
         pv_flops = score_flops
         sweep_flops = 2.0 * d_ * Bn * cfg.n_item
         gemm_peak = (PEAK_BF16_TFLOPS / nprod if x6 else PEAK_F32_MATRIX_TFLOPS) * 1e12
-        floor_mfma_ms = (gemm_flops / gemm_peak + score_flops / (PEAK_F32_MATRIX_TFLOPS * 1e12) + pv_flops / (PEAK_BF16_TFLOPS / 3.0 * 1e12)
+        # (the sequence-resident decoder computes its scores as three float16 plane products too: priced on the 16-bit pipe there)
+        seq_ = bool(job.eng.decoder_seq_last)
+        score_peak = (PEAK_BF16_TFLOPS / 3.0 if seq_ else PEAK_F32_MATRIX_TFLOPS) * 1e12
+        floor_mfma_ms = (gemm_flops / gemm_peak + score_flops / score_peak + pv_flops / (PEAK_BF16_TFLOPS / 3.0 * 1e12)
                          + sweep_flops / (PEAK_BF16_TFLOPS * 1e12)) * 1e3
         w_bytes = (nl_ * (4.0 * d_ * d_ + 2.0 * d_ * F_) + L_ * d_) * 4.0
         comp_bytes = tok * d_ * 4.0 + job.eng.n_local * d_ * (2.0 + 4.0 * 100.0 / max(job.eng.n_local, 1)) + w_bytes + Bn * (d_ * 4.0 + 100.0 * 12.0)
@@ -867,24 +870,25 @@ def main():
                                                                        "attention_pv": pv_flops / 1e9, "catalog_sweep": sweep_flops / 1e9},
                      "compulsory_hbm_gb": comp_bytes / 1e9, "floor_ms_mfma": floor_mfma_ms, "floor_ms_hbm": floor_hbm_ms,
                      "ms_per_step": ms_step_, "ms_per_step_over_floor": ms_step_ / max(floor_mfma_ms, floor_hbm_ms),
-                     "pricing": "GEMMs at %s, attention scores at the float32 matrix peak %.1f TFLOP/s, P.V at 2500 / 3, catalog sweep at 2500 TFLOP/s; "
-                                "HBM 8 TB/s" % (("2500 / %d TFLOP/s" % int(nprod)) if x6 else "the float32 matrix peak", PEAK_F32_MATRIX_TFLOPS)}
+                     "pricing": "GEMMs at %s, attention scores at %s, P.V at 2500 / 3, catalog sweep at 2500 TFLOP/s; "
+                                "HBM 8 TB/s" % (("2500 / %d TFLOP/s" % int(nprod)) if x6 else "the float32 matrix peak",
+                                                "2500 / 3 TFLOP/s (three float16 plane products)" if seq_ else "the float32 matrix peak %.1f TFLOP/s" % PEAK_F32_MATRIX_TFLOPS)}
         if job.eng.decoder_seq_last and layer["launches"] > 0:
             # the sequence-resident decoder: ONE launch per step holds layers 0 .. n - 2 AND the attention (and the last layer's
             # q | k | v + attention for the consumed tokens); it is the dominant kernel, and what bounds it is the matrix side --
-            # its arithmetic priced per pipe (GEMMs and P.V on the 16-bit pipe at 3 products per float32 product, attention scores
-            # on the float32 pipe) against its launch time; the bytes it MUST move are the embedded rows in and x of the last fused
+            # its arithmetic priced on the 16-bit pipe at 3 products per float32 product (GEMMs, attention scores, P.V) against its
+            # launch time; the bytes it MUST move are the embedded rows in and x of the last fused
             # layer out (its attention tiles and x' round trips are scratch traffic of this decomposition, counted by `traffic`).
             lt_ms = layer["ms"] / max(layer["launches"], 1)
-            dec_floor_ms = (gemm_flops / gemm_peak + score_flops / (PEAK_F32_MATRIX_TFLOPS * 1e12) + pv_flops / (PEAK_BF16_TFLOPS / 3.0 * 1e12)) * 1e3
+            dec_floor_ms = (gemm_flops / gemm_peak + score_flops / score_peak + pv_flops / (PEAK_BF16_TFLOPS / 3.0 * 1e12)) * 1e3
             alg_b = tok * d_ * 4.0 * 2.0
             roof = {"kernel": "k_block_x6<.., SEQ> (sequence-resident decoder: layers 0 .. n-2 with their attention, and the last layer's "
-                              "q|k|v + attention of the consumed tokens, in ONE launch; split-float16 MFMA GEMMs, float32-MFMA attention scores)",
+                              "q|k|v + attention of the consumed tokens, in ONE launch; GEMMs, attention scores and P.V all on exact split-float16 MFMA products)",
                     "bound": "mfma", "achieved": (gemm_flops + score_flops + pv_flops) / (lt_ms * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS / nprod,
                     "unit": "TFLOP/s", "frac": dec_floor_ms / lt_ms, "frac_mfma": dec_floor_ms / lt_ms,
                     "frac_hbm": alg_b / (lt_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
-                    "peak_basis": "frac = (GEMM flops / (2500 / 3) + attention-score flops / 157.3 + P.V flops / (2500 / 3) TFLOP/s) / launch time: the "
-                                  "fraction of the launch its arithmetic needs at each pipe's dense peak; `achieved` = all float32-equivalent flops / time",
+                    "peak_basis": "frac = (GEMM + attention-score + P.V flops) / (2500 / 3 TFLOP/s) / launch time: every float32 product is three float16 "
+                                  "plane products on the 16-bit dense peak; `achieved` = all float32-equivalent flops / time",
                     "floor_ms": {"mfma": dec_floor_ms, "hbm": alg_b / (PEAK_HBM_GBS * 1e9) * 1e3},
                     "avg_launch_ms": lt_ms, "launches_per_step": layer["launches"] / args.steps,
                     "family_ms_per_step": (roof or {}).get("family_ms_per_step"),

@@ -173,8 +173,9 @@ __global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ c
     if (tid <= C) s_hist[tid] = 0, s_fill[tid] = 0;
     if (tid < C) p_n[tid] = 0;
     if (tid == 0) s_nwg = 0;
-    for (int t = tid; t < 2 * tiles_cap; t += 1024) tile_seq[t] = -1;
-    for (int t = tid; t < (tiles_cap / SEQ_WG_TILES) * (C + 1); t += 1024) wg_members[t] = 0; // [wg][0] = count
+    // (only the member COUNT of every possible workgroup is cleared here, and the unused halves of the workgroups in use are marked
+    //  by the layout pass: clearing both tables whole was 130 rounds of stores by this one workgroup)
+    for (int t = tid; t < tiles_cap / SEQ_WG_TILES; t += 1024) wg_members[t * (C + 1)] = 0; // [wg][0] = count
     __syncthreads();
     auto blocks_of = [&](int b) {
         int nb = (cnt[b] + 15) >> 4;
@@ -277,7 +278,15 @@ __global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ c
     if (tid == 0) n_wg[0] = s_nwg;
     __threadfence_block();
     __syncthreads();
-    // layout inside the workgroups: pairs of the sequences in block-slot order, then the odd blocks two per tile
+    // layout inside the workgroups: pairs of the sequences in block-slot order, then the odd blocks two per tile; the halves
+    // behind them hold nothing
+    for (int w = tid; w < s_nwg && w * SEQ_WG_TILES < tiles_cap; w += 1024) {
+        const int nm = wg_members[w * (C + 1)] < C ? wg_members[w * (C + 1)] : C;
+        int used = 0;
+        for (int m = 0; m < nm; ++m) used += blocks_of(wg_members[w * (C + 1) + 1 + m]);
+        // (pairs fill whole tiles, the odd blocks follow two per tile: the first `used` halves of the workgroup, in order)
+        for (int h = used; h < 2 * SEQ_WG_TILES; ++h) tile_seq[2 * SEQ_WG_TILES * w + h] = -1;
+    }
     for (int b = tid; b < B; b += 1024) {
         const int w = bin_slot[b] / C, p = bin_slot[b] % C, nb = blocks_of(b);
         if (w * SEQ_WG_TILES >= tiles_cap) continue;
@@ -307,40 +316,6 @@ __global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ c
         qrow_tile[b] = 32 * t + 16 * h + (pt & 15);
     }
 }
-// x = item_emb[seq] * sqrt(d) + pe[position] into the fragment-major image in TILE order (k_embed_frag's arithmetic)
-__global__ void __launch_bounds__(256) k_embed_seq(const int64_t *__restrict__ seq, const float *__restrict__ E,
-                                                   const float *__restrict__ pe, float *__restrict__ xf,
-                                                   const int32_t *__restrict__ tok_row, const int32_t *__restrict__ tile_seq,
-                                                   const int32_t *__restrict__ tile_qb, const int32_t *__restrict__ seq_off,
-                                                   const int32_t *__restrict__ seq_cnt, const int32_t *__restrict__ n_wg, int L, int d,
-                                                   float sqrtd, int64_t n_item) {
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5;
-    if (tile >= n_wg[0] * SEQ_WG_TILES) return;
-    const int b = tile_seq[2 * tile + (li >> 4)]; // lanes 0-15 / 16-31: one 16-token block of a sequence each (k_plan_seq)
-    const int j = b >= 0 ? 16 * tile_qb[2 * tile + (li >> 4)] + (li & 15) : 0x3FFFFFFF;
-    const bool live = b >= 0 && j < seq_cnt[b];
-    const int orig = live ? tok_row[seq_off[b] + j] : 0;
-    int64_t id = live ? seq[orig] : 0;
-    if (id < 0) id = 0;
-    if (id > n_item) id = n_item;
-    const float *e = E + id * (int64_t)d;
-    const float *p = pe + (int64_t)(orig % L) * d;
-    float4 *o = reinterpret_cast<float4 *>(xf) + (size_t)tile * 16 * 64 + lane;
-#pragma unroll 4
-    for (int c = 0; c < 16; ++c) { // c = tn * 4 + g
-        const int n = (c >> 2) * 32 + (c & 3) * 8 + 4 * lk;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live) {
-            v.x = __fadd_rn(__fmul_rn(e[n + 0], sqrtd), p[n + 0]);
-            v.y = __fadd_rn(__fmul_rn(e[n + 1], sqrtd), p[n + 1]);
-            v.z = __fadd_rn(__fmul_rn(e[n + 2], sqrtd), p[n + 2]);
-            v.w = __fadd_rn(__fmul_rn(e[n + 3], sqrtd), p[n + 3]);
-        }
-        o[c * 64] = v;
-    }
-}
-
 // Few sequences (the latency path): count, scan and fill in ONE workgroup of 16 waves, together with the
 // personalised impressionability factor r_u (k_pif) and, inside a hipGraph path loop, the hand-over of the step
 // counter -- five launches of ~4.5 us each become one.
@@ -1710,6 +1685,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
     // mirror images of ONE sequence (blocks i and nb - 1 - i: causal attention costs qb + 1 key tiles for block qb, so every
     // wave of a sequence gets nb + 1 of them); the odd middle blocks of two sequences may share a tile (k_plan_seq).
     int sh_b[2] = {-1, -1}, sh_qb[2] = {0, 0}, sh_cnt[2] = {0, 0}, sh_pq[2] = {-1, -1}, sh_row0[2] = {0, 0}, sh_pb[2] = {-1, -1};
+    int sh_off[2] = {0, 0};
     float sh_ru[2] = {0.f, 0.f};
     bool sh_tgt[2] = {false, false};
     if constexpr (SEQ) {
@@ -1723,6 +1699,7 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             if (b_ >= 0) {
                 sh_qb[h] = __builtin_amdgcn_readfirstlane(a.tile_qb[2 * tg_ + h]);
                 const int off_ = __builtin_amdgcn_readfirstlane(a.seq_off[b_]);
+                sh_off[h] = off_;
                 sh_cnt[h] = __builtin_amdgcn_readfirstlane(a.seq_cnt[b_]);
                 sh_pq[h] = __builtin_amdgcn_readfirstlane(a.seq_padq[b_]), sh_row0[h] = __builtin_amdgcn_readfirstlane(a.seq_row0[b_]);
                 sh_ru[h] = irn_ ? a.r_u[b_] : 0.f;
@@ -1903,13 +1880,28 @@ __global__ void __launch_bounds__(64 * NW, (NT == 8 || NW == 8) ? 1 : 2) k_block
             asm volatile("" ::: "memory");
         }
         if constexpr (SEQ) { // x itself: the B operand of this layer's q | k | v steps (split into planes below)
+            // = item_emb[seq] * sqrt(d) + pe[position] of this lane's token (k_embed_frag's arithmetic), gathered here: the
+            // separate embedding launch wrote and this prologue re-read 0.5 GB per C2 step and took 90 us; a workgroup's gather
+            // is a few microseconds of its ~500.  The tile is stored once: layer 0's residual.  Dead lanes hold zeros.
+            const bool live = l_b >= 0 && s_j < (l_h1 ? sh_cnt[1] : sh_cnt[0]);
+            const int orig = live ? a.tok_row[(l_h1 ? sh_off[1] : sh_off[0]) + s_j] : 0;
+            int64_t id = live ? a.seq[orig] : 0;
+            id = id < 0 ? 0 : (id > a.n_item ? a.n_item : id);
+            const float *e_ = a.E + id * (int64_t)D + 4 * lk;
+            const float *p_ = a.pe + (int64_t)(orig % a.L) * D + 4 * lk;
+            float4 *xw = reinterpret_cast<float4 *>(const_cast<float *>(a.Rf)) + fbase;
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 t4 = rfrag[(tn * 4 + g) * 64];
+                    const float4 e4 = *reinterpret_cast<const float4 *>(e_ + tn * 32 + 8 * g), p4 = *reinterpret_cast<const float4 *>(p_ + tn * 32 + 8 * g);
+                    float4 t4 = make_float4(__fadd_rn(__fmul_rn(e4.x, a.sqrtd), p4.x), __fadd_rn(__fmul_rn(e4.y, a.sqrtd), p4.y),
+                                            __fadd_rn(__fmul_rn(e4.z, a.sqrtd), p4.z), __fadd_rn(__fmul_rn(e4.w, a.sqrtd), p4.w));
+                    if (!live) t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    xw[(tn * 4 + g) * 64] = t4;
                     acc[tn][4 * g + 0] = t4.x, acc[tn][4 * g + 1] = t4.y, acc[tn][4 * g + 2] = t4.z, acc[tn][4 * g + 3] = t4.w;
                 }
+            (void)rfrag;
         } else if constexpr (!RESID_LATE) {
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn)
@@ -6063,13 +6055,12 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
         const int nl = ctx->dims.n_layers;
         hipLaunchKernelGGL(k_plan_seq, dim3(1), dim3(1024), 0, s, ctx->seq_cnt, ctx->seq_off, ctx->seq_qrow, B, ctx->seq_order, ctx->seq_bin,
                            ctx->tile_seq, ctx->tile_idx, ctx->seq_row0, ctx->qrow_tile, ctx->n_wg_dev, ctx->seq_wgmem, B * SEQ_WG_TILES);
-        hipLaunchKernelGGL(k_embed_seq, dim3(2 * B), dim3(256), 0, s, seq, ctx->item_emb, ctx->pe, xf, tok, ctx->tile_seq, ctx->tile_idx,
-                           ctx->seq_off, ctx->seq_cnt, ctx->n_wg_dev, L, d, sqrtf((float)d), ctx->dims.n_item);
         {   // layers 0 .. nl - 2 in ONE launch (x resident in registers from layer to layer); the last of them writes the k | v rows
             BlockX6Args xa{};
             xa.Af = yf, xa.Rf = xf, xa.Xf = xf, xa.QKV = ctx->act_qkv, xa.M = rows, xa.m_dev = m_dev, xa.qkv_pass0 = 3;
             xa.seq_qrow = ctx->seq_qrow;
             xa.seq = seq, xa.L = L;
+            xa.E = ctx->item_emb, xa.pe = ctx->pe, xa.tok_row = tok, xa.sqrtd = sqrtf((float)d), xa.n_item = ctx->dims.n_item; // (the embedding is the launch's prologue)
             xa.Wbase = x6_stream(ctx, 2, 0), xa.wstride = (long long)(x6_layer_b(ctx, 2) / 16), xa.n_lay = nl - 1, xa.nl_total = nl;
             xa.vecpack = seq_vecpack(ctx);
             xa.c = ctx->c_l; // (non-null: the second LayerNorm always runs)

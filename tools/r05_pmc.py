@@ -23,9 +23,9 @@ KERNELS = [  # label, regex on the kernel name, algorithmic HBM bytes per packed
     ("attention", r"k_attn16h<", 4 * D * 4, "in: q | k | v rows; out: attention output (fragment-major)"),
     ("attention_last_row", r"k_attn_row32", 4 * D * 2, "in: k | v rows of every token; out: one row per sequence"),
     # the sequence-resident decoder (irs_set_decoder_seq; default from 1024 sequences up): ONE launch per step
-    ("seq_decoder", r"k_block_x6<3, 8, false, 4, 2, true>", 4 * D * 2, "layers 0 .. n-2 with attention + the last layer's q|k|v and attention: "
-     "in: x (embedded rows); out: x of the last fused layer (attention tiles and x' round trips between the layers are scratch traffic)"),
-    ("seq_embed", r"k_embed_seq", 4 * D * 2, "in: embedding row; out: x"),
+    ("seq_decoder", r"k_block_x6<3, 8, false, 4, 2, true>", 4 * D * 2, "embedding + layers 0 .. n-2 with attention + the last layer's q|k|v and attention: "
+     "in: embedding rows; out: x of the last fused layer (attention tiles and x' round trips between the layers are scratch traffic)"),
+    ("seq_plan", r"k_plan_seq\(", 0, "workgroup plan of the sequence-resident launch (one workgroup; no row traffic)"),
 ]
 
 
@@ -92,7 +92,7 @@ def main():
         for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU"):
             if c in m:
                 k[c] = m[c]
-        k["traffic_over_algorithmic"] = k["hbm_bytes_per_launch"] / k["algorithmic_bytes_per_launch"]
+        k["traffic_over_algorithmic"] = k["hbm_bytes_per_launch"] / k["algorithmic_bytes_per_launch"] if bpr else None
         res["kernels"][label] = k
         step_bytes += k["launches_per_step"] * k["hbm_bytes_per_launch"]
         step_alg += k["launches_per_step"] * k["algorithmic_bytes_per_launch"]
