@@ -5143,6 +5143,17 @@ __device__ __forceinline__ void seq_attn_block(const float *Ks, const char *Vp, 
         qf[0] = t0.x * sc, qf[1] = t0.y * sc, qf[2] = t0.z * sc, qf[3] = t0.w * sc;
         qf[4] = t1.x * sc, qf[5] = t1.y * sc, qf[6] = t1.z * sc, qf[7] = t1.w * sc;
     }
+    // The score tiles are consumed behind wave-uniform BRANCHES (does this pair hold the pad?  is the tile the diagonal one?).  The
+    // compiler pads the distance between a matrix instruction and the first vector instruction that reads its result with s_nop --
+    // along the fall-through path; on the TAKEN edge of such a branch a lab form of this function (two passes over the tiles with
+    // the scores recomputed: runtime loops instead of 16 unrolled positions) was left with 2 instructions behind a 16-cycle MFMA.
+    // The hardware does not interlock that: the reader got the register's old contents, the row maximum came out too small, exp2
+    // overflowed -- NaN rows in a third of the three-block sequences (profiles/r05/README.md).  The statement below reads and
+    // "writes" the tiles behind 12 wait states of its own: every path to a consumer is long enough whatever the block layout.
+    // (That two-pass form, for the record: 64 registers fewer, 15 % less code, bit-identical rows; 5 % FASTER on 16-token sequences,
+    //  1.5 - 2.5 % SLOWER on the bench's windows and on 208-token sequences -- a block's time is its vector + matrix instruction
+    //  count at 4 cycles of its SIMD each, two waves sharing the SIMD, and recomputing adds three matrix instructions per tile.)
+#define SEQ_MFMA_LANDED(a_, b_) asm volatile("s_nop 7\n\ts_nop 3" : "+v"(a_), "+v"(b_));
     f32x4 sacc[MAXT];
     float mx = -INFINITY;
     // scores on exact float16 plane products (round 5): K arrives as two planes (the front's epilogue splits each key row
@@ -5199,6 +5210,7 @@ __device__ __forceinline__ void seq_attn_block(const float *Ks, const char *Vp, 
                 if (k1t <= qb) {
                     score_tile(k0t, sacc[k0t]);
                     score_tile(k1t, sacc[k1t]);
+                    SEQ_MFMA_LANDED(sacc[k0t], sacc[k1t])
                     if (kp == pq_pair) {
                         pad_fix(k0t, sacc[k0t]);
                         if (k1t < qb) pad_fix(k1t, sacc[k1t]);
@@ -5208,6 +5220,7 @@ __device__ __forceinline__ void seq_attn_block(const float *Ks, const char *Vp, 
                     else mask_diag(k1t, sacc[k1t]);
                 } else if (k0t == qb) {
                     score_tile(k0t, sacc[k0t]);
+                    SEQ_MFMA_LANDED(sacc[k0t], sacc[k0t])
                     mask_diag(k0t, sacc[k0t]);
                 }
             }
@@ -5310,6 +5323,7 @@ __device__ __forceinline__ void seq_attn_block(const float *Ks, const char *Vp, 
             dst[(2 * ct + (gq >> 1)) * 64] = v;
         }
     }
+#undef SEQ_MFMA_LANDED
 }
 
 // ------------------------------------------------------------------ single-query attention (last layer, rows-only decode)

@@ -33,3 +33,5 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/irs_prof/p
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/irs_prof/pmc_seq_write -- python3 bench.py --pmc-run --steps 5 --warmup 2 > gpurun_out/pmc_seq_write.log 2>&1 || { tail -5 gpurun_out/pmc_seq_write.log; exit 1; }
 python3 tools/r05_pmc.py /tmp/irs_prof/pmc_seq_sq /tmp/irs_prof/pmc_seq_fetch /tmp/irs_prof/pmc_seq_write gpurun_out/pmc_seq_rows.json gpurun_out/c2_b4096_pmc_twokernel_${V}.json || exit 1
 unset IRS_DECODER_SEQ
+# ---- size sweep of the 6-layer decode alone: where the sequence-resident launch overtakes the two-kernel path
+for n in 128 256 384 512 768 1024 1536 2048 4096; do timeout -k 10 120 python tools/seq_probe.py $n 6 2>/dev/null | head -2; done > gpurun_out/seq_sizes_${V}.txt 2>&1; cat gpurun_out/seq_sizes_${V}.txt

@@ -17,6 +17,12 @@ dev = torch.device("cuda:0")
 cfg = synth.make_config("c2")
 eng = make_engine(cfg, synth.irn_state_dict(cfg, 1234), max_rows=B, max_seqs=B)
 seqs = bench.gpu_windows(B, cfg.max_len, cfg.n_item, dev, seed=3)
+if len(sys.argv) > 2:  # every window cut to the same number of tokens (history + target): no imbalance between the waves
+    n = int(sys.argv[2])
+    full = seqs.clone()
+    full[full == 0] = 7
+    col = torch.arange(cfg.max_len, device=dev)[None, :]
+    seqs = torch.where(col >= cfg.max_len - n, full, torch.zeros_like(full))
 users = torch.randint(0, cfg.n_user, (B,), device=dev, generator=torch.Generator(device=dev).manual_seed(1))
 pos = torch.full((B,), cfg.max_len - 2, dtype=torch.int32, device=dev)
 eng.decoder_seq = True
@@ -50,6 +56,9 @@ if st[:, :, 2].sum() > 0:  # (X6_STAMP=1 builds: the per-step stamps too)
     for i, nm in ((1, "all steps: wait for the next step's DMA (vmcnt)"), (2, "all steps: mid-step barrier"), (3, "all steps: DMA issue"),
                   (18, "  of which: first barrier behind a head's attention"), (19, "  of which: first barrier of the layer body")):
         print("  %-72s %6.1f %%   (mean %.0f ticks)" % (nm, 100 * st[:, :, i].mean() / tot.mean(), st[:, :, i].mean()))
+for i, nm in () if st[:, :, 20:24].sum() == 0 else ((20, "  attention blocks: q read + split, score tiles, masks"), (21, "  attention blocks: target column"), (22, "  attention blocks: max, exp, P split, V reads, P.V"),
+              (23, "  attention blocks: normalise + store")):
+    print("  %-72s %6.1f %%   (mean %.0f ticks)" % (nm, 100 * st[:, :, i].mean() / tot.mean(), st[:, :, i].mean()))
 # spread between the workgroups: the launch ends with its slowest workgroup
 wg = tot.max(1)
 print("workgroup life: p5 %.0f  p50 %.0f  p95 %.0f  max %.0f ticks; launch / (sum of workgroup lives / 256 CUs) = imbalance" %
