@@ -400,9 +400,10 @@ int irs_get_decoder_gemm_effective(const irs_ctx *ctx); /* the mode that runs (I
  * launch -- q | k | v from x, K / V of a head in LDS, attention, out-projection, feed-forward, layer norms -- on whole sequences
  * per workgroup (k_block_x6<.., SEQ>), instead of a layer kernel + an attention kernel exchanging q | k | v rows through HBM.
  * The launch covers layers 0 .. n - 2 (x stays in registers from layer to layer) and the q | k | v + attention of the last layer
- * for the consumed token's block: no q | k | v row ever reaches HBM.  Same arithmetic as the default kernels (bit-identical up to
- * the last layer's attention, rows within 2e-6).  mode: 0 never, 1 whenever the shape allows, 2 (default) from 1024 sequences per
- * call up, where it measured 4-8 % ahead of the two-kernel path.  Environment IRS_DECODER_SEQ=0 / 1 / auto at creation or this call.
+ * for the consumed token's block: no q | k | v row ever reaches HBM.  GEMM arithmetic as in the default kernels; attention scores as
+ * three float16 plane products (the default kernels: float32 MFMAs): rows within 2e-5 of theirs, as close to the float32 kernels.
+ * mode: 0 never, 1 whenever the shape allows, 2 (default) from 384 sequences per call up, where it measured 8-12 % ahead of the
+ * two-kernel path.  Environment IRS_DECODER_SEQ=0 / 1 / auto at creation or this call.
  * irs_decoder_seq_last: 1 when the last irs_decode took this path. */
 int irs_set_decoder_seq(irs_ctx *ctx, int32_t mode);
 int irs_get_decoder_seq(const irs_ctx *ctx);

@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256) k_plan_fill(const int64_t *__restrict__ s
 //   row of the consumed token; n_wg[0]: workgroups in use.
 #define SEQ_WG_TILES 8
 #define SEQ_WG_BLOCKS 16
-#define SEQ_AUTO_MIN_SEQS 1024
+#define SEQ_AUTO_MIN_SEQS 384
 #define SEQ_RMAX 48
 __global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ cnt, const int32_t *__restrict__ off,
                                                    const int32_t *__restrict__ qrow, int B, int32_t *__restrict__ order,

@@ -470,7 +470,7 @@ class Engine:
 
     @property
     def decoder_seq(self) -> int:
-        """Sequence-resident decoder (irs_set_decoder_seq, include/irs_hip.h): 0 off, 1 on, 2 auto (default: from 1024 sequences
+        """Sequence-resident decoder (irs_set_decoder_seq, include/irs_hip.h): 0 off, 1 on, 2 auto (default: from 384 sequences
         per call up).  The setter takes False / True / None (= auto) or the numbers."""
         return int(self.lib.irs_get_decoder_seq(self.h))
 

@@ -108,7 +108,7 @@ def main():
             continue
         print(f"{p:20s} x{k['launches_per_step']:.0f}/step  med {k['median_us']:8.1f} us  mfma_busy {100 * k['mfma_busy']:5.1f} %  clk {k['clock_ghz']:.2f} GHz  "
               f"HBM {k['hbm_bytes_per_launch'] / 1e9:.3f} GB vs algorithmic {k['algorithmic_bytes_per_launch'] / 1e9:.3f} GB "
-              f"(x{k['traffic_over_algorithmic']:.2f}) = {k['algorithmic_gbs']:.0f} GB/s of algorithmic bytes ({k['frac_hbm_peak']:.2f} of 8 TB/s)")
+              f"(x{(k['traffic_over_algorithmic'] or 0.0):.2f}) = {k['algorithmic_gbs']:.0f} GB/s of algorithmic bytes ({k['frac_hbm_peak']:.2f} of 8 TB/s)")
     print(f"decoder HBM bytes per step {step_bytes / 1e9:.2f} GB (algorithmic {step_alg / 1e9:.2f} GB), kernel time {step_us / 1e3:.2f} ms")
 
 
