@@ -787,3 +787,61 @@ def test_float16_planes_small_weights(oracle, over):
         ref = oracle.decode(sd, cfg, seqs[b], int(users[b]))[0][L - 2]
         assert np.abs(ref - ra[b].cpu().numpy()).max() < X_TOL_X6, b
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("evaluator", [False, True])
+def test_sequence_resident_decoder_every_length_against_the_two_kernel_path(evaluator):
+    """The sequence-resident launch (k_block_x6<.., SEQ>, irs_set_decoder_seq) on windows of EVERY length 1 .. L (history +
+    target, pre-padded; every 16-token block count, exact multiples of 16 and their neighbours), with the consumed position on an item or on the one pad a packed sequence may hold, IRN and causal (evaluator) masks: the
+    consumed rows against the layer + attention kernel pair on the same batch.  The two paths share their GEMM arithmetic and
+    differ in the attention scores (float16 plane products vs float32 MFMAs): 4e-5 on O(1) rows, the same NaN rows on both sides.
+    (Round 5: a lab form of the attention body produced NaN rows for sequences of three blocks and more through an unpadded
+    matrix-result read; the goldens' 32 users would have caught it, every length does so by construction.)"""
+    cfg = synth.make_config("c2", n_user=0) if evaluator else synth.make_config("c2")
+    L = cfg.max_len
+    reps = 3
+    B = L * reps  # 600 sequences: above the automatic switch as well
+    sd = synth.irn_state_dict(cfg, 23, evaluator=evaluator)
+    eng = make_engine(cfg, sd, evaluator=evaluator, max_rows=B, max_seqs=B)
+    g = np.random.default_rng(20261005)
+    seqs = np.zeros((B, L), dtype=np.int64)
+    pos = np.zeros(B, dtype=np.int32)
+    for b in range(B):
+        n = b % L + 1  # tokens in the window
+        kind = b // L
+        items = g.integers(1, cfg.n_item + 1, size=n)
+        if evaluator:
+            seqs[b, :n] = items  # post-padded (SampleNet windows)
+            pos[b] = n - 1 if kind != 1 else min(n, L - 1)  # kind 1: the consumed position is the first pad behind the items
+        else:
+            # pre-padded, target last.  (An IRN window WITHOUT a target item is outside the reference's domain: its pad rows see no
+            # key at all, PyTorch's 0 x NaN then poisons every row from layer 2 on -- the oracle returns NaN there; the kernels
+            # return finite, unspecified rows.  Not a parity case: kinds 0 and 1 are both "target present" here.)
+            seqs[b, L - n:] = items
+            pos[b] = L - 2 if n > 1 else L - 1
+            if kind == 2 and n < L - 1:
+                pos[b] = L - 1 - n - 1 if L - 1 - n - 1 >= 0 else L - 2  # a pad in front of the history: the one pad of the packed sequence
+    perm = g.permutation(B)
+    seqs, pos = seqs[perm], pos[perm]
+    seq = torch.from_numpy(seqs).cuda()
+    usr = None if evaluator else torch.from_numpy(g.integers(0, cfg.n_user, size=B)).cuda()
+    p = torch.from_numpy(pos).cuda()
+    try:
+        eng.decoder_seq = False
+        ref = eng.decode(seq, usr, want_x=False, pos=p)[1].clone()
+        assert not eng.decoder_seq_last
+        eng.decoder_seq = True
+        got = eng.decode(seq, usr, want_x=False, pos=p)[1].clone()
+        assert eng.decoder_seq_last
+        eng.decoder_seq = None
+        auto = eng.decode(seq, usr, want_x=False, pos=p)[1].clone()
+        # 600 sequences: the automatic mode takes the same launch (and the launch is deterministic)
+        assert eng.decoder_seq_last and torch.equal(torch.nan_to_num(auto, nan=7.0), torch.nan_to_num(got, nan=7.0))
+    finally:
+        eng.decoder_seq = None
+    # (a consumed position with no visible key -- a pad in front of the whole history -- is NaN on both sides, as in the reference)
+    assert torch.equal(torch.isnan(ref), torch.isnan(got))
+    fin = ~torch.isnan(ref)
+    assert fin.all(dim=1).float().mean().item() > 0.6
+    assert (ref - got)[fin].abs().max().item() < X_TOL_X6
