@@ -4417,6 +4417,13 @@ __device__ unsigned long long g_attn_stamp[8 * 65536];
 // form's transposed V^T image cost ~1K cycles of 8-way conflicted ds_write_b32 per wave and fill, its staging loads'
 // issue dominated a fill (39 % of a wave's life, profiles/r03/attn16_lab_stamps.txt), and PMC showed an LDS conflict
 // ratio of 0.47.  Keys in [L, L16) re-read row L - 1 (finite values times p = 0).
+// A score tile is consumed behind wave-uniform branches (pad in this tile? diagonal tile?).  The compiler pads the distance between a
+// matrix instruction and the first vector instruction that reads its result only along the fall-through path; on a taken edge the
+// reader may come too early -- the hardware does not interlock it, and whether it bites depends on how the wave was arbitrated
+// (round 5: NaN rows in a lab form of the sequence-resident attention; the kernels below have the same shape and get the same
+// explicit wait: 12 wait states behind the tile's last matrix instruction, then the tile counts as written here).
+#define ATTN_MFMA_LANDED(a_) asm volatile("s_nop 7\n\ts_nop 3" : "+v"(a_));
+#define ATTN_MFMA_LANDED2(a_, b_) asm volatile("s_nop 7\n\ts_nop 3" : "+v"(a_), "+v"(b_));
 typedef __attribute__((address_space(3))) void attn_lds_void;
 typedef const __attribute__((address_space(1))) void attn_glb_void;
 // NW = waves per workgroup (4).  Measured and not kept (tools/attn_lab, profiles/r04/attn_lab_variants_r04.txt): NW = 8 -- the
@@ -4600,6 +4607,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) k_attn16(const float
             sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.w, qf[7], sa, 0, 0, 0);
         };
         auto mask_tile = [&](int kt, unsigned int pm, f32x4 &sa) {
+            ATTN_MFMA_LANDED(sa)
             if (pm == 0u && kt < qb) { // clean off-diagonal tile: no masking
                 mx = fmaxf(fmaxf(mx, sa[0]), fmaxf(sa[1], fmaxf(sa[2], sa[3])));
             } else {
@@ -4635,6 +4643,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) k_attn16(const float
                 if (k1t <= qb) { // two independent MFMA chains; tile k0t lies below the diagonal
                     score_tile(k0t, sacc[k0t]);
                     score_tile(k1t, sacc[k1t]);
+                    ATTN_MFMA_LANDED2(sacc[k0t], sacc[k1t])
                     if (kp == pq_pair) {
                         pad_fix(k0t, sacc[k0t]);
                         if (k1t < qb) pad_fix(k1t, sacc[k1t]);
@@ -4930,6 +4939,7 @@ __global__ void __launch_bounds__(64 * NW, 3) k_attn16h(const float *__restrict_
             sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.w, qf[7], sa, 0, 0, 0);
         };
         auto mask_tile = [&](int kt, unsigned int pm, f32x4 &sa) __attribute__((always_inline)) {
+            ATTN_MFMA_LANDED(sa)
             if (pm == 0u && kt < qb) {
                 mx = fmaxf(fmaxf(mx, sa[0]), fmaxf(sa[1], fmaxf(sa[2], sa[3])));
             } else {
@@ -4964,6 +4974,7 @@ __global__ void __launch_bounds__(64 * NW, 3) k_attn16h(const float *__restrict_
                         if (k1t <= qb) {
                             score_tile(k0t, sacc[k0t]);
                             score_tile(k1t, sacc[k1t]);
+                            ATTN_MFMA_LANDED2(sacc[k0t], sacc[k1t])
                             if (kp == pq_pair) {
                                 pad_fix(k0t, sacc[k0t]);
                                 if (k1t < qb) pad_fix(k1t, sacc[k1t]);
