@@ -76,9 +76,10 @@ __device__ __forceinline__ bool plan_valid(const int64_t *__restrict__ sq, int t
 }
 
 __global__ void __launch_bounds__(256) k_plan_count(const int64_t *__restrict__ seq, const int32_t *__restrict__ pos, int B,
-                                                    int L, int32_t *__restrict__ cnt) {
+                                                    int L, int32_t *__restrict__ cnt, int32_t *__restrict__ tile_seq) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= B) return;
+    if (tile_seq && lane < 16) tile_seq[16 * b + lane] = -1; // (the sequence-resident plan's table: 16 half tiles per possible workgroup)
     int p = pos[b];
     p = p < 0 ? 0 : (p >= L ? L - 1 : p);
     const int64_t *sq = seq + (int64_t)b * L;
@@ -141,30 +142,47 @@ __global__ void __launch_bounds__(256) k_plan_fill(const int64_t *__restrict__ s
 
 // ------------------------------------------------------------------ plan of the sequence-resident layer kernel (round 5)
 // k_block_x6<.., SEQ> wants every sequence inside ONE workgroup of 8 wave tiles = 16 half tiles of 16 tokens.  A sequence of nb
-// 16-token blocks needs nb half tiles: its mirrored block pairs (i, nb - 1 - i) each fill one tile, and an odd middle block takes
-// ONE half -- which it may share with the middle block of another odd sequence of the workgroup (the first version gave every
-// sequence whole tiles: 0.84 lane efficiency on the bench's windows; in blocks: 0.915, tools/seq_pack_sim.py).  Any set of
-// sequences with <= 16 blocks fits (pairs first, odd blocks two per tile), so the packing is one-dimensional, best fit, largest
-// first, done class by class (nb = 16 .. 1) with the open workgroups kept as pools per free-block count f: the items of a class
-// fill the pools' free blocks smallest f first (a workgroup with f free blocks takes floor(f / nb) of them), the rest opens new
-// workgroups.  Workgroups are created as contiguous id ranges and move between pools a prefix at a time, so a pool is a short
-// list of ranges and item i of a class finds its (workgroup, first block) by arithmetic: every thread places its own items, one
-// thread does the O(pools) bookkeeping between classes (a one-thread walk over 4096 sequences took 1.7 ms).  Then the layout
-// inside each workgroup: a sequence's pairs go to tiles [pairs of the sequences placed before it ..), its odd block to half
-// (odd rank) of the tiles behind all pairs.
-//   tile_seq[2 t + h] / tile_qb[2 t + h]: sequence (-1: none) and block index in lanes 16 h .. 16 h + 15 of grid tile t = 8 wg + wave;
-//   seq_row0[b]: first row of the sequence in its workgroup's K / V images (16 x its first block slot); qrow_tile[b]: tile-order
-//   row of the consumed token; n_wg[0]: workgroups in use.
+// 16-token blocks takes nb CONSECUTIVE half tiles of its workgroup, [slot, slot + nb) (the first version gave every sequence
+// whole tiles: 0.84 lane efficiency on the bench's windows; in blocks: 0.915, tools/seq_pack_sim.py).  Any set of sequences with
+// <= 16 blocks fits, so the packing is one-dimensional, best fit, largest first, done class by class (nb = 16 .. 1) with the
+// open workgroups kept as pools per free-block count f: the items of a class fill the pools' free blocks smallest f first (a
+// workgroup with f free blocks takes floor(f / nb) of them), the rest opens new workgroups.  Workgroups are created as
+// contiguous id ranges and move between pools a prefix at a time, so a pool is a short list of ranges and item i of a class
+// finds its (workgroup, first half tile) by arithmetic: every thread places its own items, one thread does the O(pools)
+// bookkeeping between classes (a one-thread walk over 4096 sequences took 1.7 ms).
+// Which block goes to which of the sequence's half tiles depends on (slot parity, nb) alone (seq_half_of_block): the two halves of
+// a wave tile get MIRRORED blocks (i, nb - 1 - i) -- causal attention costs qb + 1 key tiles for block qb, so every wave of a
+// sequence gets nb + 1 of them -- and the one or two halves left over at an odd start / end get the middle block(s) and share
+// their tile with the neighbouring sequence's.  (The first version laid a workgroup out as "all pairs, then the odd blocks":
+// member lists per workgroup in global memory, a returning atomic per sequence and a pass of dependent loads over them -- 80 us
+// per plan, most of it those round trips.)
+//   tile_seq[2 t + h] / tile_qb[2 t + h]: sequence (-1: none, preset by k_plan_count) and block index in lanes 16 h .. 16 h + 15 of
+//   grid tile t = 8 wg + wave; seq_row0[b]: first row of the sequence in its workgroup's K / V images (16 x slot); qrow_tile[b]:
+//   tile-order row of the consumed token; n_wg[0]: workgroups in use.
 #define SEQ_WG_TILES 8
 #define SEQ_WG_BLOCKS 16
 #define SEQ_AUTO_MIN_SEQS 384
 #define SEQ_RMAX 48
+// half tile (0 .. nb - 1, relative to the sequence's first) of block blk of a sequence of nb blocks starting at an even / odd half
+__host__ __device__ __forceinline__ int seq_half_of_block(bool slot_odd, int nb, int blk) {
+    const int mir = nb - 1 - blk;
+    if (!slot_odd) {
+        if ((nb & 1) && blk == mir) return nb - 1;       // the middle block: the last half, alone
+        return blk < mir ? 2 * blk : 2 * mir + 1;
+    }
+    if (nb & 1) {
+        if (blk == mir) return 0;                         // the middle block: the first half (shares its tile with the neighbour)
+        return blk < mir ? 1 + 2 * blk : 2 + 2 * mir;
+    }
+    if (blk == nb / 2 - 1) return 0;                      // even nb at an odd start: the two middle blocks are the single halves
+    if (blk == nb / 2) return nb - 1;
+    return blk < mir ? 1 + 2 * blk : 2 + 2 * mir;
+}
 __global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ cnt, const int32_t *__restrict__ off,
                                                    const int32_t *__restrict__ qrow, int B, int32_t *__restrict__ order,
-                                                   int32_t *__restrict__ bin_slot, int32_t *__restrict__ tile_seq,
-                                                   int32_t *__restrict__ tile_qb, int32_t *__restrict__ seq_row0,
-                                                   int32_t *__restrict__ qrow_tile, int32_t *__restrict__ n_wg,
-                                                   int32_t *__restrict__ wg_members, int tiles_cap) {
+                                                   int32_t *__restrict__ tile_seq, int32_t *__restrict__ tile_qb,
+                                                   int32_t *__restrict__ seq_row0, int32_t *__restrict__ qrow_tile,
+                                                   int32_t *__restrict__ n_wg, int tiles_cap) {
     constexpr int C = SEQ_WG_BLOCKS;
     __shared__ int s_hist[C + 1], s_start[C + 2], s_fill[C + 1];
     __shared__ int p_n[C], p_s[C][SEQ_RMAX], p_l[C][SEQ_RMAX]; // pool f = 1 .. 15: ranges of workgroup ids with f free blocks
@@ -173,9 +191,6 @@ __global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ c
     if (tid <= C) s_hist[tid] = 0, s_fill[tid] = 0;
     if (tid < C) p_n[tid] = 0;
     if (tid == 0) s_nwg = 0;
-    // (only the member COUNT of every possible workgroup is cleared here, and the unused halves of the workgroups in use are marked
-    //  by the layout pass: clearing both tables whole was 130 rounds of stores by this one workgroup)
-    for (int t = tid; t < tiles_cap / SEQ_WG_TILES; t += 1024) wg_members[t * (C + 1)] = 0; // [wg][0] = count
     __syncthreads();
     auto blocks_of = [&](int b) {
         int nb = (cnt[b] + 15) >> 4;
@@ -252,11 +267,18 @@ __global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ c
                 w = c_newbase + j_ / qnew;
                 slot = (j_ % qnew) * T;
             }
-            bin_slot[b] = w * C + slot;
-            if (w * SEQ_WG_TILES < tiles_cap) { // the workgroup's member list (for the layout pass)
-                const int m = atomicAdd(&wg_members[w * (C + 1)], 1);
-                if (m < C) wg_members[w * (C + 1) + 1 + m] = b;
+            if (w * SEQ_WG_TILES >= tiles_cap) continue; // (cannot happen: at most one workgroup per sequence)
+            // the sequence's T blocks onto the half tiles [slot, slot + T) of workgroup w
+            const int h0 = 2 * SEQ_WG_TILES * w + slot;
+            for (int blk = 0; blk < T; ++blk) {
+                const int h = h0 + seq_half_of_block(slot & 1, T, blk);
+                tile_seq[h] = b, tile_qb[h] = blk;
             }
+            seq_row0[b] = 16 * slot;
+            const int pt = qrow[b] - off[b];
+            int pb = pt >> 4; // the consumed token: block pb
+            pb = pb < 0 ? 0 : (pb >= T ? T - 1 : pb);
+            qrow_tile[b] = 16 * (h0 + seq_half_of_block(slot & 1, T, pb)) + (pt & 15);
         }
         __syncthreads();
         if (tid == 0) {
@@ -276,46 +298,8 @@ __global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ c
         __syncthreads();
     }
     if (tid == 0) n_wg[0] = s_nwg;
-    __threadfence_block();
-    __syncthreads();
-    // layout inside the workgroups: pairs of the sequences in block-slot order, then the odd blocks two per tile; the halves
-    // behind them hold nothing
-    for (int w = tid; w < s_nwg && w * SEQ_WG_TILES < tiles_cap; w += 1024) {
-        const int nm = wg_members[w * (C + 1)] < C ? wg_members[w * (C + 1)] : C;
-        int used = 0;
-        for (int m = 0; m < nm; ++m) used += blocks_of(wg_members[w * (C + 1) + 1 + m]);
-        // (pairs fill whole tiles, the odd blocks follow two per tile: the first `used` halves of the workgroup, in order)
-        for (int h = used; h < 2 * SEQ_WG_TILES; ++h) tile_seq[2 * SEQ_WG_TILES * w + h] = -1;
-    }
-    for (int b = tid; b < B; b += 1024) {
-        const int w = bin_slot[b] / C, p = bin_slot[b] % C, nb = blocks_of(b);
-        if (w * SEQ_WG_TILES >= tiles_cap) continue;
-        const int nm = wg_members[w * (C + 1)] < C ? wg_members[w * (C + 1)] : C;
-        int pairs_before = 0, odd_rank = 0, pairs_total = 0;
-        for (int m = 0; m < nm; ++m) {
-            const int o = wg_members[w * (C + 1) + 1 + m], po = bin_slot[o] % C, nbo = blocks_of(o);
-            pairs_total += nbo >> 1;
-            if (po < p) pairs_before += nbo >> 1, odd_rank += nbo & 1;
-        }
-        const int t0 = w * SEQ_WG_TILES;
-        for (int i = 0; i < (nb >> 1); ++i) {
-            const int t = t0 + pairs_before + i;
-            tile_seq[2 * t] = b, tile_qb[2 * t] = i;
-            tile_seq[2 * t + 1] = b, tile_qb[2 * t + 1] = nb - 1 - i;
-        }
-        if (nb & 1) {
-            const int t = t0 + pairs_total + (odd_rank >> 1);
-            tile_seq[2 * t + (odd_rank & 1)] = b, tile_qb[2 * t + (odd_rank & 1)] = nb >> 1;
-        }
-        seq_row0[b] = 16 * p;
-        const int pt = qrow[b] - off[b], pb = pt >> 4; // the consumed token: block pb
-        int t, h;
-        if ((nb & 1) && pb == (nb >> 1)) t = t0 + pairs_total + (odd_rank >> 1), h = odd_rank & 1;
-        else if (pb < nb - 1 - pb) t = t0 + pairs_before + pb, h = 0;
-        else t = t0 + pairs_before + (nb - 1 - pb), h = 1;
-        qrow_tile[b] = 32 * t + 16 * h + (pt & 15);
-    }
 }
+
 // Few sequences (the latency path): count, scan and fill in ONE workgroup of 16 waves, together with the
 // personalised impressionability factor r_u (k_pif) and, inside a hipGraph path loop, the hand-over of the step
 // counter -- five launches of ~4.5 us each become one.
@@ -6063,7 +6047,7 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
                                ctx->tok_row, ctx->seq_padq, ctx->m_dev, user, pif ? ctx->user_emb : nullptr, ctx->um_w, ctx->um_b,
                                ctx->act_ru, ctx->dims.u_dim, ctx->dims.n_user, ctx->step_pair);
         } else {
-            hipLaunchKernelGGL(k_plan_count, dim3((B + 3) / 4), dim3(256), 0, s, seq, pos, B, L, ctx->seq_cnt);
+            hipLaunchKernelGGL(k_plan_count, dim3((B + 3) / 4), dim3(256), 0, s, seq, pos, B, L, ctx->seq_cnt, ctx->tile_seq);
             hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, s, ctx->seq_cnt, B, ctx->seq_off, ctx->m_dev);
             hipLaunchKernelGGL(k_plan_fill, dim3((B + 3) / 4), dim3(256), 0, s, seq, pos, B, L, ctx->seq_off, ctx->seq_qrow,
                                ctx->tok_row, ctx->seq_padq);
@@ -6078,8 +6062,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     int l_begin = 0;
     if (seq_mode) {
         const int nl = ctx->dims.n_layers;
-        hipLaunchKernelGGL(k_plan_seq, dim3(1), dim3(1024), 0, s, ctx->seq_cnt, ctx->seq_off, ctx->seq_qrow, B, ctx->seq_order, ctx->seq_bin,
-                           ctx->tile_seq, ctx->tile_idx, ctx->seq_row0, ctx->qrow_tile, ctx->n_wg_dev, ctx->seq_wgmem, B * SEQ_WG_TILES);
+        hipLaunchKernelGGL(k_plan_seq, dim3(1), dim3(1024), 0, s, ctx->seq_cnt, ctx->seq_off, ctx->seq_qrow, B, ctx->seq_order, ctx->tile_seq,
+                           ctx->tile_idx, ctx->seq_row0, ctx->qrow_tile, ctx->n_wg_dev, B * SEQ_WG_TILES);
         {   // layers 0 .. nl - 2 in ONE launch (x resident in registers from layer to layer); the last of them writes the k | v rows
             BlockX6Args xa{};
             xa.Af = yf, xa.Rf = xf, xa.Xf = xf, xa.QKV = ctx->act_qkv, xa.M = rows, xa.m_dev = m_dev, xa.qkv_pass0 = 3;

@@ -109,9 +109,8 @@ struct irs_ctx {
     int32_t *m_dev;    // [1] number of packed rows
     // plan of the sequence-resident layer kernel (decoder.hip: k_plan_seq; null unless the shape supports it)
     int32_t *tile_seq, *tile_idx;   // [16 max_seqs] grid half tile -> sequence (-1: none), its block index
-    int32_t *seq_wgmem;             // [max_seqs][17] members of a workgroup (count first): the plan's layout pass
     int32_t *seq_row0, *qrow_tile;  // [max_seqs] first K / V image row in its workgroup; tile-order row of the consumed token
-    int32_t *seq_order, *seq_bin;   // [max_seqs], [2 max_seqs] scratch of the plan (sorted order; workgroup slot + stack links)
+    int32_t *seq_order;             // [max_seqs] scratch of the plan (sequences sorted by block count)
     int32_t *n_wg_dev;              // [1] workgroups in use
     // scoring
     uint4 *xb;          // packed bf16 rows [m_pad/32][KS][64] x 16 B

@@ -183,3 +183,40 @@ def test_attention_block_deal_closed_form_equals_the_greedy_longest_first_rule()
 
     for nb in range(1, 17):
         assert greedy(nb) == [closed(nb, w) for w in range(4)], nb
+
+
+def test_sequence_resident_plan_half_tile_layout_is_a_mirrored_bijection():
+    """k_plan_seq lays a sequence of nb 16-token blocks onto nb consecutive half tiles [slot, slot + nb) of its workgroup by a
+    closed form of (slot parity, nb) alone (seq_half_of_block, csrc/decoder.hip; restated here): every block gets exactly one half;
+    the two halves of a whole wave tile hold MIRRORED blocks (i, nb - 1 - i), so each such wave gets nb + 1 key tiles of causal
+    attention; the one or two halves left over at an odd start / end hold the middle block(s)."""
+    def half_of_block(slot_odd, nb, blk):
+        mir = nb - 1 - blk
+        if not slot_odd:
+            if (nb & 1) and blk == mir:
+                return nb - 1
+            return 2 * blk if blk < mir else 2 * mir + 1
+        if nb & 1:
+            if blk == mir:
+                return 0
+            return 1 + 2 * blk if blk < mir else 2 + 2 * mir
+        if blk == nb // 2 - 1:
+            return 0
+        if blk == nb // 2:
+            return nb - 1
+        return 1 + 2 * blk if blk < mir else 2 + 2 * mir
+
+    for slot in range(0, 16):
+        for nb in range(1, 17 - slot):
+            halves = [half_of_block(slot & 1, nb, b) for b in range(nb)]
+            assert sorted(halves) == list(range(nb)), (slot, nb, halves)
+            block_at = {slot + h: b for b, h in enumerate(halves)}
+            singles = []
+            for t in range(8):
+                pair = [block_at.get(2 * t), block_at.get(2 * t + 1)]
+                if pair[0] is not None and pair[1] is not None:
+                    assert pair[0] + pair[1] == nb - 1, (slot, nb, t, pair)   # mirrored: qb + 1 key tiles each -> nb + 1 per wave
+                elif pair[0] is not None or pair[1] is not None:
+                    singles.append(pair[0] if pair[0] is not None else pair[1])
+            # what is left over at an odd start / end are the middle blocks (about half the attention work of a whole tile each)
+            assert len(singles) <= 2 and all(abs(2 * b - (nb - 1)) <= 1 for b in singles), (slot, nb, singles)
