@@ -4776,7 +4776,12 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) k_attn16(const float
 // stay on the exact float32 chain (v_mfma_f32_16x16x4_f32 on a float32 K image, as in k_attn16): an error in a score is
 // exponentiated, and a first form with K and q on float16 planes as well -- 26-37 % faster in the lab -- was 1e-3 off on rows
 // whose logits are large (layer 0 of the synthetic models: |q||k| ~ 2000, so 2^-22 |q||k| is 5e-4 in the exponent); an error
-// in p or V is not amplified.  What made the bf16 form of round 3 (k_attn16x) lose is gone:
+// in p or V is not amplified.  (Round 5 measured the three-product float16 form of the scores here again, K planes written by the
+// layer kernel's tail like V: the 6-layer decode of 4096 users 1.5 % faster only -- at three workgroups per CU this kernel is
+// bound by vector-instruction issue, not by the matrix pipe -- with the rows' maximum distance to the float32-MFMA kernels 8.3e-5
+// instead of 2.7e-5 and 2.7e-4 on a full decode's last-layer rows (test_throughput_shape_decode_matches_small_batches_and_oracle):
+// not kept.  The sequence-resident kernel, whose attention phase WAS matrix-pipe heavy at two waves per SIMD, keeps it: -9 %.)
+// What made the bf16 form of round 3 (k_attn16x) lose is gone:
 //   * V arrives ALREADY SPLIT: the layer kernel's q | k | v tail (k_block_x6, kv_planes) writes each (token, head) V
 //     row as [32 f16 h | 32 f16 l] -- the same 128 bytes as 32 floats -- so the fill is pure LDS-DMA (16 key rows x 64 B of
 //     one plane per instruction, chunks swizzled on the source side) and costs no vector instruction;
