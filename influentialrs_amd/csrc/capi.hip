@@ -268,7 +268,7 @@ extern "C" int irs_finalize_weights(irs_ctx *ctx, void *arena, size_t bytes, voi
 // ------------------------------------------------------------------ workspace
 struct ws_plan {
     size_t x, y, xf, yf, qkv, qkv_b1, ao, h, ru, xb, eps, thr, gm, cnt, cand, lse, ref, xrows, tval, tids, status, step, pos;
-    size_t bseq[2], bhep[2], bcum[2], bpaths[2], buser, lmax, lsum, tokrow, scnt, soff, sqrow, spadq, mdev, tseq, tidx, srow0, qtile, sorder, nwg, xlocal, ksend, krecv, gmax, fbcount, fblist, exhkeys, total;
+    size_t bseq[2], bhep[2], bcum[2], bpaths[2], buser, lmax, lsum, tokrow, scnt, soff, sqrow, spadq, mdev, tseq, tidx, srow0, qtile, nwg, xlocal, ksend, krecv, gmax, fbcount, fblist, exhkeys, total;
 };
 
 static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
@@ -332,7 +332,6 @@ static void workspace_plan(const irs_ctx *ctx, ws_plan *p) {
     p->tidx = seq_shape ? take((size_t)ctx->max_seqs * 16 * 4) : 0;
     p->srow0 = seq_shape ? take((size_t)ctx->max_seqs * 4) : 0;
     p->qtile = seq_shape ? take((size_t)ctx->max_seqs * 4) : 0;
-    p->sorder = seq_shape ? take((size_t)ctx->max_seqs * 4) : 0;
     p->nwg = seq_shape ? take(256) : 0;
     p->xlocal = take((size_t)ctx->max_seqs * D.d * 4);
     p->ksend = take((size_t)ctx->max_rows * D.max_k * 8); // exchange buffers of the item-sharded loops (comm.hip)
@@ -406,7 +405,6 @@ extern "C" int irs_bind_workspace(irs_ctx *ctx, void *ws, size_t bytes) {
         ctx->tile_idx = seq_shape ? (int32_t *)(b + p.tidx) : nullptr;
         ctx->seq_row0 = seq_shape ? (int32_t *)(b + p.srow0) : nullptr;
         ctx->qrow_tile = seq_shape ? (int32_t *)(b + p.qtile) : nullptr;
-        ctx->seq_order = seq_shape ? (int32_t *)(b + p.sorder) : nullptr;
         ctx->n_wg_dev = seq_shape ? (int32_t *)(b + p.nwg) : nullptr;
     }
     ctx->x_local = (float *)(b + p.xlocal);

@@ -178,25 +178,39 @@ __host__ __device__ __forceinline__ int seq_half_of_block(bool slot_odd, int nb,
     if (blk == nb / 2) return nb - 1;
     return blk < mir ? 1 + 2 * blk : 2 + 2 * mir;
 }
+#define SEQ_PLAN_PER_THREAD 8 // x 1024: the sequences the plan kernel's LDS tables hold (the launch takes up to 8192 sequences)
 __global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ cnt, const int32_t *__restrict__ off,
-                                                   const int32_t *__restrict__ qrow, int B, int32_t *__restrict__ order,
-                                                   int32_t *__restrict__ tile_seq, int32_t *__restrict__ tile_qb,
-                                                   int32_t *__restrict__ seq_row0, int32_t *__restrict__ qrow_tile,
-                                                   int32_t *__restrict__ n_wg, int tiles_cap) {
-    constexpr int C = SEQ_WG_BLOCKS;
-    __shared__ int s_hist[C + 1], s_start[C + 2], s_fill[C + 1];
+                                                   const int32_t *__restrict__ qrow, int B, int32_t *__restrict__ tile_seq,
+                                                   int32_t *__restrict__ tile_qb, int32_t *__restrict__ seq_row0,
+                                                   int32_t *__restrict__ qrow_tile, int32_t *__restrict__ n_wg, int tiles_cap) {
+    constexpr int C = SEQ_WG_BLOCKS, PT = SEQ_PLAN_PER_THREAD;
+    __shared__ int s_hist[C + 1], s_start[C + 2];
     __shared__ int p_n[C], p_s[C][SEQ_RMAX], p_l[C][SEQ_RMAX]; // pool f = 1 .. 15: ranges of workgroup ids with f free blocks
     __shared__ int c_cum[C + 1], c_q[C], c_exist, c_newbase, s_nwg;
+    // the sequences sorted by block count (largest first) and each one's consumed token, in LDS: the class loop below loads nothing
+    // from memory (the first version re-read a sorted index array and three per-sequence values there: a round trip per class)
+    __shared__ unsigned short s_order[1024 * PT], s_pt[1024 * PT];
     const int tid = threadIdx.x;
-    if (tid <= C) s_hist[tid] = 0, s_fill[tid] = 0;
+    if (tid <= C) s_hist[tid] = 0;
     if (tid < C) p_n[tid] = 0;
     if (tid == 0) s_nwg = 0;
     __syncthreads();
-    auto blocks_of = [&](int b) {
-        int nb = (cnt[b] + 15) >> 4;
-        return nb < 1 ? 1 : (nb > C ? C : nb);
-    };
-    for (int b = tid; b < B; b += 1024) atomicAdd(&s_hist[blocks_of(b)], 1);
+    int my_T[PT], my_rk[PT];
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const int b = tid + 1024 * j;
+        my_T[j] = 0, my_rk[j] = 0;
+        if (b < B) {
+            int nb = (cnt[b] + 15) >> 4;
+            nb = nb < 1 ? 1 : (nb > C ? C : nb);
+            my_T[j] = nb;
+            int pt = qrow[b] - off[b];
+            s_pt[b] = (unsigned short)(pt < 0 ? 0 : (pt > 65535 ? 65535 : pt));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PT; ++j)
+        if (my_T[j]) my_rk[j] = atomicAdd(&s_hist[my_T[j]], 1); // rank inside the class: the order of arrival (any order packs equally well)
     __syncthreads();
     if (tid == 0) {
         int run = 0;
@@ -206,10 +220,9 @@ __global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ c
         }
     }
     __syncthreads();
-    for (int b = tid; b < B; b += 1024) {
-        const int T = blocks_of(b);
-        order[s_start[T] + atomicAdd(&s_fill[T], 1)] = b;
-    }
+#pragma unroll
+    for (int j = 0; j < PT; ++j)
+        if (my_T[j]) s_order[s_start[my_T[j]] + my_rk[j]] = (unsigned short)(tid + 1024 * j);
     __syncthreads();
     auto pool_bins = [&](int f) {
         int n = 0;
@@ -233,8 +246,8 @@ __global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ c
             if (p_l[f][r] > 0) p_s[f][w] = p_s[f][r], p_l[f][w] = p_l[f][r], ++w;
         p_n[f] = w;
     };
-    for (int T = C; T >= 1; --T) {
-        const int n = s_hist[T], base = s_start[T], qnew = C / T;
+    for (int T = C; T >= 1; --T) { // largest first
+        const int n = s_hist[T], qnew = C / T;
         if (n == 0) continue; // (uniform: s_hist is shared)
         if (tid == 0) {
             int tot = 0;
@@ -248,9 +261,9 @@ __global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ c
             s_nwg += (n - c_exist + qnew - 1) / qnew;
         }
         __syncthreads();
-        const int exist = c_exist;
+        const int exist = c_exist, base = s_start[T];
         for (int i = tid; i < n; i += 1024) {
-            const int b = order[base + i];
+            const int b = s_order[base + i];
             int w, slot;
             if (i < exist) {
                 int f = T;
@@ -275,7 +288,7 @@ __global__ void __launch_bounds__(1024) k_plan_seq(const int32_t *__restrict__ c
                 tile_seq[h] = b, tile_qb[h] = blk;
             }
             seq_row0[b] = 16 * slot;
-            const int pt = qrow[b] - off[b];
+            const int pt = s_pt[b];
             int pb = pt >> 4; // the consumed token: block pb
             pb = pb < 0 ? 0 : (pb >= T ? T - 1 : pb);
             qrow_tile[b] = 16 * (h0 + seq_half_of_block(slot & 1, T, pb)) + (pt & 15);
@@ -6040,7 +6053,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     // workgroup per CU: below ~4 rounds of workgroups the last, partly filled round costs more than the fusion saves --
     // profiles/r05/seq_sizes.txt: 6-layer decode 0.98 vs 1.06 ms at 1024 users, 3.83 vs 3.98 at 4096, but 0.89 vs 0.80 at 768)
     const bool seq_mode = (ctx->use_seq == 1 || (ctx->use_seq == 2 && B >= SEQ_AUTO_MIN_SEQS)) && rows_only && kv_planes && d == 128 &&
-                          ctx->dims.n_heads == 4 && L <= 256 && !small_plan && ctx->tile_seq && ctx->use_x6 == IRS_GEMM_H3 && ctx->h3_ok;
+                          ctx->dims.n_heads == 4 && L <= 256 && !small_plan && ctx->tile_seq && ctx->use_x6 == IRS_GEMM_H3 && ctx->h3_ok &&
+                          B <= 1024 * SEQ_PLAN_PER_THREAD;
     ctx->seq_last = seq_mode;
     if (rows_only) {
         const bool plan_in_embed = small_plan && B == 1 && L <= 256 && ctx->dims.n_layers > 1 && (att_fused || any_cfg);
@@ -6067,8 +6081,8 @@ int irs_launch_decode(irs_ctx *ctx, const int64_t *seq, const int64_t *user, int
     int l_begin = 0;
     if (seq_mode) {
         const int nl = ctx->dims.n_layers;
-        hipLaunchKernelGGL(k_plan_seq, dim3(1), dim3(1024), 0, s, ctx->seq_cnt, ctx->seq_off, ctx->seq_qrow, B, ctx->seq_order, ctx->tile_seq,
-                           ctx->tile_idx, ctx->seq_row0, ctx->qrow_tile, ctx->n_wg_dev, B * SEQ_WG_TILES);
+        hipLaunchKernelGGL(k_plan_seq, dim3(1), dim3(1024), 0, s, ctx->seq_cnt, ctx->seq_off, ctx->seq_qrow, B, ctx->tile_seq, ctx->tile_idx,
+                           ctx->seq_row0, ctx->qrow_tile, ctx->n_wg_dev, B * SEQ_WG_TILES);
         {   // layers 0 .. nl - 2 in ONE launch (x resident in registers from layer to layer); the last of them writes the k | v rows
             BlockX6Args xa{};
             xa.Af = yf, xa.Rf = xf, xa.Xf = xf, xa.QKV = ctx->act_qkv, xa.M = rows, xa.m_dev = m_dev, xa.qkv_pass0 = 3;

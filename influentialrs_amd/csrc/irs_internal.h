@@ -110,7 +110,6 @@ struct irs_ctx {
     // plan of the sequence-resident layer kernel (decoder.hip: k_plan_seq; null unless the shape supports it)
     int32_t *tile_seq, *tile_idx;   // [16 max_seqs] grid half tile -> sequence (-1: none), its block index
     int32_t *seq_row0, *qrow_tile;  // [max_seqs] first K / V image row in its workgroup; tile-order row of the consumed token
-    int32_t *seq_order;             // [max_seqs] scratch of the plan (sequences sorted by block count)
     int32_t *n_wg_dev;              // [1] workgroups in use
     // scoring
     uint4 *xb;          // packed bf16 rows [m_pad/32][KS][64] x 16 B
