@@ -359,6 +359,14 @@ int irs_beam_search_sharded(irs_ctx *ctx, irs_comm *comm, const int64_t *dev_seq
                             int32_t split_decode, int32_t use_graph, float *dev_paths, double *dev_scores,
                             int64_t *dev_seq_final, int32_t *dev_status, void *stream);
 
+/* Opt-in overlap of irs_generate_paths_sharded's collectives with its compute (round 5; greedy choice only): the step's users run
+ * as TWO micro-batches, the row all-gather and the key all_to_all of one on a side stream (chained by events) while the other
+ * decodes / sweeps / merges on the caller's stream -- per step one all-gather and one all_to_all leave the critical path.  Same
+ * results bit for bit (rows are independent).  Off by default: two micro-batches cost decoder efficiency on small batches, and
+ * the build loop has one GPU (the overlap itself has never been measured).  Stream launches only (use_graph is ignored). */
+int irs_set_sharded_overlap(irs_ctx *ctx, int32_t on);
+int irs_get_sharded_overlap(const irs_ctx *ctx);
+
 /* State of the sharded loops' step capture (tests / diagnostics): bit 0 = a captured step is held, bit 1 = capture was
  * attempted and refused by the collective library (plain stream launches from then on). */
 int irs_sharded_graph_state(const irs_ctx *ctx);

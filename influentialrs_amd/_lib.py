@@ -81,6 +81,8 @@ SIGNATURES = {
     "irs_beam_search_sharded": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                           c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "irs_sharded_graph_state": (c_int32, [c_void_p]),
+    "irs_set_sharded_overlap": (c_int32, [c_void_p, c_int32]),
+    "irs_get_sharded_overlap": (c_int32, [c_void_p]),
     "irs_set_decoder_gemm": (c_int32, [c_void_p, c_int32]),
     "irs_get_decoder_gemm": (c_int32, [c_void_p]),
     "irs_get_decoder_gemm_effective": (c_int32, [c_void_p]),

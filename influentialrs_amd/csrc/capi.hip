@@ -92,6 +92,8 @@ extern "C" int irs_create(irs_ctx **out, const irs_dims *dims, const irs_shard *
         c->use_attn_h3 = ea ? (strcmp(ea, "h3") == 0) : 1; // (IRS_ATTN_GEMM=f32: float32 K / V rows and the float32-MFMA attention)
         const char *es = getenv("IRS_DECODER_SEQ");
         c->use_seq = es ? (strcmp(es, "auto") == 0 ? 2 : (atoi(es) != 0 ? 1 : 0)) : 2;
+        const char *eo = getenv("IRS_SHARDED_OVERLAP");
+        c->sh_overlap = eo ? (atoi(eo) != 0 ? 1 : 0) : 0; // (irs_set_sharded_overlap: off by default)
         const char *er = getenv("IRS_LSE_RING");
         c->lse_no_ring = er ? (strcmp(er, "0") == 0) : 0;
     }
@@ -104,6 +106,10 @@ extern "C" void irs_destroy(irs_ctx *ctx) {
     if (ctx->graph_exec) hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->beam_graph) hipGraphExecDestroy(ctx->beam_graph);
     if (ctx->sh_graph) hipGraphExecDestroy(ctx->sh_graph);
+    if (ctx->sh_side) {
+        for (int i = 0; i < 8; ++i) (void)hipEventDestroy(ctx->sh_ev[i]);
+        (void)hipStreamDestroy(ctx->sh_side);
+    }
     if (ctx->prof_ev) {
         for (int i = 0; i < ctx->prof_cap; ++i) {
             hipEventDestroy(ctx->prof_ev[i].a);

@@ -274,6 +274,13 @@ extern "C" int irs_exchange_topk(irs_ctx *ctx, irs_comm *comm, const uint64_t *k
     return comm_alltoall(ctx, comm, keys_send, keys_recv, (size_t)B * k * sizeof(uint64_t), (hipStream_t)stream);
 }
 
+extern "C" int irs_set_sharded_overlap(irs_ctx *ctx, int32_t on) {
+    if (!ctx) return IRS_E_INVALID;
+    ctx->sh_overlap = on ? 1 : 0;
+    return IRS_OK;
+}
+extern "C" int irs_get_sharded_overlap(const irs_ctx *ctx) { return ctx ? ctx->sh_overlap : IRS_E_INVALID; }
+
 extern "C" int irs_sharded_graph_state(const irs_ctx *ctx) {
     return ctx ? ((ctx->sh_graph ? 1 : 0) | (ctx->sh_nograph ? 2 : 0)) : 0;
 }
@@ -379,6 +386,58 @@ extern "C" int irs_generate_paths_sharded(irs_ctx *ctx, irs_comm *comm, int64_t 
             return r;
         return irs_launch_inc(ctx, ctx->step_ctr, q);
     };
+    // ---- opt-in (irs_set_sharded_overlap): the step's users as TWO micro-batches, the collectives on a side stream chained by
+    // events.  Half 1's decode runs while half 0's rows are gathered, half 0's sweep while half 1's rows are gathered, half 1's
+    // sweep while half 0's keys are exchanged, half 0's merge + path step while half 1's keys are exchanged: per step one
+    // all-gather and one all_to_all leave the critical path.  Rows are independent, so the results equal the one-batch loop's bit
+    // for bit (greedy choice only: the sampled choice draws its random numbers by row index of the call).  Off by default: RCCL
+    // with more than one rank has never run in the build loop, and two micro-batches cost decoder efficiency on small batches.
+    const bool overlap = ctx->sh_overlap && !sample && B >= 2 && world >= 1;
+    if (overlap && !ctx->sh_side) {
+        IRS_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->sh_side, hipStreamNonBlocking));
+        for (int i = 0; i < 8; ++i) IRS_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->sh_ev[i], hipEventDisableTiming));
+    }
+    auto body2 = [&](hipStream_t q) -> int {
+        int r;
+        hipStream_t c = ctx->sh_side;
+        const int d = ctx->dims.d, L = ctx->dims.max_len;
+        const int Bh[2] = {B / 2, B - B / 2}, o0[2] = {0, B / 2};
+        float *xr[2] = {ctx->xrows, ctx->xrows + (size_t)world * Bh[0] * d};
+        uint64_t *ks[2] = {ctx->keys_send, ctx->keys_send + (size_t)world * Bh[0] * k};
+        uint64_t *kr[2] = {ctx->keys_recv, ctx->keys_recv + (size_t)world * Bh[0] * k};
+        for (int h = 0; h < 2; ++h) { // decode, then the row all-gather on the side stream
+            if ((r = irs_launch_decode(ctx, seq + (size_t)o0[h] * L, user ? user + o0[h] : nullptr, Bh[h], nullptr, hep + o0[h],
+                                       ctx->x_local + (size_t)o0[h] * d, nullptr, q)))
+                return r;
+            IRS_CHECK_HIP(ctx, hipEventRecord(ctx->sh_ev[h], q));
+            IRS_CHECK_HIP(ctx, hipStreamWaitEvent(c, ctx->sh_ev[h], 0));
+            if ((r = comm_allgather(ctx, comm, ctx->x_local + (size_t)o0[h] * d, xr[h], (size_t)Bh[h] * d * sizeof(float), c))) return r;
+            IRS_CHECK_HIP(ctx, hipEventRecord(ctx->sh_ev[2 + h], c));
+        }
+        for (int h = 0; h < 2; ++h) { // sweep of this rank's item shard, keys packed; the key exchange on the side stream
+            IRS_CHECK_HIP(ctx, hipStreamWaitEvent(q, ctx->sh_ev[2 + h], 0));
+            if ((r = irs_launch_topk(ctx, xr[h], world * Bh[h], k, sweep, ctx->top_val, ctx->top_ids, ctx->row_status, q))) return r;
+            if ((r = irs_launch_pack_topk(ctx, ctx->top_val, ctx->top_ids, (int64_t)world * Bh[h] * k, ks[h], q))) return r;
+            IRS_CHECK_HIP(ctx, hipEventRecord(ctx->sh_ev[4 + h], q));
+            IRS_CHECK_HIP(ctx, hipStreamWaitEvent(c, ctx->sh_ev[4 + h], 0));
+            if ((r = comm_alltoall(ctx, comm, ks[h], kr[h], (size_t)Bh[h] * k * sizeof(uint64_t), c))) return r;
+            IRS_CHECK_HIP(ctx, hipEventRecord(ctx->sh_ev[6 + h], c));
+        }
+        for (int h = 0; h < 2; ++h) { // merge of the world's lists of this rank's own rows, the path step
+            IRS_CHECK_HIP(ctx, hipStreamWaitEvent(q, ctx->sh_ev[6 + h], 0));
+            if ((r = irs_launch_merge_keys(ctx, kr[h], world, Bh[h], k, ctx->top_val, ctx->top_ids, q))) return r;
+            hipLaunchKernelGGL(k_short_list, dim3((Bh[h] + 255) / 256), dim3(256), 0, q, ctx->top_ids, k, Bh[h], status + o0[h]);
+            if ((r = irs_launch_path_step(ctx, seq + (size_t)o0[h] * L, hep + o0[h], Bh[h], ctx->top_val, ctx->top_ids, k, 0, ctx->step_ctr,
+                                          paths + (size_t)o0[h] * max_path_len, max_path_len, sample, sample_k, seed, status + o0[h], q)))
+                return r;
+        }
+        return irs_launch_inc(ctx, ctx->step_ctr, q);
+    };
+    if (overlap) { // (stream launches: the side stream's work is ordered against `s` by the events of every step)
+        for (int i = 0; i < max_path_len; ++i)
+            if ((rc = body2(s))) return rc;
+        return IRS_OK;
+    }
     const bool reuse = ctx->sh_graph && ctx->sh_kind == 1 && ctx->sh_comm == comm && ctx->sh_B == B && ctx->sh_W == 1 &&
                        ctx->sh_P == max_path_len && ctx->sh_k == k && ctx->sh_sweep == sweep && ctx->sh_sample == sample &&
                        ctx->sh_sample_k == sample_k && ctx->sh_seed == seed && ctx->sh_ptr[0] == seq && ctx->sh_ptr[1] == (void *)user &&

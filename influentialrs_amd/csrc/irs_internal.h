@@ -146,6 +146,9 @@ struct irs_ctx {
     float *lse_gmax;          // [max_rows] all-reduced row maxima
     hipGraphExec_t sh_graph;  // captured sharded step (greedy: one step; beam: two)
     int sh_kind, sh_B, sh_W, sh_P, sh_k, sh_sweep, sh_sample, sh_sample_k, sh_nograph;
+    int sh_overlap;           // irs_set_sharded_overlap: the greedy sharded loop runs two user micro-batches per step, collectives on sh_side
+    hipStream_t sh_side;      // (created on first use)
+    hipEvent_t sh_ev[8];
     uint64_t sh_seed;
     void *sh_comm, *sh_ptr[5];
     hipGraphExec_t beam_graph;

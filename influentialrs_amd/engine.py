@@ -484,6 +484,16 @@ class Engine:
         return bool(self.lib.irs_decoder_seq_last(self.h))
 
     @property
+    def sharded_overlap(self) -> bool:
+        """irs_set_sharded_overlap: generate_paths_sharded runs two user micro-batches per step with the collectives on a side
+        stream (greedy choice; same results).  Off by default."""
+        return bool(self.lib.irs_get_sharded_overlap(self.h))
+
+    @sharded_overlap.setter
+    def sharded_overlap(self, on: bool):
+        self._check(self.lib.irs_set_sharded_overlap(self.h, 1 if on else 0))
+
+    @property
     def h3_range_bound(self) -> float:
         """Largest operand magnitude the bound weights allow in the float16-plane kernels (irs_h3_range_bound; -1 before the
         weights are finalised).  At 32752 or more IRS_GEMM_H3 runs as IRS_GEMM_X6 and `decoder_gemm_effective` reports that."""

@@ -58,6 +58,27 @@ def test_sharded_greedy_equals_single_device_loop(comm, cfgname, use_graph):
     assert eng.lib.irs_sharded_graph_state(eng.h) == (1 if use_graph else 0)
 
 
+@pytest.mark.parametrize("cfgname,n", [("tiny", 9), ("c1", 2), ("c2", 400)])
+def test_sharded_greedy_with_overlapped_collectives_equals_single_device_loop(comm, cfgname, n):
+    """irs_set_sharded_overlap (round 5): the step's users as two micro-batches (9 -> 4 + 5), each one's all-gather and all_to_all
+    on a side stream chained to the compute stream by events -- here over real RCCL calls (one rank), over gloo callbacks with 3 and
+    4 ranks in tests/test_gpu_multirank.py.  Rows are independent: ids and status flags equal irs_generate_paths'.  (c2 x 400
+    users: halves of 200 sequences below, the whole batch above the sequence-resident decoder's automatic switch.)"""
+    cfg = synth.make_config(cfgname)
+    eng = make_engine(cfg, synth.irn_state_dict(cfg, 1234), max_rows=n, max_seqs=n)
+    seqs, users = _windows(cfg, n, 5)
+    hep = torch.full((n,), cfg.max_len - 2, dtype=torch.int32, device="cuda")
+    p1, s1 = eng.generate_paths(seqs.clone(), users, hep.clone(), 5, k=100, sweep=IRS_SWEEP_BF16)
+    assert not eng.sharded_overlap
+    eng.sharded_overlap = True
+    assert eng.sharded_overlap
+    for rep in range(2):
+        p2, s2 = eng.generate_paths_sharded(comm, seqs.clone(), users, hep.clone(), 5, k=100, sweep=IRS_SWEEP_BF16)
+        torch.cuda.synchronize()
+        assert torch.equal(p1, p2) and torch.equal(s1, s2)
+    eng.sharded_overlap = False
+
+
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_sharded_beam_equals_single_device_loop(comm, split, use_graph):

@@ -220,6 +220,12 @@ def _worker_catalog(rank, world, port, ret):
         p_1, st_1 = full.generate_paths(seqs[sl].clone(), users[sl].contiguous(), hep[sl].clone(), P, k=100, sweep=IRS_SWEEP_BF16)
         torch.cuda.synchronize()
         assert torch.equal(p_s, p_1) and torch.equal(st_s, st_1), (rank, p_s, p_1)
+        # the same with irs_set_sharded_overlap: two micro-batches per step, their collectives on a side stream (round 5)
+        eng.sharded_overlap = True
+        p_o, st_o = eng.generate_paths_sharded(comm, seqs[sl].clone(), users[sl].contiguous(), hep[sl].clone(), P, k=100, sweep=IRS_SWEEP_BF16)
+        torch.cuda.synchronize()
+        eng.sharded_overlap = False
+        assert torch.equal(p_o, p_1) and torch.equal(st_o, st_1), (rank, p_o, p_1)
         # beam 32, one user, the beam windows' decode split over the ranks (BASELINE configs[4]'s layout)
         b_s = eng.beam_search_sharded(comm, seqs[:1].contiguous(), users[:1].contiguous(), hep[:1].contiguous(), P, W, k=100,
                                       sweep=IRS_SWEEP_BF16, split_decode=True)
