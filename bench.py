@@ -349,6 +349,8 @@ class Job:
         self.users = torch.randint(0, cfg.n_user, (self.B,), device=device, dtype=torch.int64)
         self.hep = torch.full((self.B,), cfg.max_len - 2, dtype=torch.int32, device=device)
         self.paths = torch.zeros((self.B, 1), dtype=torch.float32, device=device)
+        self.carry = False
+        self.last_status = None
         self.status = torch.zeros(self.B, dtype=torch.int32, device=device)
         self.comm = None
         if self.sharded:
@@ -361,7 +363,11 @@ class Job:
         eng = self.eng
         if not self.sharded:
             _, xr, _ = eng.decode(self.seqs, self.users, want_x=False, pos=self.hep)
-            val, ids, _ = eng.score_topk(xr, self.k, self.sweep)
+            # (the rows are the previous step's rows one item later: irs_score_topk_carry skips the pre-pass and the threshold
+            #  selection on 7 steps of 8 on shards of >= 524288 items -- what irs_generate_paths does between its own steps)
+            val, ids, st = eng.score_topk(xr, self.k, self.sweep, carry=self.carry)
+            self.carry = True
+            self.last_status = st
             eng.path_step(self.seqs, self.hep, val, ids, 0, self.paths, self.status)
         else:
             # one search step below the C ABI (irs_generate_paths_sharded): decode -> row all-gather -> sweep of this rank's
@@ -371,7 +377,8 @@ class Job:
                                        use_graph=SHARDED_GRAPH and self.comm.is_rccl, paths=self.paths, status=self.status)
 
 
-VERIFY_JOB_HOW = ("4 rows of the last step: ring-sweep top-100 == float32-sweep top-100 (ids and value bits); 4 users of the last step "
+VERIFY_JOB_HOW = ("4 rows of the last step: ring-sweep top-100 (emission thresholds carried from the previous step, as in the timed loop; `fallback_rows` "
+                  "counts the rows of nine such steps that had to take the exhaustive path) == float32-sweep top-100 (ids and value bits); 4 users of the last step "
                   "re-decoded 4 per call on the small-batch float32-chain kernels (pinned to the reference goldens irn_c2 / irn_c3 / "
                   "irn_c4d by tests/test_gpu_decoder_path.py): rows within 7.5e-5 of the throughput kernels'")
 VERIFY_ROW_TOL = 7.5e-5  # decoder rows through the split-precision throughput kernels vs the small-batch float32 kernels (d = 256 bound of tests/test_gpu_decoder_path.py)
@@ -386,11 +393,20 @@ def verify_job(job, n=4):
     import torch
     from influentialrs_amd._lib import IRS_SWEEP_F32
     eng = job.eng
+    # (single GPU: the loop's calls carry their emission thresholds from step to step; eight more such steps first, every row
+    #  that had to take the exhaustive path in them counted into `fallback_rows` -- a carried threshold that did not fit shows there)
+    fb_carry = 0
+    if not job.sharded and getattr(job, "carry", False):
+        acc = torch.zeros((), dtype=torch.int64, device=job.device)
+        for _ in range(8):
+            job.step()
+            acc += (job.last_status & 1).sum()
+        fb_carry = int(acc.item())
     _, xr, _ = eng.decode(job.seqs, job.users, want_x=False, pos=job.hep)
     rows = xr
     if job.sharded:
         rows = eng.allgather_rows(job.comm, xr, job.x_all)
-    v, i, st = eng.score_topk(rows, job.k, job.sweep)
+    v, i, st = eng.score_topk(rows, job.k, job.sweep, carry=(not job.sharded and getattr(job, "carry", False)))
     sel = torch.linspace(0, rows.shape[0] - 1, n, device=rows.device).long()
     vf, i_f, _ = eng.score_topk(rows[sel].contiguous(), job.k, IRS_SWEEP_F32)
     # the decoder that produced the rows (round 5): `n` of this rank's users decoded again, n per call in IRS_GEMM_F32 -- at
@@ -419,7 +435,7 @@ def verify_job(job, n=4):
         else:
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             ok = bool(t.item())
-    return ok, int((st & 1).sum().item())
+    return ok, int((st & 1).sum().item()) + fb_carry
 
 
 def verify_headline(job, n=8):
@@ -495,7 +511,7 @@ def phase_times(job, steps=3):
         ev[1].record()
         rows = eng.allgather_rows(job.comm, xr, job.x_all) if job.sharded else xr   # irs_allgather_rows
         ev[2].record()
-        v, i, _ = eng.score_topk(rows, job.k, job.sweep)
+        v, i, _ = eng.score_topk(rows, job.k, job.sweep, carry=(not job.sharded and getattr(job, "carry", False)))
         keys = eng.pack_topk(v, i).view(job.world, job.B, job.k) if job.sharded else None
         ev[3].record()
         if job.sharded:

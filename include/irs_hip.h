@@ -161,6 +161,13 @@ int irs_decode(irs_ctx *ctx, const int64_t *dev_seq, const int64_t *dev_user, in
  *  dev_status int32 [M] out, IRS_ROW_* bits */
 int irs_score_topk(irs_ctx *ctx, const float *dev_xrows, int32_t M, int32_t k, int32_t sweep, float *dev_val,
                    int64_t *dev_ids0, int32_t *dev_status, void *stream);
+/* The same call for rows that are the PREVIOUS irs_score_topk[_carry] call's rows one path-search step later (same M, k, IRS_SWEEP_BF16):
+ * the pre-pass over the catalog sample and the per-row threshold selection are skipped and the previous call's emission thresholds
+ * reused (refreshed every IRS_THR_CARRY-th call, default 8); irs_generate_paths[_sharded] do this between their own steps.  Results are
+ * exact whatever the rows are: a threshold that no longer fits is detected by the same validation as always and that row takes the
+ * exhaustive path (IRS_ROW_FALLBACK) -- rows unrelated to the previous call's only cost time. */
+int irs_score_topk_carry(irs_ctx *ctx, const float *dev_xrows, int32_t M, int32_t k, int32_t sweep, float *dev_val,
+                         int64_t *dev_ids0, int32_t *dev_status, void *stream);
 
 /* Exact scores at chosen items (replaces prob_dict[j][end][item-1],
  * evaluator.py:203-205, and the label lookup of influentialRS.py:386-388).

@@ -44,6 +44,7 @@ SIGNATURES = {
     "irs_pif": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "irs_decode": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "irs_score_topk": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "irs_score_topk_carry": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "irs_score_gather": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
     "irs_score_count_before": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "irs_score_dense": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p]),

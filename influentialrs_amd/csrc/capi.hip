@@ -92,6 +92,9 @@ extern "C" int irs_create(irs_ctx **out, const irs_dims *dims, const irs_shard *
         c->use_attn_h3 = ea ? (strcmp(ea, "h3") == 0) : 1; // (IRS_ATTN_GEMM=f32: float32 K / V rows and the float32-MFMA attention)
         const char *es = getenv("IRS_DECODER_SEQ");
         c->use_seq = es ? (strcmp(es, "auto") == 0 ? 2 : (atoi(es) != 0 ? 1 : 0)) : 2;
+        const char *ec = getenv("IRS_THR_CARRY"); // steps between two pre-pass + threshold selections inside a path search (0 / 1: every step)
+        c->carry_period = ec ? atoi(ec) : 8;
+        if (c->carry_period < 0 || c->carry_period > 1024) c->carry_period = 8;
         const char *eo = getenv("IRS_SHARDED_OVERLAP");
         c->sh_overlap = eo ? (atoi(eo) != 0 ? 1 : 0) : 0; // (irs_set_sharded_overlap: off by default)
         const char *er = getenv("IRS_LSE_RING");
@@ -256,6 +259,7 @@ extern "C" int irs_finalize_weights(irs_ctx *ctx, void *arena, size_t bytes, voi
     }
     ctx->finalized = true;
     ctx->proj_stale = false;
+    ctx->thr_valid = 0; // (carried emission thresholds belong to the catalog they were selected on)
     if (ctx->sh_graph) {
         hipGraphExecDestroy(ctx->sh_graph);
         ctx->sh_graph = nullptr;
@@ -377,6 +381,7 @@ extern "C" int irs_bind_workspace(irs_ctx *ctx, void *ws, size_t bytes) {
     ctx->xb = (uint4 *)(b + p.xb);
     ctx->eps = (float *)(b + p.eps);
     ctx->thr = (float *)(b + p.thr);
+    ctx->thr_valid = 0;
     ctx->gm = (float *)(b + p.gm);
     ctx->cand_cnt = (unsigned int *)(b + p.cnt);
     ctx->cand = (unsigned long long *)(b + p.cand);
@@ -548,6 +553,16 @@ static int check_rows(irs_ctx *ctx, const char *fn, const void *xrows, int M) {
     return IRS_OK;
 }
 
+extern "C" int irs_score_topk_carry(irs_ctx *ctx, const float *xrows, int32_t M, int32_t k, int32_t sweep, float *val,
+                                    int64_t *ids0, int32_t *status, void *stream) {
+    int rc = ready_filter(ctx, sweep);
+    if (rc) return rc;
+    if ((rc = check_rows(ctx, "irs_score_topk_carry", xrows, M))) return rc;
+    if (k < 1 || k > ctx->dims.max_k || !val || !ids0 || !status) IRS_FAIL(ctx, IRS_E_INVALID, "irs_score_topk_carry: bad k / outputs");
+    if (sweep != IRS_SWEEP_BF16) IRS_FAIL(ctx, IRS_E_INVALID, "irs_score_topk_carry: the bf16 filter only");
+    return irs_launch_topk(ctx, xrows, M, k, sweep, val, ids0, status, (hipStream_t)stream, nullptr, nullptr, nullptr, 1);
+}
+
 extern "C" int irs_score_topk(irs_ctx *ctx, const float *xrows, int32_t M, int32_t k, int32_t sweep, float *val,
                               int64_t *ids0, int32_t *status, void *stream) {
     int rc = ready_filter(ctx, sweep);
@@ -685,7 +700,7 @@ static bool step_merged(const irs_ctx *ctx, int B) { // see irs_launch_decode: t
 
 static int enqueue_step(irs_ctx *ctx, int64_t *seq, const int64_t *user, int32_t *hep, int B, int k, int sweep,
                         int sample, int sample_k, uint64_t seed, float *paths, int path_ld, int32_t *status,
-                        hipStream_t s) {
+                        hipStream_t s, int carry = 0) {
     int rc;
     const bool merged = step_merged(ctx, B);
     ctx->step_pair = merged ? ctx->step_ctr : nullptr;
@@ -698,7 +713,8 @@ static int enqueue_step(irs_ctx *ctx, int64_t *seq, const int64_t *user, int32_t
                                ctx->step_ctr, 0, ctx->step_ctr + 1, 1};
         return irs_launch_topk(ctx, ctx->xrows, B, k, sweep, ctx->top_val, ctx->top_ids, ctx->row_status, s, &pa);
     }
-    if ((rc = irs_launch_topk(ctx, ctx->xrows, B, k, sweep, ctx->top_val, ctx->top_ids, ctx->row_status, s))) return rc;
+    if ((rc = irs_launch_topk(ctx, ctx->xrows, B, k, sweep, ctx->top_val, ctx->top_ids, ctx->row_status, s, nullptr, nullptr, nullptr, carry)))
+        return rc;
     if ((rc = irs_launch_path_step(ctx, seq, hep, B, ctx->top_val, ctx->top_ids, k, 0, ctx->step_ctr, paths, path_ld,
                                    sample, sample_k, seed, status, s, merged ? ctx->step_ctr + 1 : nullptr)))
         return rc;
@@ -721,8 +737,8 @@ extern "C" int irs_generate_paths(irs_ctx *ctx, int64_t *seq, const int64_t *use
     IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->step_ctr, 0, 2 * sizeof(int32_t), s));
     IRS_CHECK_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t) * B, s));
     if (!use_graph) {
-        for (int i = 0; i < max_path_len; ++i)
-            if ((rc = enqueue_step(ctx, seq, user, hep, B, k, sweep, sample, sample_k, seed, paths, max_path_len, status, s)))
+        for (int i = 0; i < max_path_len; ++i) // (steps behind the first may reuse the previous step's emission thresholds)
+            if ((rc = enqueue_step(ctx, seq, user, hep, B, k, sweep, sample, sample_k, seed, paths, max_path_len, status, s, i > 0)))
                 return rc;
         return IRS_OK;
     }

@@ -372,11 +372,15 @@ extern "C" int irs_generate_paths_sharded(irs_ctx *ctx, irs_comm *comm, int64_t 
     const int rows = B * world;
     IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->step_ctr, 0, 2 * sizeof(int32_t), s));
     IRS_CHECK_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t) * B, s));
+    int step_no = 0; // (stream launches: steps behind the first may reuse the previous step's emission thresholds; a captured step never does)
+    const bool graph_path = use_graph && comm->rccl && ctx->prof_family == IRS_PROF_NONE && !ctx->sh_nograph;
     auto body = [&](hipStream_t q) -> int {
         int r;
+        const int carry = (!graph_path && step_no++ > 0) ? 1 : 0;
         if ((r = irs_launch_decode(ctx, seq, user, B, nullptr, hep, ctx->x_local, nullptr, q))) return r;
         if ((r = comm_allgather(ctx, comm, ctx->x_local, ctx->xrows, (size_t)B * ctx->dims.d * sizeof(float), q))) return r;
-        if ((r = irs_launch_topk(ctx, ctx->xrows, rows, k, sweep, ctx->top_val, ctx->top_ids, ctx->row_status, q))) return r;
+        if ((r = irs_launch_topk(ctx, ctx->xrows, rows, k, sweep, ctx->top_val, ctx->top_ids, ctx->row_status, q, nullptr, nullptr, nullptr, carry)))
+            return r;
         if ((r = irs_launch_pack_topk(ctx, ctx->top_val, ctx->top_ids, (int64_t)rows * k, ctx->keys_send, q))) return r;
         if ((r = comm_alltoall(ctx, comm, ctx->keys_send, ctx->keys_recv, (size_t)B * k * sizeof(uint64_t), q))) return r;
         if ((r = irs_launch_merge_keys(ctx, ctx->keys_recv, world, B, k, ctx->top_val, ctx->top_ids, q))) return r;

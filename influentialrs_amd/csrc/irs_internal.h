@@ -121,6 +121,7 @@ struct irs_ctx {
     float *lse_part;    // [lse_slots][m_pad][2]
     int lse_slots;
     float *ref_tmp;     // [m_pad]
+    int thr_valid, thr_M, thr_k, thr_age, carry_period; // carried emission thresholds (irs_launch_topk)
     unsigned int *fb_count;        // [1] rows recorded for the cooperative exhaustive fallback
     int32_t *fb_list;              // [max_rows]
     unsigned long long *exh_keys;  // [EXH_FB_MAX][strips][k] per-strip lists (null on small shards)
@@ -210,7 +211,7 @@ struct irs_path_args;
 bool irs_topk_is_direct(const irs_ctx *ctx, int M, int k);
 int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, float *val, int64_t *ids0,
                     int32_t *status, hipStream_t s, const irs_path_args *path = nullptr, float *lse_max = nullptr,
-                    float *lse_sum = nullptr);
+                    float *lse_sum = nullptr, int carry = 0);
 int irs_launch_gather(irs_ctx *ctx, const float *xrows, int M, const int64_t *ids0, int g, float *out, hipStream_t s);
 int irs_launch_count_before(irs_ctx *ctx, const float *xrows, int M, const float *ref_score, const int64_t *ref_id0,
                             const int64_t *excl, int n_excl, int64_t *count, hipStream_t s);

@@ -1729,7 +1729,8 @@ __global__ void __launch_bounds__(256) k_prep_x(const float *__restrict__ x, int
                                                 uint4 *__restrict__ xb, float *__restrict__ eps,
                                                 const float *__restrict__ wn, float acc_factor,
                                                 unsigned int *__restrict__ cand_cnt, int32_t *__restrict__ status,
-                                                unsigned int *__restrict__ fb_count) {
+                                                unsigned int *__restrict__ fb_count, float *__restrict__ thr_carry,
+                                                float *__restrict__ traw_carry) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (fb_count && blockIdx.x == 0 && threadIdx.x == 0) *fb_count = 0u; // (the cooperative fallback's row counter: a memset launch less)
@@ -1749,7 +1750,16 @@ __global__ void __launch_bounds__(256) k_prep_x(const float *__restrict__ x, int
     if (lane == 0) {
         const float nx = sqrtf(fmaxf(ss, ssr)), ndx = sqrtf(ssd);
         // 1.001: the float32 sums of squares / square roots above (relative error < d 2^-24 + 2^-23)
-        eps[row] = (row < M) ? 1.001f * (ndx * wn[0] + nx * wn[1]) + acc_factor * (1.001f * nx * wn[0] + wn[2]) : 0.f;
+        const float e = (row < M) ? 1.001f * (ndx * wn[0] + nx * wn[1]) + acc_factor * (1.001f * nx * wn[0] + wn[2]) : 0.f;
+        eps[row] = e;
+        // carried emission thresholds (irs_launch_topk, carry): EMIT keeps a >= thr as before; k_refine's check "at least k emitted
+        // items score >= traw" proves the exact top k were emitted iff traw - 2 eps >= thr for THIS row's eps: traw = thr + 2 eps.
+        // (A threshold that is not a number would disable both tests: it becomes -inf = emit everything.)
+        if (thr_carry && row < M) {
+            float t = thr_carry[row];
+            if (!(t == t)) t = -INFINITY, thr_carry[row] = t;
+            traw_carry[row] = t > -INFINITY ? t + 2.0f * e : -INFINITY;
+        }
     }
 }
 
@@ -2906,7 +2916,7 @@ bool irs_topk_is_direct(const irs_ctx *ctx, int M, int k) {
 // bf16 filter it comes out of the SAME pass as the candidates: pre-pass and threshold on the bf16 catalog sample as
 // usual, then one sweep of the float32 catalog that emits against the threshold and accumulates (max, sum exp).
 int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, float *val, int64_t *ids0,
-                    int32_t *status, hipStream_t s, const irs_path_args *path, float *lse_max, float *lse_sum) {
+                    int32_t *status, hipStream_t s, const irs_path_args *path, float *lse_max, float *lse_sum, int carry) {
     if (path && !irs_topk_is_direct(ctx, M, k)) IRS_FAIL(ctx, IRS_E_STATE, "fused path step needs the one-launch top-k");
     if (irs_topk_is_direct(ctx, M, k)) {
         // latency path on a small shard: one kernel, no fallback needed
@@ -2938,11 +2948,22 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
     static_assert(IRS_CAND_BUCKETS == 64, "k_prep_x resets one bucket counter per lane");
     // big shards: rows that need the exhaustive path are recorded by k_refine and redone cooperatively (see k_exh_strips)
     const bool coop_fb = ctx->n_local >= IRS_COOP_FALLBACK_MIN_ITEMS && ctx->exh_keys != nullptr;
+    // Threshold carry (round 5): inside a path search the rows of step t + 1 are the rows of step t one item later -- a row's k-th
+    // score moves by ~0.02 per step while the emission threshold sits ~0.2-0.4 below it (profiles/r05/thr_drift_probe.txt) -- so the
+    // pre-pass and the threshold selection run on the first step and then every carry_period-th one; in between the thresholds of
+    // the previous step are reused (k_prep_x re-derives the validation level for the new rows' eps).  k_refine validates as always:
+    // a threshold that no longer fits costs that row the exhaustive path, never a wrong list.
+    // (Only where the threshold is the speculative one of a 1/8 or 1/16 sample -- ~3k-4k candidates per row: shards of 262144 items and
+    //  more.  On a smaller shard the pre-pass sees every tile and the threshold is the tight k-th group maximum: the next step's rows
+    //  would miss it often, and the pre-pass is cheap there anyway.)
+    const bool reuse_thr = carry && ctx->carry_period > 0 && sweep == IRS_SWEEP_BF16 && !fused_lse && ctx->thr_valid && ctx->thr_M == M &&
+                           ctx->thr_k == k && ctx->thr_age + 1 < ctx->carry_period && nt >= 2 * 8 * 1024;
     if (sweep == IRS_SWEEP_BF16) {
         // |approx - exact| <= eps[row] for every item of the shard: see k_prep_x
         const float acc_factor = (float)(ctx->d_pad + 8) * 2.384185791015625e-07f; // (d_pad + 8) 2^-22
         hipLaunchKernelGGL(k_prep_x, dim3((M_pad + 3) / 4), dim3(256), 0, s, xrows, M, M_pad, d, ctx->KS,
-                           ctx->xb, ctx->eps, ctx->wnorm_max, acc_factor, ctx->cand_cnt, status, coop_fb ? ctx->fb_count : nullptr);
+                           ctx->xb, ctx->eps, ctx->wnorm_max, acc_factor, ctx->cand_cnt, status, coop_fb ? ctx->fb_count : nullptr,
+                           reuse_thr ? ctx->thr : nullptr, reuse_thr ? ctx->ref_tmp : nullptr);
     } else {
         IRS_CHECK_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int32_t) * M, s));
         IRS_CHECK_HIP(ctx, hipMemsetAsync(ctx->cand_cnt, 0, sizeof(unsigned int) * (size_t)M_pad * IRS_CAND_BUCKETS, s));
@@ -2952,6 +2973,7 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
     const int UBh = (sweep == IRS_SWEEP_BF16) ? ub_bf16(ctx->KS) : ub_f32(ctx->KS);
     const int nub = (a.UT + UBh - 1) / UBh;
 
+    if (!reuse_thr) {
     // pre-pass over a strided sample of item tiles: >= 1024 tiles (32768 items) or 1/8 of the shard; 1/16 where that still is
     // >= 1024 tiles (shards of 524288 items and more; round 4).  The threshold is then the ceil(4k/16) = 25th largest sampled
     // group maximum per row (r_sel below) instead of the 38th of twice as many: ~4k emitted items per row instead of ~3k (a third
@@ -2993,6 +3015,9 @@ int irs_launch_topk(irs_ctx *ctx, const float *xrows, int M, int k, int sweep, f
                        ctx->thr, ctx->ref_tmp);
     IRS_CHECK_HIP(ctx, hipGetLastError());
 
+    ctx->thr_valid = (sweep == IRS_SWEEP_BF16), ctx->thr_M = M, ctx->thr_k = k, ctx->thr_age = 0;
+    } else
+        ++ctx->thr_age;
     // emission sweep over the whole shard
     a.thr = ctx->thr;
     a.cnt = ctx->cand_cnt;

@@ -156,14 +156,17 @@ class Engine:
         return x, xr, ru
 
     # ------------------------------------------------------------------ scoring
-    def score_topk(self, xrows: torch.Tensor, k: int = 100, sweep: int = IRS_SWEEP_BF16):
-        """(val[M,k] float32, ids0[M,k] int64 global 0-based, status[M] int32) of this shard."""
+    def score_topk(self, xrows: torch.Tensor, k: int = 100, sweep: int = IRS_SWEEP_BF16, carry: bool = False):
+        """(val[M,k] float32, ids0[M,k] int64 global 0-based, status[M] int32) of this shard.  carry: the rows are the previous
+        call's rows one path-search step later -- irs_score_topk_carry reuses that call's emission thresholds (same exact results;
+        unrelated rows only cost time)."""
         xrows = self._dev(xrows, torch.float32)
         M = xrows.shape[0]
         val = torch.empty((M, k), dtype=torch.float32, device=self.device)
         ids = torch.empty((M, k), dtype=torch.int64, device=self.device)
         st = torch.empty(M, dtype=torch.int32, device=self.device)
-        self._call(self.lib.irs_score_topk, _ptr(xrows), M, k, sweep, _ptr(val), _ptr(ids), _ptr(st))
+        fn = self.lib.irs_score_topk_carry if (carry and sweep == IRS_SWEEP_BF16) else self.lib.irs_score_topk
+        self._call(fn, _ptr(xrows), M, k, sweep, _ptr(val), _ptr(ids), _ptr(st))
         return val, ids, st
 
     def score_topk_lse(self, xrows: torch.Tensor, k: int = 100, sweep: int = IRS_SWEEP_BF16):

@@ -553,3 +553,37 @@ def test_lse_ring_equals_register_form(oracle, monkeypatch, n_item, d, M):
     assert np.array_equal(a[1][0].cpu().numpy(), oi) and np.array_equal(a[0][0].cpu().numpy().view(np.uint32), ov.view(np.uint32))
     om, osum = oracle.max_sumexp(s0)
     assert abs(a[3][0] - (om + np.log(osum))) <= 4e-6 * max(1.0, abs(om))
+
+
+@pytest.mark.parametrize("n_item,d,M", [(600_017, 128, 70), (1_000_000, 128, 600), (150_000, 256, 33), (60_000, 64, 300)])
+def test_carried_emission_thresholds_stay_exact(n_item, d, M):
+    """irs_score_topk_carry (round 5): the pre-pass and the threshold selection are skipped and the previous call's emission
+    thresholds reused.  (a) rows that ARE the previous rows a little later (a small perturbation, as one path-search step is):
+    exact lists, no row on the exhaustive path; (b) rows that have NOTHING to do with the previous call's (fresh random rows, rows
+    scaled by 1/4 and by 4: thresholds far too high and far too low): still the exhaustive kernel's lists bit for bit -- the
+    validation in k_refine sends the rows whose threshold no longer fits to the exhaustive path (IRS_ROW_FALLBACK); (c) a plain
+    call afterwards selects fresh thresholds again (no row falls back).  Shards below 524288 items (the last two cases) never carry:
+    their pre-pass sees every tile and selects the tight k-th group maximum, which the next step's rows would often miss."""
+    W, b = _weights(n_item, d, n_item + d)
+    eng = scoring_only_engine(n_item, d, W, b, max_rows=M, max_k=100)
+    g = np.random.default_rng(M + d)
+    x0 = _rows(M, d, 5)
+
+    def check(x, carry):
+        xt = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        ev, ei, _ = eng.score_topk(xt, 100, IRS_SWEEP_EXHAUSTIVE)
+        val, ids, st = eng.score_topk(xt, 100, IRS_SWEEP_BF16, carry=carry)
+        torch.cuda.synchronize()
+        assert torch.equal(ids, ei) and torch.equal(val.view(torch.int32), ev.view(torch.int32))
+        return int((st & 1).sum().item())
+
+    assert check(x0, False) == 0
+    x = x0
+    for step in range(10):  # (the default period refreshes the thresholds on the 8th call)
+        x = (x + 0.02 * g.standard_normal(x.shape)).astype(np.float32)
+        assert check(x, True) == 0, step
+    fb = check(_rows(M, d, 99), True)            # unrelated rows: exact, some on the exhaustive path
+    fb_low = check(0.25 * _rows(M, d, 98), True)  # every threshold far too high
+    fb_high = check(4.0 * _rows(M, d, 97), True)  # every threshold far too low (buckets overflow)
+    assert (fb_low > 0 or fb_high > 0 or fb > 0) == (n_item >= 524288), (fb, fb_low, fb_high)
+    assert check(_rows(M, d, 96), False) == 0
