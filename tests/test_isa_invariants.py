@@ -79,3 +79,30 @@ def test_counted_vmcnt_waits_see_the_operations_they_count(decoder_isa):
         # stores appear only in the q | k | v tail (and the x' store of LayerNorm 3), never between a DMA issue and the wait that counts it short
         assert rest.count("W0,") <= 1 + 1, rest.count("W0,")  # the last publish (nothing in flight behind it)
         assert rest.count("|") == steps - 1, (rest.count("|"), steps)
+
+
+@pytest.fixture(scope="module")
+def score_isa(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = os.path.join(tmp_path_factory.mktemp("isa_score"), "score.s")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-I" + os.path.join(REPO, "include"),
+                        os.path.join(REPO, "influentialrs_amd", "csrc", "score.hip"), "-o", out], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return open(out).read().split("\n")
+
+
+def test_no_matrix_result_is_read_early_behind_a_taken_branch(decoder_isa, score_isa):
+    """gfx950 does not interlock a vector read of an MFMA destination still in flight; the compiler pads the distance with s_nop
+    along the paths it accounts for.  Round 5 met a taken edge of a wave-uniform branch it had not accounted for (a lab form of the
+    sequence-resident attention: the row maximum read stale registers, NaN rows): the attention kernels now wait explicitly
+    (SEQ_MFMA_LANDED / ATTN_MFMA_LANDED), and tools/isa_mfma_branch_scan.py walks every kernel with matrix instructions of both
+    kernel files -- every branch target within the hazard window behind every MFMA -- for such a read.  (The scan flags that lab
+    form's 12 reads; here it must find none.)"""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import isa_mfma_branch_scan as scan
+    for lines, min_kernels in ((decoder_isa, 40), (score_isa, 60)):
+        ks = [(n, ins) for n, ins in scan.parse(lines) if any(op and op.startswith("v_mfma") for _, op, _, _ in ins)]
+        assert len(ks) >= min_kernels, len(ks)
+        for n, ins in ks:
+            assert scan.scan_kernel(n, ins) == 0, n
