@@ -164,3 +164,29 @@ def test_rccl_version_gate_and_forced_send_recv_exchange(forced):
         out, _ = proc.communicate()
         pytest.fail("exchange probe (forced=%s) did not finish in 150 s; output so far:\n%s" % (forced, out))
     assert proc.returncode == 0 and "done" in out, out
+
+
+def test_carried_thresholds_inside_the_search_loops_million_items(comm, monkeypatch):
+    """irs_generate_paths and irs_generate_paths_sharded on a 1M-item catalog, 10 steps: steps behind the first reuse the previous
+    step's emission thresholds (round 5; shards of >= 524288 items, refreshed every 8th step).  An engine created with
+    IRS_THR_CARRY=0 (pre-pass + selection on every step) must produce the same paths and status flags id for id, single-device
+    loop and sharded loop (one RCCL rank) alike."""
+    import bench
+    cfg = synth.make_config("c3")
+    B, P = 48, 10
+    sd = synth.irn_state_dict(cfg, 1234)
+    eng = make_engine(cfg, sd, max_rows=B, max_seqs=B)
+    monkeypatch.setenv("IRS_THR_CARRY", "0")
+    plain = make_engine(cfg, sd, max_rows=B, max_seqs=B)
+    monkeypatch.delenv("IRS_THR_CARRY")
+    dev = torch.device("cuda:0")
+    seqs = bench.gpu_windows(B, cfg.max_len, cfg.n_item, dev, seed=21)
+    users = torch.arange(B, device=dev, dtype=torch.int64) * 13 % cfg.n_user
+    hep = torch.full((B,), cfg.max_len - 2, dtype=torch.int32, device=dev)
+    p0, s0 = plain.generate_paths(seqs.clone(), users, hep.clone(), P, k=100, sweep=IRS_SWEEP_BF16)
+    p1, s1 = eng.generate_paths(seqs.clone(), users, hep.clone(), P, k=100, sweep=IRS_SWEEP_BF16)
+    p2, s2 = eng.generate_paths_sharded(comm, seqs.clone(), users, hep.clone(), P, k=100, sweep=IRS_SWEEP_BF16)
+    torch.cuda.synchronize()
+    assert torch.equal(p0, p1) and torch.equal(s0, s1)
+    assert torch.equal(p0, p2) and torch.equal(s0, s2)
+    assert (p0 > 0).all()  # ten items chosen for every user
